@@ -1,0 +1,434 @@
+/* fp64 C/OpenMP restatement of the hot path -- TEST INFRASTRUCTURE ONLY.
+ *
+ * The checker, never the product: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.  Same algorithm as
+ * oracle/oracle_np.py (SPEC = DESIGN.md section 2), brute force, fp64.
+ *
+ * PARITY STATUS: "parity unpinned" for graph topology / lambda values: the
+ * reference's arithmetic lives in crates.io `arrowspace 0.18.0`
+ * (/root/reference/Cargo.toml:16, Cargo.lock:94-97), absent from the tree and
+ * unbuildable here (no cargo).  Pinned by the reference and checked in
+ * tests/test_oracle_golden.py: README.md:37-48,56-62,69 (3x3 toy scores, tau=1),
+ * tests/test_0.py:4-18,24,29-32 (tau=1 order), TAUMODE.md:33 + src/lib.rs:169-173
+ * (scorer form, topk results sorted descending over a full scan).
+ *
+ * Build: gcc -O3 -march=native -fopenmp -shared -fPIC (oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ASO_TAU_MIN 1e-12
+enum { ASO_L2 = 0, ASO_COSINE = 1 };
+enum { ASO_GAUSSIAN = 0, ASO_RATIONAL = 1 };
+
+typedef struct {
+    int64_t n, d;
+    double eps, p, sigma;
+    int64_t k;
+    int metric, kernel;
+    double *X;       /* n*d */
+    double *nrm;     /* n: squared norms */
+    double *ny;      /* n: squared norm of the graph-space vector y_i */
+    int64_t *indptr; /* n+1 */
+    int64_t *indices;
+    double *dist, *gy, *w, *lap;
+    double *deg, *E, *G, *lam;
+    double tau0;
+    int64_t *knn_idx; /* n*k directed lists (-1 padded) */
+    int64_t *knn_cnt;
+} aso_index;
+
+static double edge_weight(double d, double sigma, double p, int kernel) {
+    /* SPEC S4; GRAPH_VARIABLES.md:9 for the rational form */
+    double t = d / sigma;
+    double u = (p == 2.0) ? t * t : pow(t, p);
+    return kernel == ASO_GAUSSIAN ? exp(-0.5 * u) : 1.0 / (1.0 + u);
+}
+
+/* sequential-order dot products (no -ffast-math): sum_c a_c*b_c and sum_c (a_c-b_c)^2 */
+static inline void pair_l2(const double *a, const double *b, int64_t d, double *sq, double *dot) {
+    double s = 0.0, g = 0.0;
+    for (int64_t c = 0; c < d; ++c) {
+        double t = a[c] - b[c];
+        s += t * t;
+        g += a[c] * b[c];
+    }
+    *sq = s;
+    *dot = g;
+}
+static inline double dotp(const double *a, const double *b, int64_t d) {
+    double g = 0.0;
+    for (int64_t c = 0; c < d; ++c) g += a[c] * b[c];
+    return g;
+}
+
+/* SPEC S2: key (eps test + ordering), dist, gy for the pair (a,b) */
+static inline void pair_q(const double *a, const double *b, int64_t d, double na, double nb, int metric,
+                          double *key, double *dist, double *gy) {
+    if (metric == ASO_L2) {
+        double sq, g;
+        pair_l2(a, b, d, &sq, &g);
+        *key = sq;
+        *dist = sqrt(sq);
+        *gy = g;
+    } else {
+        double g = dotp(a, b, d);
+        double den = sqrt(na * nb);
+        double c = den > 0.0 ? g / den : 0.0;
+        double dd = 1.0 - (c > 0.0 ? c : 0.0);
+        *key = dd;
+        *dist = dd;
+        *gy = c;
+    }
+}
+
+typedef struct { double key; int64_t j; double dist, gy; } cand_t;
+
+static inline int cand_less(double ka, int64_t ja, double kb, int64_t jb) {
+    return ka < kb || (ka == kb && ja < jb);
+}
+
+/* keep the k smallest (key, j) in a sorted array */
+static inline void cand_insert(cand_t *lst, int64_t *cnt, int64_t k, cand_t c) {
+    int64_t m = *cnt;
+    if (m == k) {
+        if (!cand_less(c.key, c.j, lst[m - 1].key, lst[m - 1].j)) return;
+        m = k - 1;
+    }
+    int64_t pos = m;
+    while (pos > 0 && cand_less(c.key, c.j, lst[pos - 1].key, lst[pos - 1].j)) {
+        lst[pos] = lst[pos - 1];
+        --pos;
+    }
+    lst[pos] = c;
+    *cnt = m + 1;
+}
+
+static int cmp_i64(const void *a, const void *b) {
+    int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return (x > y) - (x < y);
+}
+static int cmp_f64(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+void aso_free(aso_index *ix) {
+    if (!ix) return;
+    free(ix->X); free(ix->nrm); free(ix->ny); free(ix->indptr); free(ix->indices);
+    free(ix->dist); free(ix->gy); free(ix->w); free(ix->lap); free(ix->deg);
+    free(ix->E); free(ix->G); free(ix->lam); free(ix->knn_idx); free(ix->knn_cnt);
+    free(ix);
+}
+
+/* ArrowSpaceBuilder.build restated (src/lib.rs:271-300 -> crate builder.build). */
+aso_index *aso_build(const double *X, int64_t n, int64_t d, double eps, int64_t k, double p, double sigma,
+                     int metric, int kernel) {
+    if (n <= 0 || d <= 0 || k <= 0) return NULL;
+    aso_index *ix = (aso_index *)calloc(1, sizeof(aso_index));
+    ix->n = n; ix->d = d; ix->eps = eps; ix->k = k; ix->p = p; ix->sigma = sigma;
+    ix->metric = metric; ix->kernel = kernel;
+    ix->X = (double *)malloc(sizeof(double) * n * d);
+    memcpy(ix->X, X, sizeof(double) * n * d);
+    ix->nrm = (double *)malloc(sizeof(double) * n);
+    ix->ny = (double *)malloc(sizeof(double) * n);
+    for (int64_t i = 0; i < n; ++i) {
+        ix->nrm[i] = dotp(X + i * d, X + i * d, d);
+        ix->ny[i] = metric == ASO_L2 ? ix->nrm[i] : (ix->nrm[i] > 0.0 ? 1.0 : 0.0);
+    }
+    const double epskey = metric == ASO_L2 ? eps * eps : eps;
+    /* S3 directed kNN lists */
+    cand_t *lists = (cand_t *)malloc(sizeof(cand_t) * n * k);
+    int64_t *cnt = (int64_t *)calloc(n, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; ++i) {
+        cand_t *lst = lists + i * k;
+        int64_t m = 0;
+        for (int64_t j = 0; j < n; ++j) {
+            if (j == i) continue;
+            cand_t c;
+            c.j = j;
+            pair_q(X + i * d, X + j * d, d, ix->nrm[i], ix->nrm[j], metric, &c.key, &c.dist, &c.gy);
+            if (c.key <= epskey) cand_insert(lst, &m, k, c);
+        }
+        cnt[i] = m;
+    }
+    ix->knn_idx = (int64_t *)malloc(sizeof(int64_t) * n * k);
+    ix->knn_cnt = cnt;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t t = 0; t < k; ++t) ix->knn_idx[i * k + t] = t < cnt[i] ? lists[i * k + t].j : -1;
+    /* S4 union symmetrisation: count reverse-only edges */
+    int64_t *rowlen = (int64_t *)calloc(n + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) rowlen[i] = cnt[i];
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t t = 0; t < cnt[i]; ++t) {
+            int64_t j = lists[i * k + t].j;
+            int found = 0;
+            for (int64_t s = 0; s < cnt[j]; ++s)
+                if (lists[j * k + s].j == i) { found = 1; break; }
+            if (!found) rowlen[j] += 1;
+        }
+    ix->indptr = (int64_t *)malloc(sizeof(int64_t) * (n + 1));
+    ix->indptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) ix->indptr[i + 1] = ix->indptr[i] + rowlen[i];
+    int64_t nnz = ix->indptr[n];
+    ix->indices = (int64_t *)malloc(sizeof(int64_t) * (nnz ? nnz : 1));
+    ix->dist = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+    ix->gy = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+    ix->w = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+    ix->lap = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * n);
+    for (int64_t i = 0; i < n; ++i) cur[i] = ix->indptr[i];
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t t = 0; t < cnt[i]; ++t) ix->indices[cur[i]++] = lists[i * k + t].j;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t t = 0; t < cnt[i]; ++t) {
+            int64_t j = lists[i * k + t].j;
+            int found = 0;
+            for (int64_t s = 0; s < cnt[j]; ++s)
+                if (lists[j * k + s].j == i) { found = 1; break; }
+            if (!found) ix->indices[cur[j]++] = i;
+        }
+    free(cur);
+    /* sort each row by column; recompute the symmetric per-edge payload */
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t lo = ix->indptr[i], hi = ix->indptr[i + 1];
+        qsort(ix->indices + lo, (size_t)(hi - lo), sizeof(int64_t), cmp_i64);
+        for (int64_t e = lo; e < hi; ++e) {
+            int64_t j = ix->indices[e];
+            double key;
+            /* evaluate the pair with the smaller index first so (i,j) and (j,i) are bit-identical */
+            int64_t a = i < j ? i : j, b = i < j ? j : i;
+            pair_q(X + a * d, X + b * d, d, ix->nrm[a], ix->nrm[b], metric, &key, &ix->dist[e], &ix->gy[e]);
+            ix->w[e] = edge_weight(ix->dist[e], sigma, p, kernel);
+        }
+    }
+    free(rowlen);
+    free(lists);
+    /* S5 degrees */
+    ix->deg = (double *)calloc(n, sizeof(double));
+    for (int64_t i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int64_t e = ix->indptr[i]; e < ix->indptr[i + 1]; ++e) s += ix->w[e];
+        ix->deg[i] = s;
+    }
+    /* S6/S7 energies */
+    ix->E = (double *)calloc(n, sizeof(double));
+    ix->G = (double *)calloc(n, sizeof(double));
+    ix->lam = (double *)calloc(n, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t lo = ix->indptr[i], hi = ix->indptr[i + 1];
+        if (hi == lo) continue;
+        double S = 0.0;
+        for (int64_t e = lo; e < hi; ++e) {
+            int64_t j = ix->indices[e];
+            double sdd = sqrt(ix->deg[i] * ix->deg[j]);
+            ix->lap[e] = -ix->w[e] / sdd;
+            double v = ix->w[e] * (ix->ny[i] / ix->deg[i] + ix->ny[j] / ix->deg[j] - 2.0 * ix->gy[e] / sdd);
+            S += v > 0.0 ? v : 0.0;
+        }
+        ix->E[i] = ix->ny[i] > 0.0 ? (0.5 * S) / ix->ny[i] : 0.0;
+        if (S > 0.0) {
+            double g = 0.0;
+            for (int64_t e = lo; e < hi; ++e) {
+                int64_t j = ix->indices[e];
+                double sdd = sqrt(ix->deg[i] * ix->deg[j]);
+                double v = ix->w[e] * (ix->ny[i] / ix->deg[i] + ix->ny[j] / ix->deg[j] - 2.0 * ix->gy[e] / sdd);
+                double r = (v > 0.0 ? v : 0.0) / S;
+                g += r * r;
+            }
+            ix->G[i] = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
+        }
+    }
+    /* S8 tau0 = lower median of positive energies, clamped */
+    double *pos = (double *)malloc(sizeof(double) * n);
+    int64_t np_ = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (ix->E[i] > 0.0) pos[np_++] = ix->E[i];
+    double tau0 = ASO_TAU_MIN;
+    if (np_ > 0) {
+        qsort(pos, (size_t)np_, sizeof(double), cmp_f64);
+        tau0 = pos[(np_ - 1) / 2];
+        if (tau0 < ASO_TAU_MIN) tau0 = ASO_TAU_MIN;
+        if (tau0 > 1.0) tau0 = 1.0;
+    }
+    free(pos);
+    ix->tau0 = tau0;
+    /* S9 */
+    for (int64_t i = 0; i < n; ++i)
+        ix->lam[i] = tau0 * (ix->E[i] / (ix->E[i] + tau0)) + (1.0 - tau0) * ix->G[i];
+    return ix;
+}
+
+/* SPEC S10: prepare_query_item (src/lib.rs:154) restated. */
+double aso_query_lambda(const aso_index *ix, const double *q) {
+    const int64_t n = ix->n, d = ix->d, k = ix->k;
+    const double nq = dotp(q, q, d);
+    const double epskey = ix->metric == ASO_L2 ? ix->eps * ix->eps : ix->eps;
+    int nth = 1;
+#ifdef _OPENMP
+    nth = omp_get_max_threads();
+#endif
+    cand_t *part = (cand_t *)malloc(sizeof(cand_t) * k * nth);
+    int64_t *pcnt = (int64_t *)calloc(nth, sizeof(int64_t));
+#pragma omp parallel
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        cand_t *lst = part + (int64_t)t * k;
+        int64_t m = 0;
+#pragma omp for schedule(static)
+        for (int64_t j = 0; j < n; ++j) {
+            cand_t c;
+            c.j = j;
+            pair_q(q, ix->X + j * d, d, nq, ix->nrm[j], ix->metric, &c.key, &c.dist, &c.gy);
+            if (c.key <= epskey) cand_insert(lst, &m, k, c);
+        }
+        pcnt[t] = m;
+    }
+    cand_t *lst = (cand_t *)malloc(sizeof(cand_t) * k);
+    int64_t m = 0;
+    for (int t = 0; t < nth; ++t)
+        for (int64_t s = 0; s < pcnt[t]; ++s) cand_insert(lst, &m, k, part[(int64_t)t * k + s]);
+    free(part);
+    free(pcnt);
+    double lam = 0.0;
+    if (m > 0) {
+        /* ascending-j order for every sum */
+        for (int64_t a = 1; a < m; ++a) {
+            cand_t c = lst[a];
+            int64_t b = a;
+            while (b > 0 && lst[b - 1].j > c.j) { lst[b] = lst[b - 1]; --b; }
+            lst[b] = c;
+        }
+        double degq = 0.0;
+        double *a = (double *)malloc(sizeof(double) * m);
+        for (int64_t t = 0; t < m; ++t) {
+            a[t] = edge_weight(lst[t].dist, ix->sigma, ix->p, ix->kernel);
+            degq += a[t];
+        }
+        const double nyq = ix->metric == ASO_L2 ? nq : (nq > 0.0 ? 1.0 : 0.0);
+        if (degq > 0.0 && nyq > 0.0) {
+            double *es = (double *)malloc(sizeof(double) * m);
+            double S = 0.0;
+            for (int64_t t = 0; t < m; ++t) {
+                int64_t j = lst[t].j;
+                double dj = ix->deg[j] + a[t];
+                double sdd = sqrt(degq * dj);
+                double v = a[t] * (nyq / degq + ix->ny[j] / dj - 2.0 * lst[t].gy / sdd);
+                es[t] = v > 0.0 ? v : 0.0;
+                S += es[t];
+            }
+            double Eq = 0.5 * S / nyq, Gq = 0.0;
+            if (S > 0.0) {
+                for (int64_t t = 0; t < m; ++t) { double r = es[t] / S; Gq += r * r; }
+                Gq = Gq < 0.0 ? 0.0 : (Gq > 1.0 ? 1.0 : Gq);
+            }
+            lam = ix->tau0 * (Eq / (Eq + ix->tau0)) + (1.0 - ix->tau0) * Gq;
+            free(es);
+        }
+        free(a);
+    }
+    free(lst);
+    return lam;
+}
+
+/* SPEC S11: search_lambda_aware (src/lib.rs:173, TAUMODE.md:33): full scan,
+ * order (score desc, index asc), first topk.  Returns number of hits written. */
+int64_t aso_search_with_lambda(const aso_index *ix, const double *q, double tau, double lambda_q, int64_t topk,
+                               int64_t *out_idx, double *out_score) {
+    const int64_t n = ix->n, d = ix->d;
+    const double nq = dotp(q, q, d);
+    if (topk > n) topk = n;
+    int nth = 1;
+#ifdef _OPENMP
+    nth = omp_get_max_threads();
+#endif
+    cand_t *part = (cand_t *)malloc(sizeof(cand_t) * topk * nth);
+    int64_t *pcnt = (int64_t *)calloc(nth, sizeof(int64_t));
+#pragma omp parallel
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        cand_t *lst = part + (int64_t)t * topk;
+        int64_t m = 0;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            double g = dotp(q, ix->X + i * d, d);
+            double den = sqrt(ix->nrm[i] * nq);
+            double c = den > 0.0 ? g / den : 0.0;
+            double s = tau * c + (1.0 - tau) / (1.0 + fabs(lambda_q - ix->lam[i]));
+            cand_t cd;
+            cd.key = -s; cd.j = i; cd.dist = s; cd.gy = 0.0;
+            cand_insert(lst, &m, topk, cd);
+        }
+        pcnt[t] = m;
+    }
+    cand_t *lst = (cand_t *)malloc(sizeof(cand_t) * topk);
+    int64_t m = 0;
+    for (int t = 0; t < nth; ++t)
+        for (int64_t s = 0; s < pcnt[t]; ++s) cand_insert(lst, &m, topk, part[(int64_t)t * topk + s]);
+    for (int64_t t = 0; t < m; ++t) { out_idx[t] = lst[t].j; out_score[t] = lst[t].dist; }
+    free(part); free(pcnt); free(lst);
+    return m;
+}
+
+/* ArrowSpace.search restated (src/lib.rs:132-174).  Returns hits written, or -1
+ * when lambda_q == 0 (the reference asserts, src/lib.rs:156-159). */
+int64_t aso_search(const aso_index *ix, const double *q, double tau, int64_t topk, int64_t *out_idx,
+                   double *out_score, double *out_lambda_q) {
+    double lq = aso_query_lambda(ix, q);
+    if (out_lambda_q) *out_lambda_q = lq;
+    if (lq == 0.0) return -1;
+    return aso_search_with_lambda(ix, q, tau, lq, topk, out_idx, out_score);
+}
+
+/* all N scores (for parity checks of the scorer itself) */
+void aso_scores(const aso_index *ix, const double *q, double tau, double lambda_q, double *out) {
+    const int64_t n = ix->n, d = ix->d;
+    const double nq = dotp(q, q, d);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double g = dotp(q, ix->X + i * d, d);
+        double den = sqrt(ix->nrm[i] * nq);
+        double c = den > 0.0 ? g / den : 0.0;
+        out[i] = tau * c + (1.0 - tau) / (1.0 + fabs(lambda_q - ix->lam[i]));
+    }
+}
+
+/* accessors for the ctypes wrapper */
+int64_t aso_n(const aso_index *ix) { return ix->n; }
+int64_t aso_d(const aso_index *ix) { return ix->d; }
+int64_t aso_nnz(const aso_index *ix) { return ix->indptr[ix->n]; }
+double aso_tau0(const aso_index *ix) { return ix->tau0; }
+const int64_t *aso_indptr(const aso_index *ix) { return ix->indptr; }
+const int64_t *aso_indices(const aso_index *ix) { return ix->indices; }
+const double *aso_dist(const aso_index *ix) { return ix->dist; }
+const double *aso_gy(const aso_index *ix) { return ix->gy; }
+const double *aso_w(const aso_index *ix) { return ix->w; }
+const double *aso_lap(const aso_index *ix) { return ix->lap; }
+const double *aso_deg(const aso_index *ix) { return ix->deg; }
+const double *aso_E(const aso_index *ix) { return ix->E; }
+const double *aso_G(const aso_index *ix) { return ix->G; }
+const double *aso_lambdas(const aso_index *ix) { return ix->lam; }
+const double *aso_norms(const aso_index *ix) { return ix->nrm; }
+const int64_t *aso_knn_idx(const aso_index *ix) { return ix->knn_idx; }
+const int64_t *aso_knn_cnt(const aso_index *ix) { return ix->knn_cnt; }
+int aso_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,134 @@
+"""ctypes wrapper over oracle/libarrowspace_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libarrowspace_oracle.so")
+_lib = None
+
+METRICS = {"l2": 0, "cosine": 1}
+KERNELS = {"gaussian": 0, "rational": 1}
+
+
+def build_lib(force: bool = False) -> str:
+    src = os.path.join(_HERE, "arrowspace_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_lib()
+        L = C.CDLL(_SO)
+        p64 = C.POINTER(C.c_double)
+        pi64 = C.POINTER(C.c_int64)
+        L.aso_build.restype = C.c_void_p
+        L.aso_build.argtypes = [p64, C.c_int64, C.c_int64, C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.aso_free.argtypes = [C.c_void_p]
+        L.aso_query_lambda.restype = C.c_double
+        L.aso_query_lambda.argtypes = [C.c_void_p, p64]
+        L.aso_search.restype = C.c_int64
+        L.aso_search.argtypes = [C.c_void_p, p64, C.c_double, C.c_int64, pi64, p64, p64]
+        L.aso_search_with_lambda.restype = C.c_int64
+        L.aso_search_with_lambda.argtypes = [C.c_void_p, p64, C.c_double, C.c_double, C.c_int64, pi64, p64]
+        L.aso_scores.argtypes = [C.c_void_p, p64, C.c_double, C.c_double, p64]
+        for name in ("aso_n", "aso_d", "aso_nnz"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.aso_tau0.restype = C.c_double
+        L.aso_tau0.argtypes = [C.c_void_p]
+        for name in ("aso_dist", "aso_gy", "aso_w", "aso_lap", "aso_deg", "aso_E", "aso_G", "aso_lambdas", "aso_norms"):
+            getattr(L, name).restype = p64
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("aso_indptr", "aso_indices", "aso_knn_idx", "aso_knn_cnt"):
+            getattr(L, name).restype = pi64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.aso_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class ZeroLambda(Exception):
+    pass
+
+
+class OracleIndex:
+    """fp64 CPU index built by the C restatement; mirrors oracle_np.build()'s dict."""
+
+    def __init__(self, X, graph_params: dict):
+        from .oracle_np import resolve_params
+
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2 or X.shape[0] == 0 or X.shape[1] == 0:
+            raise ValueError("items must be non-empty 2D array")
+        self.prm = resolve_params(graph_params)
+        self.X = X
+        L = lib()
+        self._h = L.aso_build(_p64(X), X.shape[0], X.shape[1], self.prm["eps"], self.prm["k"], self.prm["p"],
+                              self.prm["sigma"], self.prm["metric"], self.prm["kernel"])
+        if not self._h:
+            raise ValueError("aso_build failed")
+        n = X.shape[0]
+        nnz = L.aso_nnz(self._h)
+        k = self.prm["k"]
+
+        def arr(ptr, m, dt):
+            return np.ctypeslib.as_array(ptr, shape=(max(m, 1),))[:m].astype(dt, copy=True)
+
+        self.n = arr(L.aso_norms(self._h), n, np.float64)
+        self.indptr = arr(L.aso_indptr(self._h), n + 1, np.int64)
+        self.indices = arr(L.aso_indices(self._h), nnz, np.int64)
+        self.dist = arr(L.aso_dist(self._h), nnz, np.float64)
+        self.gy = arr(L.aso_gy(self._h), nnz, np.float64)
+        self.w = arr(L.aso_w(self._h), nnz, np.float64)
+        self.lap = arr(L.aso_lap(self._h), nnz, np.float64)
+        self.deg = arr(L.aso_deg(self._h), n, np.float64)
+        self.E = arr(L.aso_E(self._h), n, np.float64)
+        self.G = arr(L.aso_G(self._h), n, np.float64)
+        self.lambdas = arr(L.aso_lambdas(self._h), n, np.float64)
+        self.knn_idx = arr(L.aso_knn_idx(self._h), n * k, np.int64).reshape(n, k)
+        self.knn_cnt = arr(L.aso_knn_cnt(self._h), n, np.int64)
+        self.tau0 = L.aso_tau0(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().aso_free(self._h)
+            self._h = None
+
+    def query_lambda(self, q) -> float:
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        return lib().aso_query_lambda(self._h, _p64(q))
+
+    def scores(self, q, tau, lambda_q):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        out = np.empty(self.X.shape[0])
+        lib().aso_scores(self._h, _p64(q), tau, lambda_q, _p64(out))
+        return out
+
+    def search(self, q, tau, topk=None):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        if q.ndim != 1 or q.shape[0] != self.X.shape[1]:
+            raise ValueError(f"query length {q.shape[0]} must match nfeatures {self.X.shape[1]}")
+        topk = self.prm["topk"] if topk is None else topk
+        kk = min(topk, self.X.shape[0])
+        idx = np.empty(kk, dtype=np.int64)
+        sc = np.empty(kk)
+        lq = C.c_double(0.0)
+        m = lib().aso_search(self._h, _p64(q), tau, kk, idx.ctypes.data_as(C.POINTER(C.c_int64)), _p64(sc), C.byref(lq))
+        if m < 0:
+            raise ZeroLambda("The lambdas are zero, check the magnitude of items and eps.")
+        return [(int(idx[t]), float(sc[t])) for t in range(m)], lq.value

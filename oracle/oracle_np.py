@@ -1,0 +1,257 @@
+"""fp64 numpy restatement of the hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is the *checker*, never the product: only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import it.  The product path
+(pyarrowspace_amd) must never import anything under oracle/.
+
+PARITY STATUS: "parity unpinned" for graph topology and lambda values.  The
+reference (/root/reference, a PyO3 shim) forwards all arithmetic to the crates.io
+crate `arrowspace 0.18.0` (Cargo.toml:16, Cargo.lock:94-97), whose source is not
+in the tree and cannot be built here (no cargo/rustc).  What IS pinned by the
+reference and checked in tests/test_oracle_golden.py:
+  * README.md:37-48,56-62,69   3x3 toy, tau=1.0: three (index, score) pairs.
+  * tests/test_0.py:4-18,24,29-32   5x24 toy, tau=1.0 order [2,1,4].
+  * TAUMODE.md:33 + src/lib.rs:169-173   scorer form, result length == topk,
+    sorted by score descending, full scan.
+Everything else follows the written SPEC in DESIGN.md section 2, which restates
+BASELINE.json's north_star (L2 distance, Gaussian weights, normalised Laplacian,
+per-item spectral energy) and the documented variants of GRAPH_VARIABLES.md:7-10
+(rectified-cosine distance, rational kernel) and TAUMODE.md:8-27 (bounded energy
++ dispersion synthesis, synthesis=Median per
+tests/output/1760705545_v0_16/suggested_eps.md:3).
+
+Brute force, O(N^2 D): intended for N up to a few thousand.  The C twin
+(oracle/arrowspace_oracle.c) is the same algorithm with OpenMP for larger N.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TAU_MIN = 1e-12
+
+METRIC_L2 = 0
+METRIC_COSINE = 1
+KERNEL_GAUSSIAN = 0
+KERNEL_RATIONAL = 1
+
+
+def resolve_params(graph_params: dict) -> dict:
+    """src/helpers.rs:48-76: eps,k,topk,p required; sigma missing/None -> eps*0.5."""
+    out = {}
+    for key, typ in (("eps", float), ("k", int), ("topk", int), ("p", float)):
+        if key not in graph_params:
+            raise ValueError(f"graph_params['{key}'] is required")
+        out[key] = typ(graph_params[key])
+    sigma = graph_params.get("sigma", None)
+    out["sigma"] = float(sigma) if sigma is not None else out["eps"] * 0.5
+    metric = graph_params.get("metric", "l2")
+    kernel = graph_params.get("kernel", "gaussian")
+    out["metric"] = {"l2": METRIC_L2, "cosine": METRIC_COSINE}[metric] if isinstance(metric, str) else int(metric)
+    out["kernel"] = {"gaussian": KERNEL_GAUSSIAN, "rational": KERNEL_RATIONAL}[kernel] if isinstance(kernel, str) else int(kernel)
+    return out
+
+
+def _edge_weight(d, sigma, p, kernel):
+    """SPEC S4.  gaussian: exp(-0.5 (d/sigma)^p) (north_star); rational:
+    1/(1+(d/sigma)^p) (GRAPH_VARIABLES.md:9)."""
+    t = d / sigma
+    u = t * t if p == 2.0 else np.power(t, p)
+    if kernel == KERNEL_GAUSSIAN:
+        return np.exp(-0.5 * u)
+    return 1.0 / (1.0 + u)
+
+
+def pair_quantities(xi, X, ni, n, metric):
+    """SPEC S2 for one row xi against all rows of X.
+    Returns (key, dist, gy): key = quantity the eps test / ordering uses
+    (squared L2 distance, or cosine distance), dist = d_ij, gy = y_i.y_j."""
+    if metric == METRIC_L2:
+        diff = X - xi[None, :]
+        key = np.einsum("ij,ij->i", diff, diff)
+        dist = np.sqrt(key)
+        gy = X @ xi
+    else:
+        g = X @ xi
+        den = np.sqrt(ni * n)
+        c = np.where(den > 0, g / np.where(den > 0, den, 1.0), 0.0)
+        dist = 1.0 - np.maximum(0.0, c)
+        key = dist
+        gy = c
+    return key, dist, gy
+
+
+def _eps_key(eps, metric):
+    return eps * eps if metric == METRIC_L2 else eps
+
+
+def knn_lists(X, prm):
+    """SPEC S3: directed lists, j != i, key <= eps_key, order (key asc, j asc), cap k."""
+    N = X.shape[0]
+    n = np.einsum("ij,ij->i", X, X)
+    ek = _eps_key(prm["eps"], prm["metric"])
+    lists = []
+    for i in range(N):
+        key, dist, gy = pair_quantities(X[i], X, n[i], n, prm["metric"])
+        ok = key <= ek
+        ok[i] = False
+        idx = np.nonzero(ok)[0]
+        order = np.lexsort((idx, key[idx]))
+        idx = idx[order][: prm["k"]]
+        lists.append((idx, key[idx], dist[idx], gy[idx]))
+    return n, lists
+
+
+def build(X, graph_params: dict) -> dict:
+    """ArrowSpaceBuilder.build restated (src/lib.rs:271-300 -> crate build).
+    Returns dict with n, CSR adjacency (indptr, indices, dist, gy, w), deg,
+    Laplacian values, E, G, tau0, lambdas."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2 or X.shape[0] == 0 or X.shape[1] == 0:
+        raise ValueError("items must be non-empty 2D array")
+    prm = resolve_params(graph_params)
+    N = X.shape[0]
+    n, lists = knn_lists(X, prm)
+    # S4 symmetrise (union); per-edge payload is symmetric in (i,j)
+    adj = [dict() for _ in range(N)]
+    for i, (idx, key, dist, gy) in enumerate(lists):
+        for j, kk, dd, gg in zip(idx, key, dist, gy):
+            adj[i][int(j)] = (dd, gg)
+            if i not in adj[int(j)]:
+                adj[int(j)][i] = (dd, gg)
+    indptr = np.zeros(N + 1, dtype=np.int64)
+    cols, dists, gys = [], [], []
+    for i in range(N):
+        js = sorted(adj[i].keys())
+        indptr[i + 1] = indptr[i] + len(js)
+        cols.extend(js)
+        dists.extend(adj[i][j][0] for j in js)
+        gys.extend(adj[i][j][1] for j in js)
+    indices = np.asarray(cols, dtype=np.int64)
+    dist = np.asarray(dists, dtype=np.float64)
+    gy = np.asarray(gys, dtype=np.float64)
+    w = _edge_weight(dist, prm["sigma"], prm["p"], prm["kernel"]) if len(dist) else dist.copy()
+    # S5 degrees (ascending-j order)
+    deg = np.zeros(N)
+    for i in range(N):
+        s = 0.0
+        for e in range(indptr[i], indptr[i + 1]):
+            s += w[e]
+        deg[i] = s
+    ny = n if prm["metric"] == METRIC_L2 else np.where(n > 0, 1.0, 0.0)
+    # S6/S7 energies
+    E = np.zeros(N)
+    G = np.zeros(N)
+    lap = np.zeros_like(w)
+    for i in range(N):
+        lo, hi = indptr[i], indptr[i + 1]
+        if hi == lo:
+            continue
+        eps_e = np.zeros(hi - lo)
+        for t, e in enumerate(range(lo, hi)):
+            j = indices[e]
+            sdd = np.sqrt(deg[i] * deg[j])
+            lap[e] = -w[e] / sdd
+            v = w[e] * (ny[i] / deg[i] + ny[j] / deg[j] - 2.0 * gy[e] / sdd)
+            eps_e[t] = v if v > 0.0 else 0.0
+        S = 0.0
+        for v in eps_e:
+            S += v
+        E[i] = (0.5 * S) / ny[i] if ny[i] > 0 else 0.0
+        if S > 0:
+            g = 0.0
+            for v in eps_e:
+                r = v / S
+                g += r * r
+            G[i] = min(1.0, max(0.0, g))
+    tau0 = median_tau(E)
+    lam = synth_lambda(E, G, tau0)
+    return dict(prm=prm, X=X, n=n, ny=ny, indptr=indptr, indices=indices, dist=dist, gy=gy,
+                w=w, lap=lap, deg=deg, E=E, G=G, tau0=tau0, lambdas=lam,
+                knn=[l[0] for l in lists])
+
+
+def median_tau(E):
+    """SPEC S8: lower median of the strictly positive energies, clamped to [TAU_MIN, 1]."""
+    pos = np.sort(E[E > 0])
+    if len(pos) == 0:
+        return TAU_MIN
+    t = pos[(len(pos) - 1) // 2]
+    return float(min(1.0, max(TAU_MIN, t)))
+
+
+def synth_lambda(E, G, tau0):
+    """SPEC S9 (TAUMODE.md:8,18-27): lambda = tau0*E/(E+tau0) + (1-tau0)*G."""
+    return tau0 * (E / (E + tau0)) + (1.0 - tau0) * G
+
+
+def query_lambda(idx: dict, q) -> float:
+    """SPEC S10: prepare_query_item (src/lib.rs:154) restated: q appended as a node."""
+    prm = idx["prm"]
+    X, n = idx["X"], idx["n"]
+    q = np.asarray(q, dtype=np.float64)
+    nq = float(q @ q)
+    key, dist, gy = pair_quantities(q, X, nq, n, prm["metric"])
+    ok = key <= _eps_key(prm["eps"], prm["metric"])
+    cand = np.nonzero(ok)[0]
+    order = np.lexsort((cand, key[cand]))
+    cand = cand[order][: prm["k"]]
+    if len(cand) == 0:
+        return 0.0
+    cand = np.sort(cand)
+    a = _edge_weight(dist[cand], prm["sigma"], prm["p"], prm["kernel"])
+    degq = 0.0
+    for v in a:
+        degq += v
+    if not degq > 0.0:
+        return 0.0
+    nyq = nq if prm["metric"] == METRIC_L2 else (1.0 if nq > 0 else 0.0)
+    if not nyq > 0.0:
+        return 0.0
+    es = []
+    for t, j in enumerate(cand):
+        dj = idx["deg"][j] + a[t]
+        sdd = np.sqrt(degq * dj)
+        v = a[t] * (nyq / degq + idx["ny"][j] / dj - 2.0 * gy[j] / sdd)
+        es.append(v if v > 0 else 0.0)
+    S = 0.0
+    for v in es:
+        S += v
+    Eq = 0.5 * S / nyq
+    Gq = 0.0
+    if S > 0:
+        for v in es:
+            r = v / S
+            Gq += r * r
+        Gq = min(1.0, max(0.0, Gq))
+    tau0 = idx["tau0"]
+    return float(tau0 * (Eq / (Eq + tau0)) + (1.0 - tau0) * Gq)
+
+
+def scores(idx: dict, q, tau: float, lambda_q: float):
+    """SPEC S11 (TAUMODE.md:33): tau*cos + (1-tau)/(1+|lq-li|) for every item."""
+    X, n = idx["X"], idx["n"]
+    q = np.asarray(q, dtype=np.float64)
+    nq = float(q @ q)
+    den = np.sqrt(n * nq)
+    cos = np.where(den > 0, (X @ q) / np.where(den > 0, den, 1.0), 0.0)
+    return tau * cos + (1.0 - tau) / (1.0 + np.abs(lambda_q - idx["lambdas"]))
+
+
+def search(idx: dict, q, tau: float):
+    """ArrowSpace.search restated (src/lib.rs:132-174).  Returns (hits, lambda_q);
+    raises ZeroLambda when lambda_q == 0 (the reference asserts, src/lib.rs:156-159)."""
+    q = np.asarray(q, dtype=np.float64)
+    if q.ndim != 1 or q.shape[0] != idx["X"].shape[1]:
+        raise ValueError(f"query length {q.shape[0]} must match nfeatures {idx['X'].shape[1]}")
+    lq = query_lambda(idx, q)
+    if lq == 0.0:
+        raise ZeroLambda("The lambdas are zero, check the magnitude of items and eps.")
+    s = scores(idx, q, tau, lq)
+    N = len(s)
+    order = np.lexsort((np.arange(N), -s))
+    k = min(idx["prm"]["topk"], N)
+    return [(int(i), float(s[i])) for i in order[:k]], lq
+
+
+class ZeroLambda(Exception):
+    pass
