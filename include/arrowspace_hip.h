@@ -1,0 +1,191 @@
+/* arrowspace_hip.h -- C ABI of the MI355X-native hot path (gfx950).
+ *
+ * Drop-in boundary for the two calls the reference's PyO3 shim forwards to the
+ * `arrowspace` crate:
+ *     ArrowSpaceBuilder.build(graph_params, items)   /root/reference/src/lib.rs:271-300
+ *     ArrowSpace.search(item, gl, tau)               /root/reference/src/lib.rs:132-174
+ * plus the accessors the shim exposes (src/lib.rs:40-61, 78-124) and the debug
+ * switch (src/helpers.rs:12-21).  Plain pointers and sizes only; no torch / numpy
+ * types.  INTEGRATION.md shows the PyO3-side and ctypes-side bindings.
+ *
+ * Conventions
+ *   - every function that can fail returns an as_status; 0 == AS_OK;
+ *     as_last_error() returns a thread-local message for the last failure;
+ *   - outputs are caller-allocated; handles are opaque and immutable after build;
+ *   - AS_EINVAL maps to the shim's PyValueError, AS_EZEROLAMBDA to the
+ *     `assert_ne!(lambda_q, 0.0)` panic at src/lib.rs:156-159, AS_EHIP to a
+ *     runtime failure of the device / HIP runtime.
+ *   - "host" pointers are ordinary CPU memory, "dev" pointers are HIP device memory
+ *     on the device the handle lives on.
+ */
+#ifndef ARROWSPACE_HIP_H
+#define ARROWSPACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    AS_OK = 0,
+    AS_EINVAL = 1,       /* bad argument            -> ValueError   */
+    AS_EZEROLAMBDA = 2,  /* lambda_q == 0           -> PanicException (src/lib.rs:156-159) */
+    AS_EHIP = 3,         /* HIP runtime failure     -> RuntimeError */
+    AS_EUNSUPPORTED = 4, /* outside supported range -> ValueError   */
+    AS_ENOMEM = 5
+} as_status;
+
+/* graph_params dict of the reference (src/helpers.rs:48-76).  has_sigma == 0
+ * reproduces "sigma missing or None -> eps * 0.5" (src/helpers.rs:68-72). */
+typedef struct {
+    double eps;
+    int64_t k;
+    int64_t topk;
+    double p;
+    double sigma;
+    int32_t has_sigma;
+    int32_t _pad;
+} as_graph_params;
+
+enum { AS_METRIC_L2 = 0, AS_METRIC_COSINE = 1 };
+enum { AS_KERNEL_GAUSSIAN = 0, AS_KERNEL_RATIONAL = 1 };
+enum { AS_KEEP_F64_AUTO = 0, AS_KEEP_F64_ALWAYS = 1 };
+enum { AS_DTYPE_F32 = 0, AS_DTYPE_F64 = 1 };
+
+/* Options that have no counterpart in the reference's dict; zero-initialised ==
+ * north_star defaults (L2 distance, Gaussian weights, current device). */
+typedef struct {
+    int32_t metric;   /* AS_METRIC_*  (cosine = GRAPH_VARIABLES.md:7 variant) */
+    int32_t kernel;   /* AS_KERNEL_*  (rational = GRAPH_VARIABLES.md:9 variant) */
+    int32_t device;   /* HIP device ordinal; -1 = current device */
+    int32_t keep_f64; /* AS_KEEP_F64_*: AUTO keeps an fp64 copy of the items only when
+                         they are not exactly representable in fp32 */
+    int32_t force_exact; /* 1: skip the fp32 fast paths (fp64 everywhere; for tests) */
+    int32_t reserved[3];
+} as_opts;
+
+typedef struct as_space as_space; /* crate `ArrowSpace`      (src/lib.rs:64-67)  */
+typedef struct as_graph as_graph; /* crate `GraphLaplacian`  (src/lib.rs:26-29)  */
+typedef struct as_query as_query; /* per-search device workspace (no reference counterpart) */
+
+/* ---- index build: replaces RustBuilder::...build(rows), src/lib.rs:278-289 ---- */
+
+/* items: host fp64, element strides (numpy `as_array()` accepts any strides,
+ * src/helpers.rs:25).  n == 0 or d == 0 -> AS_EINVAL (src/helpers.rs:27-29). */
+as_status as_build(const double* items, int64_t n, int64_t d, int64_t row_stride, int64_t col_stride,
+                   const as_graph_params* gp, const as_opts* opts, as_space** out_space, as_graph** out_graph);
+
+/* Same, items already resident in HBM (row-major, leading dimension ld elements). */
+as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld,
+                       const as_graph_params* gp, const as_opts* opts, as_space** out_space, as_graph** out_graph);
+
+/* ---- staged build: the three steps as_build composes; multi-GPU hosts call them
+ *      with a row range per rank and all-gather the lists in between ---- */
+
+/* step 1: ingest items into the HBM layout (fp32 padded tile layout + norms). */
+as_status as_space_create_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld,
+                              const as_opts* opts, as_space** out_space);
+/* step 2: exact directed k-NN lists for rows [row_begin, row_end) against all n items.
+ * Outputs (device, caller-allocated, (row_end-row_begin) x k, row-major):
+ *   out_idx int32 (-1 padded), out_key / out_dist / out_gy fp64, out_cnt int32 per row. */
+as_status as_knn_rows(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                      int32_t* out_idx_dev, double* out_key_dev, double* out_dist_dev, double* out_gy_dev,
+                      int32_t* out_cnt_dev);
+/* step 3: symmetrise + normalised Laplacian + per-item energy + lambdas from the
+ * complete n x k lists (device).  Writes lambdas into the space. */
+as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx_dev,
+                            const double* dist_dev, const double* gy_dev, const int32_t* cnt_dev,
+                            as_graph** out_graph);
+
+/* ---- search: replaces prepare_query_item + search_lambda_aware, src/lib.rs:154,173 ---- */
+
+/* query: host fp64, contiguous, length d (d != nfeatures -> AS_EINVAL,
+ * src/lib.rs:140-146).  out_idx/out_score: capacity >= min(topk, nitems).
+ * lambda_q == 0 -> AS_EZEROLAMBDA.  Results: score desc, index asc. */
+as_status as_search(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
+                    int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
+
+/* B queries, row-major [b][d]; outputs [b][topk]; status per query in out_status
+ * (AS_OK / AS_EZEROLAMBDA).  Extension. */
+as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* queries, int64_t b, int64_t d,
+                          double tau, int64_t* out_idx, double* out_score, int64_t* out_len,
+                          double* out_lambda_q, int32_t* out_status);
+
+/* ---- staged search (row-sharded multi-GPU; as_search composes these on one GPU) ---- */
+
+/* fixed-size device records exchanged between ranks */
+typedef struct {
+    int64_t idx;  /* global item index, -1 = empty slot */
+    double key;   /* eps-test / ordering key: squared L2 distance or cosine distance */
+    double dist;  /* d(q, x_idx) */
+    double gy;    /* y_q . y_idx */
+    double deg;   /* degree of item idx in the index graph */
+    double ny;    /* |y_idx|^2 */
+} as_knn_rec;
+
+typedef struct {
+    int64_t idx; /* global item index, -1 = empty slot */
+    double score;
+} as_hit_rec;
+
+as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out);
+void as_query_free(as_query* q);
+/* rows [row_begin,row_end) are this rank's shard; row_offset maps local rows of a
+ * shard-only space to global indices (0 when the space holds all items). */
+as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end);
+/* k records: this shard's exact nearest items to the query (device pointer) */
+const as_knn_rec* as_query_knn_records(const as_query* q);
+int64_t as_query_knn_capacity(const as_query* q);
+/* lambda_q from m records (own, or all-gathered from every rank) */
+as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m);
+/* local scoring of the scanned rows; topk records */
+as_status as_query_score(as_query* q, double tau);
+const as_hit_rec* as_query_hit_records(const as_query* q);
+int64_t as_query_hit_capacity(const as_query* q);
+/* merge m hit records (own or all-gathered), copy to host; synchronises. */
+as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, int64_t* out_idx,
+                          double* out_score, int64_t* out_len, double* out_lambda_q);
+/* 1: run the following scans in fp64 end to end (the fallback as_search takes when the
+ * fp32 candidate lists are not provably exact); flags of the last finished search */
+void as_query_set_exact(as_query* q, int32_t exact);
+as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact);
+/* HIP stream (hipStream_t) the query's kernels run on, for event timing / ordering */
+void* as_query_stream(const as_query* q);
+
+/* ---- accessors: src/lib.rs:40-61 (GraphLaplacian), 78-124 (ArrowSpace) ---- */
+int64_t as_nitems(const as_space* sp);
+int64_t as_nfeatures(const as_space* sp);
+as_status as_get_item(const as_space* sp, int64_t idx, double* out_vec, double* out_lambda);
+as_status as_lambdas(const as_space* sp, double* out);
+int64_t as_nnodes(const as_graph* gr);
+as_status as_get_graph_params(const as_graph* gr, as_graph_params* out); /* sigma resolved */
+int64_t as_graph_nnz(const as_graph* gr); /* stored Laplacian entries incl. diagonal */
+/* CSR of the normalised Laplacian: indptr int64[n+1], indices int64[nnz], values fp64[nnz] */
+as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, double* values);
+as_status as_graph_degrees(const as_graph* gr, double* out);
+double as_graph_tau0(const as_graph* gr);
+/* device pointer to the fp64 lambdas (n) -- for multi-GPU hosts */
+const double* as_lambdas_dev(const as_space* sp);
+
+/* per-stage seconds of the last build, and kernel-only seconds of the X.X^T block:
+ * out[0]=ingest out[1]=knn_mfma out[2]=refine out[3]=fallback_exact out[4]=graph
+ * out[5]=total out[6]=fallback_rows out[7]=mfma_flops_issued */
+as_status as_build_stats(const as_graph* gr, double* out, int32_t n);
+/* per-stage device microseconds of the last search on q (HIP events):
+ * out[0]=scan out[1]=rest out[2]=exact_fallback_used */
+as_status as_query_stats(const as_query* q, double* out, int32_t n);
+
+void as_free_space(as_space* sp);
+void as_free_graph(as_graph* gr);
+
+/* ---- misc ---- */
+void as_set_debug(int32_t enabled); /* src/helpers.rs:12-14; messages "[pyarrowspace] ..." on stderr */
+const char* as_last_error(void);
+int32_t as_device_count(void);
+const char* as_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARROWSPACE_HIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libarrowspace_hip.so (C ABI: include/arrowspace_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be
+loaded this module raises ImportError, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarrowspace_hip.so")
+
+AS_OK, AS_EINVAL, AS_EZEROLAMBDA, AS_EHIP, AS_EUNSUPPORTED, AS_ENOMEM = range(6)
+METRICS = {"l2": 0, "cosine": 1}
+KERNELS = {"gaussian": 0, "rational": 1}
+DTYPE_F32, DTYPE_F64 = 0, 1
+
+
+class GraphParams(C.Structure):
+    _fields_ = [("eps", C.c_double), ("k", C.c_int64), ("topk", C.c_int64), ("p", C.c_double),
+                ("sigma", C.c_double), ("has_sigma", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("metric", C.c_int32), ("kernel", C.c_int32), ("device", C.c_int32), ("keep_f64", C.c_int32),
+                ("force_exact", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class KnnRec(C.Structure):
+    _fields_ = [("idx", C.c_int64), ("key", C.c_double), ("dist", C.c_double), ("gy", C.c_double),
+                ("deg", C.c_double), ("ny", C.c_double)]
+
+
+class HitRec(C.Structure):
+    _fields_ = [("idx", C.c_int64), ("score", C.c_double)]
+
+
+# every symbol include/arrowspace_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "as_build", "as_build_dev", "as_space_create_dev", "as_knn_rows", "as_graph_from_knn", "as_search",
+    "as_search_batch", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
+    "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
+    "as_query_finish", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_nitems", "as_nfeatures",
+    "as_get_item", "as_lambdas", "as_nnodes", "as_get_graph_params", "as_graph_nnz", "as_graph_csr",
+    "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_free_space",
+    "as_free_graph", "as_set_debug", "as_last_error", "as_device_count", "as_version",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950). "
+            "pyarrowspace_amd has no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ImportError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i64, i32, f64 = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    pvp = C.POINTER(C.c_void_p)
+    pgp, pop = C.POINTER(GraphParams), C.POINTER(Opts)
+    sig = {
+        "as_build": (i32, [vp, i64, i64, i64, i64, pgp, pop, pvp, pvp]),
+        "as_build_dev": (i32, [vp, i32, i64, i64, i64, pgp, pop, pvp, pvp]),
+        "as_space_create_dev": (i32, [vp, i32, i64, i64, i64, pop, pvp]),
+        "as_knn_rows": (i32, [vp, pgp, i64, i64, vp, vp, vp, vp, vp]),
+        "as_graph_from_knn": (i32, [vp, pgp, vp, vp, vp, vp, pvp]),
+        "as_search": (i32, [vp, vp, vp, i64, f64, vp, vp, C.POINTER(i64), C.POINTER(f64)]),
+        "as_search_batch": (i32, [vp, vp, vp, i64, i64, f64, vp, vp, vp, vp, vp]),
+        "as_query_create": (i32, [vp, vp, pvp]),
+        "as_query_free": (None, [vp]),
+        "as_query_scan": (i32, [vp, vp, i64, i64, i64]),
+        "as_query_knn_records": (vp, [vp]),
+        "as_query_knn_capacity": (i64, [vp]),
+        "as_query_lambda": (i32, [vp, vp, i64]),
+        "as_query_score": (i32, [vp, f64]),
+        "as_query_hit_records": (vp, [vp]),
+        "as_query_hit_capacity": (i64, [vp]),
+        "as_query_finish": (i32, [vp, vp, i64, vp, vp, C.POINTER(i64), C.POINTER(f64)]),
+        "as_query_set_exact": (None, [vp, i32]),
+        "as_query_flags": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "as_query_stream": (vp, [vp]),
+        "as_nitems": (i64, [vp]),
+        "as_nfeatures": (i64, [vp]),
+        "as_get_item": (i32, [vp, i64, vp, C.POINTER(f64)]),
+        "as_lambdas": (i32, [vp, vp]),
+        "as_nnodes": (i64, [vp]),
+        "as_get_graph_params": (i32, [vp, pgp]),
+        "as_graph_nnz": (i64, [vp]),
+        "as_graph_csr": (i32, [vp, vp, vp, vp]),
+        "as_graph_degrees": (i32, [vp, vp]),
+        "as_graph_tau0": (f64, [vp]),
+        "as_lambdas_dev": (vp, [vp]),
+        "as_build_stats": (i32, [vp, vp, i32]),
+        "as_query_stats": (i32, [vp, vp, i32]),
+        "as_free_space": (None, [vp]),
+        "as_free_graph": (None, [vp]),
+        "as_set_debug": (None, [i32]),
+        "as_last_error": (C.c_char_p, []),
+        "as_device_count": (i32, []),
+        "as_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().as_last_error().decode("utf-8", "replace")

@@ -1,0 +1,442 @@
+// C ABI glue (include/arrowspace_hip.h): argument validation with the reference shim's
+// error behaviour (/root/reference/src/helpers.rs:24-76, src/lib.rs:100-120,140-159),
+// handle lifetime, and the composition of the staged build / search entry points.
+#include <atomic>
+#include <chrono>
+#include <vector>
+
+#include "as_common.hpp"
+
+namespace as {
+
+static std::atomic<int> g_debug{0};
+
+std::string& err_slot() {
+    static thread_local std::string s;
+    return s;
+}
+void set_err(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err_slot() = buf;
+}
+bool debug_enabled() { return g_debug.load(std::memory_order_relaxed) != 0; }
+void dbg(const char* fmt, ...) {
+    if (!debug_enabled()) return;
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[pyarrowspace] %s\n", buf);  // src/helpers.rs:18-20
+}
+
+static inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+as_status resolve_params(const as_graph_params* gp, as_graph_params* out) {
+    if (!gp) {
+        set_err("graph_params is required");
+        return AS_EINVAL;
+    }
+    *out = *gp;
+    if (!gp->has_sigma) out->sigma = gp->eps * 0.5;  // src/helpers.rs:68-72
+    out->has_sigma = 1;
+    if (!(out->eps > 0.0) || !(out->sigma > 0.0) || !(out->p > 0.0)) {
+        set_err("graph_params: eps, sigma and p must be positive (eps=%g sigma=%g p=%g)", out->eps, out->sigma, out->p);
+        return AS_EINVAL;
+    }
+    if (out->k < 1 || out->topk < 1) {
+        set_err("graph_params: k and topk must be >= 1 (k=%lld topk=%lld)", (long long)out->k, (long long)out->topk);
+        return AS_EINVAL;
+    }
+    return AS_OK;
+}
+
+static as_status pick_device(const as_opts* opts, int* dev) {
+    int d = opts ? opts->device : -1;
+    if (d < 0) AS_HIP(hipGetDevice(&d));
+    AS_HIP(hipSetDevice(d));
+    *dev = d;
+    return AS_OK;
+}
+
+}  // namespace as
+
+using namespace as;
+
+extern "C" {
+
+void as_set_debug(int32_t enabled) { g_debug.store(enabled ? 1 : 0, std::memory_order_relaxed); }
+const char* as_last_error(void) { return err_slot().c_str(); }
+const char* as_version(void) { return "arrowspace-hip 0.1.0 (gfx950)"; }
+int32_t as_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void as_free_space(as_space* sp) {
+    if (!sp) return;
+    hipSetDevice(sp->device);
+    if (sp->qcache) as_query_free(sp->qcache);
+    if (sp->stream) hipStreamSynchronize(sp->stream);
+    hipFree(sp->x32); hipFree(sp->x64); hipFree(sp->n64); hipFree(sp->n32); hipFree(sp->inorm32);
+    hipFree(sp->lam64); hipFree(sp->lam32);
+    if (sp->stream) hipStreamDestroy(sp->stream);
+    delete sp;
+}
+
+void as_free_graph(as_graph* gr) {
+    if (!gr) return;
+    hipSetDevice(gr->device);
+    hipFree(gr->indptr); hipFree(gr->indices); hipFree(gr->dist); hipFree(gr->gy); hipFree(gr->w); hipFree(gr->lap);
+    hipFree(gr->deg); hipFree(gr->ny); hipFree(gr->E); hipFree(gr->G);
+    delete gr;
+}
+
+as_status as_space_create_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_opts* opts,
+                              as_space** out_space) {
+    if (!out_space) {
+        set_err("as_space_create_dev: null output");
+        return AS_EINVAL;
+    }
+    *out_space = nullptr;
+    if (!items_dev || n <= 0 || d <= 0) {
+        set_err("items must be non-empty 2D array");  // src/helpers.rs:27-29
+        return AS_EINVAL;
+    }
+    if (ld < d || (dtype != AS_DTYPE_F32 && dtype != AS_DTYPE_F64)) {
+        set_err("as_space_create_dev: bad leading dimension or dtype");
+        return AS_EINVAL;
+    }
+    if (n >= (int64_t)1 << 31) {
+        set_err("as_space_create_dev: n=%lld does not fit 32-bit item indices on one device", (long long)n);
+        return AS_EUNSUPPORTED;
+    }
+    int dev = 0;
+    AS_TRY(pick_device(opts, &dev));
+    as_space* sp = new as_space();
+    sp->device = dev;
+    sp->n = n;
+    sp->d = d;
+    if (opts) sp->opts = *opts;
+    sp->opts.device = dev;
+    if (sp->opts.metric != AS_METRIC_L2 && sp->opts.metric != AS_METRIC_COSINE) {
+        set_err("unknown metric %d", sp->opts.metric);
+        delete sp;
+        return AS_EINVAL;
+    }
+    if (sp->opts.kernel != AS_KERNEL_GAUSSIAN && sp->opts.kernel != AS_KERNEL_RATIONAL) {
+        set_err("unknown kernel %d", sp->opts.kernel);
+        delete sp;
+        return AS_EINVAL;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete sp;
+        return AS_EHIP;
+    }
+    as_status s = ingest(sp, items_dev, dtype, ld);
+    if (s != AS_OK) {
+        as_free_space(sp);
+        return s;
+    }
+    *out_space = sp;
+    return AS_OK;
+}
+
+as_status as_knn_rows(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t* out_idx_dev,
+                      double* out_key_dev, double* out_dist_dev, double* out_gy_dev, int32_t* out_cnt_dev) {
+    if (!sp || !out_idx_dev || !out_key_dev || !out_dist_dev || !out_gy_dev || !out_cnt_dev) {
+        set_err("as_knn_rows: null argument");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    return knn_rows(sp, &r, row_begin, row_end, out_idx_dev, out_key_dev, out_dist_dev, out_gy_dev, out_cnt_dev, nullptr);
+}
+
+as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx_dev, const double* dist_dev,
+                            const double* gy_dev, const int32_t* cnt_dev, as_graph** out_graph) {
+    if (!sp || !idx_dev || !dist_dev || !gy_dev || !cnt_dev || !out_graph) {
+        set_err("as_graph_from_knn: null argument");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    as_graph* gr = new as_graph();
+    as_status s = graph_from_knn(sp, &r, idx_dev, dist_dev, gy_dev, cnt_dev, gr);
+    if (s != AS_OK) {
+        as_free_graph(gr);
+        return s;
+    }
+    *out_graph = gr;
+    return AS_OK;
+}
+
+as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_graph_params* gp,
+                       const as_opts* opts, as_space** out_space, as_graph** out_graph) {
+    if (!out_space || !out_graph) {
+        set_err("as_build: null output");
+        return AS_EINVAL;
+    }
+    *out_space = nullptr;
+    *out_graph = nullptr;
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    const double t0 = now_s();
+    as_space* sp = nullptr;
+    AS_TRY(as_space_create_dev(items_dev, dtype, n, d, ld, opts, &sp));
+    const double t1 = now_s();
+    int32_t *idx = nullptr, *cnt = nullptr;
+    double *key = nullptr, *dist = nullptr, *gy = nullptr;
+    as_graph* gr = new as_graph();
+    as_status s = AS_OK;
+    do {
+        hipError_t e;
+        if ((e = hipMalloc(&idx, sizeof(int32_t) * n * r.k)) != hipSuccess || (e = hipMalloc(&cnt, sizeof(int32_t) * n)) != hipSuccess ||
+            (e = hipMalloc(&key, sizeof(double) * n * r.k)) != hipSuccess || (e = hipMalloc(&dist, sizeof(double) * n * r.k)) != hipSuccess ||
+            (e = hipMalloc(&gy, sizeof(double) * n * r.k)) != hipSuccess) {
+            set_err("hipMalloc of the k-NN lists failed: %s", hipGetErrorString(e));
+            s = AS_ENOMEM;
+            break;
+        }
+        s = knn_rows(sp, &r, 0, n, idx, key, dist, gy, cnt, gr->stats);
+        if (s != AS_OK) break;
+        const double t2 = now_s();
+        s = graph_from_knn(sp, &r, idx, dist, gy, cnt, gr);
+        if (s != AS_OK) break;
+        const double t3 = now_s();
+        gr->stats[0] = t1 - t0;
+        gr->stats[4] = t3 - t2;
+        gr->stats[5] = t3 - t0;
+    } while (0);
+    hipFree(idx); hipFree(cnt); hipFree(key); hipFree(dist); hipFree(gy);
+    if (s != AS_OK) {
+        as_free_graph(gr);
+        as_free_space(sp);
+        return s;
+    }
+    dbg("built ArrowSpace: nitems=%lld, nfeatures=%lld, lambdas_len=%lld", (long long)n, (long long)d, (long long)n);
+    *out_space = sp;
+    *out_graph = gr;
+    return AS_OK;
+}
+
+as_status as_build(const double* items, int64_t n, int64_t d, int64_t row_stride, int64_t col_stride, const as_graph_params* gp,
+                   const as_opts* opts, as_space** out_space, as_graph** out_graph) {
+    if (!out_space || !out_graph) {
+        set_err("as_build: null output");
+        return AS_EINVAL;
+    }
+    *out_space = nullptr;
+    *out_graph = nullptr;
+    if (!items || n <= 0 || d <= 0) {
+        set_err("items must be non-empty 2D array");  // src/helpers.rs:27-29
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    int dev = 0;
+    AS_TRY(pick_device(opts, &dev));
+    dbg("items shape: (%lld, %lld)", (long long)n, (long long)d);  // src/helpers.rs:31
+    double* staging = nullptr;
+    AS_HIP(hipMalloc(&staging, sizeof(double) * n * d));
+    hipError_t e = hipSuccess;
+    if (col_stride == 1 && row_stride >= d) {
+        e = hipMemcpy2D(staging, sizeof(double) * d, items, sizeof(double) * row_stride, sizeof(double) * d, n, hipMemcpyHostToDevice);
+    } else {
+        // arbitrary numpy strides (src/helpers.rs:25 `as_array()` accepts them): repack on the host
+        std::vector<double> tmp((size_t)n * d);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t c = 0; c < d; ++c) tmp[(size_t)i * d + c] = items[i * row_stride + c * col_stride];
+        e = hipMemcpy(staging, tmp.data(), sizeof(double) * n * d, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        set_err("upload of items failed: %s", hipGetErrorString(e));
+        hipFree(staging);
+        return AS_EHIP;
+    }
+    as_opts o{};
+    if (opts) o = *opts;
+    o.device = dev;
+    as_status s = as_build_dev(staging, AS_DTYPE_F64, n, d, d, &r, &o, out_space, out_graph);
+    hipFree(staging);
+    return s;
+}
+
+// ---------------------------------------------------------------- search
+static as_status get_cached_query(const as_space* sp, const as_graph* gr, as_query** out) {
+    if (sp->qcache && sp->qcache_gr != gr) {
+        as_query_free(sp->qcache);
+        sp->qcache = nullptr;
+    }
+    if (!sp->qcache) {
+        AS_TRY(as_query_create(sp, gr, &sp->qcache));
+        sp->qcache_gr = gr;
+    }
+    *out = sp->qcache;
+    return AS_OK;
+}
+
+as_status as_search(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau, int64_t* out_idx,
+                    double* out_score, int64_t* out_len, double* out_lambda_q) {
+    if (!sp || !gr || !query || !out_idx || !out_score) {
+        set_err("as_search: null argument");
+        return AS_EINVAL;
+    }
+    if (d != sp->d) {  // src/lib.rs:140-146
+        set_err("query length %lld must match nfeatures %lld", (long long)d, (long long)sp->d);
+        return AS_EINVAL;
+    }
+    if (gr->n != sp->n) {
+        set_err("as_search: graph has %lld nodes but the space has %lld items", (long long)gr->n, (long long)sp->n);
+        return AS_EINVAL;
+    }
+    std::lock_guard<std::mutex> lock(sp->qmu);
+    AS_HIP(hipSetDevice(sp->device));
+    as_query* q = nullptr;
+    AS_TRY(get_cached_query(sp, gr, &q));
+    as_status s = search_once(q, query, d, tau, 0, out_idx, out_score, out_len, out_lambda_q);
+    int ki = 0, si = 0;
+    query_flags(q, &ki, &si);
+    if ((s == AS_OK || s == AS_EZEROLAMBDA) && (ki || si) && !sp->opts.force_exact) {
+        dbg("search: fp32 candidate list not provably exact (knn=%d score=%d), rerunning in fp64", ki, si);
+        s = search_once(q, query, d, tau, 1, out_idx, out_score, out_len, out_lambda_q);
+    }
+    if (s == AS_OK && out_lambda_q) dbg("search: qlen=%lld, lambda_q=%.6f", (long long)d, *out_lambda_q);  // src/lib.rs:161-165
+    return s;
+}
+
+as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* queries, int64_t b, int64_t d, double tau,
+                          int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q, int32_t* out_status) {
+    if (!sp || !gr || !queries || !out_idx || !out_score || !out_len) {
+        set_err("as_search_batch: null argument");
+        return AS_EINVAL;
+    }
+    const int64_t topk = std::min<int64_t>(gr->gp.topk, sp->n);
+    for (int64_t i = 0; i < b; ++i) {
+        double lq = 0.0;
+        as_status s = as_search(sp, gr, queries + i * d, d, tau, out_idx + i * topk, out_score + i * topk, out_len + i, &lq);
+        if (out_lambda_q) out_lambda_q[i] = lq;
+        if (out_status) out_status[i] = (int32_t)s;
+        if (s != AS_OK && s != AS_EZEROLAMBDA) return s;
+    }
+    return AS_OK;
+}
+
+// ---------------------------------------------------------------- accessors
+int64_t as_nitems(const as_space* sp) { return sp ? sp->n : 0; }
+int64_t as_nfeatures(const as_space* sp) { return sp ? sp->d : 0; }
+int64_t as_nnodes(const as_graph* gr) { return gr ? gr->n : 0; }
+int64_t as_graph_nnz(const as_graph* gr) { return gr ? gr->nnz + gr->n : 0; }
+double as_graph_tau0(const as_graph* gr) { return gr ? gr->tau0 : 0.0; }
+const double* as_lambdas_dev(const as_space* sp) { return sp ? sp->lam64 : nullptr; }
+
+as_status as_get_item(const as_space* sp, int64_t idx, double* out_vec, double* out_lambda) {
+    if (!sp || !out_vec) {
+        set_err("as_get_item: null argument");
+        return AS_EINVAL;
+    }
+    if (idx < 0 || idx >= sp->n) {  // src/lib.rs:101-107
+        set_err("index %lld out of range [0, %lld)", (long long)idx, (long long)sp->n);
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    if (sp->x64) {
+        AS_HIP(hipMemcpy(out_vec, sp->x64 + idx * sp->d, sizeof(double) * sp->d, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(sp->d);
+        AS_HIP(hipMemcpy(tmp.data(), sp->x32 + idx * sp->dp, sizeof(float) * sp->d, hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < sp->d; ++c) out_vec[c] = (double)tmp[c];
+    }
+    if (out_lambda) AS_HIP(hipMemcpy(out_lambda, sp->lam64 + idx, sizeof(double), hipMemcpyDeviceToHost));
+    return AS_OK;
+}
+
+as_status as_lambdas(const as_space* sp, double* out) {
+    if (!sp || !out) {
+        set_err("as_lambdas: null argument");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    AS_HIP(hipMemcpy(out, sp->lam64, sizeof(double) * sp->n, hipMemcpyDeviceToHost));
+    return AS_OK;
+}
+
+as_status as_get_graph_params(const as_graph* gr, as_graph_params* out) {
+    if (!gr || !out) {
+        set_err("as_get_graph_params: null argument");
+        return AS_EINVAL;
+    }
+    *out = gr->gp;
+    return AS_OK;
+}
+
+as_status as_graph_degrees(const as_graph* gr, double* out) {
+    if (!gr || !out) {
+        set_err("as_graph_degrees: null argument");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(gr->device));
+    AS_HIP(hipMemcpy(out, gr->deg, sizeof(double) * gr->n, hipMemcpyDeviceToHost));
+    return AS_OK;
+}
+
+as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, double* values) {
+    if (!gr || !indptr || !indices || !values) {
+        set_err("as_graph_csr: null argument");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(gr->device));
+    const int64_t n = gr->n, nnz = gr->nnz;
+    std::vector<int64_t> ip(n + 1);
+    std::vector<int32_t> col(std::max<int64_t>(nnz, 1));
+    std::vector<double> lap(std::max<int64_t>(nnz, 1)), deg(n);
+    AS_HIP(hipMemcpy(ip.data(), gr->indptr, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost));
+    if (nnz) {
+        AS_HIP(hipMemcpy(col.data(), gr->indices, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+        AS_HIP(hipMemcpy(lap.data(), gr->lap, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+    }
+    AS_HIP(hipMemcpy(deg.data(), gr->deg, sizeof(double) * n, hipMemcpyDeviceToHost));
+    // insert the diagonal (1 for connected nodes, 0 for isolated ones) keeping columns ascending
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        indptr[i] = w;
+        bool placed = false;
+        for (int64_t e = ip[i]; e < ip[i + 1]; ++e) {
+            if (!placed && col[e] > i) {
+                indices[w] = i;
+                values[w++] = deg[i] > 0.0 ? 1.0 : 0.0;
+                placed = true;
+            }
+            indices[w] = col[e];
+            values[w++] = lap[e];
+        }
+        if (!placed) {
+            indices[w] = i;
+            values[w++] = deg[i] > 0.0 ? 1.0 : 0.0;
+        }
+    }
+    indptr[n] = w;
+    return AS_OK;
+}
+
+as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {
+    if (!gr || !out) {
+        set_err("as_build_stats: null argument");
+        return AS_EINVAL;
+    }
+    for (int i = 0; i < n && i < 8; ++i) out[i] = gr->stats[i];
+    return AS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,934 @@
+// Index build on gfx950: ingest -> fused X.X^T (fp32 MFMA) + streaming k-smallest ->
+// fp64 refinement -> union symmetrisation (CSR) -> normalised Laplacian -> per-item
+// spectral energy -> lambdas.  Replaces the crate call at /root/reference/src/lib.rs:289
+// (`builder.build(rows)`); SPEC = DESIGN.md section 2.
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+#include "as_common.hpp"
+
+namespace as {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+double err_coef(int64_t dp) {
+    // |fl32(n_i + n_j - 2 G32) - (exact)| <= coef * (n_i + n_j): k-ordered fp32 fma chain of
+    // length dp (gamma_dp), rounded norms, two adds and the fp32 rounding of the inputs.
+    const double u = 5.9604644775390625e-8;  // 2^-24
+    return (double)(dp + 16) * u;
+}
+
+// ------------------------------------------------------------------ K0 ingest
+template <typename T>
+__global__ void ingest_kernel(const T* __restrict__ src, int64_t ld, int64_t n, int64_t d, int64_t dp,
+                              float* __restrict__ x32, double* __restrict__ n64, float* __restrict__ n32,
+                              float* __restrict__ inorm32, int* lossless, unsigned long long* nmax_bits) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = lane_id();
+    double s = 0.0;
+    bool ok = true;
+    for (int64_t c = lane; c < d; c += 64) {
+        const double v = (double)src[row * ld + c];
+        const float f = (float)v;
+        x32[row * dp + c] = f;
+        s += v * v;
+        ok = ok && ((double)f == v || v != v);
+    }
+    s = wave_sum(s);
+    if (!__all(ok) && lane == 0) atomicExch(lossless, 0);
+    if (lane == 0) {
+        n64[row] = s;
+        n32[row] = (float)s;
+        inorm32[row] = s > 0.0 ? (float)(1.0 / sqrt(s)) : 0.0f;
+        if (s == s) atomicMax(nmax_bits, (unsigned long long)__double_as_longlong(s));
+    }
+}
+
+template <typename T>
+__global__ void copy_f64_kernel(const T* __restrict__ src, int64_t ld, int64_t n, int64_t d, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    dst[i] = (double)src[(i / d) * ld + (i % d)];
+}
+
+as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
+    const int64_t n = sp->n, d = sp->d;
+    sp->np = (n + ROW_TILE - 1) / ROW_TILE * ROW_TILE;
+    sp->dp = (d + COL_PAD - 1) / COL_PAD * COL_PAD;
+    const int64_t rows_alloc = sp->np + ROW_TILE;  // one extra zero tile: row blocks may start anywhere
+    AS_HIP(hipMalloc(&sp->x32, sizeof(float) * rows_alloc * sp->dp));
+    AS_HIP(hipMalloc(&sp->n64, sizeof(double) * n));
+    AS_HIP(hipMalloc(&sp->n32, sizeof(float) * rows_alloc));
+    AS_HIP(hipMalloc(&sp->inorm32, sizeof(float) * rows_alloc));
+    AS_HIP(hipMalloc(&sp->lam64, sizeof(double) * n));
+    AS_HIP(hipMalloc(&sp->lam32, sizeof(float) * rows_alloc));
+    AS_HIP(hipMemsetAsync(sp->x32, 0, sizeof(float) * rows_alloc * sp->dp, sp->stream));
+    AS_HIP(hipMemsetAsync(sp->n32, 0, sizeof(float) * rows_alloc, sp->stream));
+    AS_HIP(hipMemsetAsync(sp->inorm32, 0, sizeof(float) * rows_alloc, sp->stream));
+    AS_HIP(hipMemsetAsync(sp->lam64, 0, sizeof(double) * n, sp->stream));
+    AS_HIP(hipMemsetAsync(sp->lam32, 0, sizeof(float) * rows_alloc, sp->stream));
+    int* flags = nullptr;
+    AS_HIP(hipMalloc(&flags, 16));
+    int hinit[4] = {1, 0, 0, 0};
+    AS_HIP(hipMemcpyAsync(flags, hinit, 16, hipMemcpyHostToDevice, sp->stream));
+    unsigned long long* nmax_bits = (unsigned long long*)(flags + 2);
+    const int wpb = 4;
+    const unsigned grid = (unsigned)((n + wpb - 1) / wpb);
+    if (dtype == AS_DTYPE_F64)
+        hipLaunchKernelGGL(ingest_kernel<double>, dim3(grid), dim3(64 * wpb), 0, sp->stream, (const double*)items_dev, ld,
+                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits);
+    else
+        hipLaunchKernelGGL(ingest_kernel<float>, dim3(grid), dim3(64 * wpb), 0, sp->stream, (const float*)items_dev, ld,
+                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits);
+    AS_HIP(hipGetLastError());
+    int hout[4];
+    AS_HIP(hipMemcpyAsync(hout, flags, 16, hipMemcpyDeviceToHost, sp->stream));
+    AS_HIP(hipStreamSynchronize(sp->stream));
+    sp->lossless = hout[0];
+    unsigned long long nb;
+    memcpy(&nb, &hout[2], 8);
+    long long nbs = (long long)nb;
+    memcpy(&sp->nmax, &nbs, 8);
+    AS_HIP(hipFree(flags));
+    const bool keep = (dtype == AS_DTYPE_F64 && !sp->lossless) || sp->opts.keep_f64 == AS_KEEP_F64_ALWAYS;
+    if (keep) {
+        AS_HIP(hipMalloc(&sp->x64, sizeof(double) * n * d));
+        const int64_t tot = n * d;
+        const unsigned g2 = (unsigned)((tot + 255) / 256);
+        if (dtype == AS_DTYPE_F64)
+            hipLaunchKernelGGL(copy_f64_kernel<double>, dim3(g2), dim3(256), 0, sp->stream, (const double*)items_dev, ld, n, d, sp->x64);
+        else
+            hipLaunchKernelGGL(copy_f64_kernel<float>, dim3(g2), dim3(256), 0, sp->stream, (const float*)items_dev, ld, n, d, sp->x64);
+        AS_HIP(hipGetLastError());
+        AS_HIP(hipStreamSynchronize(sp->stream));
+    }
+    dbg("ingest: n=%lld d=%lld np=%lld dp=%lld lossless_f32=%d keep_f64=%d nmax=%.6g", (long long)n, (long long)d,
+        (long long)sp->np, (long long)sp->dp, sp->lossless, (int)keep, sp->nmax);
+    return AS_OK;
+}
+
+// ------------------------------------------------------------------ K2 fused X.X^T + k-smallest
+// Block = 4 waves, tile 256 rows x 128 cols, K-slab 32 (fp32 v_mfma_f32_32x32x2_f32).
+// Wave w owns rows [64w, 64w+64) of the tile exclusively (2x4 accumulators of 32x32), so
+// the candidate bookkeeping of a row never crosses waves.  Candidates that beat the row's
+// running bound are appended to a per-row buffer in HBM scratch; a full buffer is compacted
+// to its M smallest (key, idx) and the bound tightened.
+constexpr int BM = 256, BN = 128, BK = 32, LROW = 36, CAP = 256;
+
+struct KnnArgs {
+    const float* x32;
+    const float* n32;
+    const float* inorm32;
+    int64_t n, dp;
+    int64_t r0, r1;
+    int nrb, S, ntile, M, metric;
+    float epskey, coef, nmax;
+    float* buf_key;
+    int* buf_idx;
+    float* out_key;  // [(r1-r0)][S][M]
+    int* out_idx;
+    int* out_cnt;    // [(r1-r0)][S]: count | dropped<<30
+};
+
+__device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_l2(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Cross-lane hand-offs through LDS inside one wave: the hardware keeps a wave's LDS
+// operations in order, the compiler only needs to be told that memory changed.
+#define AS_CBAR() asm volatile("" ::: "memory")
+
+// keep the M smallest (key, idx) of the row's cnt buffered candidates; wave-cooperative
+__device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, float* ck, int* ci, int* s_cur,
+                                            float* s_thr, int* s_drop) {
+    const int lane = lane_id();
+    AS_CBAR();
+    const int cnt = s_cur[rl];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = lane; t < cnt; t += 64) {
+        ck[t] = ld_l2(bk + t);
+        ci[t] = ld_l2(bi + t);
+    }
+    AS_CBAR();
+    for (int t = lane; t < cnt; t += 64) {
+        const float k = ck[t];
+        const int i = ci[t];
+        int rank = 0;
+        for (int s = 0; s < cnt; ++s) rank += lex_less<float>(ck[s], ci[s], k, i) ? 1 : 0;
+        if (rank < M) {
+            bk[rank] = k;
+            bi[rank] = i;
+            if (rank == M - 1) s_thr[rl] = k;
+        }
+    }
+    if (lane == 0) {
+        s_cur[rl] = M;
+        s_drop[rl] = 1;
+    }
+    AS_CBAR();
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void knn_mfma_kernel(KnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = (float*)smem;
+    float* Bs = As + BM * LROW;
+    float* s_thr = Bs + BN * LROW;
+    float* s_aux = s_thr + BM;
+    int* s_cur = (int*)(s_aux + BM);
+    int* s_drop = s_cur + BM;
+    float* c_key = (float*)(s_drop + BM);
+    int* c_idx = (int*)(c_key + 4 * CAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    float* __restrict__ bkey = a.buf_key + (size_t)blockIdx.x * BM * CAP;
+    int* __restrict__ bidx = a.buf_idx + (size_t)blockIdx.x * BM * CAP;
+    float* ck = c_key + w * CAP;
+    int* ci = c_idx + w * CAP;
+    const int units = a.nrb * a.S;
+    const int nslab = (int)(a.dp / BK);
+    const float finf = __int_as_float(0x7f800000);
+    const int srow = tid >> 3, sg = tid & 7;  // staging: 8 x 16-byte chunks per 128-byte row slab
+
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int rb = u / a.S, cs = u % a.S;
+        const int64_t rowbase = a.r0 + (int64_t)rb * BM;
+        const int t0 = (int)((int64_t)a.ntile * cs / a.S), t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
+        {
+            const int64_t rg = rowbase + tid;
+            const bool valid = rg < a.r1 && rg < a.n;
+            const float ni = valid ? a.n32[rg] : 0.0f;
+            const float bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+            s_thr[tid] = valid ? bound : -finf;
+            s_aux[tid] = valid ? (a.metric == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f;
+            s_cur[tid] = 0;
+            s_drop[tid] = 0;
+        }
+        __syncthreads();
+        const float* pa = a.x32 + (size_t)(rowbase + srow) * a.dp + sg * 4;
+
+        for (int ct = t0; ct < t1; ++ct) {
+            const int64_t colbase = (int64_t)ct * BN;
+            const float* pb = a.x32 + (size_t)(colbase + srow) * a.dp + sg * 4;
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
+            f32x4 ra[8], rbv[4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ra[q] = *(const f32x4*)(pa + (size_t)q * 32 * a.dp);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rbv[q] = *(const f32x4*)(pb + (size_t)q * 32 * a.dp);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(f32x4*)(As + (srow + 32 * q) * LROW + sg * 4) = ra[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(Bs + (srow + 32 * q) * LROW + sg * 4) = rbv[q];
+            __syncthreads();
+            for (int ks = 0; ks < nslab; ++ks) {
+                const bool more = ks + 1 < nslab;
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ra[q] = *(const f32x4*)(pa + (size_t)q * 32 * a.dp + (ks + 1) * BK);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rbv[q] = *(const f32x4*)(pb + (size_t)q * 32 * a.dp + (ks + 1) * BK);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    f32x4 af[2], bf[4];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) af[m] = *(const f32x4*)(As + (w * 64 + m * 32 + l31) * LROW + s * 8 + h * 4);
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) bf[nn] = *(const f32x4*)(Bs + (nn * 32 + l31) * LROW + s * 8 + h * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int nn = 0; nn < 4; ++nn)
+                                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][t], bf[nn][t], acc[m][nn], 0, 0, 0);
+                }
+                __syncthreads();
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) *(f32x4*)(As + (srow + 32 * q) * LROW + sg * 4) = ra[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(f32x4*)(Bs + (srow + 32 * q) * LROW + sg * 4) = rbv[q];
+                    __syncthreads();
+                }
+            }
+            // ---- epilogue: keys, bound test, append
+            {
+                AS_CBAR();
+                const int rl = w * 64 + lane;
+                unsigned long long need = __ballot(s_cur[rl] > CAP - BN);
+                while (need) {
+                    const int r = __ffsll((long long)need) - 1;
+                    const unsigned rr = w * 64 + r;
+                    compact_row(rr, a.M, bkey + rr * CAP, bidx + rr * CAP, ck, ci, s_cur, s_thr, s_drop);
+                    need &= need - 1;
+                }
+                AS_CBAR();
+            }
+            float nj[4];
+            int cj[4];
+            bool cv[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                const int64_t cg = colbase + nn * 32 + l31;
+                cj[nn] = (int)cg;
+                cv[nn] = cg < a.n;
+                nj[nn] = a.metric == AS_METRIC_L2 ? a.n32[cg] : a.inorm32[cg];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = w * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float thr = s_thr[rl], ai = s_aux[rl];
+                    const int rg = (int)(rowbase + rl);
+                    float key[4];
+                    bool p[4];
+                    bool any = false;
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) {
+                        const float g = acc[m][nn][r];
+                        key[nn] = a.metric == AS_METRIC_L2 ? fmaf(-2.0f, g, ai + nj[nn]) : 1.0f - fmaxf(0.0f, g * ai * nj[nn]);
+                        p[nn] = cv[nn] && cj[nn] != rg && key[nn] <= thr;
+                        any = any || p[nn];
+                    }
+                    if (__ballot(any)) {
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn) {
+                            const unsigned long long mk = __ballot(p[nn]);
+                            if (!mk) continue;
+                            const unsigned hm = h ? (unsigned)(mk >> 32) : (unsigned)mk;
+                            const int base = s_cur[rl];
+                            if (p[nn]) {
+                                const unsigned slot = (unsigned)rl * CAP + base + __popc(hm & ((1u << l31) - 1u));
+                                bkey[slot] = key[nn];
+                                bidx[slot] = cj[nn];
+                            }
+                            // every lane of the half stores the same value: no cross-lane forwarding hazard
+                            s_cur[rl] = base + __popc(hm);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- finalize this unit's rows (each wave: its 64 rows)
+        AS_CBAR();
+        for (int r = 0; r < 64; ++r) {
+            const unsigned rl = w * 64 + r;
+            const int64_t rg = rowbase + rl;
+            if (rg >= a.r1 || rg >= a.n) break;
+            if (s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, s_thr, s_drop);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int cnt = s_cur[rl];
+            const size_t ob = ((size_t)(rg - a.r0) * a.S + cs) * a.M;
+            for (int t = lane; t < cnt; t += 64) {
+                a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
+                a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
+            }
+            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = cnt | (s_drop[rl] << 30);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ K2b fp64 refinement
+// One wave per row: merge the S segment lists to the M smallest fp32 keys, evaluate those
+// M pairs exactly in fp64, order by (key64, idx), apply eps and the k cap, and prove a
+// posteriori that no dropped candidate could belong to the answer (else flag the row).
+struct RefineArgs {
+    const float* x32;
+    const double* x64;
+    const double* n64;
+    int64_t n, d, dp;
+    int64_t r0, r1;
+    int S, M, metric;
+    int64_t k;
+    double epskey, coef, nmax;
+    const float* c_key;
+    const int* c_idx;
+    const int* c_cnt;
+    int32_t* out_idx;
+    double* out_key;
+    double* out_dist;
+    double* out_gy;
+    int32_t* out_cnt;
+    int* flag;      // [(r1-r0)]
+    int* nflag;     // counter
+};
+
+__device__ __forceinline__ void exact_pair(const float* x32, const double* x64, int64_t d, int64_t dp, int64_t i,
+                                           int64_t j, double& sq, double& dot) {
+    const int lane = lane_id();
+    double s = 0.0, g = 0.0;
+    if (x64) {
+        const double* pi = x64 + i * d;
+        const double* pj = x64 + j * d;
+        for (int64_t c = lane; c < d; c += 64) {
+            const double a = pi[c], b = pj[c], t = a - b;
+            s += t * t;
+            g += a * b;
+        }
+    } else {
+        const float* pi = x32 + i * dp;
+        const float* pj = x32 + j * dp;
+        for (int64_t c = lane; c < d; c += 64) {
+            const double a = (double)pi[c], b = (double)pj[c], t = a - b;
+            s += t * t;
+            g += a * b;
+        }
+    }
+    sq = wave_sum(s);
+    dot = wave_sum(g);
+}
+
+__global__ __launch_bounds__(256) void knn_refine_kernel(RefineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int SM = a.S * a.M;
+    // per-wave carve: ek[M] eg[M] ed[M] sk[M] (double) | ck[SM] (float) | ci[SM] li[M] (int) | lk[M] (float)
+    const size_t per_wave = sizeof(double) * 4 * a.M + sizeof(float) * (SM + a.M) + sizeof(int) * (SM + a.M);
+    char* base = smem + (size_t)w * ((per_wave + 15) / 16 * 16);
+    double* ek = (double*)base;
+    double* eg = ek + a.M;
+    double* ed = eg + a.M;
+    double* sk = ed + a.M;
+    float* ck = (float*)(sk + a.M);
+    float* lk = ck + SM;
+    int* ci = (int*)(lk + a.M);
+    int* li = ci + SM;
+
+    const int64_t row = a.r0 + (int64_t)blockIdx.x * 4 + w;
+    if (row >= a.r1) return;
+    const int64_t lr = row - a.r0;
+    int C = 0, anyfull = 0;
+    for (int cs = 0; cs < a.S; ++cs) {
+        const int cc = a.c_cnt[lr * a.S + cs];
+        const int c = cc & 0xffff;
+        anyfull |= (cc >> 30) & 1;
+        const size_t ob = ((size_t)lr * a.S + cs) * a.M;
+        for (int t = lane; t < c; t += 64) {
+            ck[C + t] = a.c_key[ob + t];
+            ci[C + t] = a.c_idx[ob + t];
+        }
+        C += c;
+    }
+    if (C > a.M) anyfull = 1;
+    const int Mp = C < a.M ? C : a.M;
+    for (int t = lane; t < C; t += 64) {
+        const float k = ck[t];
+        const int i = ci[t];
+        int rank = 0;
+        for (int s = 0; s < C; ++s) rank += lex_less<float>(ck[s], ci[s], k, i) ? 1 : 0;
+        if (rank < a.M) {
+            lk[rank] = k;
+            li[rank] = i;
+        }
+    }
+    const double ni = a.n64[row];
+    for (int t = 0; t < Mp; ++t) {
+        const int j = li[t];
+        double sq, dot;
+        exact_pair(a.x32, a.x64, a.d, a.dp, row, j, sq, dot);
+        if (lane == 0) {
+            if (a.metric == AS_METRIC_L2) {
+                ek[t] = sq;
+                ed[t] = sqrt(sq);
+                eg[t] = dot;
+            } else {
+                const double den = sqrt(ni * a.n64[j]);
+                const double c = den > 0.0 ? dot / den : 0.0;
+                const double dd = 1.0 - (c > 0.0 ? c : 0.0);
+                ek[t] = dd;
+                ed[t] = dd;
+                eg[t] = c;
+            }
+        }
+    }
+    // order by (key64, idx); entries passing eps form a prefix of that order
+    int npass_l = 0;
+    for (int t = lane; t < Mp; t += 64) {
+        const double k = ek[t];
+        const int i = li[t];
+        int rank = 0;
+        for (int s = 0; s < Mp; ++s) rank += lex_less<double>(ek[s], li[s], k, i) ? 1 : 0;
+        sk[rank] = k;
+        if (k <= a.epskey) {
+            npass_l += 1;
+            if (rank < a.k) {
+                a.out_idx[lr * a.k + rank] = i;
+                a.out_key[lr * a.k + rank] = k;
+                a.out_dist[lr * a.k + rank] = ed[t];
+                a.out_gy[lr * a.k + rank] = eg[t];
+            }
+        }
+    }
+    const int npass = wave_sum(npass_l);
+    const int cnt = npass < a.k ? npass : (int)a.k;
+    for (int64_t t = cnt + lane; t < a.k; t += 64) a.out_idx[lr * a.k + t] = -1;
+    if (lane == 0) {
+        a.out_cnt[lr] = cnt;
+        int bad = 0;
+        if (anyfull) {
+            const double B = npass >= a.k ? sk[a.k - 1] : a.epskey;
+            const double e = a.metric == AS_METRIC_L2 ? a.coef * (ni + a.nmax) : a.coef;
+            const double T32 = (double)lk[Mp - 1];
+            bad = !(T32 - e > B);
+        }
+        a.flag[lr] = bad;
+        if (bad) atomicAdd(a.nflag, 1);
+    }
+}
+
+static int pick_list_width(int64_t k) {
+    // M = k + margin rounded up to a power of two in [32, 64]; wider lists are not supported yet
+    const int64_t need = k + 8;
+    if (need <= 32) return 32;
+    if (need <= 64) return 64;
+    return -1;
+}
+
+as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int32_t* out_idx,
+                   double* out_key, double* out_dist, double* out_gy, int32_t* out_cnt, double* stats) {
+    const int64_t n = sp->n;
+    if (r0 < 0 || r1 > n || r0 > r1) {
+        set_err("as_knn_rows: bad row range [%lld,%lld) for n=%lld", (long long)r0, (long long)r1, (long long)n);
+        return AS_EINVAL;
+    }
+    const int64_t rows = r1 - r0;
+    if (rows == 0) return AS_OK;
+    const int64_t k = std::min<int64_t>(gp->k, std::max<int64_t>(n - 1, 1));
+    // caller's arrays are rows x gp->k; we write the first k slots and pad the rest
+    const int M = pick_list_width(k);
+    if (M < 0) {
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 56 for n=%lld", (long long)gp->k, (long long)n);
+        return AS_EUNSUPPORTED;
+    }
+    hipStream_t st = sp->stream;
+    const int metric = sp->opts.metric;
+    const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
+    const double coef = err_coef(sp->dp);
+
+    int32_t* t_idx = out_idx;
+    double *t_key = out_key, *t_dist = out_dist, *t_gy = out_gy;
+    // internal lists use width kk = gp->k (caller layout); k_eff may be smaller
+    const int64_t kk = gp->k;
+    AS_HIP(hipMemsetAsync(t_idx, 0xff, sizeof(int32_t) * rows * kk, st));
+    AS_HIP(hipMemsetAsync(out_cnt, 0, sizeof(int32_t) * rows, st));
+
+    int* flag = nullptr;
+    int* nflag = nullptr;
+    AS_HIP(hipMalloc(&flag, sizeof(int) * (rows + 1)));
+    nflag = flag + rows;
+    AS_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (rows + 1), st));
+    double t_mfma = 0, t_ref = 0, t_fb = 0, flops = 0;
+    int nflagged = 0;
+
+    if (!sp->opts.force_exact) {
+        const int nrb = (int)((rows + BM - 1) / BM);
+        const int ntile = (int)(sp->np / BN);
+        int S = 1;
+        {   // enough units to fill the chip several times over, but never thinner than 8 column tiles
+            int dev_cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
+            const int target_units = dev_cus * 2 * 8;
+            while (S < 8 && nrb * S < target_units && ntile / (S * 2) >= 8) S *= 2;
+        }
+        int dev_cus = 256;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
+        }
+        const int units = nrb * S;
+        const int grid = std::min(units, dev_cus * 2);
+        float *bkey = nullptr, *ckey = nullptr;
+        int *bidx = nullptr, *cidx = nullptr, *ccnt = nullptr;
+        AS_HIP(hipMalloc(&bkey, sizeof(float) * (size_t)grid * BM * CAP));
+        AS_HIP(hipMalloc(&bidx, sizeof(int) * (size_t)grid * BM * CAP));
+        AS_HIP(hipMalloc(&ckey, sizeof(float) * (size_t)rows * S * M));
+        AS_HIP(hipMalloc(&cidx, sizeof(int) * (size_t)rows * S * M));
+        AS_HIP(hipMalloc(&ccnt, sizeof(int) * (size_t)rows * S));
+        KnnArgs ka;
+        ka.x32 = sp->x32; ka.n32 = sp->n32; ka.inorm32 = sp->inorm32;
+        ka.n = n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+        ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
+        ka.epskey = (float)epskey; ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(sp->nmax * 1.0000002);
+        // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
+        ka.epskey = nextafterf(ka.epskey, INFINITY);
+        ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
+        const size_t lds = sizeof(float) * (BM + BN) * LROW + sizeof(float) * 4 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipEvent_t e0, e1, e2;
+        AS_HIP(hipEventCreate(&e0)); AS_HIP(hipEventCreate(&e1)); AS_HIP(hipEventCreate(&e2));
+        AS_HIP(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(knn_mfma_kernel, dim3(grid), dim3(256), lds, st, ka);
+        AS_HIP(hipGetLastError());
+        AS_HIP(hipEventRecord(e1, st));
+        RefineArgs ra;
+        ra.x32 = sp->x32; ra.x64 = sp->x64; ra.n64 = sp->n64; ra.n = n; ra.d = sp->d; ra.dp = sp->dp;
+        ra.r0 = r0; ra.r1 = r1; ra.S = S; ra.M = M; ra.metric = metric; ra.k = k;
+        ra.epskey = epskey; ra.coef = coef; ra.nmax = sp->nmax;
+        ra.c_key = ckey; ra.c_idx = cidx; ra.c_cnt = ccnt;
+        ra.out_idx = t_idx; ra.out_key = t_key; ra.out_dist = t_dist; ra.out_gy = t_gy; ra.out_cnt = out_cnt;
+        ra.flag = flag; ra.nflag = nflag;
+        // the refine kernel indexes outputs with stride a.k; use the caller stride kk
+        ra.k = kk;  // stride == gp->k; rows with fewer than gp->k candidates are padded with -1
+        const size_t per_wave = (sizeof(double) * 4 * M + sizeof(float) * ((size_t)S * M + M) + sizeof(int) * ((size_t)S * M + M) + 15) / 16 * 16;
+        const size_t lds2 = per_wave * 4;
+        AS_HIP(hipFuncSetAttribute((const void*)knn_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), lds2, st, ra);
+        AS_HIP(hipGetLastError());
+        AS_HIP(hipEventRecord(e2, st));
+        AS_HIP(hipMemcpyAsync(&nflagged, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+        AS_HIP(hipStreamSynchronize(st));
+        float ms01 = 0, ms12 = 0;
+        AS_HIP(hipEventElapsedTime(&ms01, e0, e1));
+        AS_HIP(hipEventElapsedTime(&ms12, e1, e2));
+        t_mfma = ms01 * 1e-3; t_ref = ms12 * 1e-3;
+        flops = 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
+        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+        hipFree(bkey); hipFree(bidx); hipFree(ckey); hipFree(cidx); hipFree(ccnt);
+        dbg("knn_rows: rows=%lld S=%d M=%d grid=%d mfma=%.3fs (%.1f TF/s) refine=%.3fs flagged=%d", (long long)rows, S, M,
+            grid, t_mfma, flops / std::max(t_mfma, 1e-9) * 1e-12, t_ref, nflagged);
+    } else {
+        nflagged = (int)rows;
+    }
+    if (nflagged > 0) {
+        const double tf0 = now_s();
+        std::vector<int> hflag(rows, 1);
+        if (!sp->opts.force_exact) AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
+        as_query* ws = nullptr;
+        AS_TRY(as_query_create(sp, nullptr, &ws));
+        as_status fs = AS_OK;
+        for (int64_t lr = 0; lr < rows && fs == AS_OK; ++lr) {
+            if (!hflag[lr]) continue;
+            fs = exact_row_knn(ws, gp, r0 + lr, t_idx + lr * kk, t_key + lr * kk, t_dist + lr * kk, t_gy + lr * kk, out_cnt + lr);
+        }
+        as_query_free(ws);  // synchronises the workspace stream
+        if (fs != AS_OK) { hipFree(flag); return fs; }
+        t_fb = now_s() - tf0;
+    }
+    hipFree(flag);
+    if (stats) {
+        stats[1] += t_mfma; stats[2] += t_ref; stats[3] += t_fb; stats[6] += nflagged; stats[7] += flops;
+    }
+    return AS_OK;
+}
+
+// ------------------------------------------------------------------ K3 symmetrise -> CSR
+__global__ void sym_count_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt, int64_t n, int64_t k,
+                                 int* __restrict__ revcnt) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * k) return;
+    const int64_t i = e / k;
+    const int t = (int)(e % k);
+    if (t >= cnt[i]) return;
+    const int j = idx[e];
+    const int cj = cnt[j];
+    bool found = false;
+    for (int s = 0; s < cj; ++s) found = found || idx[(int64_t)j * k + s] == (int)i;
+    if (!found) atomicAdd(&revcnt[j], 1);
+}
+
+__global__ void rowlen_kernel(const int32_t* __restrict__ cnt, const int* __restrict__ revcnt, int64_t n, int64_t* __restrict__ len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) len[i] = (int64_t)cnt[i] + revcnt[i];
+}
+
+// three-phase exclusive scan over int64 (1024 elements per block)
+__global__ void scan_block_sums(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ bsum) {
+    __shared__ int64_t sh[256];
+    const int64_t base = (int64_t)blockIdx.x * 1024;
+    int64_t s = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + threadIdx.x * 4 + q;
+        if (i < n) s += in[i];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
+}
+__global__ void scan_top(int64_t* bsum, int64_t nb, int64_t* total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t b = 0; b < nb; ++b) {
+            const int64_t v = bsum[b];
+            bsum[b] = run;
+            run += v;
+        }
+        *total = run;
+    }
+}
+__global__ void scan_apply(const int64_t* __restrict__ in, int64_t n, const int64_t* __restrict__ bsum, int64_t* __restrict__ out) {
+    __shared__ int64_t sh[256];
+    const int64_t base = (int64_t)blockIdx.x * 1024;
+    int64_t v[4];
+    int64_t s = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + threadIdx.x * 4 + q;
+        v[q] = i < n ? in[i] : 0;
+        s += v[q];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    // inclusive Hillis-Steele over 256 partials
+    for (int o = 1; o < 256; o <<= 1) {
+        int64_t t = 0;
+        if ((int)threadIdx.x >= o) t = sh[threadIdx.x - o];
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int64_t run = bsum[blockIdx.x] + sh[threadIdx.x] - s;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + threadIdx.x * 4 + q;
+        if (i < n) out[i] = run;
+        run += v[q];
+    }
+}
+
+__global__ void sym_fill_kernel(const int32_t* __restrict__ idx, const double* __restrict__ dist, const double* __restrict__ gy,
+                                const int32_t* __restrict__ cnt, int64_t n, int64_t k, const int64_t* __restrict__ indptr,
+                                int* __restrict__ cursor, int32_t* __restrict__ t_col, double* __restrict__ t_dist,
+                                double* __restrict__ t_gy) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * k) return;
+    const int64_t i = e / k;
+    const int t = (int)(e % k);
+    if (t >= cnt[i]) return;
+    const int j = idx[e];
+    int64_t pos = indptr[i] + t;
+    t_col[pos] = j;
+    t_dist[pos] = dist[e];
+    t_gy[pos] = gy[e];
+    const int cj = cnt[j];
+    bool found = false;
+    for (int s = 0; s < cj; ++s) found = found || idx[(int64_t)j * k + s] == (int)i;
+    if (!found) {
+        pos = indptr[j] + cj + atomicAdd(&cursor[j], 1);
+        t_col[pos] = (int)i;
+        t_dist[pos] = dist[e];
+        t_gy[pos] = gy[e];
+    }
+}
+
+// out-of-place rank sort of every row by column index (one wave per row); also edge weights
+__global__ __launch_bounds__(256) void sym_sort_kernel(int64_t n, const int64_t* __restrict__ indptr, const int32_t* __restrict__ t_col,
+                                                       const double* __restrict__ t_dist, const double* __restrict__ t_gy,
+                                                       int32_t* __restrict__ col, double* __restrict__ dist, double* __restrict__ gy,
+                                                       double* __restrict__ wgt, double sigma, double p, int kernel) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = lane_id();
+    const int64_t lo = indptr[row], hi = indptr[row + 1];
+    const int64_t len = hi - lo;
+    for (int64_t t = lane; t < len; t += 64) {
+        const int c = t_col[lo + t];
+        int64_t rank = 0;
+        for (int64_t s = 0; s < len; ++s) rank += t_col[lo + s] < c ? 1 : 0;
+        const double dd = t_dist[lo + t];
+        col[lo + rank] = c;
+        dist[lo + rank] = dd;
+        gy[lo + rank] = t_gy[lo + t];
+        wgt[lo + rank] = edge_weight(dd, sigma, p, kernel);
+    }
+}
+
+// ------------------------------------------------------------------ K4 degrees, K5 energies
+__global__ void degree_kernel(int64_t n, const int64_t* __restrict__ indptr, const double* __restrict__ wgt, double* __restrict__ deg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) s += wgt[e];
+    deg[i] = s;
+}
+
+__global__ void energy_kernel(int64_t n, const int64_t* __restrict__ indptr, const int32_t* __restrict__ col,
+                              const double* __restrict__ wgt, const double* __restrict__ gy, const double* __restrict__ deg,
+                              const double* __restrict__ n64, int metric, double* __restrict__ ny, double* __restrict__ lap,
+                              double* __restrict__ E, double* __restrict__ G) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double nyi = metric == AS_METRIC_L2 ? n64[i] : (n64[i] > 0.0 ? 1.0 : 0.0);
+    ny[i] = nyi;
+    const int64_t lo = indptr[i], hi = indptr[i + 1];
+    double Ei = 0.0, Gi = 0.0;
+    if (hi > lo) {
+        const double di = deg[i];
+        double S = 0.0;
+        for (int64_t e = lo; e < hi; ++e) {
+            const int j = col[e];
+            const double nyj = metric == AS_METRIC_L2 ? n64[j] : (n64[j] > 0.0 ? 1.0 : 0.0);
+            const double sdd = sqrt(di * deg[j]);
+            lap[e] = -wgt[e] / sdd;
+            const double v = wgt[e] * (nyi / di + nyj / deg[j] - 2.0 * gy[e] / sdd);
+            S += v > 0.0 ? v : 0.0;
+        }
+        Ei = nyi > 0.0 ? (0.5 * S) / nyi : 0.0;
+        if (S > 0.0) {
+            double g = 0.0;
+            for (int64_t e = lo; e < hi; ++e) {
+                const int j = col[e];
+                const double nyj = metric == AS_METRIC_L2 ? n64[j] : (n64[j] > 0.0 ? 1.0 : 0.0);
+                const double sdd = sqrt(di * deg[j]);
+                const double v = wgt[e] * (nyi / di + nyj / deg[j] - 2.0 * gy[e] / sdd);
+                const double r = (v > 0.0 ? v : 0.0) / S;
+                g += r * r;
+            }
+            Gi = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
+        }
+    }
+    E[i] = Ei;
+    G[i] = Gi;
+}
+
+// ------------------------------------------------------------------ K5b lower median of the positive energies
+// 8 passes of an 8-bit radix select over the IEEE bits (positive doubles order as uint64).
+struct SelState {
+    unsigned long long prefix;  // bits decided so far (high part)
+    long long rank;             // remaining rank inside the prefix bucket
+    long long npos;
+    unsigned int hist[256];
+};
+
+__global__ void sel_hist_kernel(const double* __restrict__ E, int64_t n, int pass, SelState* st) {
+    __shared__ unsigned int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const unsigned long long prefix = st->prefix;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = E[i];
+        if (!(v > 0.0)) continue;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        if (pass > 0 && (b >> (shift + 8)) != prefix) continue;
+        atomicAdd(&sh[(b >> shift) & 255ull], 1u);
+    }
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], sh[threadIdx.x]);
+}
+__global__ void sel_pick_kernel(int pass, SelState* st) {
+    if (threadIdx.x != 0) return;
+    if (pass == 0) {
+        long long tot = 0;
+        for (int b = 0; b < 256; ++b) tot += st->hist[b];
+        st->npos = tot;
+        st->rank = tot > 0 ? (tot - 1) / 2 : 0;
+        st->prefix = 0;
+    }
+    if (st->npos > 0) {
+        long long run = 0;
+        int b = 0;
+        for (; b < 256; ++b) {
+            if (run + (long long)st->hist[b] > st->rank) break;
+            run += st->hist[b];
+        }
+        st->rank -= run;
+        st->prefix = (st->prefix << 8) | (unsigned long long)b;
+    }
+    for (int b = 0; b < 256; ++b) st->hist[b] = 0;
+}
+
+__global__ void lambda_kernel(int64_t n, const double* __restrict__ E, const double* __restrict__ G, const SelState* st,
+                              double* __restrict__ lam64, float* __restrict__ lam32, double* tau_out) {
+    double tau0 = TAU_MIN;
+    if (st->npos > 0) {
+        tau0 = __longlong_as_double((long long)st->prefix);
+        tau0 = tau0 < TAU_MIN ? TAU_MIN : (tau0 > 1.0 ? 1.0 : tau0);
+    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *tau_out = tau0;
+    if (i >= n) return;
+    const double l = tau0 * (E[i] / (E[i] + tau0)) + (1.0 - tau0) * G[i];
+    lam64[i] = l;
+    lam32[i] = (float)l;
+}
+
+as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx, const double* dist, const double* gy,
+                         const int32_t* cnt, as_graph* gr) {
+    const int64_t n = sp->n, k = gp->k;
+    hipStream_t st = sp->stream;
+    gr->n = n;
+    gr->device = sp->device;
+    gr->gp = *gp;
+    gr->metric = sp->opts.metric;
+    gr->kernel = sp->opts.kernel;
+    int* revcnt = nullptr;
+    int64_t *len = nullptr, *bsum = nullptr, *total_d = nullptr;
+    AS_HIP(hipMalloc(&revcnt, sizeof(int) * n * 2));
+    int* cursor = revcnt + n;
+    AS_HIP(hipMemsetAsync(revcnt, 0, sizeof(int) * n * 2, st));
+    AS_HIP(hipMalloc(&len, sizeof(int64_t) * n));
+    const int64_t nb = (n + 1023) / 1024;
+    AS_HIP(hipMalloc(&bsum, sizeof(int64_t) * (nb + 1)));
+    total_d = bsum + nb;
+    AS_HIP(hipMalloc(&gr->indptr, sizeof(int64_t) * (n + 1)));
+    const unsigned ge = (unsigned)((n * k + 255) / 256), gn = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(sym_count_kernel, dim3(ge), dim3(256), 0, st, idx, cnt, n, k, revcnt);
+    hipLaunchKernelGGL(rowlen_kernel, dim3(gn), dim3(256), 0, st, cnt, revcnt, n, len);
+    hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(256), 0, st, len, n, bsum);
+    hipLaunchKernelGGL(scan_top, dim3(1), dim3(64), 0, st, bsum, nb, total_d);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)nb), dim3(256), 0, st, len, n, bsum, gr->indptr);
+    AS_HIP(hipGetLastError());
+    int64_t nnz = 0;
+    AS_HIP(hipMemcpyAsync(&nnz, total_d, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    AS_HIP(hipStreamSynchronize(st));
+    AS_HIP(hipMemcpyAsync(gr->indptr + n, &nnz, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    gr->nnz = nnz;
+    const int64_t na = std::max<int64_t>(nnz, 1);
+    int32_t* t_col = nullptr;
+    double *t_dist = nullptr, *t_gy = nullptr;
+    AS_HIP(hipMalloc(&t_col, sizeof(int32_t) * na));
+    AS_HIP(hipMalloc(&t_dist, sizeof(double) * na));
+    AS_HIP(hipMalloc(&t_gy, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->indices, sizeof(int32_t) * na));
+    AS_HIP(hipMalloc(&gr->dist, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->gy, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->w, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->lap, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->deg, sizeof(double) * n));
+    AS_HIP(hipMalloc(&gr->ny, sizeof(double) * n));
+    AS_HIP(hipMalloc(&gr->E, sizeof(double) * n));
+    AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
+    hipLaunchKernelGGL(sym_fill_kernel, dim3(ge), dim3(256), 0, st, idx, dist, gy, cnt, n, k, gr->indptr, cursor, t_col, t_dist, t_gy);
+    hipLaunchKernelGGL(sym_sort_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, gr->indptr, t_col, t_dist, t_gy,
+                       gr->indices, gr->dist, gr->gy, gr->w, gp->sigma, gp->p, gr->kernel);
+    hipLaunchKernelGGL(degree_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->w, gr->deg);
+    hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->gy, gr->deg, sp->n64,
+                       gr->metric, gr->ny, gr->lap, gr->E, gr->G);
+    AS_HIP(hipGetLastError());
+    SelState* sel = nullptr;
+    AS_HIP(hipMalloc(&sel, sizeof(SelState) + sizeof(double)));
+    double* tau_d = (double*)(sel + 1);
+    AS_HIP(hipMemsetAsync(sel, 0, sizeof(SelState) + sizeof(double), st));
+    const unsigned gh = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
+    for (int pass = 0; pass < 8; ++pass) {
+        hipLaunchKernelGGL(sel_hist_kernel, dim3(gh), dim3(256), 0, st, gr->E, n, pass, sel);
+        hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, sel);
+    }
+    hipLaunchKernelGGL(lambda_kernel, dim3(gn), dim3(256), 0, st, n, gr->E, gr->G, sel, sp->lam64, sp->lam32, tau_d);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipMemcpyAsync(&gr->tau0, tau_d, sizeof(double), hipMemcpyDeviceToHost, st));
+    AS_HIP(hipStreamSynchronize(st));
+    hipFree(sel); hipFree(t_col); hipFree(t_dist); hipFree(t_gy); hipFree(revcnt); hipFree(len); hipFree(bsum);
+    dbg("graph: nnz=%lld tau0=%.6g", (long long)nnz, gr->tau0);
+    return AS_OK;
+}
+
+}  // namespace as

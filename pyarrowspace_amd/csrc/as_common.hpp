@@ -1,0 +1,214 @@
+// Shared host/device definitions for the gfx950 hot path (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "arrowspace_hip.h"
+
+namespace as {
+
+constexpr int WAVE = 64;
+constexpr int ROW_TILE = 256;   // rows of the item matrix are padded to a multiple of this
+constexpr int COL_PAD = 32;     // feature dimension is padded to a multiple of this (floats)
+constexpr double TAU_MIN = 1e-12;
+constexpr int MAX_LIST = 64;    // widest wave-resident candidate list (one slot per lane)
+
+// ---------------------------------------------------------------- errors
+std::string& err_slot();
+void set_err(const char* fmt, ...);
+bool debug_enabled();
+void dbg(const char* fmt, ...);
+
+#define AS_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::as::set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AS_EHIP;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+#define AS_TRY(call)                    \
+    do {                                \
+        as_status _s = (call);          \
+        if (_s != AS_OK) return _s;     \
+    } while (0)
+
+}  // namespace as
+
+// ---------------------------------------------------------------- handles
+// HBM layout: x32 is the scan/MFMA operand, [np][dp] fp32,
+// zero padded so that every tile load is a full 16-byte vector inside the allocation.
+struct as_space {
+    int device = 0;
+    int64_t n = 0, d = 0, np = 0, dp = 0;
+    float* x32 = nullptr;     // [np][dp]
+    double* x64 = nullptr;    // [n][d] or null when the items are exactly fp32-representable
+    double* n64 = nullptr;    // [n] squared norms (fp64, from the fp64 items)
+    float* n32 = nullptr;     // [np] squared norms rounded to fp32 (0 on pad rows)
+    float* inorm32 = nullptr; // [np] 1/|x| (0 for zero rows / pad rows)
+    double* lam64 = nullptr;  // [n] lambdas (written by as_graph_from_knn)
+    float* lam32 = nullptr;   // [np]
+    double nmax = 0.0;        // max squared norm
+    int lossless = 0;         // items exactly representable in fp32
+    as_opts opts{};
+    hipStream_t stream = nullptr;
+    mutable as_query* qcache = nullptr;       // lazily created by as_search
+    mutable const as_graph* qcache_gr = nullptr;
+    mutable std::mutex qmu;
+};
+
+struct as_graph {
+    int device = 0;
+    int64_t n = 0;
+    int64_t nnz = 0;          // adjacency entries (both directions, no diagonal)
+    as_graph_params gp{};     // sigma resolved
+    int metric = 0, kernel = 0;
+    int64_t* indptr = nullptr;  // [n+1]
+    int32_t* indices = nullptr; // [nnz] ascending per row
+    double* dist = nullptr;     // [nnz] d_ij
+    double* gy = nullptr;       // [nnz] y_i . y_j
+    double* w = nullptr;        // [nnz] a_ij
+    double* lap = nullptr;      // [nnz] -a_ij / sqrt(deg_i deg_j)
+    double* deg = nullptr;      // [n]
+    double* ny = nullptr;       // [n] |y_i|^2
+    double* E = nullptr;        // [n]
+    double* G = nullptr;        // [n]
+    double tau0 = 0.0;
+    double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// ---------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+namespace as {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float bcast_lane(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ int bcast_lane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T>
+__device__ __forceinline__ bool lex_less(T ka, int ia, T kb, int ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+template <typename T>
+struct key_traits;
+template <>
+struct key_traits<float> {
+    static __device__ __forceinline__ float inf() { return __int_as_float(0x7f800000); }
+};
+template <>
+struct key_traits<double> {
+    static __device__ __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+};
+
+// Wave-resident sorted candidate list ("wavefront-shuffle top-k"): lane t holds
+// the t-th smallest (key, idx) seen so far; slots >= m stay (+inf, INT_MAX).
+template <typename T>
+struct WaveList {
+    T key;
+    int idx;
+    __device__ __forceinline__ void init() {
+        key = key_traits<T>::inf();
+        idx = 0x7fffffff;
+    }
+    // threshold = entry m-1
+    __device__ __forceinline__ void thr(int m, T& tk, int& ti) const {
+        tk = bcast_lane(key, m - 1);
+        ti = bcast_lane(idx, m - 1);
+    }
+    // insert a wave-uniform candidate; caller guarantees (ck,ci) < entry m-1
+    __device__ __forceinline__ void insert(T ck, int ci) {
+        const int lane = lane_id();
+        const bool less = lex_less<T>(key, idx, ck, ci);
+        const int pos = __popcll(__ballot(less));
+        T pk = __shfl_up(key, 1, 64);
+        int pi = __shfl_up(idx, 1, 64);
+        if (lane == pos) {
+            key = ck;
+            idx = ci;
+        } else if (lane > pos) {
+            key = pk;
+            idx = pi;
+        }
+    }
+    // offer one candidate per lane (inactive lanes pass valid=false)
+    __device__ __forceinline__ void offer(int m, T ck, int ci, bool valid) {
+        T tk;
+        int ti;
+        thr(m, tk, ti);
+        bool pass = valid && lex_less<T>(ck, ci, tk, ti);
+        unsigned long long mask = __ballot(pass);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            const T bk = bcast_lane(ck, src);
+            const int bi = bcast_lane(ci, src);
+            if (lex_less<T>(bk, bi, tk, ti)) {
+                insert(bk, bi);
+                thr(m, tk, ti);
+            }
+            mask &= mask - 1;
+            // drop lanes that no longer beat the tightened threshold
+            pass = pass && lex_less<T>(ck, ci, tk, ti);
+            mask &= __ballot(pass);
+        }
+    }
+};
+
+// SPEC S4 edge weight.  gaussian: exp(-0.5 (d/sigma)^p); rational: 1/(1+(d/sigma)^p)
+__device__ __forceinline__ double edge_weight(double d, double sigma, double p, int kernel) {
+    const double t = d / sigma;
+    const double u = (p == 2.0) ? t * t : pow(t, p);
+    return kernel == AS_KERNEL_GAUSSIAN ? exp(-0.5 * u) : 1.0 / (1.0 + u);
+}
+
+}  // namespace as
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------- internal entry points
+namespace as {
+
+struct Scratch;  // growable device scratch owned by a call
+
+as_status resolve_params(const as_graph_params* gp, as_graph_params* out);
+// per-pair fp32 error coefficient: |key32 - key64| <= coef * (n_i + n_j) for L2,
+// <= coef for cosine
+double err_coef(int64_t dp);
+
+// build stages (as_build.hip)
+as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld);
+as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int32_t* out_idx,
+                   double* out_key, double* out_dist, double* out_gy, int32_t* out_cnt, double* stats);
+as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx, const double* dist,
+                         const double* gy, const int32_t* cnt, as_graph* gr);
+
+// query-as-row exact k-NN used by the build fallback (as_search.hip)
+as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, int32_t* out_idx,
+                        double* out_key, double* out_dist, double* out_gy, int32_t* out_cnt);
+as_status search_once(as_query* q, const double* query, int64_t d, double tau, int exact, int64_t* out_idx,
+                      double* out_score, int64_t* out_len, double* out_lambda_q);
+void query_flags(const as_query* q, int* knn_inexact, int* score_inexact);
+
+}  // namespace as

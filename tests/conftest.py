@@ -1,0 +1,47 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def clustered(n, d, nclust=16, noise=0.5, seed=0, normalise=True):
+    """Synthetic clustered-Gaussian embeddings (recipe of SURVEY section 8d, scaled down)."""
+    rng = np.random.default_rng(seed)
+    C = rng.standard_normal((nclust, d))
+    z = rng.integers(0, nclust, n)
+    X = C[z] + noise * rng.standard_normal((n, d))
+    if normalise:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    return X
+
+
+def calibrate_eps(X, k, metric="l2", target=2.0, sample=256, seed=1):
+    """eps such that the mean degree before the k-cap is about target*k."""
+    rng = np.random.default_rng(seed)
+    n = X.shape[0]
+    rows = rng.choice(n, size=min(sample, n), replace=False)
+    G = X[rows] @ X.T
+    nn = np.einsum("ij,ij->i", X, X)
+    if metric == "l2":
+        D = np.sqrt(np.maximum(nn[rows][:, None] + nn[None, :] - 2 * G, 0.0))
+    else:
+        D = 1.0 - np.maximum(0.0, G / np.sqrt(nn[rows][:, None] * nn[None, :]))
+    D[np.arange(len(rows)), rows] = np.inf
+    q = min(1.0, target * k / max(n - 1, 1))
+    return float(np.quantile(D[np.isfinite(D)], q))
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import oracle_c
+    oracle_c.build_lib()
+    return oracle_c

@@ -1,0 +1,59 @@
+"""GPU parity: the HIP path (through the C ABI, via the arrowspace-compatible host
+module) against the fp64 CPU oracle on the same seeded inputs.  Bar (BASELINE.json
+north_star): returned indices rank-exact, fp64 scores within 1e-6 relative (we assert
+1e-9), lambdas within 1e-9 relative."""
+import numpy as np
+import pytest
+
+from conftest import calibrate_eps, clustered
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _build_both(X, gp, oracle_lib):
+    import pyarrowspace_amd as asp
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    return aspace, gl, ref
+
+
+def _check_index(aspace, gl, ref):
+    lam = aspace.lambdas()
+    np.testing.assert_allclose(lam, ref.lambdas, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(gl.degrees(), ref.deg, rtol=RTOL, atol=1e-300)
+    assert abs(gl.tau0 - ref.tau0) <= RTOL * abs(ref.tau0)
+    indptr, indices, values = gl.to_csr()
+    n = ref.X.shape[0]
+    # oracle CSR without the diagonal -> strip ours
+    rows = np.repeat(np.arange(n), np.diff(indptr))
+    off = indices != rows
+    assert np.array_equal(indices[off], ref.indices)
+    np.testing.assert_allclose(values[off], ref.lap, rtol=RTOL, atol=1e-300)
+    np.testing.assert_array_equal(values[~off], (ref.deg > 0).astype(np.float64))
+
+
+@pytest.mark.parametrize("metric,kernel", [("l2", "gaussian"), ("cosine", "rational"), ("l2", "rational"), ("cosine", "gaussian")])
+@pytest.mark.parametrize("n,d,k,topk", [(300, 24, 6, 5), (1000, 384, 12, 10), (2500, 768, 25, 15)])
+def test_build_and_search_match_oracle(oracle_lib, n, d, k, topk, metric, kernel):
+    X = clustered(n, d, nclust=max(4, n // 64), seed=n + d)
+    eps = calibrate_eps(X, k, metric)
+    gp = {"eps": eps, "k": k, "topk": topk, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
+    aspace, gl, ref = _build_both(X, gp, oracle_lib)
+    _check_index(aspace, gl, ref)
+    rng = np.random.default_rng(7)
+    for qi in range(6):
+        q = X[rng.integers(0, n)] + 0.05 * rng.standard_normal(d) / np.sqrt(d)
+        for tau in (1.0, 0.8, 0.62, 0.42, 0.0):
+            try:
+                want, lq_ref = ref.search(q, tau)
+            except oracle_lib.ZeroLambda:
+                import pyarrowspace_amd as asp
+                with pytest.raises(asp.PanicException):
+                    aspace.search(q, gl, tau)
+                continue
+            got = aspace.search(q, gl, tau)
+            assert [i for i, _ in got] == [i for i, _ in want], (qi, tau)
+            np.testing.assert_allclose([s for _, s in got], [s for _, s in want], rtol=RTOL)
+            assert abs(aspace.query_lambda(q, gl) - lq_ref) <= RTOL * abs(lq_ref)
