@@ -176,6 +176,9 @@ as_status as_build_stats(const as_graph* gr, double* out, int32_t n);
  * out[0]=scan out[1]=rest out[2]=exact_fallback_used */
 as_status as_query_stats(const as_query* q, double* out, int32_t n);
 
+/* same, for the workspace as_search keeps inside the space (last as_search call) */
+as_status as_last_search_stats(const as_space* sp, double* out, int32_t n);
+
 void as_free_space(as_space* sp);
 void as_free_graph(as_graph* gr);
 

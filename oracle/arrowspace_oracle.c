@@ -432,3 +432,30 @@ int aso_threads(void) {
     return 1;
 #endif
 }
+
+/* Search-only index from precomputed parts (bench.py cpu_baseline: the CPU scorer is
+ * timed at full N without paying for an all-pairs CPU build). X is borrowed, not copied. */
+aso_index *aso_from_parts(double *X, int64_t n, int64_t d, double eps, int64_t k, double p, double sigma, int metric,
+                          int kernel, const double *deg, const double *lam, double tau0) {
+    aso_index *ix = (aso_index *)calloc(1, sizeof(aso_index));
+    ix->n = n; ix->d = d; ix->eps = eps; ix->k = k; ix->p = p; ix->sigma = sigma;
+    ix->metric = metric; ix->kernel = kernel; ix->tau0 = tau0;
+    ix->X = X;
+    ix->nrm = (double *)malloc(sizeof(double) * n);
+    ix->ny = (double *)malloc(sizeof(double) * n);
+    ix->deg = (double *)malloc(sizeof(double) * n);
+    ix->lam = (double *)malloc(sizeof(double) * n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        ix->nrm[i] = dotp(X + i * d, X + i * d, d);
+        ix->ny[i] = metric == ASO_L2 ? ix->nrm[i] : (ix->nrm[i] > 0.0 ? 1.0 : 0.0);
+        ix->deg[i] = deg[i];
+        ix->lam[i] = lam[i];
+    }
+    return ix;
+}
+void aso_free_parts(aso_index *ix) {
+    if (!ix) return;
+    ix->X = NULL;
+    aso_free(ix);
+}

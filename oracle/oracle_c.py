@@ -54,6 +54,9 @@ def lib():
             getattr(L, name).restype = pi64
             getattr(L, name).argtypes = [C.c_void_p]
         L.aso_threads.restype = C.c_int
+        L.aso_from_parts.restype = C.c_void_p
+        L.aso_from_parts.argtypes = [p64, C.c_int64, C.c_int64, C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, p64, p64, C.c_double]
+        L.aso_free_parts.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -132,3 +135,30 @@ class OracleIndex:
         if m < 0:
             raise ZeroLambda("The lambdas are zero, check the magnitude of items and eps.")
         return [(int(idx[t]), float(sc[t])) for t in range(m)], lq.value
+
+
+class OracleSearchOnly:
+    """CPU scorer over precomputed lambdas/degrees (bench.py cpu_baseline leg)."""
+
+    def __init__(self, X, graph_params, deg, lambdas, tau0):
+        from .oracle_np import resolve_params
+
+        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        self.prm = resolve_params(graph_params)
+        self._deg = np.ascontiguousarray(deg, dtype=np.float64)
+        self._lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+        self._h = lib().aso_from_parts(_p64(self.X), self.X.shape[0], self.X.shape[1], self.prm["eps"], self.prm["k"],
+                                       self.prm["p"], self.prm["sigma"], self.prm["metric"], self.prm["kernel"],
+                                       _p64(self._deg), _p64(self._lam), float(tau0))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().aso_free_parts(self._h)
+            self._h = None
+
+    search = OracleIndex.search
+    query_lambda = OracleIndex.query_lambda
+
+
+def threads() -> int:
+    return int(lib().aso_threads())

@@ -43,6 +43,10 @@ def set_debug(enabled: bool) -> None:
     _L.as_set_debug(1 if enabled else 0)
 
 
+if os.environ.get("ARROWSPACE_DEBUG", "") not in ("", "0"):
+    set_debug(True)
+
+
 def _parse_graph_params(graph_params) -> tuple[GraphParams, Opts]:
     """src/helpers.rs:48-76.  eps,k,topk,p required; sigma missing/None -> eps*0.5.
     Keys the reference ignores select the documented variants: 'metric' in
@@ -244,6 +248,14 @@ class ArrowSpace:
             raise PanicException("The lambdas are zero, check the magnitude of items and eps.")
         return [[(int(idx[i, t]), float(sc[i, t])) for t in range(ln[i])] for i in range(b)]
 
+    def last_search_stats(self) -> dict:
+        """Extension: device microseconds of the last search (HIP events on its stream)."""
+        out = np.zeros(3, dtype=np.float64)
+        st = _L.as_last_search_stats(self._h, out.ctypes.data_as(C.c_void_p), 3)
+        if st:
+            _raise(st)
+        return {"scan_us": out[0], "rest_us": out[1]}
+
     def query_lambda(self, item, gl: GraphLaplacian) -> float:
         """Extension: lambda_q of `prepare_query_item` (src/lib.rs:154) without the search."""
         q = self._query(item)
@@ -285,6 +297,19 @@ class ArrowSpaceBuilder:
         sp, gr = C.c_void_p(), C.c_void_p()
         st = _L.as_build(items.ctypes.data_as(C.c_void_p), items.shape[0], items.shape[1], rs, cs, C.byref(gp),
                          C.byref(op), C.byref(sp), C.byref(gr))
+        if st:
+            _raise(st)
+        return ArrowSpace._wrap(sp), GraphLaplacian._wrap(gr)
+
+    @staticmethod
+    def build_from_device(graph_params, data_ptr: int, dtype, n: int, d: int, ld: int | None = None):
+        """Extension: items already resident in HBM (row-major fp32 or fp64 at `data_ptr`,
+        e.g. `torch_tensor.data_ptr()`); same result as build() on the same values."""
+        gp, op = _parse_graph_params(graph_params)
+        dt = {"float32": _lib.DTYPE_F32, "float64": _lib.DTYPE_F64}[str(dtype).replace("torch.", "")]
+        sp, gr = C.c_void_p(), C.c_void_p()
+        st = _L.as_build_dev(C.c_void_p(int(data_ptr)), dt, int(n), int(d), int(ld if ld is not None else d),
+                             C.byref(gp), C.byref(op), C.byref(sp), C.byref(gr))
         if st:
             _raise(st)
         return ArrowSpace._wrap(sp), GraphLaplacian._wrap(gr)

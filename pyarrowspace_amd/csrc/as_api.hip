@@ -430,6 +430,14 @@ as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, do
     return AS_OK;
 }
 
+as_status as_last_search_stats(const as_space* sp, double* out, int32_t n) {
+    if (!sp || !out || !sp->qcache) {
+        set_err("as_last_search_stats: no search has run on this space");
+        return AS_EINVAL;
+    }
+    return as_query_stats(sp->qcache, out, n);
+}
+
 as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {
     if (!gr || !out) {
         set_err("as_build_stats: null argument");
