@@ -160,6 +160,7 @@ def main():
     dt = float(tt.item())
     # kernel-level timing of the dominant kernel (scan_dots) with HIP events on its own stream,
     # taken over a second pass so the event reads do not perturb the timed region
+    asp.enable_search_stats(True)
     for i in range(min(args.steps, 50)):
         searcher(Q[(args.warmup + i) % len(Q)])
         scan_us.append(aspace.last_search_stats()["scan_us"] if world == 1 else index.last_scan_us())

@@ -146,9 +146,11 @@ int64_t as_query_hit_capacity(const as_query* q);
 /* merge m hit records (own or all-gathered), copy to host; synchronises. */
 as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, int64_t* out_idx,
                           double* out_score, int64_t* out_len, double* out_lambda_q);
-/* 1: run the following scans in fp64 end to end (the fallback as_search takes when the
- * fp32 candidate lists are not provably exact); flags of the last finished search */
-void as_query_set_exact(as_query* q, int32_t exact);
+/* flags bit0: run the following scans in fp64 end to end (the fallback as_search takes when
+ * the fp32 candidate lists are not provably exact); bit1: wavefront-list selection instead
+ * of the filter buffers (taken when a buffer overflowed).  as_query_flags reports the last
+ * finished search: bit0 = not provably exact, bit1 = a candidate buffer overflowed. */
+void as_query_set_exact(as_query* q, int32_t flags);
 as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact);
 /* HIP stream (hipStream_t) the query's kernels run on, for event timing / ordering */
 void* as_query_stream(const as_query* q);
@@ -176,6 +178,9 @@ as_status as_build_stats(const as_graph* gr, double* out, int32_t n);
  * out[0]=scan out[1]=rest out[2]=exact_fallback_used */
 as_status as_query_stats(const as_query* q, double* out, int32_t n);
 
+/* HIP-event timing of searches is off by default (the events cost a few microseconds per
+ * query); enable it before the searches whose stats are read */
+void as_enable_search_stats(int32_t enabled);
 /* same, for the workspace as_search keeps inside the space (last as_search call) */
 as_status as_last_search_stats(const as_space* sp, double* out, int32_t n);
 

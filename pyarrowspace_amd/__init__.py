@@ -47,6 +47,11 @@ if os.environ.get("ARROWSPACE_DEBUG", "") not in ("", "0"):
     set_debug(True)
 
 
+def enable_search_stats(enabled: bool) -> None:
+    """Extension: record HIP events around the scan kernel of every search (off by default)."""
+    _L.as_enable_search_stats(1 if enabled else 0)
+
+
 def _parse_graph_params(graph_params) -> tuple[GraphParams, Opts]:
     """src/helpers.rs:48-76.  eps,k,topk,p required; sigma missing/None -> eps*0.5.
     Keys the reference ignores select the documented variants: 'metric' in
@@ -80,6 +85,8 @@ def _parse_graph_params(graph_params) -> tuple[GraphParams, Opts]:
         kernel = graph_params.get("kernel", kernel)
         op.force_exact = 1 if graph_params.get("force_exact", False) else 0
         op.keep_f64 = 1 if graph_params.get("keep_f64", False) else 0
+        # test hook: start searches on a fallback path (bit0 fp64, bit1 wavefront-list selection)
+        op.reserved[0] = int(graph_params.get("_search_mode", 0))
     if metric not in _lib.METRICS:
         raise ValueError(f"unknown metric {metric!r}; expected one of {sorted(_lib.METRICS)}")
     if kernel not in _lib.KERNELS:

@@ -305,12 +305,20 @@ as_status as_search(const as_space* sp, const as_graph* gr, const double* query,
     AS_HIP(hipSetDevice(sp->device));
     as_query* q = nullptr;
     AS_TRY(get_cached_query(sp, gr, &q));
-    as_status s = search_once(q, query, d, tau, 0, out_idx, out_score, out_len, out_lambda_q);
-    int ki = 0, si = 0;
-    query_flags(q, &ki, &si);
-    if ((s == AS_OK || s == AS_EZEROLAMBDA) && (ki || si) && !sp->opts.force_exact) {
-        dbg("search: fp32 candidate list not provably exact (knn=%d score=%d), rerunning in fp64", ki, si);
-        s = search_once(q, query, d, tau, 1, out_idx, out_score, out_len, out_lambda_q);
+    // mode bit0: fp64 end to end, bit1: wavefront-list selection (candidate buffer overflowed)
+    int mode = sp->opts.reserved[0] & 3;  // tests start directly on a fallback path
+    as_status s = AS_OK;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        s = search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
+        if (s != AS_OK && s != AS_EZEROLAMBDA) break;
+        int ki = 0, si = 0;
+        query_flags(q, &ki, &si);
+        int next = mode;
+        if (ki & 2) next |= 2;
+        if (((ki & 1) || si) && !sp->opts.force_exact) next |= 1;
+        if (next == mode) break;
+        dbg("search: fast path not provably exact (knn=%d score=%d), rerunning with mode %d", ki, si, next);
+        mode = next;
     }
     if (s == AS_OK && out_lambda_q) dbg("search: qlen=%lld, lambda_q=%.6f", (long long)d, *out_lambda_q);  // src/lib.rs:161-165
     return s;

@@ -90,6 +90,10 @@ namespace as {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// LDS hand-off between lanes of ONE wave: the hardware keeps a wave's LDS operations in
+// order; wait for them and stop the compiler from caching LDS values across the point.
+#define AS_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

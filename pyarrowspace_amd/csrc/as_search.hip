@@ -1,8 +1,17 @@
 // Lambda-blended search on gfx950.  Replaces `prepare_query_item` + `search_lambda_aware`
 // (/root/reference/src/lib.rs:154,173; scorer form TAUMODE.md:33).  SPEC = DESIGN.md
-// section 2 (S10, S11).  One HBM pass over the fp32 item matrix per query (scan_dots),
+// section 2 (S10, S11).  One HBM pass over the fp32 item matrix per query (scan_dots);
 // everything after it works on N-length vectors that stay in L2 / Infinity Cache.
+//
+// Selection design: the k-NN side is a *filter* (rows whose fp32
+// key beats the eps bound are appended to a small candidate buffer by the scan kernel
+// itself); the scorer side derives a provable threshold from group maxima (the M-th best
+// of G-row group maxima is a lower bound of the M-th best score), filters against it and
+// ranks the few survivors.  Survivors are re-evaluated in fp64 and an a-posteriori check
+// proves the result equals the fp64 answer, else the search is rerun in fp64.  A
+// wavefront-shuffle list path (WaveList) is kept as the overflow fallback.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "as_common.hpp"
@@ -11,27 +20,37 @@ namespace as {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int CAND_CAP = 4096;  // candidate buffer of the filter path
+constexpr int REC_CAP = 512;    // records q_lambda / hits_final accept (ranks x k)
+
 struct QInfo {
     double nq;        // |q|^2
     double lambda_q;
     double tau;
-    float nq32, inq32;
     double inq;       // 1/|q|
+    double thr64;     // scorer threshold key (fp64 mode)
+    float nq32, inq32;
+    float thr32;      // scorer threshold key (fp32 mode)
     int status;       // as_status of the lambda step
     int knn_inexact;  // a-posteriori check of the k-NN candidate list failed
     int score_inexact;
-    int knn_total;    // candidates that passed the eps prefilter (all waves)
+    int knn_total;    // candidates that passed the eps prefilter
     int nhit;
-    int pad;
+    int knn_cnt;      // filter path: appended k-NN candidates
+    int sc_cnt;       // filter path: appended scorer candidates
+    int overflow;     // a candidate buffer overflowed -> rerun on the list path
 };
 
 struct HostOut {
+    volatile int64_t seq;
     int64_t len;
     double lambda_q;
-    int status, knn_inexact, score_inexact, pad;
+    int status, knn_inexact, score_inexact, overflow;
     int64_t idx[MAX_LIST];
     double score[MAX_LIST];
 };
+
+static std::atomic<int> g_search_stats{0};
 
 }  // namespace as
 
@@ -44,23 +63,50 @@ struct as_query {
     int nwaves = 0;
     int64_t r0 = 0, r1 = 0;
     int exact = 0;
-    double* qin = nullptr;   // [d] raw query
+    int robust = 0;          // 1: wavefront-list path instead of the filter path
+    int64_t seq = 0;
+    double* hq = nullptr;    // pinned host staging of the query (device-readable)
+    double* hq_dev = nullptr;
     double* q64 = nullptr;   // [dp] zero padded
     float* q32 = nullptr;    // [dp]
     as::QInfo* info = nullptr;
     float* dots32 = nullptr; // [np]
     double* dots64 = nullptr;
-    void* pkey = nullptr;    // [nwaves][64] keys (sized for double)
-    int* pidx = nullptr;     // [nwaves][64]
+    void* pkey = nullptr;    // list path: [nwaves][64] keys (sized for double)
+    int* pidx = nullptr;
+    void* ckey_k = nullptr;  // filter path candidate buffers (sized for double)
+    int* cidx_k = nullptr;
+    void* ckey_s = nullptr;
+    int* cidx_s = nullptr;
+    void* gmin = nullptr;    // group minima of the scorer key
     as_knn_rec* knn = nullptr;
     as_hit_rec* hits = nullptr;
     as::HostOut* hout = nullptr;  // pinned
+    as::HostOut* hout_dev = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int ev_valid = 0;
     double stats[4] = {0, 0, 0, 0};
-    std::mutex mu;
 };
 
 namespace as {
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ unsigned int ord_bits(float v) {
+    const unsigned int b = (unsigned int)__float_as_int(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long ord_bits(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ float from_ord(unsigned int u) {
+    const unsigned int b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __int_as_float((int)b);
+}
+__device__ __forceinline__ double from_ord(unsigned long long u) {
+    const unsigned long long b = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+    return __longlong_as_double((long long)b);
+}
 
 // ------------------------------------------------------------------ query staging
 __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int64_t dp, double* __restrict__ q64,
@@ -92,6 +138,11 @@ __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int6
         info->score_inexact = 0;
         info->knn_total = 0;
         info->nhit = 0;
+        info->knn_cnt = 0;
+        info->sc_cnt = 0;
+        info->overflow = 0;
+        info->thr32 = 0.0f;
+        info->thr64 = 0.0;
     }
 }
 
@@ -100,15 +151,50 @@ __global__ void q_from_row_kernel(const float* __restrict__ x32, const double* _
     for (int64_t c = threadIdx.x; c < d; c += blockDim.x) qin[c] = x64 ? x64[row * d + c] : (double)x32[row * dp + c];
 }
 
-// ------------------------------------------------------------------ K7a scan: dots[i] = x_i . q
+// ------------------------------------------------------------------ K7a scan: dots[i] = x_i . q  (+ k-NN prefilter)
+struct PreArgs {
+    const float* n32;
+    const float* inorm32;
+    const double* n64;
+    const QInfo* info;
+    QInfo* infow;
+    void* ckey;
+    int* cidx;
+    double epskey, coef;
+    int64_t n, exclude;
+    int metric, enabled;
+};
+
+__device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, float dot, float nq32, float inq32) {
+    if (!p.enabled || row >= p.n || row == p.exclude) return;
+    float key, bound;
+    if (p.metric == AS_METRIC_L2) {
+        const float ni = p.n32[row];
+        key = fmaf(-2.0f, dot, ni + nq32);
+        bound = ((float)p.epskey + (float)p.coef * (ni + nq32)) * 1.000001f;
+    } else {
+        key = 1.0f - fmaxf(0.0f, dot * p.inorm32[row] * inq32);
+        bound = ((float)p.epskey + (float)p.coef) * 1.000001f;
+    }
+    if (key <= bound) {
+        const int slot = atomicAdd(&p.infow->knn_cnt, 1);
+        if (slot < CAND_CAP) {
+            ((float*)p.ckey)[slot] = key;
+            p.cidx[slot] = (int)row;
+        }
+    }
+}
+
 // HBM-bound: one wave per row, 16 B per lane per load, query fragment in registers,
 // two rows in flight per wave.  NCH = ceil(dp / 256) chunks of 256 floats.
 template <int NCH>
 __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
-                                                            int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots) {
+                                                            int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                            PreArgs pre) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
     f32x4 qv[NCH];
     bool on[NCH];
 #pragma unroll
@@ -141,6 +227,8 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
         if (lane == 0) {
             dots[row] = sa;
             dots[row + nw] = sb;
+            prefilter_f32(pre, row, sa, nq32, inq32);
+            prefilter_f32(pre, row + nw, sb, nq32, inq32);
         }
     }
     if (row < r1) {
@@ -155,16 +243,21 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
             }
         }
         sa = wave_sum(sa);
-        if (lane == 0) dots[row] = sa;
+        if (lane == 0) {
+            dots[row] = sa;
+            prefilter_f32(pre, row, sa, nq32, inq32);
+        }
     }
 }
 
 // generic width (dp > 2048): query re-read from L1 per chunk
 __global__ __launch_bounds__(256) void scan_dots_f32_generic_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
-                                                                    int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots) {
+                                                                    int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                                    PreArgs pre) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
     for (int64_t row = r0 + gw; row < r1; row += nw) {
         const float* pa = x32 + row * dp;
         float s = 0.0f;
@@ -175,17 +268,21 @@ __global__ __launch_bounds__(256) void scan_dots_f32_generic_kernel(const float*
             for (int e = 0; e < 4; ++e) s = fmaf(v[e], q[e], s);
         }
         s = wave_sum(s);
-        if (lane == 0) dots[row] = s;
+        if (lane == 0) {
+            dots[row] = s;
+            prefilter_f32(pre, row, s, nq32, inq32);
+        }
     }
 }
 
 // exact mode: fp64 accumulation over the fp64 items (or the widened fp32 items when lossless)
 __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restrict__ x32, const double* __restrict__ x64,
                                                             const double* __restrict__ q64, int64_t d, int64_t dp, int64_t r0,
-                                                            int64_t r1, double* __restrict__ dots) {
+                                                            int64_t r1, double* __restrict__ dots, PreArgs pre) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const double nq = pre.info->nq;
     for (int64_t row = r0 + gw; row < r1; row += nw) {
         double s = 0.0;
         if (x64) {
@@ -196,11 +293,33 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
             for (int64_t c = lane; c < d; c += 64) s += (double)p[c] * q64[c];
         }
         s = wave_sum(s);
-        if (lane == 0) dots[row] = s;
+        if (lane == 0) {
+            dots[row] = s;
+            if (pre.enabled && row < pre.n && row != pre.exclude) {
+                const double ni = pre.n64[row];
+                double key, bound;
+                if (pre.metric == AS_METRIC_L2) {
+                    key = ni + nq - 2.0 * s;
+                    bound = pre.epskey + pre.coef * (ni + nq);
+                } else {
+                    const double den = sqrt(ni * nq);
+                    const double c = den > 0.0 ? s / den : 0.0;
+                    key = 1.0 - (c > 0.0 ? c : 0.0);
+                    bound = pre.epskey + pre.coef;
+                }
+                if (key <= bound) {
+                    const int slot = atomicAdd(&pre.infow->knn_cnt, 1);
+                    if (slot < CAND_CAP) {
+                        ((double*)pre.ckey)[slot] = key;
+                        pre.cidx[slot] = (int)row;
+                    }
+                }
+            }
+        }
     }
 }
 
-// ------------------------------------------------------------------ wavefront-shuffle partial selections
+// ------------------------------------------------------------------ scorer key (= -score) of one row
 template <typename T>
 struct SelArgs {
     const T* dots;
@@ -218,27 +337,157 @@ struct SelArgs {
     int* pidx;
 };
 
+struct ScoreCtx {
+    double nq, tau, lq;
+    float tau32, lq32, inq32;
+};
+__device__ __forceinline__ ScoreCtx load_ctx(const QInfo* info) {
+    ScoreCtx c;
+    c.nq = info->nq;
+    c.tau = info->tau;
+    c.lq = info->lambda_q;
+    c.tau32 = (float)c.tau;
+    c.lq32 = (float)c.lq;
+    c.inq32 = info->inq32;
+    return c;
+}
 template <typename T>
-__device__ __forceinline__ T knn_key(const SelArgs<T>& a, int64_t row, T dot, double nq, double inq);
+__device__ __forceinline__ T score_key(const SelArgs<T>& a, const ScoreCtx& c, int64_t row);
 template <>
-__device__ __forceinline__ float knn_key<float>(const SelArgs<float>& a, int64_t row, float dot, double, double) {
+__device__ __forceinline__ float score_key<float>(const SelArgs<float>& a, const ScoreCtx& c, int64_t row) {
+    const float cs = a.dots[row] * a.inorm32[row] * c.inq32;
+    const float term = 1.0f / (1.0f + fabsf(c.lq32 - a.lam32[row]));
+    return -(c.tau32 * cs + (1.0f - c.tau32) * term);
+}
+template <>
+__device__ __forceinline__ double score_key<double>(const SelArgs<double>& a, const ScoreCtx& c, int64_t row) {
+    const double den = sqrt(a.n64[row] * c.nq);
+    const double cs = den > 0.0 ? a.dots[row] / den : 0.0;
+    return -(c.tau * cs + (1.0 - c.tau) / (1.0 + fabs(c.lq - a.lam64[row])));
+}
+
+template <typename T>
+__device__ __forceinline__ T knn_key(const SelArgs<T>& a, int64_t row, T dot, double nq);
+template <>
+__device__ __forceinline__ float knn_key<float>(const SelArgs<float>& a, int64_t row, float dot, double) {
     if (a.metric == AS_METRIC_L2) return fmaf(-2.0f, dot, a.n32[row] + a.info->nq32);
     return 1.0f - fmaxf(0.0f, dot * a.inorm32[row] * a.info->inq32);
 }
 template <>
-__device__ __forceinline__ double knn_key<double>(const SelArgs<double>& a, int64_t row, double dot, double nq, double) {
+__device__ __forceinline__ double knn_key<double>(const SelArgs<double>& a, int64_t row, double dot, double nq) {
     if (a.metric == AS_METRIC_L2) return a.n64[row] + nq - 2.0 * dot;
     const double den = sqrt(a.n64[row] * nq);
     const double c = den > 0.0 ? dot / den : 0.0;
     return 1.0 - (c > 0.0 ? c : 0.0);
 }
 
+// ------------------------------------------------------------------ filter path, scorer side
+// (1) per-group minimum of the scorer key; one wave per group of G rows
+template <typename T>
+__global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G, int ngroups, T* __restrict__ gmin) {
+    const int lane = lane_id();
+    const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const ScoreCtx c = load_ctx(a.info);
+    const int64_t lo = a.r0 + g * G;
+    const int64_t hi = lo + G < a.r1 ? lo + G : a.r1;
+    T m = key_traits<T>::inf();
+    for (int64_t row = lo + lane; row < hi; row += 64) {
+        const T k = score_key<T>(a, c, row);
+        m = k < m ? k : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+    }
+    if (lane == 0) gmin[g] = m;
+}
+
+// (2) threshold = M-th smallest group minimum (radix select over the ordered bit pattern).
+// At least M rows have key <= threshold, so the M best rows all pass the filter.
+template <typename T, typename U, int PASSES>
+__global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gmin, int ng, int M, QInfo* info) {
+    __shared__ unsigned int hist[256];
+    __shared__ U s_prefix;
+    __shared__ int s_rank;
+    const int tid = threadIdx.x;
+    if (ng <= M) {
+        if (tid == 0) {
+            if (sizeof(T) == 4) info->thr32 = key_traits<float>::inf();
+            else info->thr64 = key_traits<double>::inf();
+        }
+        return;
+    }
+    U v[4];
+    bool have[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * 1024;
+        have[q] = i < ng;
+        v[q] = have[q] ? ord_bits(gmin[i]) : (U)0;
+    }
+    if (tid == 0) {
+        s_prefix = 0;
+        s_rank = M - 1;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int shift = 8 * (PASSES - 1 - pass);
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const U prefix = s_prefix;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!have[q]) continue;
+            if (pass > 0 && (v[q] >> (shift + 8)) != prefix) continue;
+            atomicAdd(&hist[(unsigned int)((v[q] >> shift) & (U)255)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0, b = 0;
+            const int rank = s_rank;
+            for (; b < 256; ++b) {
+                if (run + (int)hist[b] > rank) break;
+                run += (int)hist[b];
+            }
+            s_rank = rank - run;
+            s_prefix = (prefix << 8) | (U)b;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const T thr = from_ord(s_prefix);
+        if (sizeof(T) == 4) info->thr32 = (float)thr;
+        else info->thr64 = (double)thr;
+    }
+}
+
+// (3) append every row whose key <= threshold
+template <typename T>
+__global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a, T* __restrict__ ckey, int* __restrict__ cidx) {
+    const ScoreCtx c = load_ctx(a.info);
+    const T thr = sizeof(T) == 4 ? (T)a.info->thr32 : (T)a.info->thr64;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
+        const T k = score_key<T>(a, c, row);
+        if (k <= thr) {
+            const int slot = atomicAdd(&a.info_w->sc_cnt, 1);
+            if (slot < CAND_CAP) {
+                ckey[slot] = k;
+                cidx[slot] = (int)row;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ list path (overflow fallback): wavefront-shuffle partial lists
 template <typename T>
 __global__ __launch_bounds__(256) void knn_partial_kernel(SelArgs<T> a) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const double nq = a.info->nq, inq = a.info->inq;
+    const double nq = a.info->nq;
     WaveList<T> lst;
     lst.init();
     int npass = 0;
@@ -247,10 +496,10 @@ __global__ __launch_bounds__(256) void knn_partial_kernel(SelArgs<T> a) {
         bool valid = row < a.r1 && row < a.n && row != a.exclude;
         T key = key_traits<T>::inf();
         if (valid) {
-            key = knn_key<T>(a, row, a.dots[row], nq, inq);
+            key = knn_key<T>(a, row, a.dots[row], nq);
             const double ni = sizeof(T) == 4 ? (double)a.n32[row] : a.n64[row];
             const double bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + nq) : a.epskey + a.coef;
-            valid = (double)key <= bound;
+            valid = (double)key <= bound * 1.000001;
         }
         npass += valid ? 1 : 0;
         lst.offer(a.M, key, (int)row, valid);
@@ -266,34 +515,20 @@ __global__ __launch_bounds__(256) void score_partial_kernel(SelArgs<T> a) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const double nq = a.info->nq;
-    const double tau = a.info->tau, lq = a.info->lambda_q;
-    const float tau32 = (float)tau, lq32 = (float)lq, inq32 = a.info->inq32;
+    const ScoreCtx c = load_ctx(a.info);
     WaveList<T> lst;
     lst.init();
     for (int64_t base = a.r0 + gw * 64; base < a.r1; base += nw * 64) {
         const int64_t row = base + lane;
         const bool valid = row < a.r1 && row < a.n;
-        T key = key_traits<T>::inf();
-        if (valid) {
-            if (sizeof(T) == 4) {
-                const float c = (float)a.dots[row] * a.inorm32[row] * inq32;
-                const float term = 1.0f / (1.0f + fabsf(lq32 - a.lam32[row]));
-                key = (T)(-(tau32 * c + (1.0f - tau32) * term));
-            } else {
-                const double den = sqrt(a.n64[row] * nq);
-                const double c = den > 0.0 ? (double)a.dots[row] / den : 0.0;
-                key = (T)(-(tau * c + (1.0 - tau) / (1.0 + fabs(lq - a.lam64[row]))));
-            }
-        }
+        const T key = valid ? score_key<T>(a, c, row) : key_traits<T>::inf();
         lst.offer(a.M, key, (int)row, valid);
     }
     a.pkey[gw * 64 + lane] = lst.key;
     a.pidx[gw * 64 + lane] = lst.idx;
 }
 
-// merge nlists partial lists (64 slots each) down to one sorted list in LDS (fk, fi);
-// block of 1024 threads (16 waves).  Returns valid count in *fcount.
+// merge nlists partial lists (64 slots each) down to one sorted list in LDS (fk, fi)
 template <typename T>
 __device__ __forceinline__ void merge_partials(const T* pkey, const int* pidx, int nlists, int M, T* wk, int* wi, T* fk,
                                                int* fi, int* fcount) {
@@ -320,6 +555,29 @@ __device__ __forceinline__ void merge_partials(const T* pkey, const int* pidx, i
         fi[lane] = fin.idx;
         const int c = __popcll(__ballot(lane < M && fin.idx != 0x7fffffff));
         if (lane == 0) *fcount = c;
+    }
+    __syncthreads();
+}
+
+// rank-select the M smallest (key, idx) of the C buffered candidates into (fk, fi), sorted
+template <typename T>
+__device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx, int C, int M, T* sk, int* si, T* fk, int* fi,
+                                                  int* fcount) {
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+        sk[t] = ckey[t];
+        si[t] = cidx[t];
+    }
+    if (threadIdx.x == 0) *fcount = C < M ? C : M;
+    __syncthreads();
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+        const T k = sk[t];
+        const int i = si[t];
+        int rank = 0;
+        for (int s = 0; s < C; ++s) rank += lex_less<T>(sk[s], si[s], k, i) ? 1 : 0;
+        if (rank < M) {
+            fk[rank] = k;
+            fi[rank] = i;
+        }
     }
     __syncthreads();
 }
@@ -357,10 +615,14 @@ struct FinishArgs {
     const double* lam64;
     QInfo* info;
     int64_t n, d, dp, k, topk, nrows;
-    int nlists, M, metric;
-    double epskey, coef, nmax;
+    int nlists, M, metric, kernel;
+    double epskey, coef, nmax, sigma, p, tau0;
     as_knn_rec* recs;
     as_hit_rec* hits;
+    HostOut* hout;      // non-null: also publish the final answer (single-GPU fused tail)
+    int64_t seq;
+    int fuse;           // knn: compute lambda_q in the same launch; score: publish to hout
+    int from_list;      // candidates come from the wavefront lists instead of the filter buffer
     // build-fallback outputs (row-list form); null for searches
     int32_t* o_idx;
     double* o_key;
@@ -369,129 +631,10 @@ struct FinishArgs {
     int32_t* o_cnt;
 };
 
-template <typename T>
-__global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a, const T* pkey, const int* pidx) {
-    __shared__ T wk[16 * 64];
-    __shared__ int wi[16 * 64];
-    __shared__ T fk[64];
-    __shared__ int fi[64];
-    __shared__ double ek[64], ed[64], eg[64], sk[64];
-    __shared__ int fcount;
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    merge_partials<T>(pkey, pidx, a.nlists, a.M, wk, wi, fk, fi, &fcount);
-    const int Mp = fcount;
-    const double nq = a.info->nq;
-    for (int t = w; t < Mp; t += 16) {
-        const int j = fi[t];
-        double sq, dot;
-        exact_pair_q(a.x32, a.x64, a.q64, a.d, a.dp, j, sq, dot);
-        if (lane == 0) {
-            if (a.metric == AS_METRIC_L2) {
-                ek[t] = sq;
-                ed[t] = sqrt(sq);
-                eg[t] = dot;
-            } else {
-                const double den = sqrt(nq * a.n64[j]);
-                const double c = den > 0.0 ? dot / den : 0.0;
-                const double dd = 1.0 - (c > 0.0 ? c : 0.0);
-                ek[t] = dd;
-                ed[t] = dd;
-                eg[t] = c;
-            }
-        }
-    }
-    __syncthreads();
-    if (w != 0) return;
-    // rank by (key64, idx): one candidate per lane
-    const bool have = lane < Mp;
-    const double myk = have ? ek[lane] : 0.0;
-    const int myi = have ? fi[lane] : 0x7fffffff;
-    int rank = 0;
-    for (int s = 0; s < Mp; ++s) rank += lex_less<double>(ek[s], fi[s], myk, myi) ? 1 : 0;
-    if (have) sk[rank] = myk;
-    const bool pass = have && myk <= a.epskey;
-    const int npass = __popcll(__ballot(pass));
-    const int cnt = npass < a.k ? npass : (int)a.k;
-    if (a.recs) {
-        for (int64_t t = lane; t < a.k; t += 64) {
-            as_knn_rec r;
-            r.idx = -1;
-            r.key = key_traits<double>::inf();
-            r.dist = 0; r.gy = 0; r.deg = 0; r.ny = 0;
-            a.recs[t] = r;
-        }
-    }
-    if (a.o_idx)
-        for (int64_t t = lane; t < a.k; t += 64) a.o_idx[t] = -1;
-    if (pass && rank < a.k) {
-        if (a.recs) {
-            as_knn_rec r;
-            r.idx = myi;
-            r.key = myk;
-            r.dist = ed[lane];
-            r.gy = eg[lane];
-            r.deg = a.deg ? a.deg[myi] : 0.0;
-            r.ny = a.ny ? a.ny[myi] : 0.0;
-            a.recs[rank] = r;
-        }
-        if (a.o_idx) {
-            a.o_idx[rank] = myi;
-            a.o_key[rank] = myk;
-            a.o_dist[rank] = ed[lane];
-            a.o_gy[rank] = eg[lane];
-        }
-    }
-    if (lane == 0) {
-        if (a.o_cnt) *a.o_cnt = cnt;
-        int bad = 0;
-        if (a.info->knn_total > a.M && Mp > 0) {
-            const double B = npass >= a.k ? sk[a.k - 1] : a.epskey;
-            // dropped items' norms are unknown: bound them by the largest norm in the space
-            const double e = a.metric == AS_METRIC_L2 ? a.coef * (a.nmax + nq) : a.coef;
-            const double Tm = (double)fk[Mp - 1];
-            bad = !(Tm - e > B);
-        }
-        a.info->knn_inexact = bad;
-    }
-}
-
-// SPEC S10: lambda_q from m candidate records (this shard's, or all shards' gathered)
-__global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs, int64_t m, int64_t k, int M,
-                                                      int metric, int kernel, double sigma, double p, double tau0, QInfo* info) {
-    __shared__ double s_dist[64], s_gy[64], s_deg[64], s_ny[64];
-    __shared__ int s_id[64];
-    const int lane = lane_id();
-    WaveList<double> lst;
-    lst.init();
-    for (int64_t base = 0; base < m; base += 64) {
-        const int64_t t = base + lane;
-        const bool valid = t < m && recs[t].idx >= 0;
-        const double key = valid ? recs[t].key : key_traits<double>::inf();
-        const int id = valid ? (int)recs[t].idx : 0x7fffffff;
-        lst.offer(M, key, id, valid);
-    }
-    const bool sel = lane < k && lst.idx != 0x7fffffff;
-    const int cnt = __popcll(__ballot(sel));
-    // ascending-index order
-    int rank = 0;
-    for (int s = 0; s < 64; ++s) {
-        const int oi = bcast_lane(lst.idx, s);
-        const bool osel = s < k && oi != 0x7fffffff;
-        rank += (osel && oi < lst.idx) ? 1 : 0;
-    }
-    if (sel) {
-        // locate the record carrying this item (first match; duplicates are identical)
-        int64_t pos = -1;
-        for (int64_t t = 0; t < m; ++t)
-            if (pos < 0 && recs[t].idx == (int64_t)lst.idx) pos = t;
-        s_id[rank] = lst.idx;
-        s_dist[rank] = recs[pos].dist;
-        s_gy[rank] = recs[pos].gy;
-        s_deg[rank] = recs[pos].deg;
-        s_ny[rank] = recs[pos].ny;
-    }
-    __syncthreads();
-    if (lane != 0) return;
+// SPEC S10 given the selected neighbours in ascending index order (lane 0 only)
+__device__ __forceinline__ void lambda_from_sorted(int cnt, double* s_dist, const double* s_gy, const double* s_deg,
+                                                   const double* s_ny, int metric, int kernel, double sigma, double p,
+                                                   double tau0, QInfo* info) {
     double lam = 0.0;
     const double nq = info->nq;
     const double nyq = metric == AS_METRIC_L2 ? nq : (nq > 0.0 ? 1.0 : 0.0);
@@ -525,16 +668,193 @@ __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restri
     info->status = lam == 0.0 ? AS_EZEROLAMBDA : AS_OK;
 }
 
+// k-NN of the query: candidates -> M smallest fp32 keys -> fp64 re-evaluation -> (key64, idx)
+// order, eps, k cap, a-posteriori exactness check; optionally lambda_q in the same launch.
 template <typename T>
-__global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, const T* pkey, const int* pidx, double coef_s) {
-    __shared__ T wk[16 * 64];
-    __shared__ int wi[16 * 64];
+__global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a, const T* ckey, const int* cidx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sk = (T*)smem;                       // CAND_CAP keys (filter) or 16x64 wave lists
+    int* si = (int*)(sk + CAND_CAP);
     __shared__ T fk[64];
     __shared__ int fi[64];
-    __shared__ double es[64], sk[64];
+    __shared__ double ek[64], ed[64], eg[64], sk2[64];
+    __shared__ double l_dist[64], l_gy[64], l_deg[64], l_ny[64];
     __shared__ int fcount;
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    merge_partials<T>(pkey, pidx, a.nlists, a.M, wk, wi, fk, fi, &fcount);
+    int total;
+    if (a.from_list) {
+        merge_partials<T>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
+        total = a.info->knn_total;
+    } else {
+        const int raw = a.info->knn_cnt;
+        if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow = 1;
+        total = raw < CAND_CAP ? raw : CAND_CAP;
+        select_candidates<T>(ckey, cidx, total, a.M, sk, si, fk, fi, &fcount);
+    }
+    const int Mp = fcount;
+    const double nq = a.info->nq;
+    for (int t = w; t < Mp; t += 16) {
+        const int j = fi[t];
+        double sq, dot;
+        exact_pair_q(a.x32, a.x64, a.q64, a.d, a.dp, j, sq, dot);
+        if (lane == 0) {
+            if (a.metric == AS_METRIC_L2) {
+                ek[t] = sq;
+                ed[t] = sqrt(sq);
+                eg[t] = dot;
+            } else {
+                const double den = sqrt(nq * a.n64[j]);
+                const double c = den > 0.0 ? dot / den : 0.0;
+                const double dd = 1.0 - (c > 0.0 ? c : 0.0);
+                ek[t] = dd;
+                ed[t] = dd;
+                eg[t] = c;
+            }
+        }
+    }
+    __syncthreads();
+    if (w != 0) return;
+    // rank by (key64, idx): one candidate per lane
+    const bool have = lane < Mp;
+    const double myk = have ? ek[lane] : 0.0;
+    const int myi = have ? fi[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int s = 0; s < Mp; ++s) rank += lex_less<double>(ek[s], fi[s], myk, myi) ? 1 : 0;
+    if (have) sk2[rank] = myk;
+    const bool pass = have && myk <= a.epskey;
+    const int npass = __popcll(__ballot(pass));
+    const int cnt = npass < a.k ? npass : (int)a.k;
+    const bool sel = pass && rank < a.k;
+    if (a.recs) {
+        for (int64_t t = lane; t < a.k; t += 64) {
+            as_knn_rec r;
+            r.idx = -1;
+            r.key = key_traits<double>::inf();
+            r.dist = 0; r.gy = 0; r.deg = 0; r.ny = 0;
+            a.recs[t] = r;
+        }
+    }
+    if (a.o_idx)
+        for (int64_t t = lane; t < a.k; t += 64) a.o_idx[t] = -1;
+    const double mydeg = sel && a.deg ? a.deg[myi] : 0.0;
+    const double myny = sel && a.ny ? a.ny[myi] : 0.0;
+    if (sel) {
+        if (a.recs) {
+            as_knn_rec r;
+            r.idx = myi;
+            r.key = myk;
+            r.dist = ed[lane];
+            r.gy = eg[lane];
+            r.deg = mydeg;
+            r.ny = myny;
+            a.recs[rank] = r;
+        }
+        if (a.o_idx) {
+            a.o_idx[rank] = myi;
+            a.o_key[rank] = myk;
+            a.o_dist[rank] = ed[lane];
+            a.o_gy[rank] = eg[lane];
+        }
+    }
+    if (a.fuse) {
+        // ascending-index order of the selected neighbours
+        int irank = 0;
+        for (int s = 0; s < 64; ++s) {
+            const int oi = bcast_lane(myi, s);
+            const bool osel = (__ballot(sel) >> s) & 1ull;
+            irank += (osel && oi < myi) ? 1 : 0;
+        }
+        if (sel) {
+            l_dist[irank] = ed[lane];
+            l_gy[irank] = eg[lane];
+            l_deg[irank] = mydeg;
+            l_ny[irank] = myny;
+        }
+    }
+    AS_LDS_FENCE();
+    if (lane == 0) {
+        if (a.o_cnt) *a.o_cnt = cnt;
+        int bad = 0;
+        a.info->knn_total = total;
+        if (total > a.M && Mp > 0) {
+            const double B = npass >= a.k ? sk2[a.k - 1] : a.epskey;
+            // dropped items' norms are unknown: bound them by the largest norm in the space
+            const double e = a.metric == AS_METRIC_L2 ? a.coef * (a.nmax + nq) : a.coef;
+            const double Tm = (double)fk[Mp - 1];
+            bad = !(Tm - e > B);
+        }
+        a.info->knn_inexact = bad;
+        if (a.fuse) lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, a.metric, a.kernel, a.sigma, a.p, a.tau0, a.info);
+    }
+}
+
+// SPEC S10 from m candidate records (this shard's, or all shards' all-gathered)
+__global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs, int64_t m, int64_t k, int metric,
+                                                      int kernel, double sigma, double p, double tau0, QInfo* info) {
+    __shared__ double r_key[REC_CAP];
+    __shared__ int r_idx[REC_CAP];
+    __shared__ double l_dist[64], l_gy[64], l_deg[64], l_ny[64];
+    __shared__ int l_pos[64];
+    const int lane = lane_id();
+    const int mm = (int)(m < REC_CAP ? m : REC_CAP);
+    for (int t = lane; t < mm; t += 64) {
+        const bool valid = recs[t].idx >= 0;
+        r_key[t] = valid ? recs[t].key : key_traits<double>::inf();
+        r_idx[t] = valid ? (int)recs[t].idx : 0x7fffffff;
+    }
+    AS_LDS_FENCE();
+    // rank every record by (key, idx); the k best valid ones are the neighbours
+    int cnt_l = 0;
+    for (int t = lane; t < mm; t += 64) {
+        if (r_idx[t] == 0x7fffffff) continue;
+        int rank = 0;
+        for (int s = 0; s < mm; ++s) rank += lex_less<double>(r_key[s], r_idx[s], r_key[t], r_idx[t]) ? 1 : 0;
+        if (rank < k && rank < 64) {
+            l_pos[rank] = t;
+            cnt_l += 1;
+        }
+    }
+    const int cnt = wave_sum(cnt_l);
+    AS_LDS_FENCE();
+    // ascending-index order
+    if (lane < cnt) {
+        const int t = l_pos[lane];
+        int irank = 0;
+        for (int s = 0; s < cnt; ++s) irank += r_idx[l_pos[s]] < r_idx[t] ? 1 : 0;
+        l_dist[irank] = recs[t].dist;
+        l_gy[irank] = recs[t].gy;
+        l_deg[irank] = recs[t].deg;
+        l_ny[irank] = recs[t].ny;
+    }
+    AS_LDS_FENCE();
+    if (lane == 0) lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
+}
+
+__device__ __forceinline__ void publish(HostOut* out, int64_t seq) {
+    __threadfence_system();
+    out->seq = seq;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, const T* ckey, const int* cidx, double coef_s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sk = (T*)smem;
+    int* si = (int*)(sk + CAND_CAP);
+    __shared__ T fk[64];
+    __shared__ int fi[64];
+    __shared__ double es[64], sk2[64];
+    __shared__ int fcount;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    int total;
+    if (a.from_list) {
+        merge_partials<T>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
+        total = (int)(a.nrows < 0x7fffffff ? a.nrows : 0x7fffffff);
+    } else {
+        const int raw = a.info->sc_cnt;
+        if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow = 1;
+        total = raw < CAND_CAP ? raw : CAND_CAP;
+        select_candidates<T>(ckey, cidx, total, a.M, sk, si, fk, fi, &fcount);
+    }
     const int Mp = fcount;
     const double nq = a.info->nq, tau = a.info->tau, lq = a.info->lambda_q;
     for (int t = w; t < Mp; t += 16) {
@@ -554,58 +874,87 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, const 
     const int myi = have ? fi[lane] : 0x7fffffff;
     int rank = 0;
     for (int s = 0; s < Mp; ++s) rank += lex_less<double>(-es[s], fi[s], myk, myi) ? 1 : 0;
-    if (have) sk[rank] = es[lane];
-    for (int64_t t = lane; t < a.topk; t += 64) {
-        as_hit_rec r;
-        r.idx = -1;
-        r.score = -key_traits<double>::inf();
-        a.hits[t] = r;
+    if (have) sk2[rank] = es[lane];
+    const int64_t want = a.topk < a.nrows ? a.topk : a.nrows;
+    const int nhit = (int)(Mp < want ? Mp : want);
+    if (a.hits) {
+        for (int64_t t = lane; t < a.topk; t += 64) {
+            as_hit_rec r;
+            r.idx = -1;
+            r.score = -key_traits<double>::inf();
+            a.hits[t] = r;
+        }
+        if (have && rank < a.topk) {
+            as_hit_rec r;
+            r.idx = myi;
+            r.score = es[lane];
+            a.hits[rank] = r;
+        }
     }
-    if (have && rank < a.topk) {
-        as_hit_rec r;
-        r.idx = myi;
-        r.score = es[lane];
-        a.hits[rank] = r;
+    if (a.fuse && a.hout && have && rank < nhit) {
+        a.hout->idx[rank] = myi;
+        a.hout->score[rank] = es[lane];
     }
+    AS_LDS_FENCE();
     if (lane == 0) {
         int bad = 0;
-        const int64_t want = a.topk < a.nrows ? a.topk : a.nrows;
         if (a.nrows > a.M && Mp > 0) {
-            // every dropped item has score32 <= -fk[Mp-1]; exact score <= that + coef_s
-            const double kth = Mp >= want ? sk[want - 1] : -key_traits<double>::inf();
+            // every row outside the list has score32 <= -fk[Mp-1]; its exact score <= that + coef_s
+            const double kth = Mp >= want ? sk2[want - 1] : -key_traits<double>::inf();
             const double ub = -(double)fk[Mp - 1] + coef_s;
             bad = !(ub < kth);
         }
         a.info->score_inexact = bad;
-        a.info->nhit = (int)(Mp < want ? Mp : want);
+        a.info->nhit = nhit;
+        if (a.fuse && a.hout) {
+            a.hout->len = nhit;
+            a.hout->lambda_q = a.info->lambda_q;
+            a.hout->status = a.info->status;
+            a.hout->knn_inexact = a.info->knn_inexact;
+            a.hout->score_inexact = bad;
+            a.hout->overflow = a.info->overflow;
+            publish(a.hout, a.seq);
+        }
     }
 }
 
-// merge m hit records -> final topk, written to pinned host memory
-__global__ __launch_bounds__(64) void hits_final_kernel(const as_hit_rec* __restrict__ hits, int64_t m, int64_t topk, int M,
-                                                        const QInfo* info, HostOut* out) {
+// merge m hit records (own or all-gathered) -> final topk, written to pinned host memory
+__global__ __launch_bounds__(64) void hits_final_kernel(const as_hit_rec* __restrict__ hits, int64_t m, int64_t topk,
+                                                        const QInfo* info, HostOut* out, int64_t seq) {
+    __shared__ double r_key[REC_CAP];
+    __shared__ int r_idx[REC_CAP];
     const int lane = lane_id();
-    WaveList<double> lst;
-    lst.init();
-    for (int64_t base = 0; base < m; base += 64) {
-        const int64_t t = base + lane;
-        const bool valid = t < m && hits[t].idx >= 0;
-        lst.offer(M, valid ? -hits[t].score : key_traits<double>::inf(), valid ? (int)hits[t].idx : 0x7fffffff, valid);
+    const int mm = (int)(m < REC_CAP ? m : REC_CAP);
+    for (int t = lane; t < mm; t += 64) {
+        const bool valid = hits[t].idx >= 0;
+        r_key[t] = valid ? -hits[t].score : key_traits<double>::inf();
+        r_idx[t] = valid ? (int)hits[t].idx : 0x7fffffff;
     }
-    const bool sel = lane < topk && lst.idx != 0x7fffffff;
-    const int cnt = __popcll(__ballot(sel));
-    if (sel) {
-        out->idx[lane] = lst.idx;
-        out->score[lane] = -lst.key;
+    AS_LDS_FENCE();
+    int cnt_l = 0;
+    for (int t = lane; t < mm; t += 64) {
+        if (r_idx[t] == 0x7fffffff) continue;
+        int rank = 0;
+        for (int s = 0; s < mm; ++s) rank += lex_less<double>(r_key[s], r_idx[s], r_key[t], r_idx[t]) ? 1 : 0;
+        if (rank < topk && rank < MAX_LIST) {
+            out->idx[rank] = r_idx[t];
+            out->score[rank] = -r_key[t];
+            cnt_l += 1;
+        }
     }
+    const int cnt = wave_sum(cnt_l);
     if (lane == 0) {
         out->len = cnt;
         out->lambda_q = info->lambda_q;
         out->status = info->status;
         out->knn_inexact = info->knn_inexact;
         out->score_inexact = info->score_inexact;
+        out->overflow = info->overflow;
+        publish(out, seq);
     }
 }
+
+__global__ void set_tau_kernel(QInfo* info, double tau) { info->tau = tau; }
 
 // ------------------------------------------------------------------ host side
 static int list_width(int64_t k) {
@@ -620,7 +969,19 @@ static double coef_query(int64_t dp, bool exact) {
     return (double)(dp / 64 + 24) * u;
 }
 
-static as_status launch_scan(as_query* q) {
+static PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
+    const as_space* sp = q->sp;
+    PreArgs p;
+    p.n32 = sp->n32; p.inorm32 = sp->inorm32; p.n64 = sp->n64; p.info = q->info; p.infow = q->info;
+    p.ckey = q->ckey_k; p.cidx = q->cidx_k;
+    p.metric = sp->opts.metric;
+    p.epskey = p.metric == AS_METRIC_L2 ? eps * eps : eps;
+    p.coef = coef_query(sp->dp, q->exact != 0);
+    p.n = sp->n; p.exclude = exclude; p.enabled = enabled ? 1 : 0;
+    return p;
+}
+
+static as_status launch_scan(as_query* q, const PreArgs& pre) {
     const as_space* sp = q->sp;
     const int64_t rows = q->r1 - q->r0;
     if (rows <= 0) return AS_OK;
@@ -629,11 +990,11 @@ static as_status launch_scan(as_query* q) {
         if (!q->dots64) AS_HIP(hipMalloc(&q->dots64, sizeof(double) * (sp->np + ROW_TILE)));
         const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, 4096);
         hipLaunchKernelGGL(scan_dots_f64_kernel, dim3(grid), dim3(256), 0, st, sp->x32, sp->x64, q->q64, sp->d, sp->dp, q->r0,
-                           q->r1, q->dots64);
+                           q->r1, q->dots64, pre);
     } else {
         const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, 2048);
         const int nch = (int)((sp->dp + 255) / 256);
-#define AS_SCAN(N) hipLaunchKernelGGL(scan_dots_f32_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, q->dots32)
+#define AS_SCAN(N) hipLaunchKernelGGL(scan_dots_f32_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, q->dots32, pre)
         switch (nch) {
             case 1: AS_SCAN(1); break;
             case 2: AS_SCAN(2); break;
@@ -644,7 +1005,7 @@ static as_status launch_scan(as_query* q) {
             case 7: AS_SCAN(7); break;
             case 8: AS_SCAN(8); break;
             default:
-                hipLaunchKernelGGL(scan_dots_f32_generic_kernel, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, q->dots32);
+                hipLaunchKernelGGL(scan_dots_f32_generic_kernel, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, q->dots32, pre);
         }
 #undef AS_SCAN
     }
@@ -673,38 +1034,165 @@ static int sel_grid(as_query* q, int* nwaves) {
     return (int)(nw / 4);
 }
 
-static as_status run_knn(as_query* q, double eps, int64_t exclude, int32_t* o_idx, double* o_key, double* o_dist, double* o_gy,
-                         int32_t* o_cnt) {
+static FinishArgs make_finish(as_query* q) {
+    const as_space* sp = q->sp;
+    FinishArgs f;
+    memset(&f, 0, sizeof(f));
+    f.x32 = sp->x32; f.x64 = sp->x64; f.n64 = sp->n64; f.q64 = q->q64; f.lam64 = sp->lam64;
+    f.deg = q->gr ? q->gr->deg : nullptr; f.ny = q->gr ? q->gr->ny : nullptr;
+    f.info = q->info; f.n = sp->n; f.d = sp->d; f.dp = sp->dp; f.k = q->k; f.topk = q->topk; f.nrows = q->r1 - q->r0;
+    f.metric = sp->opts.metric; f.kernel = sp->opts.kernel; f.nmax = sp->nmax;
+    if (q->gr) {
+        f.sigma = q->gr->gp.sigma; f.p = q->gr->gp.p; f.tau0 = q->gr->tau0;
+    }
+    f.from_list = q->robust;
+    return f;
+}
+
+template <typename T>
+static size_t finish_lds() {
+    return (sizeof(T) + sizeof(int)) * (size_t)CAND_CAP;
+}
+
+// k-NN candidates of the scanned rows -> records (or row lists for the build fallback)
+static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lambda, int32_t* o_idx, double* o_key,
+                         double* o_dist, double* o_gy, int32_t* o_cnt) {
     const as_space* sp = q->sp;
     hipStream_t st = q->stream;
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? eps * eps : eps;
-    int nw = 0;
-    const int grid = sel_grid(q, &nw);
-    FinishArgs f;
-    memset(&f, 0, sizeof(f));
-    f.x32 = sp->x32; f.x64 = sp->x64; f.n64 = sp->n64; f.q64 = q->q64;
-    f.deg = q->gr ? q->gr->deg : nullptr; f.ny = q->gr ? q->gr->ny : nullptr; f.lam64 = sp->lam64;
-    f.info = q->info; f.n = sp->n; f.d = sp->d; f.dp = sp->dp; f.k = q->k; f.topk = q->topk; f.nrows = q->r1 - q->r0;
-    f.nlists = nw; f.M = q->Mk; f.metric = metric; f.epskey = epskey; f.nmax = sp->nmax;
-    f.recs = o_idx ? nullptr : q->knn; f.hits = nullptr;
+    FinishArgs f = make_finish(q);
+    f.M = q->Mk; f.epskey = epskey; f.coef = coef_query(sp->dp, q->exact != 0);
+    f.recs = o_idx ? nullptr : q->knn;
     f.o_idx = o_idx; f.o_key = o_key; f.o_dist = o_dist; f.o_gy = o_gy; f.o_cnt = o_cnt;
-    if (q->exact) {
-        SelArgs<double> a = make_sel<double>(q, q->dots64, q->Mk, exclude);
-        a.epskey = epskey;
-        a.coef = coef_query(sp->dp, true);
-        hipLaunchKernelGGL(knn_partial_kernel<double>, dim3(grid), dim3(256), 0, st, a);
-        f.coef = a.coef;
-        hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1), dim3(1024), 0, st, f, (const double*)q->pkey, (const int*)q->pidx);
+    f.fuse = fuse_lambda;
+    if (q->robust) {
+        int nw = 0;
+        const int grid = sel_grid(q, &nw);
+        f.nlists = nw;
+        if (q->exact) {
+            SelArgs<double> a = make_sel<double>(q, q->dots64, q->Mk, exclude);
+            a.epskey = epskey; a.coef = f.coef;
+            hipLaunchKernelGGL(knn_partial_kernel<double>, dim3(grid), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1), dim3(1024), finish_lds<double>(), st, f, (const double*)q->pkey, (const int*)q->pidx);
+        } else {
+            SelArgs<float> a = make_sel<float>(q, q->dots32, q->Mk, exclude);
+            a.epskey = epskey; a.coef = f.coef;
+            hipLaunchKernelGGL(knn_partial_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1), dim3(1024), finish_lds<float>(), st, f, (const float*)q->pkey, (const int*)q->pidx);
+        }
     } else {
-        SelArgs<float> a = make_sel<float>(q, q->dots32, q->Mk, exclude);
-        a.epskey = epskey;
-        a.coef = coef_query(sp->dp, false);
-        hipLaunchKernelGGL(knn_partial_kernel<float>, dim3(grid), dim3(256), 0, st, a);
-        f.coef = a.coef;
-        hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1), dim3(1024), 0, st, f, (const float*)q->pkey, (const int*)q->pidx);
+        if (q->exact)
+            hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1), dim3(1024), finish_lds<double>(), st, f, (const double*)q->ckey_k, (const int*)q->cidx_k);
+        else
+            hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1), dim3(1024), finish_lds<float>(), st, f, (const float*)q->ckey_k, (const int*)q->cidx_k);
     }
     AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+template <typename T, typename U, int PASSES>
+static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_final) {
+    hipStream_t st = q->stream;
+    f.M = q->Ms; f.hits = q->hits; f.fuse = fuse_final; f.hout = q->hout_dev; f.seq = q->seq;
+    const double coef_s = coef_query(q->sp->dp, sizeof(T) == 8);
+    if (q->robust) {
+        int nw = 0;
+        const int grid = sel_grid(q, &nw);
+        f.nlists = nw;
+        SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        hipLaunchKernelGGL(score_partial_kernel<T>, dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), finish_lds<T>(), st, f, (const T*)q->pkey, (const int*)q->pidx, coef_s);
+    } else {
+        const int64_t rows = q->r1 - q->r0;
+        int64_t G = (rows + CAND_CAP - 1) / CAND_CAP;
+        G = std::max<int64_t>(64, (G + 63) / 64 * 64);
+        const int ng = (int)((rows + G - 1) / G);
+        SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        hipLaunchKernelGGL(score_gmin_kernel<T>, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, st, a, G, ng, (T*)q->gmin);
+        hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
+        const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
+        hipLaunchKernelGGL(score_filter_kernel<T>, dim3(fg), dim3(256), 0, st, a, (T*)q->ckey_s, q->cidx_s);
+        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), finish_lds<T>(), st, f, (const T*)q->ckey_s, (const int*)q->cidx_s, coef_s);
+    }
+}
+
+static as_status run_score(as_query* q, double tau, int fuse_final) {
+    hipStream_t st = q->stream;
+    hipLaunchKernelGGL(set_tau_kernel, dim3(1), dim3(1), 0, st, q->info, tau);
+    if (q->r1 - q->r0 <= 0) {
+        AS_HIP(hipMemsetAsync(q->hits, 0xff, sizeof(as_hit_rec) * q->topk, st));
+        return AS_OK;
+    }
+    FinishArgs f = make_finish(q);
+    if (q->exact) launch_score<double, unsigned long long, 8>(q, q->dots64, f, fuse_final);
+    else launch_score<float, unsigned int, 4>(q, q->dots32, f, fuse_final);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+static as_status query_begin(as_query* q, const double* query_host, int64_t src_row, int64_t d, int64_t r0, int64_t r1,
+                             double eps, int64_t exclude) {
+    const as_space* sp = q->sp;
+    if (d != sp->d) {
+        set_err("query length %lld must match nfeatures %lld", (long long)d, (long long)sp->d);
+        return AS_EINVAL;
+    }
+    if (r0 < 0 || r1 > sp->n || r0 > r1) {
+        set_err("as_query_scan: bad row range");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    q->r0 = r0;
+    q->r1 = r1;
+    hipStream_t st = q->stream;
+    const bool stats = g_search_stats.load(std::memory_order_relaxed) != 0;
+    if (query_host) {
+        memcpy(q->hq, query_host, sizeof(double) * d);  // pinned + device-mapped: the kernel reads it in place
+    } else {
+        hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->hq_dev);
+    }
+    hipLaunchKernelGGL(q_prepare_kernel, dim3(1), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
+    if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
+    const PreArgs pre = make_pre(q, eps, exclude, !q->robust);
+    AS_TRY(launch_scan(q, pre));
+    if (stats) AS_HIP(hipEventRecord(q->ev[1], st));
+    q->ev_valid = stats ? 1 : 0;
+    return AS_OK;
+}
+
+// wait for the final kernel's publication (pinned memory), without the driver's sync path
+static as_status wait_published(as_query* q) {
+    const int64_t want = q->seq;
+    for (int spin = 0; spin < 2000000; ++spin) {
+        if (q->hout->seq == want) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return AS_OK;
+        }
+        if ((spin & 1023) == 1023 && hipStreamQuery(q->stream) == hipSuccess) break;
+    }
+    AS_HIP(hipStreamSynchronize(q->stream));
+    if (q->hout->seq != want) {
+        set_err("search result was not published (seq %lld != %lld)", (long long)q->hout->seq, (long long)want);
+        return AS_EHIP;
+    }
+    return AS_OK;
+}
+
+static as_status collect(as_query* q, int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q) {
+    const HostOut* h = q->hout;
+    if (out_lambda_q) *out_lambda_q = h->lambda_q;
+    if (h->status == AS_EZEROLAMBDA) {
+        if (out_len) *out_len = 0;
+        set_err("The lambdas are zero, check the magnitude of items and eps.");
+        return AS_EZEROLAMBDA;
+    }
+    const int64_t len = h->len;
+    for (int64_t t = 0; t < len; ++t) {
+        out_idx[t] = h->idx[t];
+        out_score[t] = h->score[t];
+    }
+    if (out_len) *out_len = len;
     return AS_OK;
 }
 
@@ -713,6 +1201,8 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int32_t* o_id
 using namespace as;
 
 extern "C" {
+
+void as_enable_search_stats(int32_t enabled) { g_search_stats.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out) {
     if (!sp || !out) {
@@ -734,17 +1224,27 @@ as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out
     }
     q->nwaves = 4096;
     AS_HIP(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
-    AS_HIP(hipMalloc(&q->qin, sizeof(double) * sp->d));
+    AS_HIP(hipHostMalloc(&q->hq, sizeof(double) * sp->d, hipHostMallocMapped | hipHostMallocCoherent));
+    AS_HIP(hipHostGetDevicePointer((void**)&q->hq_dev, q->hq, 0));
     AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp));
     AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp));
     AS_HIP(hipMalloc(&q->info, sizeof(QInfo)));
     AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE)));
     AS_HIP(hipMalloc(&q->pkey, sizeof(double) * (size_t)q->nwaves * 64));
     AS_HIP(hipMalloc(&q->pidx, sizeof(int) * (size_t)q->nwaves * 64));
+    AS_HIP(hipMalloc(&q->ckey_k, sizeof(double) * CAND_CAP));
+    AS_HIP(hipMalloc(&q->cidx_k, sizeof(int) * CAND_CAP));
+    AS_HIP(hipMalloc(&q->ckey_s, sizeof(double) * CAND_CAP));
+    AS_HIP(hipMalloc(&q->cidx_s, sizeof(int) * CAND_CAP));
+    AS_HIP(hipMalloc(&q->gmin, sizeof(double) * CAND_CAP));
     AS_HIP(hipMalloc(&q->knn, sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1)));
     AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * std::max<int64_t>(q->topk, 1)));
-    AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut), hipHostMallocDefault));
+    AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut), hipHostMallocMapped | hipHostMallocCoherent));
+    AS_HIP(hipHostGetDevicePointer((void**)&q->hout_dev, q->hout, 0));
+    memset(q->hout, 0, sizeof(HostOut));
     for (int i = 0; i < 3; ++i) AS_HIP(hipEventCreate(&q->ev[i]));
+    AS_HIP(hipFuncSetAttribute((const void*)knn_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<double>()));
+    AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<double>()));
     q->r0 = 0;
     q->r1 = sp->n;
     *out = q;
@@ -755,9 +1255,10 @@ void as_query_free(as_query* q) {
     if (!q) return;
     hipSetDevice(q->sp->device);
     hipStreamSynchronize(q->stream);
-    hipFree(q->qin); hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32);
+    hipHostFree(q->hq); hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32);
     if (q->dots64) hipFree(q->dots64);
-    hipFree(q->pkey); hipFree(q->pidx); hipFree(q->knn); hipFree(q->hits);
+    hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
+    hipFree(q->gmin); hipFree(q->knn); hipFree(q->hits);
     hipHostFree(q->hout);
     for (int i = 0; i < 3; ++i) hipEventDestroy(q->ev[i]);
     hipStreamDestroy(q->stream);
@@ -770,42 +1271,13 @@ int64_t as_query_knn_capacity(const as_query* q) { return q->k; }
 const as_hit_rec* as_query_hit_records(const as_query* q) { return q->hits; }
 int64_t as_query_hit_capacity(const as_query* q) { return q->topk; }
 
-static as_status query_scan_impl(as_query* q, const double* query_host, const double* query_dev_row_of, int64_t src_row,
-                                 int64_t d, int64_t r0, int64_t r1, double tau_unused) {
-    (void)tau_unused;
-    const as_space* sp = q->sp;
-    if (d != sp->d) {
-        set_err("query length %lld must match nfeatures %lld", (long long)d, (long long)sp->d);
-        return AS_EINVAL;
-    }
-    if (r0 < 0 || r1 > sp->n || r0 > r1) {
-        set_err("as_query_scan: bad row range");
-        return AS_EINVAL;
-    }
-    AS_HIP(hipSetDevice(sp->device));
-    q->r0 = r0;
-    q->r1 = r1;
-    hipStream_t st = q->stream;
-    if (query_host) {
-        AS_HIP(hipMemcpyAsync(q->qin, query_host, sizeof(double) * d, hipMemcpyHostToDevice, st));
-    } else {
-        (void)query_dev_row_of;
-        hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->qin);
-    }
-    hipLaunchKernelGGL(q_prepare_kernel, dim3(1), dim3(256), 0, st, q->qin, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
-    AS_HIP(hipEventRecord(q->ev[0], st));
-    AS_TRY(launch_scan(q));
-    AS_HIP(hipEventRecord(q->ev[1], st));
-    return AS_OK;
-}
-
 as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end) {
-    if (!q || !query_host) {
+    if (!q || !query_host || !q->gr) {
         set_err("as_query_scan: null argument");
         return AS_EINVAL;
     }
-    AS_TRY(query_scan_impl(q, query_host, nullptr, -1, d, row_begin, row_end, 0.0));
-    return run_knn(q, q->gr->gp.eps, -1, nullptr, nullptr, nullptr, nullptr, nullptr);
+    AS_TRY(query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1));
+    return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {
@@ -813,48 +1285,23 @@ as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {
         set_err("as_query_lambda: null argument");
         return AS_EINVAL;
     }
+    if (m > REC_CAP) {
+        set_err("as_query_lambda: %lld records exceed the supported %d", (long long)m, REC_CAP);
+        return AS_EUNSUPPORTED;
+    }
     const as_graph* gr = q->gr;
-    hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, q->stream, recs_dev, m, q->k, q->Mk, gr->metric, gr->kernel,
+    hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, q->stream, recs_dev, m, q->k, gr->metric, gr->kernel,
                        gr->gp.sigma, gr->gp.p, gr->tau0, q->info);
     AS_HIP(hipGetLastError());
     return AS_OK;
 }
-
-__global__ void set_tau_kernel(QInfo* info, double tau) { info->tau = tau; }
 
 as_status as_query_score(as_query* q, double tau) {
     if (!q || !q->gr) {
         set_err("as_query_score: null argument");
         return AS_EINVAL;
     }
-    const as_space* sp = q->sp;
-    hipStream_t st = q->stream;
-    hipLaunchKernelGGL(set_tau_kernel, dim3(1), dim3(1), 0, st, q->info, tau);
-    int nw = 0;
-    const int grid = sel_grid(q, &nw);
-    FinishArgs f;
-    memset(&f, 0, sizeof(f));
-    f.x32 = sp->x32; f.x64 = sp->x64; f.n64 = sp->n64; f.q64 = q->q64; f.lam64 = sp->lam64;
-    f.info = q->info; f.n = sp->n; f.d = sp->d; f.dp = sp->dp; f.k = q->k; f.topk = q->topk; f.nrows = q->r1 - q->r0;
-    f.nlists = nw; f.M = q->Ms; f.metric = sp->opts.metric; f.hits = q->hits;
-    if (q->r1 - q->r0 <= 0) {
-        // empty shard: publish empty hit records
-        AS_HIP(hipMemsetAsync(q->hits, 0xff, sizeof(as_hit_rec) * q->topk, st));
-        return AS_OK;
-    }
-    if (q->exact) {
-        SelArgs<double> a = make_sel<double>(q, q->dots64, q->Ms, -1);
-        hipLaunchKernelGGL(score_partial_kernel<double>, dim3(grid), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(score_finish_kernel<double>, dim3(1), dim3(1024), 0, st, f, (const double*)q->pkey, (const int*)q->pidx,
-                           coef_query(sp->dp, true));
-    } else {
-        SelArgs<float> a = make_sel<float>(q, q->dots32, q->Ms, -1);
-        hipLaunchKernelGGL(score_partial_kernel<float>, dim3(grid), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(score_finish_kernel<float>, dim3(1), dim3(1024), 0, st, f, (const float*)q->pkey, (const int*)q->pidx,
-                           coef_query(sp->dp, false));
-    }
-    AS_HIP(hipGetLastError());
-    return AS_OK;
+    return run_score(q, tau, 0);
 }
 
 as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, int64_t* out_idx, double* out_score,
@@ -863,44 +1310,41 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
         set_err("as_query_finish: null argument");
         return AS_EINVAL;
     }
+    if (m > REC_CAP) {
+        set_err("as_query_finish: %lld records exceed the supported %d", (long long)m, REC_CAP);
+        return AS_EUNSUPPORTED;
+    }
     hipStream_t st = q->stream;
     const int64_t topk = std::min<int64_t>(q->gr->gp.topk, q->sp->n);
-    hipLaunchKernelGGL(hits_final_kernel, dim3(1), dim3(64), 0, st, hits_dev, m, topk, q->Ms, q->info, q->hout);
+    q->seq += 1;
+    hipLaunchKernelGGL(hits_final_kernel, dim3(1), dim3(64), 0, st, hits_dev, m, topk, q->info, q->hout_dev, q->seq);
     AS_HIP(hipGetLastError());
-    AS_HIP(hipEventRecord(q->ev[2], st));
-    AS_HIP(hipStreamSynchronize(st));
-    const HostOut* h = q->hout;
-    if (out_lambda_q) *out_lambda_q = h->lambda_q;
-    if (h->status == AS_EZEROLAMBDA) {
-        if (out_len) *out_len = 0;
-        set_err("The lambdas are zero, check the magnitude of items and eps.");
-        return AS_EZEROLAMBDA;
-    }
-    const int64_t len = h->len;
-    for (int64_t t = 0; t < len; ++t) {
-        out_idx[t] = h->idx[t];
-        out_score[t] = h->score[t];
-    }
-    if (out_len) *out_len = len;
-    return AS_OK;
+    if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], st));
+    AS_TRY(wait_published(q));
+    return collect(q, out_idx, out_score, out_len, out_lambda_q);
 }
 
-void as_query_set_exact(as_query* q, int32_t exact) {
-    if (q) q->exact = exact ? 1 : 0;
+void as_query_set_exact(as_query* q, int32_t flags) {
+    if (!q) return;
+    q->exact = (flags & 1) ? 1 : 0;
+    q->robust = (flags & 2) ? 1 : 0;
 }
 
 as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact) {
     if (!q) return AS_EINVAL;
-    if (knn_inexact) *knn_inexact = q->hout->knn_inexact;
-    if (score_inexact) *score_inexact = q->hout->score_inexact;
+    if (knn_inexact) *knn_inexact = q->hout->knn_inexact | (q->hout->overflow ? 2 : 0);
+    if (score_inexact) *score_inexact = q->hout->score_inexact | (q->hout->overflow ? 2 : 0);
     return AS_OK;
 }
 
 as_status as_query_stats(const as_query* q, double* out, int32_t n) {
     if (!q || !out) return AS_EINVAL;
     float ms01 = 0, ms12 = 0;
-    hipEventElapsedTime(&ms01, q->ev[0], q->ev[1]);
-    hipEventElapsedTime(&ms12, q->ev[1], q->ev[2]);
+    if (q->ev_valid) {
+        hipEventSynchronize(q->ev[2]);
+        hipEventElapsedTime(&ms01, q->ev[0], q->ev[1]);
+        hipEventElapsedTime(&ms12, q->ev[1], q->ev[2]);
+    }
     const double v[3] = {ms01 * 1e3, ms12 * 1e3, q->stats[2]};
     for (int i = 0; i < n && i < 3; ++i) out[i] = v[i];
     return AS_OK;
@@ -913,16 +1357,21 @@ namespace as {
 void query_flags(const as_query* q, int* knn_inexact, int* score_inexact) {
     *knn_inexact = q->hout->knn_inexact;
     *score_inexact = q->hout->score_inexact;
+    if (q->hout->overflow) *knn_inexact |= 2;
 }
 
-// one full search on q's stream; exact=1 reruns everything in fp64
-as_status search_once(as_query* q, const double* query, int64_t d, double tau, int exact, int64_t* out_idx, double* out_score,
+// one full single-GPU search on q's stream: 6 launches, one host wait
+as_status search_once(as_query* q, const double* query, int64_t d, double tau, int mode, int64_t* out_idx, double* out_score,
                       int64_t* out_len, double* out_lambda_q) {
-    q->exact = exact || q->sp->opts.force_exact;
-    AS_TRY(as_query_scan(q, query, d, 0, q->sp->n));
-    AS_TRY(as_query_lambda(q, q->knn, q->k));
-    AS_TRY(as_query_score(q, tau));
-    return as_query_finish(q, q->hits, q->topk, out_idx, out_score, out_len, out_lambda_q);
+    q->exact = (mode & 1) || q->sp->opts.force_exact;
+    q->robust = (mode & 2) ? 1 : 0;
+    AS_TRY(query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1));
+    AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+    q->seq += 1;
+    AS_TRY(run_score(q, tau, 1));
+    if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
+    AS_TRY(wait_published(q));
+    return collect(q, out_idx, out_score, out_len, out_lambda_q);
 }
 
 as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, int32_t* out_idx, double* out_key,
@@ -935,10 +1384,9 @@ as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, in
         return AS_EUNSUPPORTED;
     }
     ws->exact = 1;
-    AS_TRY(query_scan_impl(ws, nullptr, nullptr, row, sp->d, 0, sp->n, 0.0));
-    AS_TRY(run_knn(ws, gp->eps, row, out_idx, out_key, out_dist, out_gy, out_cnt));
-    return AS_OK;
+    ws->robust = 1;  // rows with many near-ties are exactly the ones that overflow a filter buffer
+    AS_TRY(query_begin(ws, nullptr, row, sp->d, 0, sp->n, gp->eps, row));
+    return run_knn(ws, gp->eps, row, 0, out_idx, out_key, out_dist, out_gy, out_cnt);
 }
-
 
 }  // namespace as

@@ -57,3 +57,48 @@ def test_build_and_search_match_oracle(oracle_lib, n, d, k, topk, metric, kernel
             assert [i for i, _ in got] == [i for i, _ in want], (qi, tau)
             np.testing.assert_allclose([s for _, s in got], [s for _, s in want], rtol=RTOL)
             assert abs(aspace.query_lambda(q, gl) - lq_ref) <= RTOL * abs(lq_ref)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_search_fallback_paths_match_oracle(oracle_lib, mode):
+    """bit0 = fp64 end to end, bit1 = wavefront-shuffle list selection (overflow fallback)."""
+    import pyarrowspace_amd as asp
+    n, d, k, topk = 1500, 96, 10, 8
+    X = clustered(n, d, nclust=12, seed=11)
+    eps = calibrate_eps(X, k)
+    gp = {"eps": eps, "k": k, "topk": topk, "p": 2.0, "sigma": None, "_search_mode": mode}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
+        for tau in (1.0, 0.62, 0.0):
+            want, _ = ref.search(q, tau)
+            got = aspace.search(q, gl, tau)
+            assert [i for i, _ in got] == [i for i, _ in want]
+            np.testing.assert_allclose([s for _, s in got], [s for _, s in want], rtol=RTOL)
+
+
+def test_build_exact_fallback_matches_oracle(oracle_lib):
+    """force_exact routes every row through the fp64 brute-force fallback of the build."""
+    n, d, k = 400, 40, 7
+    X = clustered(n, d, nclust=6, seed=5)
+    gp = {"eps": calibrate_eps(X, k), "k": k, "topk": 5, "p": 2.0, "sigma": None, "force_exact": True}
+    aspace, gl, ref = _build_both(X, gp, oracle_lib)
+    _check_index(aspace, gl, ref)
+
+
+def test_non_fp32_representable_items_keep_fp64(oracle_lib):
+    """Items that do not round-trip through fp32 keep an fp64 copy for the exact re-evaluation."""
+    n, d, k = 600, 48, 6
+    X = clustered(n, d, nclust=8, seed=9) * (1.0 + 1e-9)
+    assert not np.array_equal(X.astype(np.float32).astype(np.float64), X)
+    gp = {"eps": calibrate_eps(X, k), "k": k, "topk": 6, "p": 2.0, "sigma": None}
+    aspace, gl, ref = _build_both(X, gp, oracle_lib)
+    _check_index(aspace, gl, ref)
+    v, lam = aspace.get_item(17)
+    assert np.array_equal(v, X[17]) and abs(lam - ref.lambdas[17]) <= RTOL * abs(ref.lambdas[17])
+    q = X[5] * 1.01
+    want, _ = ref.search(q, 0.62)
+    got = aspace.search(q, gl, 0.62)
+    assert [i for i, _ in got] == [i for i, _ in want]
