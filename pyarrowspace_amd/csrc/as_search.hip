@@ -61,6 +61,8 @@ struct as_query {
     int64_t k = 0, topk = 0;
     int Mk = 32, Ms = 32;
     int nwaves = 0;
+    int cus = 256;
+    int scan_grid = 0;
     int64_t r0 = 0, r1 = 0;
     int exact = 0;
     int robust = 0;          // 1: wavefront-list path instead of the filter path
@@ -165,15 +167,15 @@ struct PreArgs {
     int metric, enabled;
 };
 
-__device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, float dot, float nq32, float inq32) {
+// aux = n32[row] (L2) or inorm32[row] (cosine), loaded by the caller together with the row
+__device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, float dot, float aux, float nq32, float inq32) {
     if (!p.enabled || row >= p.n || row == p.exclude) return;
     float key, bound;
     if (p.metric == AS_METRIC_L2) {
-        const float ni = p.n32[row];
-        key = fmaf(-2.0f, dot, ni + nq32);
-        bound = ((float)p.epskey + (float)p.coef * (ni + nq32)) * 1.000001f;
+        key = fmaf(-2.0f, dot, aux + nq32);
+        bound = ((float)p.epskey + (float)p.coef * (aux + nq32)) * 1.000001f;
     } else {
-        key = 1.0f - fmaxf(0.0f, dot * p.inorm32[row] * inq32);
+        key = 1.0f - fmaxf(0.0f, dot * aux * inq32);
         bound = ((float)p.epskey + (float)p.coef) * 1.000001f;
     }
     if (key <= bound) {
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     const float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
     f32x4 qv[NCH];
     bool on[NCH];
 #pragma unroll
@@ -213,6 +216,9 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
             va[u] = on[u] ? __builtin_nontemporal_load((const f32x4*)(pa + 256 * u)) : f32x4{0, 0, 0, 0};
             vb[u] = on[u] ? __builtin_nontemporal_load((const f32x4*)(pb + 256 * u)) : f32x4{0, 0, 0, 0};
         }
+        // lanes 0 / 1 own the two results; their aux value is in flight with the row loads
+        const int64_t myrow = row + (lane & 1) * nw;
+        const float aux = auxv[myrow];
         float sa = 0.0f, sb = 0.0f;
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
@@ -224,11 +230,10 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
         }
         sa = wave_sum(sa);
         sb = wave_sum(sb);
-        if (lane == 0) {
-            dots[row] = sa;
-            dots[row + nw] = sb;
-            prefilter_f32(pre, row, sa, nq32, inq32);
-            prefilter_f32(pre, row + nw, sb, nq32, inq32);
+        if (lane < 2) {
+            const float dot = lane ? sb : sa;
+            dots[myrow] = dot;
+            prefilter_f32(pre, myrow, dot, aux, nq32, inq32);
         }
     }
     if (row < r1) {
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
         sa = wave_sum(sa);
         if (lane == 0) {
             dots[row] = sa;
-            prefilter_f32(pre, row, sa, nq32, inq32);
+            prefilter_f32(pre, row, sa, auxv[row], nq32, inq32);
         }
     }
 }
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_generic_kernel(const float*
         s = wave_sum(s);
         if (lane == 0) {
             dots[row] = s;
-            prefilter_f32(pre, row, s, nq32, inq32);
+            prefilter_f32(pre, row, s, (pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32)[row], nq32, inq32);
         }
     }
 }
@@ -332,7 +337,7 @@ struct SelArgs {
     QInfo* info_w;
     int64_t n, r0, r1, exclude;
     int M, metric;
-    double epskey, coef;
+    double epskey, coef, tau;
     T* pkey;
     int* pidx;
 };
@@ -341,10 +346,10 @@ struct ScoreCtx {
     double nq, tau, lq;
     float tau32, lq32, inq32;
 };
-__device__ __forceinline__ ScoreCtx load_ctx(const QInfo* info) {
+__device__ __forceinline__ ScoreCtx load_ctx(const QInfo* info, double tau) {
     ScoreCtx c;
     c.nq = info->nq;
-    c.tau = info->tau;
+    c.tau = tau;
     c.lq = info->lambda_q;
     c.tau32 = (float)c.tau;
     c.lq32 = (float)c.lq;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G
     const int lane = lane_id();
     const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= ngroups) return;
-    const ScoreCtx c = load_ctx(a.info);
+    const ScoreCtx c = load_ctx(a.info, a.tau);
     const int64_t lo = a.r0 + g * G;
     const int64_t hi = lo + G < a.r1 ? lo + G : a.r1;
     T m = key_traits<T>::inf();
@@ -444,15 +449,34 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
             atomicAdd(&hist[(unsigned int)((v[q] >> shift) & (U)255)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int run = 0, b = 0;
+        if (tid < 64) {
+            // wave 0: 4 bins per lane, inclusive scan over lanes, the lane whose range holds the rank finishes
             const int rank = s_rank;
-            for (; b < 256; ++b) {
-                if (run + (int)hist[b] > rank) break;
-                run += (int)hist[b];
+            unsigned int h[4];
+            unsigned int tot = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[j] = hist[4 * tid + j];
+                tot += h[j];
             }
-            s_rank = rank - run;
-            s_prefix = (prefix << 8) | (U)b;
+            unsigned int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += t;
+            }
+            const int excl = (int)(incl - tot);
+            if (rank >= excl && rank < (int)incl) {
+                int run = excl, b = 4 * tid;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (run + (int)h[j] > rank) break;
+                    run += (int)h[j];
+                    b += 1;
+                }
+                s_rank = rank - run;
+                s_prefix = (prefix << 8) | (U)b;
+            }
         }
         __syncthreads();
     }
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
 // (3) append every row whose key <= threshold
 template <typename T>
 __global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a, T* __restrict__ ckey, int* __restrict__ cidx) {
-    const ScoreCtx c = load_ctx(a.info);
+    const ScoreCtx c = load_ctx(a.info, a.tau);
     const T thr = sizeof(T) == 4 ? (T)a.info->thr32 : (T)a.info->thr64;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(256) void score_partial_kernel(SelArgs<T> a) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const ScoreCtx c = load_ctx(a.info);
+    const ScoreCtx c = load_ctx(a.info, a.tau);
     WaveList<T> lst;
     lst.init();
     for (int64_t base = a.r0 + gw * 64; base < a.r1; base += nw * 64) {
@@ -582,27 +606,43 @@ __device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx
     __syncthreads();
 }
 
-__device__ __forceinline__ void exact_pair_q(const float* x32, const double* x64, const double* q64, int64_t d, int64_t dp,
-                                             int64_t j, double& sq, double& dot) {
-    const int lane = lane_id();
+// exact fp64 (squared distance, dot) of the query against up to 64 candidate rows at once:
+// 16 lanes per candidate (thread t -> candidate t>>4), block of 1024 threads
+__device__ __forceinline__ void exact_eval_all(const float* x32, const double* x64, const double* q64, int64_t d, int64_t dp,
+                                               const int* fi, int Mp, double* o_sq, double* o_dot) {
+    const int c = threadIdx.x >> 4, sub = threadIdx.x & 15;
     double s = 0.0, g = 0.0;
-    if (x64) {
-        const double* pj = x64 + j * d;
-        for (int64_t c = lane; c < d; c += 64) {
-            const double a = q64[c], b = pj[c], t = a - b;
-            s += t * t;
-            g += a * b;
-        }
-    } else {
-        const float* pj = x32 + j * dp;
-        for (int64_t c = lane; c < d; c += 64) {
-            const double a = q64[c], b = (double)pj[c], t = a - b;
-            s += t * t;
-            g += a * b;
+    if (c < Mp) {
+        const int64_t j = fi[c];
+        if (x64) {
+            const double* pj = x64 + j * d;
+            for (int64_t e = sub; e < d; e += 16) {
+                const double a = q64[e], b = pj[e], t = a - b;
+                s += t * t;
+                g += a * b;
+            }
+        } else {
+            const float* pj = x32 + j * dp;  // rows and the query are zero padded to dp
+            for (int64_t e = 4 * sub; e < dp; e += 64) {
+                const f32x4 v = *(const f32x4*)(pj + e);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double a = q64[e + u], b = (double)v[u], t = a - b;
+                    s += t * t;
+                    g += a * b;
+                }
+            }
         }
     }
-    sq = wave_sum(s);
-    dot = wave_sum(g);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        g += __shfl_xor(g, o, 64);
+    }
+    if (c < Mp && sub == 0) {
+        o_sq[c] = s;
+        o_dot[c] = g;
+    }
 }
 
 struct FinishArgs {
@@ -616,7 +656,7 @@ struct FinishArgs {
     QInfo* info;
     int64_t n, d, dp, k, topk, nrows;
     int nlists, M, metric, kernel;
-    double epskey, coef, nmax, sigma, p, tau0;
+    double epskey, coef, nmax, sigma, p, tau0, tau;
     as_knn_rec* recs;
     as_hit_rec* hits;
     HostOut* hout;      // non-null: also publish the final answer (single-GPU fused tail)
@@ -631,41 +671,40 @@ struct FinishArgs {
     int32_t* o_cnt;
 };
 
-// SPEC S10 given the selected neighbours in ascending index order (lane 0 only)
-__device__ __forceinline__ void lambda_from_sorted(int cnt, double* s_dist, const double* s_gy, const double* s_deg,
+// SPEC S10 given the selected neighbours in ascending index order in LDS; one wave, lane t
+// owns neighbour t, sums are fixed-order butterflies (deterministic).
+__device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist, const double* s_gy, const double* s_deg,
                                                    const double* s_ny, int metric, int kernel, double sigma, double p,
                                                    double tau0, QInfo* info) {
-    double lam = 0.0;
+    const int lane = lane_id();
     const double nq = info->nq;
     const double nyq = metric == AS_METRIC_L2 ? nq : (nq > 0.0 ? 1.0 : 0.0);
-    if (cnt > 0 && nyq > 0.0) {
-        double degq = 0.0;
-        for (int t = 0; t < cnt; ++t) degq += edge_weight(s_dist[t], sigma, p, kernel);
-        if (degq > 0.0) {
-            double S = 0.0;
-            for (int t = 0; t < cnt; ++t) {
-                const double at = edge_weight(s_dist[t], sigma, p, kernel);
-                const double dj = s_deg[t] + at;
-                const double sdd = sqrt(degq * dj);
-                const double v = at * (nyq / degq + s_ny[t] / dj - 2.0 * s_gy[t] / sdd);
-                const double ev = v > 0.0 ? v : 0.0;
-                s_dist[t] = ev;  // reuse as the edge energy
-                S += ev;
-            }
-            const double Eq = 0.5 * S / nyq;
-            double Gq = 0.0;
-            if (S > 0.0) {
-                for (int t = 0; t < cnt; ++t) {
-                    const double r = s_dist[t] / S;
-                    Gq += r * r;
-                }
-                Gq = Gq < 0.0 ? 0.0 : (Gq > 1.0 ? 1.0 : Gq);
-            }
-            lam = tau0 * (Eq / (Eq + tau0)) + (1.0 - tau0) * Gq;
+    const bool on = lane < cnt;
+    const double at = on ? edge_weight(s_dist[lane], sigma, p, kernel) : 0.0;
+    const double degq = wave_sum(at);
+    double lam = 0.0;
+    if (cnt > 0 && nyq > 0.0 && degq > 0.0) {
+        double ev = 0.0;
+        if (on) {
+            const double dj = s_deg[lane] + at;
+            const double sdd = sqrt(degq * dj);
+            const double v = at * (nyq / degq + s_ny[lane] / dj - 2.0 * s_gy[lane] / sdd);
+            ev = v > 0.0 ? v : 0.0;
         }
+        const double S = wave_sum(ev);
+        const double Eq = 0.5 * S / nyq;
+        double Gq = 0.0;
+        if (S > 0.0) {
+            const double r = ev / S;
+            Gq = wave_sum(r * r);
+            Gq = Gq < 0.0 ? 0.0 : (Gq > 1.0 ? 1.0 : Gq);
+        }
+        lam = tau0 * (Eq / (Eq + tau0)) + (1.0 - tau0) * Gq;
     }
-    info->lambda_q = lam;
-    info->status = lam == 0.0 ? AS_EZEROLAMBDA : AS_OK;
+    if (lane == 0) {
+        info->lambda_q = lam;
+        info->status = lam == 0.0 ? AS_EZEROLAMBDA : AS_OK;
+    }
 }
 
 // k-NN of the query: candidates -> M smallest fp32 keys -> fp64 re-evaluation -> (key64, idx)
@@ -693,23 +732,20 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a, const T*
     }
     const int Mp = fcount;
     const double nq = a.info->nq;
-    for (int t = w; t < Mp; t += 16) {
-        const int j = fi[t];
-        double sq, dot;
-        exact_pair_q(a.x32, a.x64, a.q64, a.d, a.dp, j, sq, dot);
-        if (lane == 0) {
-            if (a.metric == AS_METRIC_L2) {
-                ek[t] = sq;
-                ed[t] = sqrt(sq);
-                eg[t] = dot;
-            } else {
-                const double den = sqrt(nq * a.n64[j]);
-                const double c = den > 0.0 ? dot / den : 0.0;
-                const double dd = 1.0 - (c > 0.0 ? c : 0.0);
-                ek[t] = dd;
-                ed[t] = dd;
-                eg[t] = c;
-            }
+    exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, fi, Mp, ek, eg);
+    __syncthreads();
+    if (threadIdx.x < Mp) {
+        const int t = threadIdx.x;
+        const double sq = ek[t], dot = eg[t];
+        if (a.metric == AS_METRIC_L2) {
+            ed[t] = sqrt(sq);
+        } else {
+            const double den = sqrt(nq * a.n64[fi[t]]);
+            const double c = den > 0.0 ? dot / den : 0.0;
+            const double dd = 1.0 - (c > 0.0 ? c : 0.0);
+            ek[t] = dd;
+            ed[t] = dd;
+            eg[t] = c;
         }
     }
     __syncthreads();
@@ -784,8 +820,8 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a, const T*
             bad = !(Tm - e > B);
         }
         a.info->knn_inexact = bad;
-        if (a.fuse) lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, a.metric, a.kernel, a.sigma, a.p, a.tau0, a.info);
     }
+    if (a.fuse) lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, a.metric, a.kernel, a.sigma, a.p, a.tau0, a.info);
 }
 
 // SPEC S10 from m candidate records (this shard's, or all shards' all-gathered)
@@ -827,7 +863,7 @@ __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restri
         l_ny[irank] = recs[t].ny;
     }
     AS_LDS_FENCE();
-    if (lane == 0) lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
+    lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
 }
 
 __device__ __forceinline__ void publish(HostOut* out, int64_t seq) {
@@ -856,16 +892,15 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, const 
         select_candidates<T>(ckey, cidx, total, a.M, sk, si, fk, fi, &fcount);
     }
     const int Mp = fcount;
-    const double nq = a.info->nq, tau = a.info->tau, lq = a.info->lambda_q;
-    for (int t = w; t < Mp; t += 16) {
+    const double nq = a.info->nq, tau = a.tau, lq = a.info->lambda_q;
+    exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, fi, Mp, sk2, es);
+    __syncthreads();
+    if (threadIdx.x < Mp) {
+        const int t = threadIdx.x;
         const int j = fi[t];
-        double sq, dot;
-        exact_pair_q(a.x32, a.x64, a.q64, a.d, a.dp, j, sq, dot);
-        if (lane == 0) {
-            const double den = sqrt(a.n64[j] * nq);
-            const double c = den > 0.0 ? dot / den : 0.0;
-            es[t] = tau * c + (1.0 - tau) / (1.0 + fabs(lq - a.lam64[j]));
-        }
+        const double den = sqrt(a.n64[j] * nq);
+        const double c = den > 0.0 ? es[t] / den : 0.0;
+        es[t] = tau * c + (1.0 - tau) / (1.0 + fabs(lq - a.lam64[j]));
     }
     __syncthreads();
     if (w != 0) return;
@@ -954,8 +989,6 @@ __global__ __launch_bounds__(64) void hits_final_kernel(const as_hit_rec* __rest
     }
 }
 
-__global__ void set_tau_kernel(QInfo* info, double tau) { info->tau = tau; }
-
 // ------------------------------------------------------------------ host side
 static int list_width(int64_t k) {
     const int64_t need = k + 8;
@@ -992,9 +1025,20 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
         hipLaunchKernelGGL(scan_dots_f64_kernel, dim3(grid), dim3(256), 0, st, sp->x32, sp->x64, q->q64, sp->d, sp->dp, q->r0,
                            q->r1, q->dots64, pre);
     } else {
-        const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, 2048);
         const int nch = (int)((sp->dp + 255) / 256);
-#define AS_SCAN(N) hipLaunchKernelGGL(scan_dots_f32_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, q->dots32, pre)
+        // resident grid: every wave gets the same number of rows and all of them run at once
+        // (a grid one block over residency costs a whole extra round at 1/8 occupancy)
+#define AS_SCAN(N)                                                                                                     \
+    do {                                                                                                               \
+        if (!q->scan_grid) {                                                                                           \
+            int nb = 0;                                                                                                \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_dots_f32_kernel<N>, 256, 0) != hipSuccess) nb = 4; \
+            q->scan_grid = q->cus * std::max(1, std::min(nb, 8));                                                      \
+        }                                                                                                              \
+        const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->scan_grid);                               \
+        hipLaunchKernelGGL(scan_dots_f32_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0,      \
+                           q->r1, q->dots32, pre);                                                                     \
+    } while (0)
         switch (nch) {
             case 1: AS_SCAN(1); break;
             case 2: AS_SCAN(2); break;
@@ -1004,8 +1048,10 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
             case 6: AS_SCAN(6); break;
             case 7: AS_SCAN(7); break;
             case 8: AS_SCAN(8); break;
-            default:
+            default: {
+                const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->cus * 8);
                 hipLaunchKernelGGL(scan_dots_f32_generic_kernel, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, q->dots32, pre);
+            }
         }
 #undef AS_SCAN
     }
@@ -1020,7 +1066,7 @@ static SelArgs<T> make_sel(as_query* q, const T* dots, int M, int64_t exclude) {
     a.dots = dots; a.n32 = sp->n32; a.inorm32 = sp->inorm32; a.n64 = sp->n64; a.lam32 = sp->lam32; a.lam64 = sp->lam64;
     a.info = q->info; a.info_w = q->info; a.n = sp->n; a.r0 = q->r0; a.r1 = q->r1; a.exclude = exclude;
     a.M = M; a.metric = sp->opts.metric;
-    a.epskey = 0; a.coef = 0;
+    a.epskey = 0; a.coef = 0; a.tau = 1.0;
     a.pkey = (T*)q->pkey; a.pidx = q->pidx;
     return a;
 }
@@ -1101,6 +1147,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         const int grid = sel_grid(q, &nw);
         f.nlists = nw;
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        a.tau = f.tau;
         hipLaunchKernelGGL(score_partial_kernel<T>, dim3(grid), dim3(256), 0, st, a);
         hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), finish_lds<T>(), st, f, (const T*)q->pkey, (const int*)q->pidx, coef_s);
     } else {
@@ -1109,6 +1156,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         G = std::max<int64_t>(64, (G + 63) / 64 * 64);
         const int ng = (int)((rows + G - 1) / G);
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        a.tau = f.tau;
         hipLaunchKernelGGL(score_gmin_kernel<T>, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, st, a, G, ng, (T*)q->gmin);
         hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
         const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
@@ -1119,12 +1167,12 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
 
 static as_status run_score(as_query* q, double tau, int fuse_final) {
     hipStream_t st = q->stream;
-    hipLaunchKernelGGL(set_tau_kernel, dim3(1), dim3(1), 0, st, q->info, tau);
     if (q->r1 - q->r0 <= 0) {
         AS_HIP(hipMemsetAsync(q->hits, 0xff, sizeof(as_hit_rec) * q->topk, st));
         return AS_OK;
     }
     FinishArgs f = make_finish(q);
+    f.tau = tau;
     if (q->exact) launch_score<double, unsigned long long, 8>(q, q->dots64, f, fuse_final);
     else launch_score<float, unsigned int, 4>(q, q->dots32, f, fuse_final);
     AS_HIP(hipGetLastError());
@@ -1223,6 +1271,10 @@ as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out
         return AS_EUNSUPPORTED;
     }
     q->nwaves = 4096;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) q->cus = prop.multiProcessorCount;
+    }
     AS_HIP(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
     AS_HIP(hipHostMalloc(&q->hq, sizeof(double) * sp->d, hipHostMallocMapped | hipHostMallocCoherent));
     AS_HIP(hipHostGetDevicePointer((void**)&q->hq_dev, q->hq, 0));
