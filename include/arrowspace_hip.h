@@ -152,7 +152,13 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
  * finished search: bit0 = not provably exact, bit1 = a candidate buffer overflowed. */
 void as_query_set_exact(as_query* q, int32_t flags);
 as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact);
-/* HIP stream (hipStream_t) the query's kernels run on, for event timing / ordering */
+/* HIP stream (hipStream_t) the query's kernels run on, for event timing / ordering;
+ * as_query_set_stream makes them run on the caller's stream (NULL restores the private one),
+ * e.g. the stream torch.distributed orders its RCCL collectives against. */
+void as_query_set_stream(as_query* q, void* hip_stream);
+/* Make the query write its k k-NN records and its topk+1 hit records (the last one carries
+ * the exactness flags) into caller-owned device buffers, e.g. all-gather send buffers. */
+as_status as_query_bind_records(as_query* q, as_knn_rec* knn_dev, as_hit_rec* hits_dev);
 void* as_query_stream(const as_query* q);
 
 /* ---- accessors: src/lib.rs:40-61 (GraphLaplacian), 78-124 (ArrowSpace) ---- */

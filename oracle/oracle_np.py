@@ -109,8 +109,13 @@ def build(X, graph_params: dict) -> dict:
     if X.ndim != 2 or X.shape[0] == 0 or X.shape[1] == 0:
         raise ValueError("items must be non-empty 2D array")
     prm = resolve_params(graph_params)
-    N = X.shape[0]
     n, lists = knn_lists(X, prm)
+    return graph_from_lists(X, prm, n, lists)
+
+
+def graph_from_lists(X, prm, n, lists) -> dict:
+    """SPEC S4-S9 from the directed lists: lists[i] = (idx, key, dist, gy) of row i."""
+    N = X.shape[0]
     # S4 symmetrise (union); per-edge payload is symmetric in (i,j)
     adj = [dict() for _ in range(N)]
     for i, (idx, key, dist, gy) in enumerate(lists):
@@ -184,21 +189,34 @@ def synth_lambda(E, G, tau0):
     return tau0 * (E / (E + tau0)) + (1.0 - tau0) * G
 
 
-def query_lambda(idx: dict, q) -> float:
-    """SPEC S10: prepare_query_item (src/lib.rs:154) restated: q appended as a node."""
+def query_neighbours(idx: dict, q, r0=0, r1=None):
+    """SPEC S10, first half: the k nearest items of q within eps among rows [r0, r1):
+    (item index, key, dist, gy), ordered by (key asc, index asc)."""
     prm = idx["prm"]
     X, n = idx["X"], idx["n"]
+    r1 = X.shape[0] if r1 is None else r1
     q = np.asarray(q, dtype=np.float64)
     nq = float(q @ q)
-    key, dist, gy = pair_quantities(q, X, nq, n, prm["metric"])
+    key, dist, gy = pair_quantities(q, X[r0:r1], nq, n[r0:r1], prm["metric"])
     ok = key <= _eps_key(prm["eps"], prm["metric"])
     cand = np.nonzero(ok)[0]
     order = np.lexsort((cand, key[cand]))
     cand = cand[order][: prm["k"]]
-    if len(cand) == 0:
+    return cand + r0, key[cand], dist[cand], gy[cand]
+
+
+def lambda_from_neighbours(idx: dict, q, items, dist, gy, deg=None, ny=None) -> float:
+    """SPEC S10, second half: q appended as a node with the given neighbours."""
+    prm = idx["prm"]
+    q = np.asarray(q, dtype=np.float64)
+    nq = float(q @ q)
+    if len(items) == 0:
         return 0.0
-    cand = np.sort(cand)
-    a = _edge_weight(dist[cand], prm["sigma"], prm["p"], prm["kernel"])
+    o = np.argsort(items, kind="stable")
+    items, dist, gy = np.asarray(items)[o], np.asarray(dist)[o], np.asarray(gy)[o]
+    deg = idx["deg"][items] if deg is None else np.asarray(deg)[o]
+    ny = idx["ny"][items] if ny is None else np.asarray(ny)[o]
+    a = _edge_weight(dist, prm["sigma"], prm["p"], prm["kernel"])
     degq = 0.0
     for v in a:
         degq += v
@@ -208,10 +226,10 @@ def query_lambda(idx: dict, q) -> float:
     if not nyq > 0.0:
         return 0.0
     es = []
-    for t, j in enumerate(cand):
-        dj = idx["deg"][j] + a[t]
+    for t in range(len(items)):
+        dj = deg[t] + a[t]
         sdd = np.sqrt(degq * dj)
-        v = a[t] * (nyq / degq + idx["ny"][j] / dj - 2.0 * gy[j] / sdd)
+        v = a[t] * (nyq / degq + ny[t] / dj - 2.0 * gy[t] / sdd)
         es.append(v if v > 0 else 0.0)
     S = 0.0
     for v in es:
@@ -225,6 +243,12 @@ def query_lambda(idx: dict, q) -> float:
         Gq = min(1.0, max(0.0, Gq))
     tau0 = idx["tau0"]
     return float(tau0 * (Eq / (Eq + tau0)) + (1.0 - tau0) * Gq)
+
+
+def query_lambda(idx: dict, q) -> float:
+    """SPEC S10: prepare_query_item (src/lib.rs:154) restated: q appended as a node."""
+    items, _, dist, gy = query_neighbours(idx, q)
+    return lambda_from_neighbours(idx, q, items, dist, gy)
 
 
 def scores(idx: dict, q, tau: float, lambda_q: float):

@@ -41,7 +41,7 @@ SYMBOLS = [
     "as_build", "as_build_dev", "as_space_create_dev", "as_knn_rows", "as_graph_from_knn", "as_search",
     "as_search_batch", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
-    "as_query_finish", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_nitems", "as_nfeatures",
+    "as_query_finish", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
     "as_get_item", "as_lambdas", "as_nnodes", "as_get_graph_params", "as_graph_nnz", "as_graph_csr",
     "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_last_search_stats", "as_enable_search_stats", "as_free_space",
     "as_free_graph", "as_set_debug", "as_last_error", "as_device_count", "as_version",
@@ -86,6 +86,8 @@ def load():
         "as_query_set_exact": (None, [vp, i32]),
         "as_query_flags": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "as_query_stream": (vp, [vp]),
+        "as_query_set_stream": (None, [vp, vp]),
+        "as_query_bind_records": (i32, [vp, vp, vp]),
         "as_nitems": (i64, [vp]),
         "as_nfeatures": (i64, [vp]),
         "as_get_item": (i32, [vp, i64, vp, C.POINTER(f64)]),

@@ -160,7 +160,7 @@ as_status as_knn_rows(const as_space* sp, const as_graph_params* gp, int64_t row
     as_graph_params r;
     AS_TRY(resolve_params(gp, &r));
     AS_HIP(hipSetDevice(sp->device));
-    return knn_rows(sp, &r, row_begin, row_end, out_idx_dev, out_key_dev, out_dist_dev, out_gy_dev, out_cnt_dev, nullptr);
+    return knn_rows(sp, &r, row_begin, row_end, out_idx_dev, out_key_dev, out_dist_dev, out_gy_dev, out_cnt_dev, sp->kstats);
 }
 
 as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx_dev, const double* dist_dev,
@@ -173,11 +173,14 @@ as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32
     AS_TRY(resolve_params(gp, &r));
     AS_HIP(hipSetDevice(sp->device));
     as_graph* gr = new as_graph();
+    const double t0 = now_s();
     as_status s = graph_from_knn(sp, &r, idx_dev, dist_dev, gy_dev, cnt_dev, gr);
     if (s != AS_OK) {
         as_free_graph(gr);
         return s;
     }
+    for (int i = 0; i < 8; ++i) gr->stats[i] = sp->kstats[i];  // k-NN stage of this rank's rows
+    gr->stats[4] = now_s() - t0;
     *out_graph = gr;
     return AS_OK;
 }

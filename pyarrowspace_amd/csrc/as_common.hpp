@@ -62,6 +62,7 @@ struct as_space {
     mutable as_query* qcache = nullptr;       // lazily created by as_search
     mutable const as_graph* qcache_gr = nullptr;
     mutable std::mutex qmu;
+    mutable double kstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // accumulated by as_knn_rows
 };
 
 struct as_graph {

@@ -58,6 +58,8 @@ struct as_query {
     const as_space* sp = nullptr;
     const as_graph* gr = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int own_records = 1;
     int64_t k = 0, topk = 0;
     int Mk = 32, Ms = 32;
     int nwaves = 0;
@@ -941,6 +943,13 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, const 
         }
         a.info->score_inexact = bad;
         a.info->nhit = nhit;
+        if (a.hits) {
+            // trailing flag record: every rank sees every rank's flags after the all-gather
+            as_hit_rec r;
+            r.idx = -2;
+            r.score = (double)((a.info->knn_inexact ? 1 : 0) | (bad ? 2 : 0) | (a.info->overflow ? 4 : 0));
+            a.hits[a.topk] = r;
+        }
         if (a.fuse && a.hout) {
             a.hout->len = nhit;
             a.hout->lambda_q = a.info->lambda_q;
@@ -960,11 +969,15 @@ __global__ __launch_bounds__(64) void hits_final_kernel(const as_hit_rec* __rest
     __shared__ int r_idx[REC_CAP];
     const int lane = lane_id();
     const int mm = (int)(m < REC_CAP ? m : REC_CAP);
+    int flags_l = 0;
     for (int t = lane; t < mm; t += 64) {
         const bool valid = hits[t].idx >= 0;
+        if (hits[t].idx == -2) flags_l |= (int)hits[t].score;
         r_key[t] = valid ? -hits[t].score : key_traits<double>::inf();
         r_idx[t] = valid ? (int)hits[t].idx : 0x7fffffff;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) flags_l |= __shfl_xor(flags_l, o, 64);
     AS_LDS_FENCE();
     int cnt_l = 0;
     for (int t = lane; t < mm; t += 64) {
@@ -982,9 +995,9 @@ __global__ __launch_bounds__(64) void hits_final_kernel(const as_hit_rec* __rest
         out->len = cnt;
         out->lambda_q = info->lambda_q;
         out->status = info->status;
-        out->knn_inexact = info->knn_inexact;
-        out->score_inexact = info->score_inexact;
-        out->overflow = info->overflow;
+        out->knn_inexact = (info->knn_inexact || (flags_l & 1)) ? 1 : 0;
+        out->score_inexact = (info->score_inexact || (flags_l & 2)) ? 1 : 0;
+        out->overflow = (info->overflow || (flags_l & 4)) ? 1 : 0;
         publish(out, seq);
     }
 }
@@ -1168,7 +1181,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
 static as_status run_score(as_query* q, double tau, int fuse_final) {
     hipStream_t st = q->stream;
     if (q->r1 - q->r0 <= 0) {
-        AS_HIP(hipMemsetAsync(q->hits, 0xff, sizeof(as_hit_rec) * q->topk, st));
+        AS_HIP(hipMemsetAsync(q->hits, 0xff, sizeof(as_hit_rec) * (q->topk + 1), st));
         return AS_OK;
     }
     FinishArgs f = make_finish(q);
@@ -1275,7 +1288,8 @@ as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) q->cus = prop.multiProcessorCount;
     }
-    AS_HIP(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+    AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));
+    q->stream = q->own_stream;
     AS_HIP(hipHostMalloc(&q->hq, sizeof(double) * sp->d, hipHostMallocMapped | hipHostMallocCoherent));
     AS_HIP(hipHostGetDevicePointer((void**)&q->hq_dev, q->hq, 0));
     AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp));
@@ -1290,7 +1304,7 @@ as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out
     AS_HIP(hipMalloc(&q->cidx_s, sizeof(int) * CAND_CAP));
     AS_HIP(hipMalloc(&q->gmin, sizeof(double) * CAND_CAP));
     AS_HIP(hipMalloc(&q->knn, sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1)));
-    AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * std::max<int64_t>(q->topk, 1)));
+    AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * (q->topk + 1)));
     AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut), hipHostMallocMapped | hipHostMallocCoherent));
     AS_HIP(hipHostGetDevicePointer((void**)&q->hout_dev, q->hout, 0));
     memset(q->hout, 0, sizeof(HostOut));
@@ -1310,18 +1324,43 @@ void as_query_free(as_query* q) {
     hipHostFree(q->hq); hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32);
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
-    hipFree(q->gmin); hipFree(q->knn); hipFree(q->hits);
+    hipFree(q->gmin);
+    if (q->own_records) {
+        hipFree(q->knn);
+        hipFree(q->hits);
+    }
     hipHostFree(q->hout);
     for (int i = 0; i < 3; ++i) hipEventDestroy(q->ev[i]);
-    hipStreamDestroy(q->stream);
+    hipStreamDestroy(q->own_stream);
     delete q;
 }
 
 void* as_query_stream(const as_query* q) { return (void*)q->stream; }
+
+void as_query_set_stream(as_query* q, void* stream) {
+    if (!q) return;
+    hipStreamSynchronize(q->stream);
+    q->stream = stream ? (hipStream_t)stream : q->own_stream;
+}
+
+as_status as_query_bind_records(as_query* q, as_knn_rec* knn_dev, as_hit_rec* hits_dev) {
+    if (!q || !knn_dev || !hits_dev) {
+        set_err("as_query_bind_records: null argument");
+        return AS_EINVAL;
+    }
+    if (q->own_records) {
+        hipFree(q->knn);
+        hipFree(q->hits);
+        q->own_records = 0;
+    }
+    q->knn = knn_dev;
+    q->hits = hits_dev;
+    return AS_OK;
+}
 const as_knn_rec* as_query_knn_records(const as_query* q) { return q->knn; }
 int64_t as_query_knn_capacity(const as_query* q) { return q->k; }
 const as_hit_rec* as_query_hit_records(const as_query* q) { return q->hits; }
-int64_t as_query_hit_capacity(const as_query* q) { return q->topk; }
+int64_t as_query_hit_capacity(const as_query* q) { return q->topk + 1; }
 
 as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end) {
     if (!q || !query_host || !q->gr) {

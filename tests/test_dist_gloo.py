@@ -1,0 +1,194 @@
+"""CPU, world_size 2, gloo: the row-sharded host logic of pyarrowspace_amd.dist
+(shard bounds, padded all-gathers of uneven shards, record exchange, flag agreement,
+identical results on every rank) with the CPU oracle injected as the per-rank engine.
+The product engine (HipEngine) needs a GPU and is covered by tests/test_gpu_dist.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import calibrate_eps, clustered  # noqa: E402
+
+
+class OracleEngine:
+    """Per-rank engine on numpy (test infrastructure): same interface and the same
+    fixed-size record layout (include/arrowspace_hip.h as_knn_rec / as_hit_rec) as HipEngine."""
+
+    def __init__(self, graph_params):
+        from oracle import oracle_np
+        self.o = oracle_np
+        self.prm = oracle_np.resolve_params(graph_params)
+        self.mode = 0
+
+    def create_space(self, X):
+        self.X = X.double().numpy().copy()
+        self.n, self.d = self.X.shape
+        self.nn = np.einsum("ij,ij->i", self.X, self.X)
+
+    def knn_rows(self, r0, r1):
+        import torch
+        k = self.prm["k"]
+        rows = r1 - r0
+        idx = np.full((rows, k), -1, dtype=np.int32)
+        dist = np.zeros((rows, k))
+        gy = np.zeros((rows, k))
+        cnt = np.zeros(rows, dtype=np.int32)
+        ek = self.o._eps_key(self.prm["eps"], self.prm["metric"])
+        for i in range(r0, r1):
+            key, dd, gg = self.o.pair_quantities(self.X[i], self.X, self.nn[i], self.nn, self.prm["metric"])
+            ok = key <= ek
+            ok[i] = False
+            c = np.nonzero(ok)[0]
+            c = c[np.lexsort((c, key[c]))][:k]
+            idx[i - r0, : len(c)] = c
+            dist[i - r0, : len(c)] = dd[c]
+            gy[i - r0, : len(c)] = gg[c]
+            cnt[i - r0] = len(c)
+        return torch.from_numpy(idx), torch.from_numpy(dist), torch.from_numpy(gy), torch.from_numpy(cnt)
+
+    def graph_from_knn(self, idx, dist, gy, cnt):
+        idx, dist, gy, cnt = idx.numpy(), dist.numpy(), gy.numpy(), cnt.numpy()
+        lists = [(idx[i, : cnt[i]].astype(np.int64), None, dist[i, : cnt[i]], gy[i, : cnt[i]]) for i in range(self.n)]
+        lists = [(a, d, d, g) for a, _, d, g in lists]
+        self.index = self.o.graph_from_lists(self.X, self.prm, self.nn, lists)
+
+    def query_open(self):
+        import torch
+        self.k, self.topk = self.prm["k"], min(self.prm["topk"], self.n)
+        self.knn_local = torch.zeros((self.k, 6), dtype=torch.float64)
+        self.hits_local = torch.zeros((self.topk + 1, 2), dtype=torch.float64)
+
+    def set_mode(self, mode):
+        self.mode = mode
+
+    def query_scan(self, q, r0, r1):
+        self.q = np.asarray(q, dtype=np.float64)
+        self.r0, self.r1 = r0, r1
+        items, key, dist, gy = self.o.query_neighbours(self.index, self.q, r0, r1)
+        rec = np.zeros((self.k, 6))
+        rec[:, 0] = np.array([-1], dtype=np.int64).view(np.float64)[0]
+        rec[:, 1] = np.inf
+        m = len(items)
+        rec[:m, 0] = items.astype(np.int64).view(np.float64)
+        rec[:m, 1], rec[:m, 2], rec[:m, 3] = key, dist, gy
+        rec[:m, 4], rec[:m, 5] = self.index["deg"][items], self.index["ny"][items]
+        self.knn_local.copy_(__import__("torch").from_numpy(rec))
+
+    def query_lambda(self, knn_all):
+        r = knn_all.numpy()
+        ids = r[:, 0].copy().view(np.int64)
+        ok = ids >= 0
+        ids, key = ids[ok], r[ok, 1]
+        o = np.lexsort((ids, key))[: self.k]
+        sel = np.nonzero(ok)[0][o]
+        self.lq = self.o.lambda_from_neighbours(self.index, self.q, ids[o], r[sel, 2], r[sel, 3], r[sel, 4], r[sel, 5])
+
+    def query_score(self, tau):
+        rec = np.zeros((self.topk + 1, 2))
+        rec[:, 0] = np.array([-1], dtype=np.int64).view(np.float64)[0]
+        rec[:, 1] = -np.inf
+        if self.r1 > self.r0:
+            s = self.o.scores(self.index, self.q, tau, self.lq)[self.r0 : self.r1]
+            o = np.lexsort((np.arange(len(s)), -s))[: self.topk]
+            rec[: len(o), 0] = (o + self.r0).astype(np.int64).view(np.float64)
+            rec[: len(o), 1] = s[o]
+        rec[self.topk, 0] = np.array([-2], dtype=np.int64).view(np.float64)[0]
+        rec[self.topk, 1] = 0.0
+        self.hits_local.copy_(__import__("torch").from_numpy(rec))
+
+    def query_finish(self, hits_all):
+        r = hits_all.numpy()
+        ids = r[:, 0].copy().view(np.int64)
+        ok = ids >= 0
+        ids, sc = ids[ok], r[ok, 1]
+        o = np.lexsort((ids, -sc))[: self.topk]
+        hits = [(int(ids[t]), float(sc[t])) for t in o]
+        return hits, self.lq, self.lq == 0.0, False, False
+
+    def lambdas(self):
+        return self.index["lambdas"]
+
+    def close(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, d, split, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyarrowspace_amd.dist import ShardedIndex
+        X = clustered(n, d, nclust=6, seed=21)
+        gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+        bounds = [0, split, n] if world == 2 else [0, n]
+        shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy())
+        index = ShardedIndex.build(gp, shard, dist, engine=OracleEngine(gp))
+        assert (index.r0, index.r1) == (bounds[rank], bounds[rank + 1]) and index.n == n
+        rng = np.random.default_rng(5)
+        res = []
+        for _ in range(4):
+            q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
+            for tau in (1.0, 0.62, 0.0):
+                res.append((index.search(q, tau), index.last_lambda_q))
+        out[rank] = (index.lambdas().copy(), res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("split", [97, 150, 0])
+def test_two_rank_sharded_index_matches_single_process(split):
+    import torch.multiprocessing as mp
+    from oracle import oracle_np
+    n, d, world = 300, 24, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, d, split, out), nprocs=world, join=True)
+    X = clustered(n, d, nclust=6, seed=21)
+    gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_np.build(X, gp)
+    rng = np.random.default_rng(5)
+    want = []
+    for _ in range(4):
+        q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
+        for tau in (1.0, 0.62, 0.0):
+            want.append(oracle_np.search(ref, q, tau))
+    for rank in range(world):
+        lam, res = out[rank]
+        np.testing.assert_allclose(lam, ref["lambdas"], rtol=1e-12)
+        for (hits, lq), (whits, wlq) in zip(res, want):
+            assert [i for i, _ in hits] == [i for i, _ in whits]
+            np.testing.assert_allclose([s for _, s in hits], [s for _, s in whits], rtol=1e-12)
+            assert abs(lq - wlq) <= 1e-12 * abs(wlq)
+    assert out[0][1] == out[1][1]          # every rank returns the same answer
+
+
+def test_shard_bounds():
+    from pyarrowspace_amd.dist import shard_bounds
+    assert shard_bounds(10, 4) == [0, 3, 6, 8, 10]
+    assert shard_bounds(3, 8) == [0, 1, 2, 3, 3, 3, 3, 3, 3]
+    assert shard_bounds(1_000_000, 8)[-1] == 1_000_000
+
+
+def test_record_layouts_match_the_c_structs():
+    from pyarrowspace_amd import _lib
+    from pyarrowspace_amd.dist import HIT_REC_F64, KNN_REC_F64
+    import ctypes
+    assert ctypes.sizeof(_lib.KnnRec) == 8 * KNN_REC_F64
+    assert ctypes.sizeof(_lib.HitRec) == 8 * HIT_REC_F64

@@ -1,0 +1,96 @@
+"""GPU: the staged C ABI (what multi-GPU hosts call) through pyarrowspace_amd.dist.HipEngine.
+world_size 1 in-process, and world_size 2 with both ranks sharing the one visible GPU
+(records staged through the CPU because RCCL wants one GPU per rank; on a multi-GPU node
+bench.py --gpus N uses the nccl backend directly)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import calibrate_eps, clustered  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _queries(X, n, d):
+    rng = np.random.default_rng(5)
+    return [(X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d), tau)
+            for _ in range(4) for tau in (1.0, 0.62, 0.0)]
+
+
+def test_single_rank_staged_path_matches_oracle(oracle_lib):
+    import torch
+    from pyarrowspace_amd.dist import ShardedIndex
+    n, d = 1200, 64
+    X = clustered(n, d, nclust=8, seed=31)
+    gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
+    index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())
+    ref = oracle_lib.OracleIndex(X, gp)
+    np.testing.assert_allclose(index.lambdas(), ref.lambdas, rtol=1e-9)
+    for q, tau in _queries(X, n, d):
+        want, lq = ref.search(q, tau)
+        got = index.search(q, tau)
+        assert [i for i, _ in got] == [i for i, _ in want]
+        np.testing.assert_allclose([s for _, s in got], [s for _, s in want], rtol=1e-9)
+        assert abs(index.last_lambda_q - lq) <= 1e-9 * abs(lq)
+    index.close()
+
+
+def _worker(rank, world, port, n, d, split, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyarrowspace_amd.dist import ShardedIndex
+
+        class CpuStaged(ShardedIndex):
+            def _gather_rows(self, t, counts):
+                return super()._gather_rows(t.cpu(), counts).cuda()
+
+            def _gather_fixed(self, t):
+                torch.cuda.synchronize()
+                return super()._gather_fixed(t.cpu()).cuda()
+
+        X = clustered(n, d, nclust=8, seed=31)
+        gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
+        bounds = [0, split, n]
+        shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy()).cuda()
+        index = CpuStaged.build(gp, shard, dist)
+        res = [(index.search(q, tau), index.last_lambda_q) for q, tau in _queries(X, n, d)]
+        out[rank] = (index.lambdas().copy(), res)
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_oracle(oracle_lib):
+    import torch.multiprocessing as mp
+    n, d, world, split = 1200, 64, 2, 500
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n, d, split, out), nprocs=world, join=True)
+    X = clustered(n, d, nclust=8, seed=31)
+    gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
+    ref = oracle_lib.OracleIndex(X, gp)
+    want = [ref.search(q, tau) for q, tau in _queries(X, n, d)]
+    for rank in range(world):
+        lam, res = out[rank]
+        np.testing.assert_allclose(lam, ref.lambdas, rtol=1e-9)
+        for (hits, lq), (whits, wlq) in zip(res, want):
+            assert [i for i, _ in hits] == [i for i, _ in whits]
+            np.testing.assert_allclose([s for _, s in hits], [s for _, s in whits], rtol=1e-9)
+            assert abs(lq - wlq) <= 1e-9 * abs(wlq)
+    assert out[0][1] == out[1][1]

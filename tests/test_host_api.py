@@ -1,0 +1,92 @@
+"""CPU: host-side mirror of the reference interface (names, argument checks, errors) and
+the C ABI: libarrowspace_hip.so loads and exports every symbol include/arrowspace_hip.h
+declares.  No compute call is made without a GPU; the product has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def asp():
+    import __graft_entry__ as g
+    g.build()
+    import pyarrowspace_amd
+    return pyarrowspace_amd
+
+
+def test_library_exports_every_declared_symbol(asp):
+    hdr = open(os.path.join(ROOT, "include", "arrowspace_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(as_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(asp._lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(asp._lib.SYMBOLS) == declared, set(asp._lib.SYMBOLS) ^ set(declared)
+
+
+def test_module_surface_matches_reference(asp):
+    """src/lib.rs:379-386: three classes + set_debug under the module name `arrowspace`."""
+    import arrowspace
+    for name in ("ArrowSpaceBuilder", "ArrowSpace", "GraphLaplacian", "set_debug"):
+        assert hasattr(arrowspace, name)
+    assert arrowspace.ArrowSpaceBuilder is asp.ArrowSpaceBuilder
+    arrowspace.set_debug(True)
+    arrowspace.set_debug(False)
+
+
+def test_direct_construction_raises_valueerror(asp):
+    """src/lib.rs:33-38,71-76."""
+    with pytest.raises(ValueError, match="cannot be constructed directly"):
+        asp.ArrowSpace()
+    with pytest.raises(ValueError, match="cannot be constructed directly"):
+        asp.GraphLaplacian()
+
+
+def test_build_argument_checks(asp):
+    gp = {"eps": 1.0, "k": 3, "topk": 2, "p": 2.0}
+    X = np.zeros((4, 3))
+    with pytest.raises(TypeError):
+        asp.ArrowSpaceBuilder.build(gp, X.astype(np.float32))      # PyReadonlyArray2<f64>
+    with pytest.raises(TypeError):
+        asp.ArrowSpaceBuilder.build(gp, np.zeros(3))
+    with pytest.raises(ValueError, match="non-empty"):
+        asp.ArrowSpaceBuilder.build(gp, np.zeros((0, 3)))            # src/helpers.rs:27-29
+    for key in ("eps", "k", "topk", "p"):
+        bad = dict(gp)
+        del bad[key]
+        with pytest.raises(ValueError, match=key):                   # src/helpers.rs:52-67
+            asp.ArrowSpaceBuilder.build(bad, np.ones((4, 3)))
+    with pytest.raises(ValueError, match="metric"):
+        asp.ArrowSpaceBuilder.build(dict(gp, metric="manhattan"), np.ones((4, 3)))
+    with pytest.raises(NotImplementedError):
+        asp.ArrowSpaceBuilder.build_energy(np.ones((4, 3)))
+
+
+def test_sigma_default_is_half_eps(asp):
+    gp, _ = asp._parse_graph_params({"eps": 0.5, "k": 3, "topk": 2, "p": 2.0, "sigma": None})
+    assert gp.has_sigma == 0          # resolved to eps*0.5 inside the library (src/helpers.rs:68-72)
+    gp, _ = asp._parse_graph_params({"eps": 0.5, "k": 3, "topk": 2, "p": 2.0, "sigma": 0.1})
+    assert gp.has_sigma == 1 and gp.sigma == 0.1
+
+
+def test_no_cpu_fallback_without_a_gpu(asp):
+    """On a box without a device the build fails loudly instead of computing on the CPU."""
+    if asp._lib.load().as_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        asp.ArrowSpaceBuilder.build({"eps": 1.0, "k": 2, "topk": 2, "p": 2.0}, np.eye(3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pyarrowspace_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and "oracle" not in txt, (dirpath, f)
