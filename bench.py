@@ -120,7 +120,8 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------- index build (timed once, inputs resident in HBM)
-    if world == 1:
+    single = world == 1 and os.environ.get("ARROWSPACE_BENCH_FORCE_DIST", "") in ("", "0")
+    if single:
         barrier()
         t0 = time.perf_counter()
         aspace, gl = asp.ArrowSpaceBuilder.build_from_device(gp, X.data_ptr(), "float32", n, d, d)
@@ -131,13 +132,17 @@ def main():
     else:
         from pyarrowspace_amd import dist as asdist
 
+        b = asdist.shard_bounds(n, world)
+        shard = X[b[rank]:b[rank + 1]].clone()      # this rank's rows; the rest arrives by RCCL all-gather
+        del X
+        torch.cuda.empty_cache()
         barrier()
         t0 = time.perf_counter()
-        index = asdist.ShardedIndex.build(gp, X, dist)
+        index = asdist.ShardedIndex.build(gp, shard, dist)
         barrier()
         build_s = time.perf_counter() - t0
         searcher = lambda q: index.search(q, args.tau)  # noqa: E731
-        aspace, gl = index.aspace, index.gl
+        aspace = gl = None
         bstats = index.build_stats()
     bt = torch.tensor([build_s], device=device, dtype=torch.float64)
     if dist is not None:
@@ -163,7 +168,7 @@ def main():
     asp.enable_search_stats(True)
     for i in range(min(args.steps, 50)):
         searcher(Q[(args.warmup + i) % len(Q)])
-        scan_us.append(aspace.last_search_stats()["scan_us"] if world == 1 else index.last_scan_us())
+        scan_us.append(aspace.last_search_stats()["scan_us"] if single else index.last_scan_us())
     scan_ms = float(np.mean(scan_us)) * 1e-3
 
     qps = args.steps / dt
@@ -204,7 +209,7 @@ def main():
     }
 
     # ---------------- CPU baseline: the oracle (fp64 C/OpenMP restatement) on this box's host cores
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and single and not args.no_cpu_baseline:
         from oracle import oracle_c
 
         cores = oracle_c.threads()
