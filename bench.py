@@ -178,6 +178,16 @@ def main():
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
     mfma_tf = bstats["mfma_flops"] / max(bstats["knn_mfma_s"], 1e-9) / 1e12
 
+    # HBM-side traffic per launch from the committed PMC profile (only for the profiled workload)
+    traffic_scan = traffic_mfma = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj["workload"] == {"n": n, "d": d} and world == 1:
+            traffic_scan = tj["scan_dots_f32_kernel"]["bytes_per_launch"]
+            traffic_mfma = tj["knn_mfma_kernel"]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     out = {
         "metric": "queries/sec (single-query search, B=1) at N=%dx D=%d fp32; index-build sec alongside" % (n, d),
         "value": qps,
@@ -198,13 +208,13 @@ def main():
         "build_stages_sec": {k: bstats[k] for k in ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s")},
         "build_fallback_rows": bstats["fallback_rows"],
         "roofline": {"kernel": "scan_dots_f32_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
                      "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes},
         "roofline_query": {"bound": "hbm", "achieved": query_bytes / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "note": "whole query, host-visible latency, per GPU"},
         "roofline_build": {"kernel": "knn_mfma_kernel", "bound": "mfma", "achieved": mfma_tf, "peak": MFMA_F32_PEAK_TF,
-                           "unit": "TFLOP/s", "frac": mfma_tf / MFMA_F32_PEAK_TF, "traffic": None,
+                           "unit": "TFLOP/s", "frac": mfma_tf / MFMA_F32_PEAK_TF, "traffic": traffic_mfma,
                            "flops_issued": bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"]},
     }
 
