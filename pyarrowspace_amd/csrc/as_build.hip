@@ -174,11 +174,17 @@ __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, f
     AS_CBAR();
 }
 
+// V bit0: XCD-grouped unit order (blocks that share an XCD's L2 work on the same few row
+// blocks across the column segments); bit1: double-buffered LDS slabs (one barrier per slab);
+// bit2: non-temporal loads for the streamed column operand.
+template <int V>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void knn_mfma_kernel(KnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NBUF = (V & 2) ? 2 : 1;
+    constexpr int SLAB = (BM + BN) * LROW;  // floats per staged slab (A rows then B rows)
     float* As = (float*)smem;
     float* Bs = As + BM * LROW;
-    float* s_thr = Bs + BN * LROW;
+    float* s_thr = As + NBUF * SLAB;
     float* s_aux = s_thr + BM;
     int* s_cur = (int*)(s_aux + BM);
     int* s_drop = s_cur + BM;
@@ -195,8 +201,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float finf = __int_as_float(0x7f800000);
     const int srow = tid >> 3, sg = tid & 7;  // staging: 8 x 16-byte chunks per 128-byte row slab
 
-    for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        const int rb = u / a.S, cs = u % a.S;
+    const int xslots = gridDim.x >> 3;          // blocks per XCD label (V&1: gridDim.x is a multiple of 8)
+    const int rb_per_group = (V & 1) ? (xslots / a.S > 0 ? xslots / a.S : 1) : 1;
+    for (int it = 0;; ++it) {
+        int rb, cs;
+        if (V & 1) {
+            const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+            const int g = it * 8 + x;
+            if (g * rb_per_group >= a.nrb) break;
+            rb = g * rb_per_group + sl / a.S;
+            cs = sl % a.S;
+            if (sl >= rb_per_group * a.S || rb >= a.nrb) continue;
+        } else {
+            const int u = blockIdx.x + it * gridDim.x;
+            if (u >= units) break;
+            rb = u / a.S;
+            cs = u % a.S;
+        }
         const int64_t rowbase = a.r0 + (int64_t)rb * BM;
         const int t0 = (int)((int64_t)a.ntile * cs / a.S), t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
         {
@@ -223,30 +244,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
             f32x4 ra[8], rbv[4];
+            auto gload = [&](int ks) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ra[q] = *(const f32x4*)(pa + (size_t)q * 32 * a.dp);
+                for (int q = 0; q < 8; ++q) ra[q] = *(const f32x4*)(pa + (size_t)q * 32 * a.dp + ks * BK);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rbv[q] = *(const f32x4*)(pb + (size_t)q * 32 * a.dp);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) *(f32x4*)(As + (srow + 32 * q) * LROW + sg * 4) = ra[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *(f32x4*)(Bs + (srow + 32 * q) * LROW + sg * 4) = rbv[q];
-            __syncthreads();
-            for (int ks = 0; ks < nslab; ++ks) {
-                const bool more = ks + 1 < nslab;
-                if (more) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) ra[q] = *(const f32x4*)(pa + (size_t)q * 32 * a.dp + (ks + 1) * BK);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rbv[q] = *(const f32x4*)(pb + (size_t)q * 32 * a.dp + (ks + 1) * BK);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4* src = (const f32x4*)(pb + (size_t)q * 32 * a.dp + ks * BK);
+                    rbv[q] = (V & 4) ? __builtin_nontemporal_load(src) : *src;
                 }
+            };
+            auto lstore = [&](int buf) {
+                float* Ad = As + buf * SLAB;
+                float* Bd = Bs + buf * SLAB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *(f32x4*)(Ad + (srow + 32 * q) * LROW + sg * 4) = ra[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4*)(Bd + (srow + 32 * q) * LROW + sg * 4) = rbv[q];
+            };
+            auto compute = [&](int buf) {
+                const float* Ar = As + buf * SLAB;
+                const float* Br = Bs + buf * SLAB;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     f32x4 af[2], bf[4];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m] = *(const f32x4*)(As + (w * 64 + m * 32 + l31) * LROW + s * 8 + h * 4);
+                    for (int m = 0; m < 2; ++m) af[m] = *(const f32x4*)(Ar + (w * 64 + m * 32 + l31) * LROW + s * 8 + h * 4);
 #pragma unroll
-                    for (int nn = 0; nn < 4; ++nn) bf[nn] = *(const f32x4*)(Bs + (nn * 32 + l31) * LROW + s * 8 + h * 4);
+                    for (int nn = 0; nn < 4; ++nn) bf[nn] = *(const f32x4*)(Br + (nn * 32 + l31) * LROW + s * 8 + h * 4);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -255,13 +279,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             for (int nn = 0; nn < 4; ++nn)
                                 acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][t], bf[nn][t], acc[m][nn], 0, 0, 0);
                 }
-                __syncthreads();
-                if (more) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) *(f32x4*)(As + (srow + 32 * q) * LROW + sg * 4) = ra[q];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *(f32x4*)(Bs + (srow + 32 * q) * LROW + sg * 4) = rbv[q];
+            };
+            gload(0);
+            lstore(0);
+            __syncthreads();
+            if (V & 2) {
+                // double-buffered, branch-free body: slab ks+1 goes regs->LDS (other buffer) and slab
+                // ks+2 global->regs in the shadow of slab ks's MFMAs (the tail iterations re-stage the
+                // last slab, which nobody reads).
+                gload(nslab > 1 ? 1 : 0);
+                for (int ks = 0; ks < nslab; ++ks) {
+                    const int cur = ks & 1;
+                    lstore(cur ^ 1);
+                    gload(ks + 2 < nslab ? ks + 2 : nslab - 1);
+                    compute(cur);
                     __syncthreads();
+                }
+            } else {
+                for (int ks = 0; ks < nslab; ++ks) {
+                    const bool more = ks + 1 < nslab;
+                    if (more) gload(ks + 1);
+                    compute(0);
+                    __syncthreads();
+                    if (more) {
+                        lstore(0);
+                        __syncthreads();
+                    }
                 }
             }
             // ---- epilogue: keys, bound test, append
@@ -538,6 +581,8 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     if (!sp->opts.force_exact) {
         const int nrb = (int)((rows + BM - 1) / BM);
         const int ntile = (int)(sp->np / BN);
+        int variant = 0;
+        if (const char* ev = getenv("ARROWSPACE_KNN_VARIANT")) variant = atoi(ev) & 7;
         int S = 1;
         {   // enough units to fill the chip several times over, but never thinner than 8 column tiles
             int dev_cus = 256;
@@ -545,6 +590,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
             const int target_units = dev_cus * 2 * 8;
             while (S < 8 && nrb * S < target_units && ntile / (S * 2) >= 8) S *= 2;
+            if ((variant & 1) && ntile >= 64) S = 8;  // XCD-grouped order: 4 row blocks x 8 column segments per XCD
         }
         int dev_cus = 256;
         {
@@ -568,12 +614,23 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
         ka.epskey = nextafterf(ka.epskey, INFINITY);
         ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-        const size_t lds = sizeof(float) * (BM + BN) * LROW + sizeof(float) * 4 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t lds = sizeof(float) * (BM + BN) * LROW * ((variant & 2) ? 2 : 1) + sizeof(float) * 4 * BM +
+                           (sizeof(float) + sizeof(int)) * 4 * CAP;
+        int lgrid = grid;
+        if (variant & 1) lgrid = std::max(8, std::min(units, dev_cus) / 8 * 8);  // one resident block per CU, 8 XCD labels
         hipEvent_t e0, e1, e2;
         AS_HIP(hipEventCreate(&e0)); AS_HIP(hipEventCreate(&e1)); AS_HIP(hipEventCreate(&e2));
-        AS_HIP(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(knn_mfma_kernel, dim3(grid), dim3(256), lds, st, ka);
+#define AS_KNN_LAUNCH(VV)                                                                                              \
+    case VV:                                                                                                           \
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_kernel<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        AS_HIP(hipEventRecord(e0, st));                                                                                \
+        hipLaunchKernelGGL(knn_mfma_kernel<VV>, dim3(lgrid), dim3(256), lds, st, ka);                                  \
+        break;
+        switch (variant) {
+            AS_KNN_LAUNCH(0) AS_KNN_LAUNCH(1) AS_KNN_LAUNCH(2) AS_KNN_LAUNCH(3)
+            AS_KNN_LAUNCH(4) AS_KNN_LAUNCH(5) AS_KNN_LAUNCH(6) AS_KNN_LAUNCH(7)
+        }
+#undef AS_KNN_LAUNCH
         AS_HIP(hipGetLastError());
         AS_HIP(hipEventRecord(e1, st));
         RefineArgs ra;
