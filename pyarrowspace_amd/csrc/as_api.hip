@@ -84,6 +84,7 @@ void as_free_space(as_space* sp) {
     if (!sp) return;
     hipSetDevice(sp->device);
     if (sp->qcache) as_query_free(sp->qcache);
+    if (sp->qcache_b) as_query_free(sp->qcache_b);
     if (sp->stream) hipStreamSynchronize(sp->stream);
     hipFree(sp->x32); hipFree(sp->x64); hipFree(sp->n64); hipFree(sp->n32); hipFree(sp->inorm32);
     hipFree(sp->lam64); hipFree(sp->lam32);
@@ -290,6 +291,9 @@ static as_status get_cached_query(const as_space* sp, const as_graph* gr, as_que
     return AS_OK;
 }
 
+static as_status search_single_locked(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
+                                      int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
+
 as_status as_search(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau, int64_t* out_idx,
                     double* out_score, int64_t* out_len, double* out_lambda_q) {
     if (!sp || !gr || !query || !out_idx || !out_score) {
@@ -305,6 +309,11 @@ as_status as_search(const as_space* sp, const as_graph* gr, const double* query,
         return AS_EINVAL;
     }
     std::lock_guard<std::mutex> lock(sp->qmu);
+    return search_single_locked(sp, gr, query, d, tau, out_idx, out_score, out_len, out_lambda_q);
+}
+
+static as_status search_single_locked(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
+                                      int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q) {
     AS_HIP(hipSetDevice(sp->device));
     as_query* q = nullptr;
     AS_TRY(get_cached_query(sp, gr, &q));
@@ -333,13 +342,47 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
         set_err("as_search_batch: null argument");
         return AS_EINVAL;
     }
+    if (d != sp->d) {
+        set_err("query length %lld must match nfeatures %lld", (long long)d, (long long)sp->d);
+        return AS_EINVAL;
+    }
     const int64_t topk = std::min<int64_t>(gr->gp.topk, sp->n);
-    for (int64_t i = 0; i < b; ++i) {
-        double lq = 0.0;
-        as_status s = as_search(sp, gr, queries + i * d, d, tau, out_idx + i * topk, out_score + i * topk, out_len + i, &lq);
-        if (out_lambda_q) out_lambda_q[i] = lq;
-        if (out_status) out_status[i] = (int32_t)s;
-        if (s != AS_OK && s != AS_EZEROLAMBDA) return s;
+    std::lock_guard<std::mutex> lock(sp->qmu);
+    AS_HIP(hipSetDevice(sp->device));
+    // the batched pass keeps QUERY_BATCH query fragments in registers: rows up to 1024 floats, fp32 fast path
+    const bool batched = sp->dp <= 1024 && !sp->opts.force_exact && (sp->opts.reserved[0] & 3) == 0 && b > 1;
+    if (batched) {
+        if (sp->qcache_b && sp->qcache_b_gr != gr) {
+            as_query_free(sp->qcache_b);
+            sp->qcache_b = nullptr;
+        }
+        if (!sp->qcache_b) {
+            AS_TRY(query_create(sp, gr, QUERY_BATCH, &sp->qcache_b));
+            sp->qcache_b_gr = gr;
+        }
+    }
+    int32_t st_chunk[QUERY_BATCH];
+    for (int64_t i0 = 0; i0 < b; i0 += QUERY_BATCH) {
+        const int nb = (int)std::min<int64_t>(QUERY_BATCH, b - i0);
+        if (batched) {
+            AS_TRY(search_batch_once(sp->qcache_b, queries + i0 * d, nb, d, tau, topk, out_idx + i0 * topk, out_score + i0 * topk,
+                                     out_len + i0, out_lambda_q ? out_lambda_q + i0 : nullptr, st_chunk));
+        } else {
+            for (int t = 0; t < nb; ++t) st_chunk[t] = -1;
+        }
+        for (int t = 0; t < nb; ++t) {
+            const int64_t i = i0 + t;
+            if (st_chunk[t] == -1) {  // not provably exact on the batched fast path (or batching unavailable)
+                double lq = 0.0;
+                const as_status s1 = search_single_locked(sp, gr, queries + i * d, d, tau, out_idx + i * topk, out_score + i * topk,
+                                                          out_len + i, &lq);
+                if (out_lambda_q) out_lambda_q[i] = lq;
+                st_chunk[t] = (int32_t)s1;
+                if (s1 != AS_OK && s1 != AS_EZEROLAMBDA) return s1;
+            }
+            if (st_chunk[t] == AS_EZEROLAMBDA) out_len[i] = 0;
+            if (out_status) out_status[i] = st_chunk[t];
+        }
     }
     return AS_OK;
 }

@@ -61,6 +61,8 @@ struct as_space {
     hipStream_t stream = nullptr;
     mutable as_query* qcache = nullptr;       // lazily created by as_search
     mutable const as_graph* qcache_gr = nullptr;
+    mutable as_query* qcache_b = nullptr;     // batched workspace (QUERY_BATCH slots), lazily created
+    mutable const as_graph* qcache_b_gr = nullptr;
     mutable std::mutex qmu;
     mutable double kstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // accumulated by as_knn_rows
 };
@@ -215,5 +217,9 @@ as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, in
 as_status search_once(as_query* q, const double* query, int64_t d, double tau, int exact, int64_t* out_idx,
                       double* out_score, int64_t* out_len, double* out_lambda_q);
 void query_flags(const as_query* q, int* knn_inexact, int* score_inexact);
+as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out);
+as_status search_batch_once(as_query* q, const double* queries, int nb, int64_t d, double tau, int64_t topk, int64_t* out_idx,
+                            double* out_score, int64_t* out_len, double* out_lambda_q, int32_t* out_status);
+constexpr int QUERY_BATCH = 8;  // == QB in as_search.hip
 
 }  // namespace as

@@ -22,6 +22,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CAND_CAP = 4096;  // candidate buffer of the filter path
 constexpr int REC_CAP = 512;    // records q_lambda / hits_final accept (ranks x k)
+constexpr int QB = 8;           // queries per batched scan pass (query fragments live in registers)
+
+// Batched searches run QB independent query "slots" side by side: every per-query buffer is
+// an array over slots and blockIdx.z selects the slot (z = 0 for single-query searches).
+struct SlotStride {
+    int64_t dots;   // elements between consecutive slots' dots arrays
+    int64_t q;      // dp
+    int64_t qin;    // d
+    int64_t knn;    // k records
+    int64_t hits;   // topk + 1 records
+};
 
 struct QInfo {
     double nq;        // |q|^2
@@ -63,6 +74,9 @@ struct as_query {
     int64_t k = 0, topk = 0;
     int Mk = 32, Ms = 32;
     int nwaves = 0;
+    int cap = 1;             // query slots (QB for the batched workspace)
+    int nb = 1;              // active slots of the current launch sequence
+    as::SlotStride ss{};
     int cus = 256;
     int scan_grid = 0;
     int64_t r0 = 0, r1 = 0;
@@ -116,6 +130,10 @@ __device__ __forceinline__ double from_ord(unsigned long long u) {
 __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int64_t dp, double* __restrict__ q64,
                                  float* __restrict__ q32, QInfo* info, double tau) {
     __shared__ double sh[256];
+    qin += (int64_t)blockIdx.z * d;
+    q64 += (int64_t)blockIdx.z * dp;
+    q32 += (int64_t)blockIdx.z * dp;
+    info += blockIdx.z;
     double s = 0.0;
     for (int64_t c = threadIdx.x; c < dp; c += blockDim.x) {
         const double v = c < d ? qin[c] : 0.0;
@@ -257,6 +275,87 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
     }
 }
 
+// Batched scan (as_search_batch): QB query fragments live in registers, every row is read from
+// HBM once for QB queries.  The QB partial sums per lane are reduced with a halving butterfly
+// (4+2+1 exchanges, then 3 on the single survivor): lane L with (L & 7) == 0 ends up owning
+// query ((L>>5)&1)*4 + ((L>>4)&1)*2 + ((L>>3)&1).
+template <int NCH>
+__global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
+                                                              int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                              int64_t sd, PreArgs pre) {
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    f32x4 qv[QB][NCH];
+    bool on[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int64_t c = 4 * (lane + 64 * u);
+        on[u] = c < dp;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) qv[b][u] = on[u] ? *(const f32x4*)(q32 + (int64_t)b * dp + c) : f32x4{0, 0, 0, 0};
+    }
+    const int myq = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    const bool owner = (lane & 7) == 0;
+    const float nq32 = pre.info[myq].nq32, inq32 = pre.info[myq].inq32;
+    PreArgs mine = pre;
+    mine.info = pre.info + myq;
+    mine.infow = pre.infow + myq;
+    mine.ckey = (void*)((float*)pre.ckey + (int64_t)myq * CAND_CAP);
+    mine.cidx = pre.cidx + (int64_t)myq * CAND_CAP;
+    float* __restrict__ mydots = dots + (int64_t)myq * sd;
+    for (int64_t row = r0 + gw; row < r1; row += nw) {
+        const float* pa = x32 + row * dp + 4 * lane;
+        f32x4 v[NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) v[u] = on[u] ? __builtin_nontemporal_load((const f32x4*)(pa + 256 * u)) : f32x4{0, 0, 0, 0};
+        const float aux = auxv[row];
+        float acc[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) acc[b] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < QB; ++b) acc[b] = fmaf(v[u][e], qv[b][u][e], acc[b]);
+        // halving butterfly: keep the half selected by this lane's bit, send the other half
+        float k4[4], k2[2], k1;
+        {
+            const bool hi = (lane >> 5) & 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float keep = hi ? acc[j + 4] : acc[j];
+                const float send = hi ? acc[j] : acc[j + 4];
+                k4[j] = keep + __shfl_xor(send, 32, 64);
+            }
+        }
+        {
+            const bool hi = (lane >> 4) & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float keep = hi ? k4[j + 2] : k4[j];
+                const float send = hi ? k4[j] : k4[j + 2];
+                k2[j] = keep + __shfl_xor(send, 16, 64);
+            }
+        }
+        {
+            const bool hi = (lane >> 3) & 1;
+            const float keep = hi ? k2[1] : k2[0];
+            const float send = hi ? k2[0] : k2[1];
+            k1 = keep + __shfl_xor(send, 8, 64);
+        }
+        k1 += __shfl_xor(k1, 4, 64);
+        k1 += __shfl_xor(k1, 2, 64);
+        k1 += __shfl_xor(k1, 1, 64);
+        if (owner) {
+            mydots[row] = k1;
+            prefilter_f32(mine, row, k1, aux, nq32, inq32);
+        }
+    }
+}
+
 // generic width (dp > 2048): query re-read from L1 per chunk
 __global__ __launch_bounds__(256) void scan_dots_f32_generic_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
                                                                     int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
@@ -342,7 +441,22 @@ struct SelArgs {
     double epskey, coef, tau;
     T* pkey;
     int* pidx;
+    T* gmin;      // filter path: group minima, candidate buffers (CAND_CAP per slot)
+    T* ckey;
+    int* cidx;
+    int64_t sd;   // dots stride between slots
 };
+
+template <typename T>
+__device__ __forceinline__ void sel_slot(SelArgs<T>& a) {
+    const int z = blockIdx.z;
+    a.dots += (int64_t)z * a.sd;
+    a.info += z;
+    a.info_w += z;
+    a.gmin += (int64_t)z * CAND_CAP;
+    a.ckey += (int64_t)z * CAND_CAP;
+    a.cidx += (int64_t)z * CAND_CAP;
+}
 
 struct ScoreCtx {
     double nq, tau, lq;
@@ -391,7 +505,9 @@ __device__ __forceinline__ double knn_key<double>(const SelArgs<double>& a, int6
 // ------------------------------------------------------------------ filter path, scorer side
 // (1) per-group minimum of the scorer key; one wave per group of G rows
 template <typename T>
-__global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G, int ngroups, T* __restrict__ gmin) {
+__global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G, int ngroups) {
+    sel_slot(a);
+    T* __restrict__ gmin = a.gmin;
     const int lane = lane_id();
     const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= ngroups) return;
@@ -416,6 +532,8 @@ __global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G
 template <typename T, typename U, int PASSES>
 __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gmin, int ng, int M, QInfo* info) {
     __shared__ unsigned int hist[256];
+    gmin += (int64_t)blockIdx.z * CAND_CAP;
+    info += blockIdx.z;
     __shared__ U s_prefix;
     __shared__ int s_rank;
     const int tid = threadIdx.x;
@@ -491,7 +609,10 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
 
 // (3) append every row whose key <= threshold
 template <typename T>
-__global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a, T* __restrict__ ckey, int* __restrict__ cidx) {
+__global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a) {
+    sel_slot(a);
+    T* __restrict__ ckey = a.ckey;
+    int* __restrict__ cidx = a.cidx;
     const ScoreCtx c = load_ctx(a.info, a.tau);
     const T thr = sizeof(T) == 4 ? (T)a.info->thr32 : (T)a.info->thr64;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -663,6 +784,9 @@ struct FinishArgs {
     as_hit_rec* hits;
     HostOut* hout;      // non-null: also publish the final answer (single-GPU fused tail)
     int64_t seq;
+    const void* ck;     // candidate keys / indices (filter buffers or wave lists)
+    const int* ci;
+    SlotStride ss;
     int fuse;           // knn: compute lambda_q in the same launch; score: publish to hout
     int from_list;      // candidates come from the wavefront lists instead of the filter buffer
     // build-fallback outputs (row-list form); null for searches
@@ -712,8 +836,14 @@ __device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist
 // k-NN of the query: candidates -> M smallest fp32 keys -> fp64 re-evaluation -> (key64, idx)
 // order, eps, k cap, a-posteriori exactness check; optionally lambda_q in the same launch.
 template <typename T>
-__global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a, const T* ckey, const int* cidx) {
+__global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int z = blockIdx.z;
+    const T* ckey = (const T*)a.ck + (int64_t)z * CAND_CAP;
+    const int* cidx = a.ci + (int64_t)z * CAND_CAP;
+    a.info += z;
+    a.q64 += (int64_t)z * a.ss.q;
+    if (a.recs) a.recs += (int64_t)z * a.ss.knn;
     T* sk = (T*)smem;                       // CAND_CAP keys (filter) or 16x64 wave lists
     int* si = (int*)(sk + CAND_CAP);
     __shared__ T fk[64];
@@ -874,8 +1004,15 @@ __device__ __forceinline__ void publish(HostOut* out, int64_t seq) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, const T* ckey, const int* cidx, double coef_s) {
+__global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double coef_s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int z = blockIdx.z;
+    const T* ckey = (const T*)a.ck + (int64_t)z * CAND_CAP;
+    const int* cidx = a.ci + (int64_t)z * CAND_CAP;
+    a.info += z;
+    a.q64 += (int64_t)z * a.ss.q;
+    if (a.hits) a.hits += (int64_t)z * a.ss.hits;
+    if (a.hout) a.hout += z;
     T* sk = (T*)smem;
     int* si = (int*)(sk + CAND_CAP);
     __shared__ T fk[64];
@@ -1039,6 +1176,29 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
                            q->r1, q->dots64, pre);
     } else {
         const int nch = (int)((sp->dp + 255) / 256);
+        if (q->cap > 1) {
+            // batched pass: QB queries per row read (query fragments in registers); dp <= 1024 only
+#define AS_BSCAN(N)                                                                                                    \
+    do {                                                                                                               \
+        if (!q->scan_grid) {                                                                                           \
+            int nb_ = 0;                                                                                               \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, scan_dots_batch_kernel<N>, 256, 0) != hipSuccess) nb_ = 2; \
+            q->scan_grid = q->cus * std::max(1, std::min(nb_, 8));                                                     \
+        }                                                                                                              \
+        const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->scan_grid);                               \
+        hipLaunchKernelGGL(scan_dots_batch_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0,    \
+                           q->r1, q->dots32, q->ss.dots, pre);                                                         \
+    } while (0)
+            switch (nch) {
+                case 1: AS_BSCAN(1); break;
+                case 2: AS_BSCAN(2); break;
+                case 3: AS_BSCAN(3); break;
+                default: AS_BSCAN(4); break;
+            }
+#undef AS_BSCAN
+            AS_HIP(hipGetLastError());
+            return AS_OK;
+        }
         // resident grid: every wave gets the same number of rows and all of them run at once
         // (a grid one block over residency costs a whole extra round at 1/8 occupancy)
 #define AS_SCAN(N)                                                                                                     \
@@ -1081,6 +1241,7 @@ static SelArgs<T> make_sel(as_query* q, const T* dots, int M, int64_t exclude) {
     a.M = M; a.metric = sp->opts.metric;
     a.epskey = 0; a.coef = 0; a.tau = 1.0;
     a.pkey = (T*)q->pkey; a.pidx = q->pidx;
+    a.gmin = (T*)q->gmin; a.ckey = (T*)q->ckey_s; a.cidx = q->cidx_s; a.sd = q->ss.dots;
     return a;
 }
 
@@ -1105,6 +1266,7 @@ static FinishArgs make_finish(as_query* q) {
         f.sigma = q->gr->gp.sigma; f.p = q->gr->gp.p; f.tau0 = q->gr->tau0;
     }
     f.from_list = q->robust;
+    f.ss = q->ss;
     return f;
 }
 
@@ -1133,18 +1295,21 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lamb
             SelArgs<double> a = make_sel<double>(q, q->dots64, q->Mk, exclude);
             a.epskey = epskey; a.coef = f.coef;
             hipLaunchKernelGGL(knn_partial_kernel<double>, dim3(grid), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1), dim3(1024), finish_lds<double>(), st, f, (const double*)q->pkey, (const int*)q->pidx);
+            f.ck = q->pkey; f.ci = q->pidx;
+            hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1), dim3(1024), finish_lds<double>(), st, f);
         } else {
             SelArgs<float> a = make_sel<float>(q, q->dots32, q->Mk, exclude);
             a.epskey = epskey; a.coef = f.coef;
             hipLaunchKernelGGL(knn_partial_kernel<float>, dim3(grid), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1), dim3(1024), finish_lds<float>(), st, f, (const float*)q->pkey, (const int*)q->pidx);
+            f.ck = q->pkey; f.ci = q->pidx;
+            hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1), dim3(1024), finish_lds<float>(), st, f);
         }
     } else {
+        f.ck = q->ckey_k; f.ci = q->cidx_k;
         if (q->exact)
-            hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1), dim3(1024), finish_lds<double>(), st, f, (const double*)q->ckey_k, (const int*)q->cidx_k);
+            hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1, 1, q->nb), dim3(1024), finish_lds<double>(), st, f);
         else
-            hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1), dim3(1024), finish_lds<float>(), st, f, (const float*)q->ckey_k, (const int*)q->cidx_k);
+            hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1, 1, q->nb), dim3(1024), finish_lds<float>(), st, f);
     }
     AS_HIP(hipGetLastError());
     return AS_OK;
@@ -1162,7 +1327,8 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
         a.tau = f.tau;
         hipLaunchKernelGGL(score_partial_kernel<T>, dim3(grid), dim3(256), 0, st, a);
-        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), finish_lds<T>(), st, f, (const T*)q->pkey, (const int*)q->pidx, coef_s);
+        f.ck = q->pkey; f.ci = q->pidx;
+        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), finish_lds<T>(), st, f, coef_s);
     } else {
         const int64_t rows = q->r1 - q->r0;
         int64_t G = (rows + CAND_CAP - 1) / CAND_CAP;
@@ -1170,11 +1336,13 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         const int ng = (int)((rows + G - 1) / G);
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
         a.tau = f.tau;
-        hipLaunchKernelGGL(score_gmin_kernel<T>, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, st, a, G, ng, (T*)q->gmin);
-        hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
+        const unsigned nb = (unsigned)q->nb;
+        hipLaunchKernelGGL(score_gmin_kernel<T>, dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
+        hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
         const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
-        hipLaunchKernelGGL(score_filter_kernel<T>, dim3(fg), dim3(256), 0, st, a, (T*)q->ckey_s, q->cidx_s);
-        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), finish_lds<T>(), st, f, (const T*)q->ckey_s, (const int*)q->cidx_s, coef_s);
+        hipLaunchKernelGGL(score_filter_kernel<T>, dim3(fg, 1, nb), dim3(256), 0, st, a);
+        f.ck = q->ckey_s; f.ci = q->cidx_s;
+        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1, 1, nb), dim3(1024), finish_lds<T>(), st, f, coef_s);
     }
 }
 
@@ -1209,11 +1377,12 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     hipStream_t st = q->stream;
     const bool stats = g_search_stats.load(std::memory_order_relaxed) != 0;
     if (query_host) {
-        memcpy(q->hq, query_host, sizeof(double) * d);  // pinned + device-mapped: the kernel reads it in place
+        memcpy(q->hq, query_host, sizeof(double) * d * q->nb);  // pinned + device-mapped: read in place by the kernel
+        if (q->cap > q->nb) memset(q->hq + d * q->nb, 0, sizeof(double) * d * (q->cap - q->nb));  // idle slots: zero query
     } else {
         hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->hq_dev);
     }
-    hipLaunchKernelGGL(q_prepare_kernel, dim3(1), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
+    hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, q->cap > 1 ? q->cap : q->nb), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
     if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
     const PreArgs pre = make_pre(q, eps, exclude, !q->robust);
     AS_TRY(launch_scan(q, pre));
@@ -1223,25 +1392,26 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
 }
 
 // wait for the final kernel's publication (pinned memory), without the driver's sync path
-static as_status wait_published(as_query* q) {
+static as_status wait_published(as_query* q, int slot = 0) {
     const int64_t want = q->seq;
     for (int spin = 0; spin < 2000000; ++spin) {
-        if (q->hout->seq == want) {
+        if (q->hout[slot].seq == want) {
             std::atomic_thread_fence(std::memory_order_acquire);
             return AS_OK;
         }
         if ((spin & 1023) == 1023 && hipStreamQuery(q->stream) == hipSuccess) break;
     }
     AS_HIP(hipStreamSynchronize(q->stream));
-    if (q->hout->seq != want) {
-        set_err("search result was not published (seq %lld != %lld)", (long long)q->hout->seq, (long long)want);
+    if (q->hout[slot].seq != want) {
+        set_err("search result was not published (seq %lld != %lld)", (long long)q->hout[slot].seq, (long long)want);
         return AS_EHIP;
     }
     return AS_OK;
 }
 
-static as_status collect(as_query* q, int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q) {
-    const HostOut* h = q->hout;
+static as_status collect(as_query* q, int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q,
+                         int slot = 0) {
+    const HostOut* h = q->hout + slot;
     if (out_lambda_q) *out_lambda_q = h->lambda_q;
     if (h->status == AS_EZEROLAMBDA) {
         if (out_len) *out_len = 0;
@@ -1265,13 +1435,18 @@ extern "C" {
 
 void as_enable_search_stats(int32_t enabled) { g_search_stats.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 
-as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out) {
+}  // extern "C"
+
+namespace as {
+as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out) {
     if (!sp || !out) {
         set_err("as_query_create: null argument");
         return AS_EINVAL;
     }
     AS_HIP(hipSetDevice(sp->device));
     as_query* q = new as_query();
+    q->cap = cap;
+    const size_t C = (size_t)cap;
     q->sp = sp;
     q->gr = gr;
     q->k = gr ? gr->gp.k : 1;
@@ -1290,24 +1465,29 @@ as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out
     }
     AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));
     q->stream = q->own_stream;
-    AS_HIP(hipHostMalloc(&q->hq, sizeof(double) * sp->d, hipHostMallocMapped | hipHostMallocCoherent));
+    AS_HIP(hipHostMalloc(&q->hq, sizeof(double) * sp->d * C, hipHostMallocMapped | hipHostMallocCoherent));
     AS_HIP(hipHostGetDevicePointer((void**)&q->hq_dev, q->hq, 0));
-    AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp));
-    AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp));
-    AS_HIP(hipMalloc(&q->info, sizeof(QInfo)));
-    AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE)));
+    AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp * C));
+    AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp * C));
+    AS_HIP(hipMalloc(&q->info, sizeof(QInfo) * C));
+    AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE) * C));
+    q->ss.dots = sp->np + ROW_TILE;
+    q->ss.q = sp->dp;
+    q->ss.qin = sp->d;
+    q->ss.knn = std::max<int64_t>(q->k, 1);
+    q->ss.hits = q->topk + 1;
     AS_HIP(hipMalloc(&q->pkey, sizeof(double) * (size_t)q->nwaves * 64));
     AS_HIP(hipMalloc(&q->pidx, sizeof(int) * (size_t)q->nwaves * 64));
-    AS_HIP(hipMalloc(&q->ckey_k, sizeof(double) * CAND_CAP));
-    AS_HIP(hipMalloc(&q->cidx_k, sizeof(int) * CAND_CAP));
-    AS_HIP(hipMalloc(&q->ckey_s, sizeof(double) * CAND_CAP));
-    AS_HIP(hipMalloc(&q->cidx_s, sizeof(int) * CAND_CAP));
-    AS_HIP(hipMalloc(&q->gmin, sizeof(double) * CAND_CAP));
-    AS_HIP(hipMalloc(&q->knn, sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1)));
-    AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * (q->topk + 1)));
-    AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut), hipHostMallocMapped | hipHostMallocCoherent));
+    AS_HIP(hipMalloc(&q->ckey_k, sizeof(double) * CAND_CAP * C));
+    AS_HIP(hipMalloc(&q->cidx_k, sizeof(int) * CAND_CAP * C));
+    AS_HIP(hipMalloc(&q->ckey_s, sizeof(double) * CAND_CAP * C));
+    AS_HIP(hipMalloc(&q->cidx_s, sizeof(int) * CAND_CAP * C));
+    AS_HIP(hipMalloc(&q->gmin, sizeof(double) * CAND_CAP * C));
+    AS_HIP(hipMalloc(&q->knn, sizeof(as_knn_rec) * q->ss.knn * C));
+    AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * q->ss.hits * C));
+    AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut) * C, hipHostMallocMapped | hipHostMallocCoherent));
     AS_HIP(hipHostGetDevicePointer((void**)&q->hout_dev, q->hout, 0));
-    memset(q->hout, 0, sizeof(HostOut));
+    memset(q->hout, 0, sizeof(HostOut) * C);
     for (int i = 0; i < 3; ++i) AS_HIP(hipEventCreate(&q->ev[i]));
     AS_HIP(hipFuncSetAttribute((const void*)knn_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<double>()));
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<double>()));
@@ -1316,6 +1496,11 @@ as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out
     *out = q;
     return AS_OK;
 }
+}  // namespace as
+
+extern "C" {
+
+as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out) { return query_create(sp, gr, 1, out); }
 
 void as_query_free(as_query* q) {
     if (!q) return;
@@ -1463,6 +1648,31 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
     AS_TRY(wait_published(q));
     return collect(q, out_idx, out_score, out_len, out_lambda_q);
+}
+
+// up to QB queries in one pass over the items (filter path, fp32 prefilters); out_status[b] is
+// AS_OK / AS_EZEROLAMBDA, or -1 when slot b must be rerun on the single-query path (a candidate
+// buffer overflowed or an a-posteriori check failed)
+as_status search_batch_once(as_query* q, const double* queries, int nb, int64_t d, double tau, int64_t topk, int64_t* out_idx,
+                            double* out_score, int64_t* out_len, double* out_lambda_q, int32_t* out_status) {
+    q->exact = 0;
+    q->robust = 0;
+    q->nb = nb;
+    AS_TRY(query_begin(q, queries, -1, d, 0, q->sp->n, q->gr->gp.eps, -1));
+    AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+    q->seq += 1;
+    AS_TRY(run_score(q, tau, 1));
+    for (int b = 0; b < nb; ++b) {
+        AS_TRY(wait_published(q, b));
+        const HostOut* h = q->hout + b;
+        if (h->overflow || h->knn_inexact || h->score_inexact) {
+            out_status[b] = -1;
+            continue;
+        }
+        const as_status s = collect(q, out_idx + b * topk, out_score + b * topk, out_len + b, out_lambda_q ? out_lambda_q + b : nullptr, b);
+        out_status[b] = (int32_t)s;
+    }
+    return AS_OK;
 }
 
 as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, int32_t* out_idx, double* out_key,

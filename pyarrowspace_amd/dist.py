@@ -166,6 +166,7 @@ class ShardedIndex:
 
     def __init__(self):
         self.engine = None
+        self._gbuf = {}
 
     # ---- collectives (all_gather of equally sized tensors works on nccl and gloo alike)
     def _gather_rows(self, t, counts):
@@ -185,6 +186,15 @@ class ShardedIndex:
         torch = self.torch
         if self.world == 1:
             return t
+        if t.is_cuda:
+            # RCCL: one collective into a preallocated [world * rows, ...] buffer, no per-call allocation
+            key = (t.data_ptr(), tuple(t.shape))
+            out = self._gbuf.get(key)
+            if out is None:
+                out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                self._gbuf[key] = out
+            self.dist.all_gather_into_tensor(out, t, group=self.group)
+            return out
         parts = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(parts, t, group=self.group)
         return torch.cat(parts, dim=0)

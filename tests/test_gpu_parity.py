@@ -102,3 +102,29 @@ def test_non_fp32_representable_items_keep_fp64(oracle_lib):
     want, _ = ref.search(q, 0.62)
     got = aspace.search(q, gl, 0.62)
     assert [i for i, _ in got] == [i for i, _ in want]
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_search_batch_matches_single_and_oracle(oracle_lib, metric):
+    """as_search_batch: 8 query slots per pass over the items; chunks of 8, 8 and 3."""
+    import pyarrowspace_amd as asp
+    n, d, k, topk = 3000, 200, 9, 7
+    X = clustered(n, d, nclust=10, seed=13)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": topk, "p": 2.0, "sigma": None, "metric": metric}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(17)
+    Q = np.stack([X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d) for _ in range(19)])
+    for tau in (0.62, 1.0):
+        got = aspace.search_batch(Q, gl, tau)
+        assert len(got) == 19
+        for b in range(19):
+            want, _ = ref.search(Q[b], tau)
+            assert [i for i, _ in got[b]] == [i for i, _ in want], (b, tau)
+            np.testing.assert_allclose([s for _, s in got[b]], [s for _, s in want], rtol=RTOL)
+            assert got[b] == aspace.search(np.ascontiguousarray(Q[b]), gl, tau)
+    far = Q.copy()
+    far[4] = 0.0
+    far[4, 0] = 40.0                      # one query without neighbours poisons the batch like the reference's assert
+    with pytest.raises(asp.PanicException):
+        aspace.search_batch(far, gl, 0.62)
