@@ -45,3 +45,27 @@ def oracle_lib():
     from oracle import oracle_c
     oracle_c.build_lib()
     return oracle_c
+
+
+def assert_hits_match(got, want, all_scores=None, rtol=1e-9, tie=1e-12):
+    """Returned (index, score) lists against the oracle's.  Indices must be identical except
+    where the oracle's scores tie to rounding (|ds| <= tie*|s|): two implementations that sum
+    in different orders cannot agree on the order of mathematically equal scores.  With
+    `all_scores` (the oracle's score of every item) a tie across the top-k boundary is accepted
+    too: every returned score must be right and no left-out item may beat the last returned one."""
+    gi, gs = [i for i, _ in got], np.array([s for _, s in got])
+    wi, ws = [i for i, _ in want], np.array([s for _, s in want])
+    assert len(gi) == len(wi)
+    np.testing.assert_allclose(gs, ws, rtol=rtol)
+    assert all(gs[t] >= gs[t + 1] for t in range(len(gs) - 1))
+    if gi == wi:
+        return
+    for t, (a, b) in enumerate(zip(gi, wi)):
+        if a == b:
+            continue
+        # position t differs: it must sit inside a run of tied oracle scores
+        tied = [u for u in range(len(ws)) if abs(ws[u] - ws[t]) <= tie * max(abs(ws[t]), 1e-300)]
+        if all_scores is not None:
+            assert abs(all_scores[a] - ws[t]) <= tie * max(abs(ws[t]), 1e-300) * 10, (t, a, b)
+        else:
+            assert len(tied) > 1 and a in [wi[u] for u in tied], (t, gi, wi)

@@ -14,7 +14,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from conftest import calibrate_eps, clustered  # noqa: E402
+from conftest import assert_hits_match, calibrate_eps, clustered  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 

@@ -1,0 +1,98 @@
+"""GPU: edge cases of the hot path against the oracle -- tile boundaries, odd feature
+counts, tiny inputs, isolated graphs, exact duplicates (ties), wide rows (generic scan)."""
+import numpy as np
+import pytest
+
+from conftest import assert_hits_match, calibrate_eps, clustered
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _compare(X, gp, oracle_lib, queries, taus=(1.0, 0.62, 0.0)):
+    import pyarrowspace_amd as asp
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    np.testing.assert_allclose(aspace.lambdas(), ref.lambdas, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(gl.degrees(), ref.deg, rtol=RTOL, atol=1e-300)
+    indptr, indices, values = gl.to_csr()
+    rows = np.repeat(np.arange(X.shape[0]), np.diff(indptr))
+    assert np.array_equal(indices[indices != rows], ref.indices)
+    for q in queries:
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        for tau in taus:
+            try:
+                want, lq = ref.search(q, tau)
+            except oracle_lib.ZeroLambda:
+                with pytest.raises(asp.PanicException):
+                    aspace.search(q, gl, tau)
+                continue
+            got = aspace.search(q, gl, tau)
+            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=RTOL)
+    return aspace, gl, ref
+
+
+@pytest.mark.parametrize("n", [2, 3, 63, 64, 65, 255, 256, 257, 511, 513])
+def test_row_tile_boundaries(oracle_lib, n):
+    d = 40
+    X = clustered(n, d, nclust=3, seed=n)
+    k = min(6, n)
+    gp = {"eps": calibrate_eps(X, max(1, min(k, n - 1))), "k": k, "topk": 4, "p": 2.0, "sigma": None}
+    _compare(X, gp, oracle_lib, [X[0] * 1.01, X[n - 1] + 0.01])
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 31, 32, 33, 255, 257, 1000])
+def test_feature_counts(oracle_lib, d):
+    n = 300
+    X = clustered(n, d, nclust=4, seed=100 + d, normalise=d > 1)
+    if d == 1:
+        X = X + 3.0
+    gp = {"eps": calibrate_eps(X, 5), "k": 5, "topk": 5, "p": 2.0, "sigma": None}
+    _compare(X, gp, oracle_lib, [X[7] * 1.02, X[100] + 0.01 / np.sqrt(d)])
+
+
+def test_wide_rows_use_the_generic_scan(oracle_lib):
+    n, d = 200, 2100                      # dp = 2112 floats > 8 x 256: generic scan kernel
+    X = clustered(n, d, nclust=4, seed=77)
+    gp = {"eps": calibrate_eps(X, 4), "k": 4, "topk": 3, "p": 2.0, "sigma": None}
+    _compare(X, gp, oracle_lib, [X[3] * 1.01])
+
+
+def test_single_item_and_no_edges(oracle_lib):
+    import pyarrowspace_amd as asp
+    X = np.array([[1.0, 2.0, 3.0]])
+    aspace, gl = asp.ArrowSpaceBuilder.build({"eps": 1.0, "k": 3, "topk": 2, "p": 2.0}, X)
+    assert aspace.nitems == 1 and gl.nnodes == 1 and aspace.lambdas().tolist() == [0.0]
+    hits = aspace.search(np.array([1.0, 2.0, 3.1]), gl, 1.0)   # the item is within eps of the query
+    assert len(hits) == 1 and hits[0][0] == 0
+    # eps so small that no pair is connected: every lambda is 0, tau0 floors, queries hit the zero-lambda assert
+    Y = clustered(100, 8, nclust=2, seed=1)
+    a2, g2 = asp.ArrowSpaceBuilder.build({"eps": 1e-9, "k": 3, "topk": 2, "p": 2.0}, Y)
+    assert not a2.lambdas().any() and not g2.degrees().any() and g2.tau0 == 1e-12
+    with pytest.raises(asp.PanicException):
+        a2.search(np.ascontiguousarray(Y[0] * 1.5), g2, 0.5)
+
+
+def test_exact_duplicates_break_ties_by_index(oracle_lib):
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((6, 16))
+    X = np.repeat(base, 50, axis=0)       # 300 rows, 6 distinct points x 50 copies: massive exact ties
+    gp = {"eps": 0.5, "k": 5, "topk": 6, "p": 2.0, "sigma": 0.3}
+    _compare(X, gp, oracle_lib, [base[2] + 0.01, base[5]])
+
+
+def test_unnormalised_scaled_items(oracle_lib):
+    """The reference's harnesses feed x100-scaled, unnormalised embeddings (tests/test_3_beir.py:155-156,190)."""
+    n, d = 500, 96
+    X = clustered(n, d, nclust=6, seed=3, normalise=False) * 100.0
+    gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 5, "p": 2.0, "sigma": None}
+    _compare(X, gp, oracle_lib, [X[11] * 1.001, X[400] + 0.5])
+
+
+def test_p_not_two_and_explicit_sigma(oracle_lib):
+    n, d = 400, 32
+    X = clustered(n, d, nclust=5, seed=8)
+    eps = calibrate_eps(X, 6)
+    for kern in ("gaussian", "rational"):
+        gp = {"eps": eps, "k": 6, "topk": 4, "p": 3.0, "sigma": eps * 0.8, "kernel": kern}
+        _compare(X, gp, oracle_lib, [X[9] * 1.01], taus=(0.62,))

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import clustered
+from conftest import assert_hits_match, clustered
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

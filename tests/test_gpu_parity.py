@@ -5,7 +5,7 @@ north_star): returned indices rank-exact, fp64 scores within 1e-6 relative (we a
 import numpy as np
 import pytest
 
-from conftest import calibrate_eps, clustered
+from conftest import assert_hits_match, calibrate_eps, clustered
 
 pytestmark = pytest.mark.gpu
 
@@ -54,8 +54,7 @@ def test_build_and_search_match_oracle(oracle_lib, n, d, k, topk, metric, kernel
                     aspace.search(q, gl, tau)
                 continue
             got = aspace.search(q, gl, tau)
-            assert [i for i, _ in got] == [i for i, _ in want], (qi, tau)
-            np.testing.assert_allclose([s for _, s in got], [s for _, s in want], rtol=RTOL)
+            assert_hits_match(got, want, ref.scores(q, tau, lq_ref), rtol=RTOL)
             assert abs(aspace.query_lambda(q, gl) - lq_ref) <= RTOL * abs(lq_ref)
 
 
