@@ -94,11 +94,14 @@ def main():
     device = torch.device("cuda", local_rank)
     os.environ["ARROWSPACE_DEVICE"] = str(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("ARROWSPACE_BENCH_FORCE_DIST", "") not in ("", "0")   # 1-GPU rehearsal of the N>1 path
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     import pyarrowspace_amd as asp
 
@@ -120,7 +123,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------- index build (timed once, inputs resident in HBM)
-    single = world == 1 and os.environ.get("ARROWSPACE_BENCH_FORCE_DIST", "") in ("", "0")
+    single = world == 1 and not force_dist
     if single:
         barrier()
         t0 = time.perf_counter()
@@ -138,7 +141,7 @@ def main():
         torch.cuda.empty_cache()
         barrier()
         t0 = time.perf_counter()
-        index = asdist.ShardedIndex.build(gp, shard, dist)
+        index = asdist.ShardedIndex.build(gp, shard, dist, force_collectives=force_dist)
         barrier()
         build_s = time.perf_counter() - t0
         searcher = lambda q: index.search(q, args.tau)  # noqa: E731

@@ -59,7 +59,7 @@ class HipEngine:
         torch = self.torch
         assert X.is_cuda and X.is_contiguous() and X.dtype in (torch.float32, torch.float64)
         dt = self._lib.DTYPE_F32 if X.dtype == torch.float32 else self._lib.DTYPE_F64
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         self._check(self.L.as_space_create_dev(C.c_void_p(X.data_ptr()), dt, X.shape[0], X.shape[1], X.shape[1],
                                                C.byref(self.op), C.byref(self.sp)))
         self.n, self.d = int(X.shape[0]), int(X.shape[1])
@@ -73,7 +73,7 @@ class HipEngine:
         dist = torch.zeros_like(key)
         gy = torch.zeros_like(key)
         cnt = torch.zeros((max(rows, 1),), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         if rows > 0:
             self._check(self.L.as_knn_rows(self.sp, C.byref(self.gp), r0, r1, C.c_void_p(idx.data_ptr()),
                                            C.c_void_p(key.data_ptr()), C.c_void_p(dist.data_ptr()),
@@ -81,7 +81,7 @@ class HipEngine:
         return idx[:rows], dist[:rows], gy[:rows], cnt[:rows]
 
     def graph_from_knn(self, idx, dist, gy, cnt):
-        self.torch.cuda.synchronize()
+        self.torch.cuda.current_stream().synchronize()
         self._check(self.L.as_graph_from_knn(self.sp, C.byref(self.gp), C.c_void_p(idx.data_ptr()),
                                              C.c_void_p(dist.data_ptr()), C.c_void_p(gy.data_ptr()),
                                              C.c_void_p(cnt.data_ptr()), C.byref(self.gr)))
@@ -167,27 +167,43 @@ class ShardedIndex:
     def __init__(self):
         self.engine = None
         self._gbuf = {}
+        self.stream = None
+        self.force_collectives = False
 
-    # ---- collectives (all_gather of equally sized tensors works on nccl and gloo alike)
+    # ---- collectives
+    def _collective(self):
+        return self.world > 1 or self.force_collectives
+
     def _gather_rows(self, t, counts):
         """t: this rank's [rows_r, ...] tensor -> concatenation over ranks, [sum(counts), ...]."""
         torch = self.torch
         world = len(counts)
-        if world == 1:
+        if not self._collective():
             return t
         mx = max(max(counts), 1)
+        if t.is_cuda and all(c == mx for c in counts):
+            # RCCL all-gather straight into the final buffer (equal shards: no padding, no copies)
+            out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            return out
         pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        self.dist.all_gather(parts, pad, group=self.group)
-        return torch.cat([parts[r][: counts[r]] for r in range(world)], dim=0)
+        if t.is_cuda:
+            buf = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(buf, pad, group=self.group)
+            parts = [buf[r * mx : r * mx + counts[r]] for r in range(world)]
+        else:
+            full = [torch.empty_like(pad) for _ in range(world)]
+            self.dist.all_gather(full, pad, group=self.group)
+            parts = [full[r][: counts[r]] for r in range(world)]
+        return torch.cat(parts, dim=0)
 
     def _gather_fixed(self, t):
         torch = self.torch
-        if self.world == 1:
+        if not self._collective():
             return t
         if t.is_cuda:
-            # RCCL: one collective into a preallocated [world * rows, ...] buffer, no per-call allocation
+            # one collective into a preallocated [world * rows, ...] buffer, no per-call allocation
             key = (t.data_ptr(), tuple(t.shape))
             out = self._gbuf.get(key)
             if out is None:
@@ -200,60 +216,80 @@ class ShardedIndex:
         return torch.cat(parts, dim=0)
 
     @classmethod
-    def build(cls, graph_params, X_shard, dist=None, group=None, engine=None):
+    def build(cls, graph_params, X_shard, dist=None, group=None, engine=None, force_collectives=False):
         """X_shard: this rank's contiguous block of rows (torch tensor on this rank's device,
         fp32 or fp64).  Ranks hold consecutive blocks in rank order."""
+        import contextlib
+
         import torch
 
         self = cls()
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
+        self.force_collectives = bool(force_collectives) and dist is not None
         self.engine = engine if engine is not None else HipEngine(graph_params)
-        rows = int(X_shard.shape[0])
-        if self.world > 1:
-            c = torch.tensor([rows], dtype=torch.int64, device=X_shard.device)
-            cs = [torch.zeros_like(c) for _ in range(self.world)]
-            dist.all_gather(cs, c, group=group)
-            counts = [int(v.item()) for v in cs]
-        else:
-            counts = [rows]
-        self.counts = counts
-        self.bounds = [0]
-        for v in counts:
-            self.bounds.append(self.bounds[-1] + v)
-        self.n = self.bounds[-1]
-        self.r0, self.r1 = self.bounds[self.rank], self.bounds[self.rank + 1]
-        X_full = self._gather_rows(X_shard.contiguous(), counts).contiguous()
-        self.engine.create_space(X_full)
-        del X_full
-        idx, dst, gy, cnt = self.engine.knn_rows(self.r0, self.r1)
-        idx = self._gather_rows(idx, counts).contiguous()
-        dst = self._gather_rows(dst, counts).contiguous()
-        gy = self._gather_rows(gy, counts).contiguous()
-        cnt = self._gather_rows(cnt, counts).contiguous()
-        self.engine.graph_from_knn(idx, dst, gy, cnt)
-        self.engine.query_open()
+        # CUDA: kernels and RCCL collectives are ordered on ONE dedicated, non-default stream
+        # (the legacy default stream has handle 0 and cannot be handed to the library)
+        self.stream = torch.cuda.Stream() if X_shard.is_cuda else None
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+        with ctx:
+            rows = int(X_shard.shape[0])
+            if self.world > 1:
+                c = torch.tensor([rows], dtype=torch.int64, device=X_shard.device)
+                cs = [torch.zeros_like(c) for _ in range(self.world)]
+                dist.all_gather(cs, c, group=group)
+                counts = [int(v.item()) for v in cs]
+            else:
+                counts = [rows]
+            self.counts = counts
+            self.bounds = [0]
+            for v in counts:
+                self.bounds.append(self.bounds[-1] + v)
+            self.n = self.bounds[-1]
+            self.r0, self.r1 = self.bounds[self.rank], self.bounds[self.rank + 1]
+            X_full = self._gather_rows(X_shard.contiguous(), counts).contiguous()
+            self._sync()
+            self.engine.create_space(X_full)
+            del X_full
+            idx, dst, gy, cnt = self.engine.knn_rows(self.r0, self.r1)
+            idx = self._gather_rows(idx, counts).contiguous()
+            dst = self._gather_rows(dst, counts).contiguous()
+            gy = self._gather_rows(gy, counts).contiguous()
+            cnt = self._gather_rows(cnt, counts).contiguous()
+            self._sync()
+            self.engine.graph_from_knn(idx, dst, gy, cnt)
+            self.engine.query_open()
         return self
+
+    def _sync(self):
+        if self.stream is not None:
+            self.stream.synchronize()
 
     def search(self, q, tau):
         """Same contract as ArrowSpace.search (src/lib.rs:132-174); every rank passes the same q."""
+        import contextlib
+
         from . import PanicException
 
         e = self.engine
+        ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
         mode = 0
-        for _ in range(3):
-            e.set_mode(mode)
-            e.query_scan(q, self.r0, self.r1)
-            knn_all = self._gather_fixed(e.knn_local)
-            e.query_lambda(knn_all)
-            e.query_score(tau)
-            hits_all = self._gather_fixed(e.hits_local)
-            hits, lq, zero, inexact, overflow = e.query_finish(hits_all)
-            nxt = mode | (2 if overflow else 0) | (1 if inexact else 0)
-            if nxt == mode:
-                break
-            mode = nxt
+        with ctx:
+            for _ in range(3):
+                e.set_mode(mode)
+                e.query_scan(q, self.r0, self.r1)
+                knn_all = self._gather_fixed(e.knn_local)
+                e.query_lambda(knn_all)
+                e.query_score(tau)
+                hits_all = self._gather_fixed(e.hits_local)
+                hits, lq, zero, inexact, overflow = e.query_finish(hits_all)
+                nxt = mode | (2 if overflow else 0) | (1 if inexact else 0)
+                if nxt == mode:
+                    break
+                mode = nxt
         self.last_lambda_q = lq
         if zero:
             raise PanicException("The lambdas are zero, check the magnitude of items and eps.")
