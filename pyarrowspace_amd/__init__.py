@@ -109,7 +109,7 @@ class GraphLaplacian:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _L is not None:      # _L is None once the interpreter tears the module down
             _L.as_free_graph(h)
             self._h = None
 
@@ -175,7 +175,7 @@ class ArrowSpace:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _L is not None:
             _L.as_free_space(h)
             self._h = None
 

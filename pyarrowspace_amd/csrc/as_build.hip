@@ -146,7 +146,7 @@ __device__ __forceinline__ int ld_l2(const int* p) { return __hip_atomic_load(p,
 
 // keep the M smallest (key, idx) of the row's cnt buffered candidates; wave-cooperative
 __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, float* ck, int* ci, int* s_cur,
-                                            float* s_thr, int* s_drop) {
+                                            float* s_thr, int* s_drop, int tstride = 1) {
     const int lane = lane_id();
     AS_CBAR();
     const int cnt = s_cur[rl];
@@ -164,7 +164,7 @@ __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, f
         if (rank < M) {
             bk[rank] = k;
             bi[rank] = i;
-            if (rank == M - 1) s_thr[rl] = k;
+            if (rank == M - 1) s_thr[rl * tstride] = k;
         }
     }
     if (lane == 0) {
@@ -295,6 +295,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     compute(cur);
                     __syncthreads();
                 }
+            } else if (V & 16) {
+                // diagnostic: MFMA + fragment reads only (no staging after the first slab)
+                for (int ks = 0; ks < nslab; ++ks) compute(0);
             } else {
                 for (int ks = 0; ks < nslab; ++ks) {
                     const bool more = ks + 1 < nslab;
@@ -306,6 +309,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         __syncthreads();
                     }
                 }
+            }
+            if (V & 8) {
+                // diagnostic: no epilogue; keep the accumulators alive
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) asm volatile("" ::"v"(acc[m][nn]));
+                continue;
             }
             // ---- epilogue: keys, bound test, append
             {
@@ -373,6 +384,219 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int64_t rg = rowbase + rl;
             if (rg >= a.r1 || rg >= a.n) break;
             if (s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, s_thr, s_drop);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int cnt = s_cur[rl];
+            const size_t ob = ((size_t)(rg - a.r0) * a.S + cs) * a.M;
+            for (int t = lane; t < cnt; t += 64) {
+                a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
+                a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
+            }
+            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = cnt | (s_drop[rl] << 30);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- K2 (LDS-DMA form).  Same tile, same MFMA loop, same bookkeeping as knn_mfma_kernel; the
+// slabs reach LDS by `global_load_lds_dwordx4` (no VGPR staging, no ds_write), double-buffered
+// across slabs AND across column tiles, one barrier per slab.  LDS-DMA writes a wave-linear
+// image (lane L -> base + 16 L), so rows cannot be padded; bank conflicts are avoided by an XOR
+// swizzle applied to the per-lane SOURCE address and to the fragment reads: 16-byte chunk c of
+// row r lives at chunk c ^ ((r >> 1) & 7) (any 16 rows distinct mod 16 then cover all 64 banks).
+constexpr int DROW = 32;                       // floats per row of a DMA slab (no padding)
+constexpr int DSLAB = (BM + BN) * DROW;        // floats per slab buffer: A rows then B rows
+
+template <bool INTERLEAVE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void knn_mfma_dma_kernel(KnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Sl = (float*)smem;                  // 2 slab buffers
+    float2* s_ta = (float2*)(Sl + 2 * DSLAB);  // per row: (running bound, n_i or 1/|x_i|)
+    int* s_cur = (int*)(s_ta + BM);
+    int* s_drop = s_cur + BM;
+    float* c_key = (float*)(s_drop + BM);
+    int* c_idx = (int*)(c_key + 4 * CAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    float* __restrict__ bkey = a.buf_key + (size_t)blockIdx.x * BM * CAP;
+    int* __restrict__ bidx = a.buf_idx + (size_t)blockIdx.x * BM * CAP;
+    float* ck = c_key + w * CAP;
+    int* ci = c_idx + w * CAP;
+    const int units = a.nrb * a.S;
+    const int nslab = (int)(a.dp / BK);
+    const float finf = __int_as_float(0x7f800000);
+
+    // DMA source decomposition (see header comment): piece j of this wave covers rows
+    // [8 j, 8 j + 8) of the wave's 64 A rows (32 B rows); lane L -> row + (L >> 3), stored chunk L & 7
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: SGPR address math, M0 by SALU
+    const int drow = lane >> 3;
+    const int csw0 = (lane & 7) ^ ((lane >> 4) & 7);            // source chunk for even pieces
+    const int csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);      // source chunk for odd pieces
+    // per-lane byte offsets inside a piece (32-bit: saddr + voffset form of the DMA)
+    const unsigned lo0 = (unsigned)((drow * a.dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * a.dp + csw1 * 4) * 4);
+    // fragment read offsets (floats) inside a row, per k-group s: chunk (2 s + h) ^ ((l31 >> 1) & 7)
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = (((2 * s + h) ^ ((l31 >> 1) & 7)) << 2);
+
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int rb = u / a.S, cs = u % a.S;
+        const int64_t rowbase = a.r0 + (int64_t)rb * BM;
+        const int t0 = (int)((int64_t)a.ntile * cs / a.S), t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
+        {
+            const int64_t rg = rowbase + tid;
+            const bool valid = rg < a.r1 && rg < a.n;
+            const float ni = valid ? a.n32[rg] : 0.0f;
+            const float bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+            s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (a.metric == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f);
+            s_cur[tid] = 0;
+            s_drop[tid] = 0;
+        }
+        // uniform source bases (bytes): A rows of this wave, B rows of this wave's 32-row share
+        const char* pa0 = (const char*)(a.x32 + (size_t)(rowbase + wu * 64) * a.dp);
+        // one 1-KiB LDS-DMA piece: j < 8 -> A rows [8j, 8j+8) of this wave's 64, j >= 8 -> B rows of its 32
+        auto dma_piece = [&](const char* srcA, const char* srcB, float* dst, int j) {
+            if (j < 8) {
+                const char* src = srcA + (size_t)(8 * j) * a.dp * 4 + ((j & 1) ? lo1 : lo0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + (wu * 64 + 8 * j) * DROW), 16, 0, 0);
+            } else {
+                const int jb = j - 8;
+                const char* src = srcB + (size_t)(8 * jb) * a.dp * 4 + ((jb & 1) ? lo1 : lo0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + BM * DROW + (wu * 32 + 8 * jb) * DROW), 16, 0, 0);
+            }
+        };
+        auto colptr = [&](int ct) { return (const char*)(a.x32 + (size_t)((int64_t)ct * BN + wu * 32) * a.dp); };
+        {
+            const char* pb0 = colptr(t0);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) dma_piece(pa0, pb0, Sl, j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int g = 0;
+        for (int ct = t0; ct < t1; ++ct) {
+            const int64_t colbase = (int64_t)ct * BN;
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
+            const char* pbc = colptr(ct);
+            const char* pbn = colptr(ct + 1 < t1 ? ct + 1 : ct);
+            // column norms of this tile: issued now, consumed by the epilogue (latency hidden by the K loop)
+            float nj[4];
+            int cj[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                const int64_t cg = colbase + nn * 32 + l31;
+                cj[nn] = (int)cg;
+                nj[nn] = a.metric == AS_METRIC_L2 ? a.n32[cg] : a.inorm32[cg];
+            }
+            for (int ks = 0; ks < nslab; ++ks, ++g) {
+                const int cur = g & 1;
+                // next slab: (ct, ks+1), or slab 0 of the next column tile; the very last slab of the unit
+                // re-stages itself into the idle buffer (branch-free body, nobody reads it)
+                const bool lastk = ks + 1 == nslab;
+                const char* nxa = pa0 + (lastk ? 0 : ks + 1) * BK * 4;
+                const char* nxb = (lastk ? pbn : pbc) + (lastk ? 0 : ks + 1) * BK * 4;
+                float* nxd = Sl + (cur ^ 1) * DSLAB;
+                if (!INTERLEAVE) {
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) dma_piece(nxa, nxb, nxd, j);
+                }
+                const float* Ar = Sl + cur * DSLAB + (w * 64 + l31) * DROW;
+                const float* Br = Sl + cur * DSLAB + BM * DROW + l31 * DROW;
+                // fragments are software-pipelined by hand: the LDS-DMA intrinsic is an LDS write the
+                // compiler will not move reads across, so group s+1's reads sit between two DMA pieces
+                f32x4 af[2][2], bf[2][4];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[0][m] = *(const f32x4*)(Ar + m * 32 * DROW + foff[0]);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) bf[0][nn] = *(const f32x4*)(Br + nn * 32 * DROW + foff[0]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int nn = 0; nn < 4; ++nn) {
+                                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][m][t], bf[s & 1][nn][t], acc[m][nn], 0, 0, 0);
+                                const int id = t * 8 + m * 4 + nn;
+                                if (INTERLEAVE && id == 4) dma_piece(nxa, nxb, nxd, 3 * s);
+                                if (INTERLEAVE && id == 12) dma_piece(nxa, nxb, nxd, 3 * s + 1);
+                                if (id == 18 && s < 3) {
+#pragma unroll
+                                    for (int m2 = 0; m2 < 2; ++m2) af[(s + 1) & 1][m2] = *(const f32x4*)(Ar + m2 * 32 * DROW + foff[s + 1]);
+#pragma unroll
+                                    for (int n2 = 0; n2 < 4; ++n2) bf[(s + 1) & 1][n2] = *(const f32x4*)(Br + n2 * 32 * DROW + foff[s + 1]);
+                                }
+                                if (INTERLEAVE && id == 24) dma_piece(nxa, nxb, nxd, 3 * s + 2);
+                            }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // ---- epilogue: keys, bound test, append
+            {
+                AS_CBAR();
+                const int rl = w * 64 + lane;
+                unsigned long long need = __ballot(s_cur[rl] > CAP - BN);
+                while (need) {
+                    const int r = __ffsll((long long)need) - 1;
+                    const unsigned rr = w * 64 + r;
+                    compact_row(rr, a.M, bkey + rr * CAP, bidx + rr * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
+                    need &= need - 1;
+                }
+                AS_CBAR();
+            }
+            // tiles that touch the diagonal or the padded tail need the per-element exclusions
+            const bool edge = colbase + BN > a.n || (colbase < rowbase + BM && colbase + BN > rowbase);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = w * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float2 ta = s_ta[rl];
+                    const float thr = ta.x, ai = ta.y;
+                    const int rg = (int)(rowbase + rl);
+                    float key[4];
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) {
+                        const float gg = acc[m][nn][r];
+                        key[nn] = a.metric == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * ai * nj[nn]);
+                        if (edge && (cj[nn] >= a.n || cj[nn] == rg)) key[nn] = finf;
+                    }
+                    const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
+                    if (__ballot(kmin <= thr)) {
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn) {
+                            const bool p = key[nn] <= thr;
+                            const unsigned long long mk = __ballot(p);
+                            if (!mk) continue;
+                            const unsigned hm = h ? (unsigned)(mk >> 32) : (unsigned)mk;
+                            const int base = s_cur[rl];
+                            if (p) {
+                                const unsigned slot = (unsigned)rl * CAP + base + __popc(hm & ((1u << l31) - 1u));
+                                bkey[slot] = key[nn];
+                                bidx[slot] = cj[nn];
+                            }
+                            s_cur[rl] = base + __popc(hm);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- finalize this unit's rows (each wave: its 64 rows)
+        AS_CBAR();
+        for (int r = 0; r < 64; ++r) {
+            const unsigned rl = w * 64 + r;
+            const int64_t rg = rowbase + rl;
+            if (rg >= a.r1 || rg >= a.n) break;
+            if (s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int cnt = s_cur[rl];
             const size_t ob = ((size_t)(rg - a.r0) * a.S + cs) * a.M;
@@ -581,8 +805,9 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     if (!sp->opts.force_exact) {
         const int nrb = (int)((rows + BM - 1) / BM);
         const int ntile = (int)(sp->np / BN);
-        int variant = 0;
-        if (const char* ev = getenv("ARROWSPACE_KNN_VARIANT")) variant = atoi(ev) & 7;
+        // default: LDS-DMA staged kernel (32); 0..31 select the register-staged kernel and its A/B variants
+        int variant = 32;
+        if (const char* ev = getenv("ARROWSPACE_KNN_VARIANT")) variant = atoi(ev) & 63;
         int S = 1;
         {   // enough units to fill the chip several times over, but never thinner than 8 column tiles
             int dev_cus = 256;
@@ -590,7 +815,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
             const int target_units = dev_cus * 2 * 8;
             while (S < 8 && nrb * S < target_units && ntile / (S * 2) >= 8) S *= 2;
-            if ((variant & 1) && ntile >= 64) S = 8;  // XCD-grouped order: 4 row blocks x 8 column segments per XCD
+            if ((variant & 1) && !(variant & 32) && ntile >= 64) S = 8;  // XCD-grouped order: 4 row blocks x 8 column segments per XCD
         }
         int dev_cus = 256;
         {
@@ -614,10 +839,10 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
         ka.epskey = nextafterf(ka.epskey, INFINITY);
         ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-        const size_t lds = sizeof(float) * (BM + BN) * LROW * ((variant & 2) ? 2 : 1) + sizeof(float) * 4 * BM +
+        const size_t lds = sizeof(float) * (BM + BN) * LROW * (((variant & 2) && !(variant & 16)) ? 2 : 1) + sizeof(float) * 4 * BM +
                            (sizeof(float) + sizeof(int)) * 4 * CAP;
         int lgrid = grid;
-        if (variant & 1) lgrid = std::max(8, std::min(units, dev_cus) / 8 * 8);  // one resident block per CU, 8 XCD labels
+        if ((variant & 1) && !(variant & 32)) lgrid = std::max(8, std::min(units, dev_cus) / 8 * 8);  // one resident block per CU, 8 XCD labels
         hipEvent_t e0, e1, e2;
         AS_HIP(hipEventCreate(&e0)); AS_HIP(hipEventCreate(&e1)); AS_HIP(hipEventCreate(&e2));
 #define AS_KNN_LAUNCH(VV)                                                                                              \
@@ -626,9 +851,21 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         AS_HIP(hipEventRecord(e0, st));                                                                                \
         hipLaunchKernelGGL(knn_mfma_kernel<VV>, dim3(lgrid), dim3(256), lds, st, ka);                                  \
         break;
+        if (variant & 32) {
+            const size_t ldsd = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+            AS_HIP(hipEventRecord(e0, st));
+            if (variant & 1) hipLaunchKernelGGL(knn_mfma_dma_kernel<true>, dim3(grid), dim3(256), ldsd, st, ka);
+            else hipLaunchKernelGGL(knn_mfma_dma_kernel<false>, dim3(grid), dim3(256), ldsd, st, ka);
+        } else
         switch (variant) {
             AS_KNN_LAUNCH(0) AS_KNN_LAUNCH(1) AS_KNN_LAUNCH(2) AS_KNN_LAUNCH(3)
             AS_KNN_LAUNCH(4) AS_KNN_LAUNCH(5) AS_KNN_LAUNCH(6) AS_KNN_LAUNCH(7)
+            AS_KNN_LAUNCH(8) AS_KNN_LAUNCH(16) AS_KNN_LAUNCH(24) AS_KNN_LAUNCH(10)
+            default:
+                set_err("unknown ARROWSPACE_KNN_VARIANT %d", variant);
+                return AS_EINVAL;
         }
 #undef AS_KNN_LAUNCH
         AS_HIP(hipGetLastError());

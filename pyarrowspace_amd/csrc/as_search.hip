@@ -79,6 +79,8 @@ struct as_query {
     as::SlotStride ss{};
     int cus = 256;
     int scan_grid = 0;
+    int scan_variant = 0;    // bit0: alternate scan direction per query, bit1: temporal row loads
+    int64_t scan_count = 0;
     int64_t r0 = 0, r1 = 0;
     int exact = 0;
     int robust = 0;          // 1: wavefront-list path instead of the filter path
@@ -209,10 +211,12 @@ __device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, flo
 
 // HBM-bound: one wave per row, 16 B per lane per load, query fragment in registers,
 // two rows in flight per wave.  NCH = ceil(dp / 256) chunks of 256 floats.
-template <int NCH>
+// NT: non-temporal row loads.  rev: walk the rows from the end -- consecutive queries alternate
+// direction, so the tail of one scan (still in the 256 MiB Infinity Cache) is the head of the next.
+template <int NCH, bool NT>
 __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
                                                             int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
-                                                            PreArgs pre) {
+                                                            PreArgs pre, int rev) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -226,18 +230,21 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
         on[u] = c < dp;
         qv[u] = on[u] ? *(const f32x4*)(q32 + c) : f32x4{0, 0, 0, 0};
     }
+    auto ld = [&](const float* p) -> f32x4 { return NT ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p; };
+    const int64_t last = r0 + r1 - 1;   // rev: logical row t maps to physical row last - t
     int64_t row = r0 + gw;
     for (; row + nw < r1; row += 2 * nw) {
-        const float* pa = x32 + row * dp + 4 * lane;
-        const float* pb = pa + nw * dp;
+        const int64_t ra = rev ? last - row : row, rb = rev ? last - (row + nw) : row + nw;
+        const float* pa = x32 + ra * dp + 4 * lane;
+        const float* pb = x32 + rb * dp + 4 * lane;
         f32x4 va[NCH], vb[NCH];
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
-            va[u] = on[u] ? __builtin_nontemporal_load((const f32x4*)(pa + 256 * u)) : f32x4{0, 0, 0, 0};
-            vb[u] = on[u] ? __builtin_nontemporal_load((const f32x4*)(pb + 256 * u)) : f32x4{0, 0, 0, 0};
+            va[u] = on[u] ? ld(pa + 256 * u) : f32x4{0, 0, 0, 0};
+            vb[u] = on[u] ? ld(pb + 256 * u) : f32x4{0, 0, 0, 0};
         }
         // lanes 0 / 1 own the two results; their aux value is in flight with the row loads
-        const int64_t myrow = row + (lane & 1) * nw;
+        const int64_t myrow = (lane & 1) ? rb : ra;
         const float aux = auxv[myrow];
         float sa = 0.0f, sb = 0.0f;
 #pragma unroll
@@ -257,20 +264,21 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
         }
     }
     if (row < r1) {
-        const float* pa = x32 + row * dp + 4 * lane;
+        const int64_t ra = rev ? last - row : row;
+        const float* pa = x32 + ra * dp + 4 * lane;
         float sa = 0.0f;
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             if (on[u]) {
-                const f32x4 v = __builtin_nontemporal_load((const f32x4*)(pa + 256 * u));
+                const f32x4 v = ld(pa + 256 * u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sa = fmaf(v[e], qv[u][e], sa);
             }
         }
         sa = wave_sum(sa);
         if (lane == 0) {
-            dots[row] = sa;
-            prefilter_f32(pre, row, sa, auxv[row], nq32, inq32);
+            dots[ra] = sa;
+            prefilter_f32(pre, ra, sa, auxv[ra], nq32, inq32);
         }
     }
 }
@@ -1199,18 +1207,23 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
             AS_HIP(hipGetLastError());
             return AS_OK;
         }
+        const int rev = (q->scan_variant & 1) ? (int)(q->scan_count++ & 1) : 0;
         // resident grid: every wave gets the same number of rows and all of them run at once
         // (a grid one block over residency costs a whole extra round at 1/8 occupancy)
 #define AS_SCAN(N)                                                                                                     \
     do {                                                                                                               \
         if (!q->scan_grid) {                                                                                           \
             int nb = 0;                                                                                                \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_dots_f32_kernel<N>, 256, 0) != hipSuccess) nb = 4; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_dots_f32_kernel<N, true>, 256, 0) != hipSuccess) nb = 4; \
             q->scan_grid = q->cus * std::max(1, std::min(nb, 8));                                                      \
         }                                                                                                              \
         const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->scan_grid);                               \
-        hipLaunchKernelGGL(scan_dots_f32_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0,      \
-                           q->r1, q->dots32, pre);                                                                     \
+        if (q->scan_variant & 2)                                                                                       \
+            hipLaunchKernelGGL((scan_dots_f32_kernel<N, false>), dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, \
+                               q->r0, q->r1, q->dots32, pre, rev);                                                     \
+        else                                                                                                           \
+            hipLaunchKernelGGL((scan_dots_f32_kernel<N, true>), dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp,  \
+                               q->r0, q->r1, q->dots32, pre, rev);                                                     \
     } while (0)
         switch (nch) {
             case 1: AS_SCAN(1); break;
@@ -1459,6 +1472,7 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
         return AS_EUNSUPPORTED;
     }
     q->nwaves = 4096;
+    if (const char* ev = getenv("ARROWSPACE_SCAN_VARIANT")) q->scan_variant = atoi(ev) & 3;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) q->cus = prop.multiProcessorCount;
