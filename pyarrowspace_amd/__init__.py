@@ -223,15 +223,20 @@ class ArrowSpace:
         if not isinstance(gl, GraphLaplacian):
             raise TypeError("argument 'gl': expected GraphLaplacian")
         q = self._query(item)
-        topk = min(int(gl.graph_params["topk"]), self.nitems)
-        idx = np.empty(max(topk, 1), dtype=np.int64)
-        sc = np.empty(max(topk, 1), dtype=np.float64)
-        ln, lq = C.c_int64(0), C.c_double(0.0)
-        st = _L.as_search(self._h, gl._h, q.ctypes.data_as(C.c_void_p), q.shape[0], float(tau),
-                          idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), C.byref(ln), C.byref(lq))
+        # per-(space, graph) call state: output buffers and ctypes arguments are built once
+        st_ = getattr(self, "_sstate", None)
+        if st_ is None or st_[0] is not gl:
+            topk = max(min(int(gl.graph_params["topk"]), self.nitems), 1)
+            idx = (C.c_int64 * topk)()
+            sc = (C.c_double * topk)()
+            ln, lq = C.c_int64(0), C.c_double(0.0)
+            st_ = self._sstate = (gl, idx, sc, ln, lq, C.byref(ln), C.byref(lq))
+        _, idx, sc, ln, lq, pln, plq = st_
+        st = _L.as_search(self._h, gl._h, q.ctypes.data, q.shape[0], tau, idx, sc, pln, plq)
         if st:
             _raise(st)
-        return [(int(idx[t]), float(sc[t])) for t in range(ln.value)]
+        n = ln.value
+        return list(zip(idx[:n], sc[:n]))
 
     def search_batch(self, items, gl: GraphLaplacian, tau: float):
         """Extension: B queries [B, D] -> list of B hit lists."""

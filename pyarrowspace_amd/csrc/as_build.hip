@@ -610,6 +610,192 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---- K2 (LDS-DMA, 8 waves).  Same tile and LDS image as knn_mfma_dma_kernel, but 512 threads:
+// two waves share every SIMD's matrix pipe (wave w owns rows [32w, 32w+32) as 1x4 accumulators),
+// so one wave's DMA issue, fragment-read latency and epilogue run in the shadow of its
+// partner's MFMAs.  Waves 4-7 issue their DMA pieces mid-slab, waves 0-3 at the slab start.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_mfma_dma8_kernel(KnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Sl = (float*)smem;                  // 2 slab buffers
+    float2* s_ta = (float2*)(Sl + 2 * DSLAB);  // per row: (running bound, n_i or 1/|x_i|)
+    int* s_cur = (int*)(s_ta + BM);
+    int* s_drop = s_cur + BM;
+    float* c_key = (float*)(s_drop + BM);
+    int* c_idx = (int*)(c_key + 8 * CAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* __restrict__ bkey = a.buf_key + (size_t)blockIdx.x * BM * CAP;
+    int* __restrict__ bidx = a.buf_idx + (size_t)blockIdx.x * BM * CAP;
+    float* ck = c_key + w * CAP;
+    int* ci = c_idx + w * CAP;
+    const int units = a.nrb * a.S;
+    const int nslab = (int)(a.dp / BK);
+    const float finf = __int_as_float(0x7f800000);
+    const int drow = lane >> 3;
+    const int csw0 = (lane & 7) ^ ((lane >> 4) & 7);
+    const int csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+    const unsigned lo0 = (unsigned)((drow * a.dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * a.dp + csw1 * 4) * 4);
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = (((2 * s + h) ^ ((l31 >> 1) & 7)) << 2);
+    const bool late = wu >= 4;   // wave-uniform: second-dispatched half issues its DMA mid-slab
+
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int rb = u / a.S, cs = u % a.S;
+        const int64_t rowbase = a.r0 + (int64_t)rb * BM;
+        const int t0 = (int)((int64_t)a.ntile * cs / a.S), t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
+        if (tid < BM) {
+            const int64_t rg = rowbase + tid;
+            const bool valid = rg < a.r1 && rg < a.n;
+            const float ni = valid ? a.n32[rg] : 0.0f;
+            const float bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+            s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (a.metric == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f);
+            s_cur[tid] = 0;
+            s_drop[tid] = 0;
+        }
+        const char* pa0 = (const char*)(a.x32 + (size_t)(rowbase + wu * 32) * a.dp);
+        // 6 pieces per wave and slab: j < 4 -> A rows [8j, 8j+8) of this wave's 32, j >= 4 -> B rows of its 16
+        auto dma_piece = [&](const char* srcA, const char* srcB, float* dst, int j) {
+            if (j < 4) {
+                const char* src = srcA + (size_t)(8 * j) * a.dp * 4 + ((j & 1) ? lo1 : lo0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + (wu * 32 + 8 * j) * DROW), 16, 0, 0);
+            } else {
+                const int jb = j - 4;
+                const char* src = srcB + (size_t)(8 * jb) * a.dp * 4 + ((jb & 1) ? lo1 : lo0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + BM * DROW + (wu * 16 + 8 * jb) * DROW), 16, 0, 0);
+            }
+        };
+        auto colptr = [&](int ct) { return (const char*)(a.x32 + (size_t)((int64_t)ct * BN + wu * 16) * a.dp); };
+        {
+            const char* pb0 = colptr(t0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dma_piece(pa0, pb0, Sl, j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int g = 0;
+        for (int ct = t0; ct < t1; ++ct) {
+            const int64_t colbase = (int64_t)ct * BN;
+            f32x16 acc[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nn][r] = 0.0f;
+            const char* pbc = colptr(ct);
+            const char* pbn = colptr(ct + 1 < t1 ? ct + 1 : ct);
+            float nj[4];
+            int cj[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                const int64_t cg = colbase + nn * 32 + l31;
+                cj[nn] = (int)cg;
+                nj[nn] = a.metric == AS_METRIC_L2 ? a.n32[cg] : a.inorm32[cg];
+            }
+            for (int ks = 0; ks < nslab; ++ks, ++g) {
+                const int cur = g & 1;
+                const bool lastk = ks + 1 == nslab;
+                const char* nxa = pa0 + (lastk ? 0 : ks + 1) * BK * 4;
+                const char* nxb = (lastk ? pbn : pbc) + (lastk ? 0 : ks + 1) * BK * 4;
+                float* nxd = Sl + (cur ^ 1) * DSLAB;
+                if (!late) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) dma_piece(nxa, nxb, nxd, j);
+                }
+                const float* Ar = Sl + cur * DSLAB + (w * 32 + l31) * DROW;
+                const float* Br = Sl + cur * DSLAB + BM * DROW + l31 * DROW;
+                f32x4 af[2], bf[2][4];
+                af[0] = *(const f32x4*)(Ar + foff[0]);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) bf[0][nn] = *(const f32x4*)(Br + nn * 32 * DROW + foff[0]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s < 3) {
+                        af[(s + 1) & 1] = *(const f32x4*)(Ar + foff[s + 1]);
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn) bf[(s + 1) & 1][nn] = *(const f32x4*)(Br + nn * 32 * DROW + foff[s + 1]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn)
+                            acc[nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][t], bf[s & 1][nn][t], acc[nn], 0, 0, 0);
+                    if (s == 1 && late) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) dma_piece(nxa, nxb, nxd, j);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // ---- epilogue: keys, bound test, append (32 rows per wave)
+            {
+                AS_CBAR();
+                const int rl = w * 32 + l31;
+                unsigned long long need = __ballot(lane < 32 && s_cur[rl] > CAP - BN);
+                while (need) {
+                    const int r = __ffsll((long long)need) - 1;
+                    const unsigned rr = w * 32 + r;
+                    compact_row(rr, a.M, bkey + rr * CAP, bidx + rr * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
+                    need &= need - 1;
+                }
+                AS_CBAR();
+            }
+            const bool edge = colbase + BN > a.n || (colbase < rowbase + BM && colbase + BN > rowbase);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float2 ta = s_ta[rl];
+                const float thr = ta.x, ai = ta.y;
+                const int rg = (int)(rowbase + rl);
+                float key[4];
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    const float gg = acc[nn][r];
+                    key[nn] = a.metric == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * ai * nj[nn]);
+                    if (edge && (cj[nn] >= a.n || cj[nn] == rg)) key[nn] = finf;
+                }
+                const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
+                if (__ballot(kmin <= thr)) {
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) {
+                        const bool p = key[nn] <= thr;
+                        const unsigned long long mk = __ballot(p);
+                        if (!mk) continue;
+                        const unsigned hm = h ? (unsigned)(mk >> 32) : (unsigned)mk;
+                        const int base = s_cur[rl];
+                        if (p) {
+                            const unsigned slot = (unsigned)rl * CAP + base + __popc(hm & ((1u << l31) - 1u));
+                            bkey[slot] = key[nn];
+                            bidx[slot] = cj[nn];
+                        }
+                        s_cur[rl] = base + __popc(hm);
+                    }
+                }
+            }
+        }
+        // ---- finalize this unit's rows (each wave: its 32 rows)
+        AS_CBAR();
+        for (int r = 0; r < 32; ++r) {
+            const unsigned rl = w * 32 + r;
+            const int64_t rg = rowbase + rl;
+            if (rg >= a.r1 || rg >= a.n) break;
+            if (s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int cnt = s_cur[rl];
+            const size_t ob = ((size_t)(rg - a.r0) * a.S + cs) * a.M;
+            for (int t = lane; t < cnt; t += 64) {
+                a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
+                a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
+            }
+            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = cnt | (s_drop[rl] << 30);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ K2b fp64 refinement
 // One wave per row: merge the S segment lists to the M smallest fp32 keys, evaluate those
 // M pairs exactly in fp64, order by (key64, idx), apply eps and the k cap, and prove a
@@ -805,8 +991,8 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     if (!sp->opts.force_exact) {
         const int nrb = (int)((rows + BM - 1) / BM);
         const int ntile = (int)(sp->np / BN);
-        // default: LDS-DMA staged kernel (32); 0..31 select the register-staged kernel and its A/B variants
-        int variant = 32;
+        // default: 8-wave LDS-DMA kernel (48); 32 = 4-wave LDS-DMA; 0..31 = register-staged kernel and its A/B variants
+        int variant = 48;
         if (const char* ev = getenv("ARROWSPACE_KNN_VARIANT")) variant = atoi(ev) & 63;
         int S = 1;
         {   // enough units to fill the chip several times over, but never thinner than 8 column tiles
@@ -851,7 +1037,12 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         AS_HIP(hipEventRecord(e0, st));                                                                                \
         hipLaunchKernelGGL(knn_mfma_kernel<VV>, dim3(lgrid), dim3(256), lds, st, ka);                                  \
         break;
-        if (variant & 32) {
+        if ((variant & 48) == 48) {
+            const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            AS_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(knn_mfma_dma8_kernel, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+        } else if (variant & 32) {
             const size_t ldsd = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));

@@ -535,41 +535,22 @@ __global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G
     if (lane == 0) gmin[g] = m;
 }
 
-// (2) threshold = M-th smallest group minimum (radix select over the ordered bit pattern).
-// At least M rows have key <= threshold, so the M best rows all pass the filter.
-template <typename T, typename U, int PASSES>
-__global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gmin, int ng, int M, QInfo* info) {
-    __shared__ unsigned int hist[256];
-    gmin += (int64_t)blockIdx.z * CAND_CAP;
-    info += blockIdx.z;
-    __shared__ U s_prefix;
-    __shared__ int s_rank;
+// k-th smallest (0-based) of up to 4 x 1024 ordered-bit values held 4 per thread; whole block
+// (1024 threads) calls it.  PASSES x 8-bit radix select with an LDS histogram.
+template <typename U, int PASSES>
+__device__ __forceinline__ U block_kth(const U (&v)[4], const bool (&have)[4], int kth, unsigned int* hist, U* s_prefix,
+                                       int* s_rank) {
     const int tid = threadIdx.x;
-    if (ng <= M) {
-        if (tid == 0) {
-            if (sizeof(T) == 4) info->thr32 = key_traits<float>::inf();
-            else info->thr64 = key_traits<double>::inf();
-        }
-        return;
-    }
-    U v[4];
-    bool have[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid + q * 1024;
-        have[q] = i < ng;
-        v[q] = have[q] ? ord_bits(gmin[i]) : (U)0;
-    }
     if (tid == 0) {
-        s_prefix = 0;
-        s_rank = M - 1;
+        *s_prefix = 0;
+        *s_rank = kth;
     }
     __syncthreads();
     for (int pass = 0; pass < PASSES; ++pass) {
         const int shift = 8 * (PASSES - 1 - pass);
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        const U prefix = s_prefix;
+        const U prefix = *s_prefix;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (!have[q]) continue;
@@ -579,7 +560,7 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
         __syncthreads();
         if (tid < 64) {
             // wave 0: 4 bins per lane, inclusive scan over lanes, the lane whose range holds the rank finishes
-            const int rank = s_rank;
+            const int rank = *s_rank;
             unsigned int h[4];
             unsigned int tot = 0;
 #pragma unroll
@@ -602,14 +583,43 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
                     run += (int)h[j];
                     b += 1;
                 }
-                s_rank = rank - run;
-                s_prefix = (prefix << 8) | (U)b;
+                *s_rank = rank - run;
+                *s_prefix = (prefix << 8) | (U)b;
             }
         }
         __syncthreads();
     }
+    return *s_prefix;
+}
+
+// (2) threshold = M-th smallest group minimum (radix select over the ordered bit pattern).
+// At least M rows have key <= threshold, so the M best rows all pass the filter.
+template <typename T, typename U, int PASSES>
+__global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gmin, int ng, int M, QInfo* info) {
+    __shared__ unsigned int hist[256];
+    __shared__ U s_prefix;
+    __shared__ int s_rank;
+    gmin += (int64_t)blockIdx.z * CAND_CAP;
+    info += blockIdx.z;
+    const int tid = threadIdx.x;
+    if (ng <= M) {
+        if (tid == 0) {
+            if (sizeof(T) == 4) info->thr32 = key_traits<float>::inf();
+            else info->thr64 = key_traits<double>::inf();
+        }
+        return;
+    }
+    U v[4];
+    bool have[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * 1024;
+        have[q] = i < ng;
+        v[q] = have[q] ? ord_bits(gmin[i]) : (U)0;
+    }
+    const U kth = block_kth<U, PASSES>(v, have, M - 1, hist, &s_prefix, &s_rank);
     if (tid == 0) {
-        const T thr = from_ord(s_prefix);
+        const T thr = from_ord(kth);
         if (sizeof(T) == 4) info->thr32 = (float)thr;
         else info->thr64 = (double)thr;
     }
@@ -714,21 +724,67 @@ __device__ __forceinline__ void merge_partials(const T* pkey, const int* pidx, i
     __syncthreads();
 }
 
-// rank-select the M smallest (key, idx) of the C buffered candidates into (fk, fi), sorted
+template <typename T> struct ord_of;
+template <> struct ord_of<float> { typedef unsigned int type; static constexpr int passes = 4; };
+template <> struct ord_of<double> { typedef unsigned long long type; static constexpr int passes = 8; };
+
+constexpr int PRUNE_CAP = 1024;  // compact list of the radix-pruned candidates
+
+// rank-select the M smallest (key, idx) of the C buffered candidates into (fk, fi), sorted.
+// Large C (dense neighbourhoods) is first pruned to the candidates at or below the M-th
+// smallest key by a radix select, so the quadratic ranking only ever sees ~M entries.
 template <typename T>
-__device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx, int C, int M, T* sk, int* si, T* fk, int* fi,
-                                                  int* fcount) {
+__device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx, int C, int M, T* sk, int* si, T* pk, int* pi,
+                                                  T* fk, int* fi, int* fcount) {
+    typedef typename ord_of<T>::type U;
+    __shared__ unsigned int hist[256];
+    __shared__ U s_prefix;
+    __shared__ int s_rank, s_cnt;
     for (int t = threadIdx.x; t < C; t += blockDim.x) {
         sk[t] = ckey[t];
         si[t] = cidx[t];
     }
-    if (threadIdx.x == 0) *fcount = C < M ? C : M;
+    if (threadIdx.x == 0) {
+        *fcount = C < M ? C : M;
+        s_cnt = 0;
+    }
     __syncthreads();
-    for (int t = threadIdx.x; t < C; t += blockDim.x) {
-        const T k = sk[t];
-        const int i = si[t];
+    const T* rk = sk;
+    const int* ri = si;
+    int R = C;
+    if (C > 512) {
+        U v[4];
+        bool have[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + q * 1024;
+            have[q] = i < C;
+            v[q] = have[q] ? ord_bits(sk[i]) : (U)0;
+        }
+        const U kth = block_kth<U, ord_of<T>::passes>(v, have, M - 1, hist, &s_prefix, &s_rank);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (have[q] && v[q] <= kth) {
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < PRUNE_CAP) {
+                    const int i = threadIdx.x + q * 1024;
+                    pk[slot] = sk[i];
+                    pi[slot] = si[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (s_cnt <= PRUNE_CAP) {  // otherwise (mass ties at the threshold) rank the full set
+            rk = pk;
+            ri = pi;
+            R = s_cnt;
+        }
+    }
+    for (int t = threadIdx.x; t < R; t += blockDim.x) {
+        const T k = rk[t];
+        const int i = ri[t];
         int rank = 0;
-        for (int s = 0; s < C; ++s) rank += lex_less<T>(sk[s], si[s], k, i) ? 1 : 0;
+        for (int s = 0; s < R; ++s) rank += lex_less<T>(rk[s], ri[s], k, i) ? 1 : 0;
         if (rank < M) {
             fk[rank] = k;
             fi[rank] = i;
@@ -854,6 +910,8 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     if (a.recs) a.recs += (int64_t)z * a.ss.knn;
     T* sk = (T*)smem;                       // CAND_CAP keys (filter) or 16x64 wave lists
     int* si = (int*)(sk + CAND_CAP);
+    T* pk = (T*)(si + CAND_CAP);            // PRUNE_CAP pruned candidates
+    int* pi = (int*)(pk + PRUNE_CAP);
     __shared__ T fk[64];
     __shared__ int fi[64];
     __shared__ double ek[64], ed[64], eg[64], sk2[64];
@@ -868,7 +926,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         const int raw = a.info->knn_cnt;
         if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow = 1;
         total = raw < CAND_CAP ? raw : CAND_CAP;
-        select_candidates<T>(ckey, cidx, total, a.M, sk, si, fk, fi, &fcount);
+        select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
     const int Mp = fcount;
     const double nq = a.info->nq;
@@ -1023,6 +1081,8 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
     if (a.hout) a.hout += z;
     T* sk = (T*)smem;
     int* si = (int*)(sk + CAND_CAP);
+    T* pk = (T*)(si + CAND_CAP);
+    int* pi = (int*)(pk + PRUNE_CAP);
     __shared__ T fk[64];
     __shared__ int fi[64];
     __shared__ double es[64], sk2[64];
@@ -1036,7 +1096,7 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
         const int raw = a.info->sc_cnt;
         if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow = 1;
         total = raw < CAND_CAP ? raw : CAND_CAP;
-        select_candidates<T>(ckey, cidx, total, a.M, sk, si, fk, fi, &fcount);
+        select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
     const int Mp = fcount;
     const double nq = a.info->nq, tau = a.tau, lq = a.info->lambda_q;
@@ -1285,7 +1345,7 @@ static FinishArgs make_finish(as_query* q) {
 
 template <typename T>
 static size_t finish_lds() {
-    return (sizeof(T) + sizeof(int)) * (size_t)CAND_CAP;
+    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP);
 }
 
 // k-NN candidates of the scanned rows -> records (or row lists for the build fallback)

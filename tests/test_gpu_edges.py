@@ -96,3 +96,12 @@ def test_p_not_two_and_explicit_sigma(oracle_lib):
     for kern in ("gaussian", "rational"):
         gp = {"eps": eps, "k": 6, "topk": 4, "p": 3.0, "sigma": eps * 0.8, "kernel": kern}
         _compare(X, gp, oracle_lib, [X[9] * 1.01], taus=(0.62,))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_dense_neighbourhoods_prune_thousands_of_candidates(oracle_lib, mode):
+    """eps admits ~2000 candidates per query: the finish kernels prune by radix select before ranking."""
+    n, d = 6000, 48
+    X = clustered(n, d, nclust=2, noise=0.3, seed=19)
+    gp = {"eps": 0.9, "k": 12, "topk": 9, "p": 2.0, "sigma": None, "_search_mode": mode}
+    _compare(X, gp, oracle_lib, [X[5] * 1.01, X[n - 3] + 0.01 / np.sqrt(d)], taus=(0.62, 1.0))
