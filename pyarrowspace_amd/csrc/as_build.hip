@@ -614,6 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // two waves share every SIMD's matrix pipe (wave w owns rows [32w, 32w+32) as 1x4 accumulators),
 // so one wave's DMA issue, fragment-read latency and epilogue run in the shadow of its
 // partner's MFMAs.  Waves 4-7 issue their DMA pieces mid-slab, waves 0-3 at the slab start.
+template <int METRIC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_mfma_dma8_kernel(KnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Sl = (float*)smem;                  // 2 slab buffers
@@ -649,8 +650,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int64_t rg = rowbase + tid;
             const bool valid = rg < a.r1 && rg < a.n;
             const float ni = valid ? a.n32[rg] : 0.0f;
-            const float bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
-            s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (a.metric == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f);
+            const float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+            s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f);
             s_cur[tid] = 0;
             s_drop[tid] = 0;
         }
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int nn = 0; nn < 4; ++nn) {
                 const int64_t cg = colbase + nn * 32 + l31;
                 cj[nn] = (int)cg;
-                nj[nn] = a.metric == AS_METRIC_L2 ? a.n32[cg] : a.inorm32[cg];
+                nj[nn] = METRIC == AS_METRIC_L2 ? a.n32[cg] : a.inorm32[cg];
             }
             for (int ks = 0; ks < nslab; ++ks, ++g) {
                 const int cur = g & 1;
@@ -754,8 +755,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
                     const float gg = acc[nn][r];
-                    key[nn] = a.metric == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * ai * nj[nn]);
-                    if (edge && (cj[nn] >= a.n || cj[nn] == rg)) key[nn] = finf;
+                    key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * ai * nj[nn]);
+                }
+                if (edge) {  // wave-uniform: only tiles on the diagonal or at the padded tail pay for the exclusions
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn)
+                        if (cj[nn] >= (int)a.n || cj[nn] == rg) key[nn] = finf;
                 }
                 const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
                 if (__ballot(kmin <= thr)) {
@@ -1039,9 +1044,13 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         break;
         if ((variant & 48) == 48) {
             const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
-            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             AS_HIP(hipEventRecord(e0, st));
-            hipLaunchKernelGGL(knn_mfma_dma8_kernel, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+            if (metric == AS_METRIC_L2)
+                hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+            else
+                hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
         } else if (variant & 32) {
             const size_t ldsd = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
