@@ -21,7 +21,10 @@ namespace as {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CAND_CAP = 4096;  // candidate buffer of the filter path
-constexpr int REC_CAP = 512;    // records q_lambda / hits_final accept (ranks x k)
+constexpr int REC_CAP = 512;    // k-NN records q_lambda accepts (ranks x k)
+constexpr int MAX_TOPK = 1024;  // largest topk
+constexpr int MS_MAX = MAX_TOPK + 64;  // widest scorer candidate list (topk + margin, rounded to 64)
+constexpr int HIT_CAP = 8 * (MAX_TOPK + 1) + 8;  // hit records hits_final accepts (ranks x (topk + 1))
 constexpr int QB = 8;           // queries per batched scan pass (query fragments live in registers)
 
 // Batched searches run QB independent query "slots" side by side: every per-query buffer is
@@ -57,11 +60,12 @@ struct HostOut {
     int64_t len;
     double lambda_q;
     int status, knn_inexact, score_inexact, overflow;
-    int64_t idx[MAX_LIST];
-    double score[MAX_LIST];
+    int64_t idx[MAX_TOPK];
+    double score[MAX_TOPK];
 };
 
 static std::atomic<int> g_search_stats{0};
+struct RSel;
 
 }  // namespace as
 
@@ -99,6 +103,7 @@ struct as_query {
     void* ckey_s = nullptr;
     int* cidx_s = nullptr;
     void* gmin = nullptr;    // group minima of the scorer key
+    as::RSel* rsel = nullptr; // state of the exact global selection
     as_knn_rec* knn = nullptr;
     as_hit_rec* hits = nullptr;
     as::HostOut* hout = nullptr;  // pinned
@@ -127,6 +132,10 @@ __device__ __forceinline__ double from_ord(unsigned long long u) {
     const unsigned long long b = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
     return __longlong_as_double((long long)b);
 }
+
+template <typename T> struct ord_of;
+template <> struct ord_of<float> { typedef unsigned int type; static constexpr int passes = 4; };
+template <> struct ord_of<double> { typedef unsigned long long type; static constexpr int passes = 8; };
 
 // ------------------------------------------------------------------ query staging
 __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int64_t dp, double* __restrict__ q64,
@@ -646,6 +655,92 @@ __global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a) {
     }
 }
 
+// ------------------------------------------------------------------ exact global selection (overflow fallback for wide lists)
+// Radix select over the composite (ordered key bits, row index) of ALL scanned rows: KP passes
+// over the key bytes, then 4 over the index bytes among the rows tied at the M-th key.  The
+// filter that follows appends exactly the M smallest (key, idx) rows -- no tie can overflow it.
+struct RSel {
+    unsigned long long kprefix;  // decided key bits (ordered), complete after the key passes
+    unsigned int iprefix;        // decided index bits
+    int rank;                    // remaining 0-based rank inside the current bucket
+    int take_all;                // fewer than M rows exist
+    unsigned int hist[256];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void rsel_hist_kernel(SelArgs<T> a, int pass, int KP, RSel* rs) {
+    typedef typename ord_of<T>::type U;
+    __shared__ unsigned int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const ScoreCtx c = load_ctx(a.info, a.tau);
+    const unsigned long long kprefix = rs->kprefix;
+    const unsigned int iprefix = rs->iprefix;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
+        const U kb = ord_bits(score_key<T>(a, c, row));
+        unsigned int digit;
+        if (pass < KP) {
+            const int shift = 8 * (KP - 1 - pass);
+            if (pass > 0 && (unsigned long long)(kb >> (shift + 8)) != kprefix) continue;
+            digit = (unsigned int)((kb >> shift) & (U)255);
+        } else {
+            if ((unsigned long long)kb != kprefix) continue;
+            const int ip = pass - KP, shift = 8 * (3 - ip);
+            const unsigned int ib = (unsigned int)row;
+            if (ip > 0 && (ib >> (shift + 8)) != iprefix) continue;
+            digit = (ib >> shift) & 255u;
+        }
+        atomicAdd(&sh[digit], 1u);
+    }
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&rs->hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void rsel_pick_kernel(int pass, int KP, int M, RSel* rs) {
+    if (threadIdx.x != 0) return;
+    if (pass == 0) {
+        long long tot = 0;
+        for (int b = 0; b < 256; ++b) tot += rs->hist[b];
+        rs->take_all = tot <= M ? 1 : 0;
+        rs->rank = M - 1;
+        rs->kprefix = 0;
+        rs->iprefix = 0;
+    }
+    if (!rs->take_all) {
+        int run = 0, b = 0;
+        for (; b < 256; ++b) {
+            if (run + (int)rs->hist[b] > rs->rank) break;
+            run += (int)rs->hist[b];
+        }
+        rs->rank -= run;
+        if (pass < KP) rs->kprefix = (rs->kprefix << 8) | (unsigned long long)b;
+        else rs->iprefix = (rs->iprefix << 8) | (unsigned int)b;
+    }
+    for (int b = 0; b < 256; ++b) rs->hist[b] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rsel_filter_kernel(SelArgs<T> a, const RSel* rs) {
+    typedef typename ord_of<T>::type U;
+    const ScoreCtx c = load_ctx(a.info, a.tau);
+    const unsigned long long kprefix = rs->kprefix;
+    const unsigned int iprefix = rs->iprefix;
+    const bool all = rs->take_all != 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
+        const T k = score_key<T>(a, c, row);
+        const unsigned long long kb = (unsigned long long)ord_bits(k);
+        if (all || kb < kprefix || (kb == kprefix && (unsigned int)row <= iprefix)) {
+            const int slot = atomicAdd(&a.info_w->sc_cnt, 1);
+            if (slot < CAND_CAP) {
+                a.ckey[slot] = k;
+                a.cidx[slot] = (int)row;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ list path (overflow fallback): wavefront-shuffle partial lists
 template <typename T>
 __global__ __launch_bounds__(256) void knn_partial_kernel(SelArgs<T> a) {
@@ -724,11 +819,7 @@ __device__ __forceinline__ void merge_partials(const T* pkey, const int* pidx, i
     __syncthreads();
 }
 
-template <typename T> struct ord_of;
-template <> struct ord_of<float> { typedef unsigned int type; static constexpr int passes = 4; };
-template <> struct ord_of<double> { typedef unsigned long long type; static constexpr int passes = 8; };
-
-constexpr int PRUNE_CAP = 1024;  // compact list of the radix-pruned candidates
+constexpr int PRUNE_CAP = 2048;  // compact list of the radix-pruned candidates
 
 // rank-select the M smallest (key, idx) of the C buffered candidates into (fk, fi), sorted.
 // Large C (dense neighbourhoods) is first pruned to the candidates at or below the M-th
@@ -1083,11 +1174,11 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
     int* si = (int*)(sk + CAND_CAP);
     T* pk = (T*)(si + CAND_CAP);
     int* pi = (int*)(pk + PRUNE_CAP);
-    __shared__ T fk[64];
-    __shared__ int fi[64];
-    __shared__ double es[64], sk2[64];
+    double* es = (double*)(pi + PRUNE_CAP);   // MS_MAX exact scores
+    double* sk2 = es + MS_MAX;                 // MS_MAX: scratch, then scores in rank order
+    T* fk = (T*)(sk2 + MS_MAX);               // MS_MAX best fp32 keys, sorted
+    int* fi = (int*)(fk + MS_MAX);
     __shared__ int fcount;
-    const int lane = lane_id(), w = threadIdx.x >> 6;
     int total;
     if (a.from_list) {
         merge_partials<T>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
@@ -1100,45 +1191,48 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
     }
     const int Mp = fcount;
     const double nq = a.info->nq, tau = a.tau, lq = a.info->lambda_q;
-    exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, fi, Mp, sk2, es);
+    for (int base = 0; base < Mp; base += 64)   // 64 candidates per round, 16 lanes each
+        exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, fi + base, Mp - base < 64 ? Mp - base : 64, sk2 + base, es + base);
     __syncthreads();
-    if (threadIdx.x < Mp) {
-        const int t = threadIdx.x;
+    for (int t = threadIdx.x; t < Mp; t += blockDim.x) {
         const int j = fi[t];
         const double den = sqrt(a.n64[j] * nq);
         const double c = den > 0.0 ? es[t] / den : 0.0;
         es[t] = tau * c + (1.0 - tau) / (1.0 + fabs(lq - a.lam64[j]));
     }
     __syncthreads();
-    if (w != 0) return;
-    const bool have = lane < Mp;
-    const double myk = have ? -es[lane] : 0.0;
-    const int myi = have ? fi[lane] : 0x7fffffff;
-    int rank = 0;
-    for (int s = 0; s < Mp; ++s) rank += lex_less<double>(-es[s], fi[s], myk, myi) ? 1 : 0;
-    if (have) sk2[rank] = es[lane];
     const int64_t want = a.topk < a.nrows ? a.topk : a.nrows;
     const int nhit = (int)(Mp < want ? Mp : want);
     if (a.hits) {
-        for (int64_t t = lane; t < a.topk; t += 64) {
+        for (int64_t t = threadIdx.x; t < a.topk; t += blockDim.x) {
             as_hit_rec r;
             r.idx = -1;
             r.score = -key_traits<double>::inf();
             a.hits[t] = r;
         }
-        if (have && rank < a.topk) {
+    }
+    __syncthreads();
+    // rank by (score desc, idx asc)
+    for (int t = threadIdx.x; t < Mp; t += blockDim.x) {
+        const double myk = -es[t];
+        const int myi = fi[t];
+        int rank = 0;
+        for (int s2 = 0; s2 < Mp; ++s2) rank += lex_less<double>(-es[s2], fi[s2], myk, myi) ? 1 : 0;
+        sk2[rank] = es[t];
+        if (a.hits && rank < a.topk) {
             as_hit_rec r;
             r.idx = myi;
-            r.score = es[lane];
+            r.score = es[t];
             a.hits[rank] = r;
         }
+        if (a.fuse && a.hout && rank < nhit) {
+            a.hout->idx[rank] = myi;
+            a.hout->score[rank] = es[t];
+        }
     }
-    if (a.fuse && a.hout && have && rank < nhit) {
-        a.hout->idx[rank] = myi;
-        a.hout->score[rank] = es[lane];
-    }
-    AS_LDS_FENCE();
-    if (lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int bad = 0;
         if (a.nrows > a.M && Mp > 0) {
             // every row outside the list has score32 <= -fk[Mp-1]; its exact score <= that + coef_s
@@ -1168,46 +1262,61 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
 }
 
 // merge m hit records (own or all-gathered) -> final topk, written to pinned host memory
-__global__ __launch_bounds__(64) void hits_final_kernel(const as_hit_rec* __restrict__ hits, int64_t m, int64_t topk,
-                                                        const QInfo* info, HostOut* out, int64_t seq) {
-    __shared__ double r_key[REC_CAP];
-    __shared__ int r_idx[REC_CAP];
-    const int lane = lane_id();
-    const int mm = (int)(m < REC_CAP ? m : REC_CAP);
+__global__ __launch_bounds__(1024) void hits_final_kernel(const as_hit_rec* __restrict__ hits, int64_t m, int64_t topk,
+                                                          const QInfo* info, HostOut* out, int64_t seq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* r_key = (double*)smem;           // mm
+    int* r_idx = (int*)(r_key + HIT_CAP);
+    __shared__ int s_flags, s_cnt;
+    const int mm = (int)(m < HIT_CAP ? m : HIT_CAP);
+    if (threadIdx.x == 0) {
+        s_flags = 0;
+        s_cnt = 0;
+    }
+    __syncthreads();
     int flags_l = 0;
-    for (int t = lane; t < mm; t += 64) {
+    for (int t = threadIdx.x; t < mm; t += blockDim.x) {
         const bool valid = hits[t].idx >= 0;
         if (hits[t].idx == -2) flags_l |= (int)hits[t].score;
         r_key[t] = valid ? -hits[t].score : key_traits<double>::inf();
         r_idx[t] = valid ? (int)hits[t].idx : 0x7fffffff;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) flags_l |= __shfl_xor(flags_l, o, 64);
-    AS_LDS_FENCE();
+    if (flags_l) atomicOr(&s_flags, flags_l);
+    __syncthreads();
     int cnt_l = 0;
-    for (int t = lane; t < mm; t += 64) {
+    for (int t = threadIdx.x; t < mm; t += blockDim.x) {
         if (r_idx[t] == 0x7fffffff) continue;
         int rank = 0;
-        for (int s = 0; s < mm; ++s) rank += lex_less<double>(r_key[s], r_idx[s], r_key[t], r_idx[t]) ? 1 : 0;
-        if (rank < topk && rank < MAX_LIST) {
+        for (int s2 = 0; s2 < mm; ++s2) rank += lex_less<double>(r_key[s2], r_idx[s2], r_key[t], r_idx[t]) ? 1 : 0;
+        if (rank < topk && rank < MAX_TOPK) {
             out->idx[rank] = r_idx[t];
             out->score[rank] = -r_key[t];
             cnt_l += 1;
         }
     }
-    const int cnt = wave_sum(cnt_l);
-    if (lane == 0) {
-        out->len = cnt;
+    if (cnt_l) atomicAdd(&s_cnt, cnt_l);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int fl = s_flags;
+        out->len = s_cnt;
         out->lambda_q = info->lambda_q;
         out->status = info->status;
-        out->knn_inexact = (info->knn_inexact || (flags_l & 1)) ? 1 : 0;
-        out->score_inexact = (info->score_inexact || (flags_l & 2)) ? 1 : 0;
-        out->overflow = (info->overflow || (flags_l & 4)) ? 1 : 0;
+        out->knn_inexact = (info->knn_inexact || (fl & 1)) ? 1 : 0;
+        out->score_inexact = (info->score_inexact || (fl & 2)) ? 1 : 0;
+        out->overflow = (info->overflow || (fl & 4)) ? 1 : 0;
         publish(out, seq);
     }
 }
 
 // ------------------------------------------------------------------ host side
+static int score_width(int64_t topk) {
+    if (topk > MAX_TOPK) return -1;
+    const int64_t need = topk + 8;
+    if (need <= 32) return 32;
+    return (int)((need + 63) / 64 * 64);   // <= MS_MAX
+}
+
 static int list_width(int64_t k) {
     const int64_t need = k + 8;
     if (need <= 32) return 32;
@@ -1344,6 +1453,11 @@ static FinishArgs make_finish(as_query* q) {
 }
 
 template <typename T>
+static size_t score_lds() {
+    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP + MS_MAX) + 2 * sizeof(double) * MS_MAX;
+}
+
+template <typename T>
 static size_t finish_lds() {
     return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP);
 }
@@ -1393,7 +1507,23 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
     hipStream_t st = q->stream;
     f.M = q->Ms; f.hits = q->hits; f.fuse = fuse_final; f.hout = q->hout_dev; f.seq = q->seq;
     const double coef_s = coef_query(q->sp->dp, sizeof(T) == 8);
-    if (q->robust) {
+    if (q->robust && q->Ms > MAX_LIST) {
+        // wide lists: exact global selection, then the filter-path finish kernel on exactly M rows
+        const int64_t rows = q->r1 - q->r0;
+        const int KP = (int)sizeof(T);
+        SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        a.tau = f.tau;
+        const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
+        hipMemsetAsync(q->rsel, 0, sizeof(RSel), st);
+        hipMemsetAsync(&q->info->sc_cnt, 0, sizeof(int), st);
+        for (int pass = 0; pass < KP + 4; ++pass) {
+            hipLaunchKernelGGL(rsel_hist_kernel<T>, dim3(fg), dim3(256), 0, st, a, pass, KP, q->rsel);
+            hipLaunchKernelGGL(rsel_pick_kernel, dim3(1), dim3(64), 0, st, pass, KP, q->Ms, q->rsel);
+        }
+        hipLaunchKernelGGL(rsel_filter_kernel<T>, dim3(fg), dim3(256), 0, st, a, (const RSel*)q->rsel);
+        f.ck = q->ckey_s; f.ci = q->cidx_s; f.from_list = 0;
+        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), score_lds<T>(), st, f, coef_s);
+    } else if (q->robust) {
         int nw = 0;
         const int grid = sel_grid(q, &nw);
         f.nlists = nw;
@@ -1401,7 +1531,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         a.tau = f.tau;
         hipLaunchKernelGGL(score_partial_kernel<T>, dim3(grid), dim3(256), 0, st, a);
         f.ck = q->pkey; f.ci = q->pidx;
-        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), finish_lds<T>(), st, f, coef_s);
+        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1), dim3(1024), score_lds<T>(), st, f, coef_s);
     } else {
         const int64_t rows = q->r1 - q->r0;
         int64_t G = (rows + CAND_CAP - 1) / CAND_CAP;
@@ -1415,12 +1545,13 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
         hipLaunchKernelGGL(score_filter_kernel<T>, dim3(fg, 1, nb), dim3(256), 0, st, a);
         f.ck = q->ckey_s; f.ci = q->cidx_s;
-        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1, 1, nb), dim3(1024), finish_lds<T>(), st, f, coef_s);
+        hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1, 1, nb), dim3(1024), score_lds<T>(), st, f, coef_s);
     }
 }
 
 static as_status run_score(as_query* q, double tau, int fuse_final) {
     hipStream_t st = q->stream;
+
     if (q->r1 - q->r0 <= 0) {
         AS_HIP(hipMemsetAsync(q->hits, 0xff, sizeof(as_hit_rec) * (q->topk + 1), st));
         return AS_OK;
@@ -1525,9 +1656,9 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     q->k = gr ? gr->gp.k : 1;
     q->topk = gr ? std::min<int64_t>(gr->gp.topk, sp->n) : 1;
     q->Mk = list_width(std::min<int64_t>(q->k, sp->n));
-    q->Ms = list_width(q->topk);
+    q->Ms = score_width(q->topk);
     if (q->Mk < 0 || q->Ms < 0) {
-        set_err("k=%lld / topk=%lld exceed the supported maximum of 56", (long long)q->k, (long long)q->topk);
+        set_err("k=%lld exceeds the supported maximum of 56, or topk=%lld the maximum of 1024", (long long)q->k, (long long)q->topk);
         delete q;
         return AS_EUNSUPPORTED;
     }
@@ -1557,6 +1688,7 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     AS_HIP(hipMalloc(&q->ckey_s, sizeof(double) * CAND_CAP * C));
     AS_HIP(hipMalloc(&q->cidx_s, sizeof(int) * CAND_CAP * C));
     AS_HIP(hipMalloc(&q->gmin, sizeof(double) * CAND_CAP * C));
+    AS_HIP(hipMalloc(&q->rsel, sizeof(RSel)));
     AS_HIP(hipMalloc(&q->knn, sizeof(as_knn_rec) * q->ss.knn * C));
     AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * q->ss.hits * C));
     AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut) * C, hipHostMallocMapped | hipHostMallocCoherent));
@@ -1564,7 +1696,9 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     memset(q->hout, 0, sizeof(HostOut) * C);
     for (int i = 0; i < 3; ++i) AS_HIP(hipEventCreate(&q->ev[i]));
     AS_HIP(hipFuncSetAttribute((const void*)knn_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<double>()));
-    AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<double>()));
+    AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<double>()));
+    AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<float>()));
+    AS_HIP(hipFuncSetAttribute((const void*)hits_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((sizeof(double) + sizeof(int)) * HIT_CAP)));
     q->r0 = 0;
     q->r1 = sp->n;
     *out = q;
@@ -1584,6 +1718,7 @@ void as_query_free(as_query* q) {
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
     hipFree(q->gmin);
+    hipFree(q->rsel);
     if (q->own_records) {
         hipFree(q->knn);
         hipFree(q->hits);
@@ -1660,14 +1795,15 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
         set_err("as_query_finish: null argument");
         return AS_EINVAL;
     }
-    if (m > REC_CAP) {
-        set_err("as_query_finish: %lld records exceed the supported %d", (long long)m, REC_CAP);
+    if (m > HIT_CAP) {
+        set_err("as_query_finish: %lld records exceed the supported %d", (long long)m, HIT_CAP);
         return AS_EUNSUPPORTED;
     }
     hipStream_t st = q->stream;
     const int64_t topk = std::min<int64_t>(q->gr->gp.topk, q->sp->n);
     q->seq += 1;
-    hipLaunchKernelGGL(hits_final_kernel, dim3(1), dim3(64), 0, st, hits_dev, m, topk, q->info, q->hout_dev, q->seq);
+    hipLaunchKernelGGL(hits_final_kernel, dim3(1), dim3(1024), (sizeof(double) + sizeof(int)) * HIT_CAP, st, hits_dev, m, topk, q->info,
+                       q->hout_dev, q->seq);
     AS_HIP(hipGetLastError());
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], st));
     AS_TRY(wait_published(q));

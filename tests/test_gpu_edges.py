@@ -105,3 +105,29 @@ def test_dense_neighbourhoods_prune_thousands_of_candidates(oracle_lib, mode):
     X = clustered(n, d, nclust=2, noise=0.3, seed=19)
     gp = {"eps": 0.9, "k": 12, "topk": 9, "p": 2.0, "sigma": None, "_search_mode": mode}
     _compare(X, gp, oracle_lib, [X[5] * 1.01, X[n - 3] + 0.01 / np.sqrt(d)], taus=(0.62, 1.0))
+
+
+@pytest.mark.parametrize("topk", [57, 100, 1000, 1024])
+def test_large_topk(oracle_lib, topk):
+    """topk up to 1024 (candidate list = topk + margin, exact re-scoring in rounds of 64)."""
+    n, d = 5000, 64
+    X = clustered(n, d, nclust=10, seed=23)
+    gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": topk, "p": 2.0, "sigma": None}
+    aspace, gl, ref = _compare(X, gp, oracle_lib, [X[17] * 1.01, X[4000] + 0.01 / np.sqrt(d)])
+    got = aspace.search_batch(np.stack([X[17] * 1.01, X[3] * 0.99, X[99]]), gl, 0.62)
+    for b, q in enumerate([X[17] * 1.01, X[3] * 0.99, X[99]]):
+        want, lq = ref.search(np.ascontiguousarray(q), 0.62)
+        assert_hits_match(got[b], want, ref.scores(np.ascontiguousarray(q), 0.62, lq), rtol=RTOL)
+
+
+def test_limits_are_reported_as_value_errors():
+    import pyarrowspace_amd as asp
+    X = clustered(300, 16, nclust=3, seed=1)
+    a, g = asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 5, "topk": 2000, "p": 2.0}, X)   # topk > nitems is clamped
+    assert len(a.search(np.ascontiguousarray(X[0]), g, 1.0)) == 300
+    with pytest.raises(ValueError, match="k"):
+        asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 80, "topk": 5, "p": 2.0}, X)
+    Y = clustered(1500, 16, nclust=3, seed=1)
+    a2, g2 = asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 5, "topk": 1300, "p": 2.0}, Y)
+    with pytest.raises(ValueError, match="topk"):
+        a2.search(np.ascontiguousarray(Y[0]), g2, 1.0)
