@@ -190,6 +190,12 @@ void as_enable_search_stats(int32_t enabled);
 /* same, for the workspace as_search keeps inside the space (last as_search call) */
 as_status as_last_search_stats(const as_space* sp, double* out, int32_t n);
 
+/* ---- index persistence (extension; the reference exposes none): one flat file
+ * holding the items, lambdas and graph arrays.  Loading re-ingests the items and uploads the
+ * rest; no k-NN work is redone.  opts->device selects the GPU, metric/kernel come from the file. */
+as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path);
+as_status as_index_load(const char* path, const as_opts* opts, as_space** out_space, as_graph** out_graph);
+
 void as_free_space(as_space* sp);
 void as_free_graph(as_graph* gr);
 

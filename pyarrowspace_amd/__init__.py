@@ -268,6 +268,12 @@ class ArrowSpace:
             _raise(st)
         return {"scan_us": out[0], "rest_us": out[1]}
 
+    def save(self, gl: GraphLaplacian, path: str) -> None:
+        """Extension: write the built index (items, lambdas, graph) to one file."""
+        st = _L.as_index_save(self._h, gl._h, os.fsencode(path))
+        if st:
+            _raise(st)
+
     def query_lambda(self, item, gl: GraphLaplacian) -> float:
         """Extension: lambda_q of `prepare_query_item` (src/lib.rs:154) without the search."""
         q = self._query(item)
@@ -322,6 +328,17 @@ class ArrowSpaceBuilder:
         sp, gr = C.c_void_p(), C.c_void_p()
         st = _L.as_build_dev(C.c_void_p(int(data_ptr)), dt, int(n), int(d), int(ld if ld is not None else d),
                              C.byref(gp), C.byref(op), C.byref(sp), C.byref(gr))
+        if st:
+            _raise(st)
+        return ArrowSpace._wrap(sp), GraphLaplacian._wrap(gr)
+
+    @staticmethod
+    def load(path: str):
+        """Extension: (ArrowSpace, GraphLaplacian) from a file written by ArrowSpace.save()."""
+        op = Opts()
+        op.device = int(os.environ.get("ARROWSPACE_DEVICE", "-1"))
+        sp, gr = C.c_void_p(), C.c_void_p()
+        st = _L.as_index_load(os.fsencode(path), C.byref(op), C.byref(sp), C.byref(gr))
         if st:
             _raise(st)
         return ArrowSpace._wrap(sp), GraphLaplacian._wrap(gr)

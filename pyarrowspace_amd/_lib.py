@@ -43,7 +43,7 @@ SYMBOLS = [
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
     "as_query_finish", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
     "as_get_item", "as_lambdas", "as_nnodes", "as_get_graph_params", "as_graph_nnz", "as_graph_csr",
-    "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_last_search_stats", "as_enable_search_stats", "as_free_space",
+    "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_last_search_stats", "as_enable_search_stats", "as_index_save", "as_index_load", "as_free_space",
     "as_free_graph", "as_set_debug", "as_last_error", "as_device_count", "as_version",
 ]
 
@@ -103,6 +103,8 @@ def load():
         "as_query_stats": (i32, [vp, vp, i32]),
         "as_last_search_stats": (i32, [vp, vp, i32]),
         "as_enable_search_stats": (None, [i32]),
+        "as_index_save": (i32, [vp, vp, C.c_char_p]),
+        "as_index_load": (i32, [C.c_char_p, pop, pvp, pvp]),
         "as_free_space": (None, [vp]),
         "as_free_graph": (None, [vp]),
         "as_set_debug": (None, [i32]),

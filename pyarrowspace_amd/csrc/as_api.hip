@@ -502,3 +502,170 @@ as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- index persistence
+// One flat little-endian file: header, the items (fp64 when an fp64 copy is kept, else the exact
+// fp32 values), lambdas, and the graph arrays.  Loading re-ingests the items (norms and the padded
+// fp32 layout are recomputed deterministically) and uploads the rest; no k-NN work is redone.
+namespace {
+struct IndexHeader {
+    char magic[8];      // "ASIDX01\0"
+    int64_t n, d, nnz;
+    int32_t has_f64, metric, kernel, pad;
+    as_graph_params gp;
+    double tau0;
+};
+
+template <typename T>
+as_status dev_to_file(FILE* f, const T* dev, size_t count) {
+    std::vector<T> h(std::max<size_t>(count, 1));
+    if (count) AS_HIP(hipMemcpy(h.data(), dev, sizeof(T) * count, hipMemcpyDeviceToHost));
+    if (count && fwrite(h.data(), sizeof(T), count, f) != count) {
+        set_err("as_index_save: short write");
+        return AS_EINVAL;
+    }
+    return AS_OK;
+}
+template <typename T>
+as_status file_to_dev(FILE* f, T** dev, size_t count) {
+    std::vector<T> h(std::max<size_t>(count, 1));
+    if (count && fread(h.data(), sizeof(T), count, f) != count) {
+        set_err("as_index_load: truncated file");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipMalloc(dev, sizeof(T) * std::max<size_t>(count, 1)));
+    if (count) AS_HIP(hipMemcpy(*dev, h.data(), sizeof(T) * count, hipMemcpyHostToDevice));
+    return AS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path) {
+    if (!sp || !gr || !path) {
+        set_err("as_index_save: null argument");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    FILE* f = fopen(path, "wb");
+    if (!f) {
+        set_err("as_index_save: cannot open %s", path);
+        return AS_EINVAL;
+    }
+    IndexHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "ASIDX01", 8);
+    h.n = sp->n; h.d = sp->d; h.nnz = gr->nnz;
+    h.has_f64 = sp->x64 ? 1 : 0; h.metric = gr->metric; h.kernel = gr->kernel;
+    h.gp = gr->gp; h.tau0 = gr->tau0;
+    as_status s = fwrite(&h, sizeof(h), 1, f) == 1 ? AS_OK : AS_EINVAL;
+    const size_t n = (size_t)sp->n, d = (size_t)sp->d, nnz = (size_t)gr->nnz;
+    if (s == AS_OK) {
+        if (sp->x64) {
+            s = dev_to_file(f, sp->x64, n * d);
+        } else {
+            std::vector<float> row(sp->dp), all(n * d);
+            std::vector<float> pad(n * (size_t)sp->dp);
+            hipError_t e = hipMemcpy(pad.data(), sp->x32, sizeof(float) * pad.size(), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) s = AS_EHIP;
+            for (size_t i = 0; i < n && s == AS_OK; ++i) memcpy(&all[i * d], &pad[i * sp->dp], sizeof(float) * d);
+            if (s == AS_OK && fwrite(all.data(), sizeof(float), n * d, f) != n * d) s = AS_EINVAL;
+        }
+    }
+    if (s == AS_OK) s = dev_to_file(f, sp->lam64, n);
+    if (s == AS_OK) s = dev_to_file(f, gr->indptr, n + 1);
+    if (s == AS_OK) s = dev_to_file(f, gr->indices, nnz);
+    if (s == AS_OK) s = dev_to_file(f, gr->dist, nnz);
+    if (s == AS_OK) s = dev_to_file(f, gr->gy, nnz);
+    if (s == AS_OK) s = dev_to_file(f, gr->w, nnz);
+    if (s == AS_OK) s = dev_to_file(f, gr->lap, nnz);
+    if (s == AS_OK) s = dev_to_file(f, gr->deg, n);
+    if (s == AS_OK) s = dev_to_file(f, gr->ny, n);
+    if (s == AS_OK) s = dev_to_file(f, gr->E, n);
+    if (s == AS_OK) s = dev_to_file(f, gr->G, n);
+    if (fclose(f) != 0 && s == AS_OK) s = AS_EINVAL;
+    if (s != AS_OK && err_slot().empty()) set_err("as_index_save: write to %s failed", path);
+    return s;
+}
+
+__global__ void lam32_kernel(int64_t n, const double* __restrict__ lam64, float* __restrict__ lam32) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lam32[i] = (float)lam64[i];
+}
+
+as_status as_index_load(const char* path, const as_opts* opts, as_space** out_space, as_graph** out_graph) {
+    if (!path || !out_space || !out_graph) {
+        set_err("as_index_load: null argument");
+        return AS_EINVAL;
+    }
+    *out_space = nullptr;
+    *out_graph = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        set_err("as_index_load: cannot open %s", path);
+        return AS_EINVAL;
+    }
+    IndexHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ASIDX01", 8) != 0 || h.n <= 0 || h.d <= 0 || h.nnz < 0) {
+        fclose(f);
+        set_err("as_index_load: %s is not an arrowspace index file", path);
+        return AS_EINVAL;
+    }
+    as_opts o{};
+    if (opts) o = *opts;
+    o.metric = h.metric;
+    o.kernel = h.kernel;
+    o.keep_f64 = h.has_f64 ? AS_KEEP_F64_ALWAYS : AS_KEEP_F64_AUTO;
+    int dev = 0;
+    as_status s = pick_device(&o, &dev);
+    as_space* sp = nullptr;
+    as_graph* gr = nullptr;
+    void* items = nullptr;
+    const size_t n = (size_t)h.n, d = (size_t)h.d, nnz = (size_t)h.nnz;
+    do {
+        if (s != AS_OK) break;
+        o.device = dev;
+        if (h.has_f64) {
+            double* p = nullptr;
+            s = file_to_dev(f, &p, n * d);
+            items = p;
+        } else {
+            float* p = nullptr;
+            s = file_to_dev(f, &p, n * d);
+            items = p;
+        }
+        if (s != AS_OK) break;
+        s = as_space_create_dev(items, h.has_f64 ? AS_DTYPE_F64 : AS_DTYPE_F32, h.n, h.d, h.d, &o, &sp);
+        if (s != AS_OK) break;
+        hipFree(sp->lam64);
+        sp->lam64 = nullptr;
+        s = file_to_dev(f, &sp->lam64, n);
+        if (s != AS_OK) break;
+        hipLaunchKernelGGL(lam32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sp->stream, h.n, sp->lam64, sp->lam32);
+        gr = new as_graph();
+        gr->device = dev; gr->n = h.n; gr->nnz = h.nnz; gr->gp = h.gp; gr->metric = h.metric; gr->kernel = h.kernel; gr->tau0 = h.tau0;
+        if ((s = file_to_dev(f, &gr->indptr, n + 1)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->indices, nnz)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->dist, nnz)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->gy, nnz)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->w, nnz)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->lap, nnz)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->deg, n)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->ny, n)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->E, n)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->G, n)) != AS_OK) break;
+        if (hipStreamSynchronize(sp->stream) != hipSuccess) s = AS_EHIP;
+    } while (0);
+    fclose(f);
+    if (items) hipFree(items);
+    if (s != AS_OK) {
+        if (gr) as_free_graph(gr);
+        if (sp) as_free_space(sp);
+        return s;
+    }
+    *out_space = sp;
+    *out_graph = gr;
+    return AS_OK;
+}
+
+}  // extern "C"

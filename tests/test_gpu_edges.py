@@ -131,3 +131,30 @@ def test_limits_are_reported_as_value_errors():
     a2, g2 = asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 5, "topk": 1300, "p": 2.0}, Y)
     with pytest.raises(ValueError, match="topk"):
         a2.search(np.ascontiguousarray(Y[0]), g2, 1.0)
+
+
+@pytest.mark.parametrize("keep64", [False, True])
+def test_save_and_load_round_trip(tmp_path, keep64):
+    """Extension: a loaded index answers exactly like the one that was saved."""
+    import pyarrowspace_amd as asp
+    n, d = 2000, 72
+    X = clustered(n, d, nclust=6, seed=29)
+    if not keep64:
+        X = X.astype(np.float32).astype(np.float64)      # exactly fp32-representable: no fp64 copy is kept
+    gp = {"eps": calibrate_eps(X, 7), "k": 7, "topk": 9, "p": 2.0, "sigma": None, "metric": "cosine" if keep64 else "l2"}
+    a, g = asp.ArrowSpaceBuilder.build(gp, X)
+    path = str(tmp_path / "index.asidx")
+    a.save(g, path)
+    b, h = asp.ArrowSpaceBuilder.load(path)
+    assert (b.nitems, b.nfeatures, h.nnodes, h.graph_params, h.tau0) == (a.nitems, a.nfeatures, g.nnodes, g.graph_params, g.tau0)
+    np.testing.assert_array_equal(b.lambdas(), a.lambdas())
+    for x, y in zip(h.to_csr(), g.to_csr()):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(b.get_item(5)[0], X[5])
+    rng = np.random.default_rng(1)
+    for _ in range(4):
+        q = np.ascontiguousarray(X[rng.integers(0, n)] * 1.01 + 0.002 * rng.standard_normal(d))
+        for tau in (1.0, 0.62):
+            assert b.search(q, h, tau) == a.search(q, g, tau)
+    with pytest.raises(ValueError):
+        asp.ArrowSpaceBuilder.load(str(tmp_path / "missing.asidx"))
