@@ -220,6 +220,6 @@ void query_flags(const as_query* q, int* knn_inexact, int* score_inexact);
 as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out);
 as_status search_batch_once(as_query* q, const double* queries, int nb, int64_t d, double tau, int64_t topk, int64_t* out_idx,
                             double* out_score, int64_t* out_len, double* out_lambda_q, int32_t* out_status);
-constexpr int QUERY_BATCH = 8;  // == QB in as_search.hip
+constexpr int QUERY_BATCH = 32;  // == GQ in as_search.hip: query slots of the batched workspace
 
 }  // namespace as

@@ -25,7 +25,8 @@ constexpr int REC_CAP = 512;    // k-NN records q_lambda accepts (ranks x k)
 constexpr int MAX_TOPK = 1024;  // largest topk
 constexpr int MS_MAX = MAX_TOPK + 64;  // widest scorer candidate list (topk + margin, rounded to 64)
 constexpr int HIT_CAP = 8 * (MAX_TOPK + 1) + 8;  // hit records hits_final accepts (ranks x (topk + 1))
-constexpr int QB = 8;           // queries per batched scan pass (query fragments live in registers)
+constexpr int QB = 8;           // queries per VALU batched scan launch (query fragments live in registers)
+constexpr int GQ = 32;          // queries per MFMA (GEMM-shaped) batched scan pass == slots of the batched workspace
 
 // Batched searches run QB independent query "slots" side by side: every per-query buffer is
 // an array over slots and blockIdx.z selects the slot (z = 0 for single-query searches).
@@ -78,7 +79,8 @@ struct as_query {
     int64_t k = 0, topk = 0;
     int Mk = 32, Ms = 32;
     int nwaves = 0;
-    int cap = 1;             // query slots (QB for the batched workspace)
+    int cap = 1;             // query slots (GQ for the batched workspace)
+    int gemm_variant = 0;    // batched MFMA scan shape: 0 = 8 waves x 2 slabs, 1 = 4 x 2, 2 = 4 x 3 (ARROWSPACE_GEMM_VARIANT)
     int nb = 1;              // active slots of the current launch sequence
     as::SlotStride ss{};
     int cus = 256;
@@ -369,6 +371,122 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
         if (owner) {
             mydots[row] = k1;
             prefilter_f32(mine, row, k1, aux, nq32, inq32);
+        }
+    }
+}
+
+// Batched scan as a GEMM (rows up to 768 floats): dots[GQ x rows] = Q . X^T on fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, A = 32 queries, B = 32 item rows per wave).  The GQ queries stay in
+// LDS for the whole launch ([GQ][dp], 16-byte chunks XOR-swizzled by the query index so the
+// fragment reads are conflict-free without padding); every wave streams its own 32-row blocks
+// by LDS-DMA into a private ring of NBUF XOR-swizzled slabs (same image as knn_mfma_dma_kernel),
+// so the K loop needs no block barrier at all, only the wave's own vmcnt.  One HBM pass serves
+// GQ queries: 2*GQ*dp flops per row against dp*4 bytes -- still HBM-bound at GQ=32.
+template <int WAVES, int NBUF>
+__global__ __launch_bounds__(WAVES * 64) void scan_gemm_kernel(const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp,
+                                                               int64_t r0, int64_t r1, float* __restrict__ dots, int64_t sd, PreArgs pre,
+                                                               int nb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    float* Qs = (float*)smem;                   // [GQ][dp], chunk c of query i at chunk (c & ~7) | ((c ^ i) & 7)
+    float* St = Qs + GQ * dp;                   // per wave: NBUF slabs x [32 rows][32 floats]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nc4 = (int)(dp / 4);
+    for (int i = tid; i < GQ * nc4; i += WAVES * 64) {
+        const int qi = i / nc4, c4 = i % nc4;
+        *(f32x4*)(Qs + (int64_t)qi * dp + (((c4 & ~7) | ((c4 ^ qi) & 7)) << 2)) = *(const f32x4*)(q32 + (int64_t)qi * dp + c4 * 4);
+    }
+    __syncthreads();
+    float* my = St + wu * NBUF * 1024;
+    const int drow = lane >> 3;
+    const int csw0 = (lane & 7) ^ ((lane >> 4) & 7), csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+    const unsigned lo0 = (unsigned)((drow * dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * dp + csw1 * 4) * 4);
+    int foff[4], qoff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        foff[s] = (((2 * s + h) ^ ((l31 >> 1) & 7)) << 2);
+        qoff[s] = (((2 * s + h) ^ (l31 & 7)) << 2);
+    }
+    const int nslab = (int)(dp / 32);
+    const int64_t nrb = (r1 - r0 + 31) / 32;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + wu, NWV = (int64_t)gridDim.x * WAVES;
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    // prefetch cursor: the wave's slab sequence (row block, k slab), NBUF-1 slabs ahead of the MFMAs
+    int64_t prb = gw;
+    int pks = 0, pbuf = 0, inflight = 0;
+    auto issue = [&]() {
+        if (prb >= nrb) return;
+        // 4 x 1 KiB pieces per 32-row slab: piece j = rows [8j, 8j+8)
+        const char* base = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + pks * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* src = base + (size_t)(8 * j) * dp * 4 + ((j & 1) ? lo1 : lo0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(my + pbuf * 1024 + 8 * j * 32), 16, 0, 0);
+        }
+        pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;
+        if (++pks == nslab) {
+            pks = 0;
+            prb += NWV;
+        }
+        ++inflight;
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) issue();
+    int cur = 0;
+    for (int64_t rb = gw; rb < nrb; rb += NWV) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const int64_t row = r0 + rb * 32 + l31;
+        for (int ks = 0; ks < nslab; ++ks) {
+            // slab `cur` has landed once at most inflight-1 newer slabs (4 DMA ops each) are outstanding;
+            // loads retire in order, so the count is conservative whatever else is in flight
+            if (NBUF >= 3 && inflight >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            --inflight;
+            issue();   // overwrites the slab read in the previous iteration (its ds_reads were consumed by MFMAs)
+            const float* Xr = my + cur * 1024 + l31 * 32;
+            const float* Qr = Qs + (int64_t)l31 * dp + ks * 32;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 qf = *(const f32x4*)(Qr + qoff[s]);
+                const f32x4 xf = *(const f32x4*)(Xr + foff[s]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], xf[t], acc, 0, 0, 0);
+            }
+            cur = cur + 1 == NBUF ? 0 : cur + 1;
+        }
+        // C[i = query][j = row]: lane owns row l31 of the block, register r <-> query (r&3) + 8 (r>>2) + 4 h
+        if (row < r1) {
+            const bool pf = pre.enabled && row < pre.n && row != pre.exclude;
+            const float aux = pf ? auxv[row] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (b >= nb) continue;   // idle slot
+                const float dot = acc[r];
+                dots[(int64_t)b * sd + row] = dot;
+                if (pf) {
+                    float key, bound;
+                    if (pre.metric == AS_METRIC_L2) {
+                        const float nq = pre.info[b].nq32;
+                        key = fmaf(-2.0f, dot, aux + nq);
+                        bound = ((float)pre.epskey + (float)pre.coef * (aux + nq)) * 1.000001f;
+                    } else {
+                        key = 1.0f - fmaxf(0.0f, dot * aux * pre.info[b].inq32);
+                        bound = ((float)pre.epskey + (float)pre.coef) * 1.000001f;
+                    }
+                    if (key <= bound) {
+                        const int slot = atomicAdd(&pre.infow[b].knn_cnt, 1);
+                        if (slot < CAND_CAP) {
+                            ((float*)pre.ckey)[(int64_t)b * CAND_CAP + slot] = key;
+                            pre.cidx[(int64_t)b * CAND_CAP + slot] = (int)row;
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -1353,8 +1471,32 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
                            q->r1, q->dots64, pre);
     } else {
         const int nch = (int)((sp->dp + 255) / 256);
+        if (q->cap > 1 && sp->dp <= 768) {
+            // batched pass, GEMM-shaped: GQ queries resident in LDS, fp32 MFMA
+            const int gv = q->gemm_variant;
+#define AS_GSCAN(W, NB_)                                                                                               \
+    do {                                                                                                               \
+        const size_t lds = sizeof(float) * ((size_t)GQ * sp->dp + (size_t)(W) * (NB_) * 1024);                         \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            AS_HIP(hipFuncSetAttribute((const void*)scan_gemm_kernel<W, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)(sizeof(float) * ((size_t)GQ * 768 + (size_t)(W) * (NB_) * 1024))));        \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        const int64_t nrb = (rows + 31) / 32;                                                                          \
+        const unsigned grid = (unsigned)std::min<int64_t>((nrb + (W) - 1) / (W), q->cus);                              \
+        hipLaunchKernelGGL((scan_gemm_kernel<W, NB_>), dim3(grid), dim3((W) * 64), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
+                           q->r1, q->dots32, q->ss.dots, pre, q->nb);                                                  \
+    } while (0)
+            if (gv == 1) AS_GSCAN(4, 2);
+            else if (gv == 2) AS_GSCAN(4, 3);
+            else AS_GSCAN(8, 2);
+#undef AS_GSCAN
+            AS_HIP(hipGetLastError());
+            return AS_OK;
+        }
         if (q->cap > 1) {
-            // batched pass: QB queries per row read (query fragments in registers); dp <= 1024 only
+            // batched pass on VALU FMAs: QB queries per launch (query fragments in registers); dp <= 1024 only
 #define AS_BSCAN(N)                                                                                                    \
     do {                                                                                                               \
         if (!q->scan_grid) {                                                                                           \
@@ -1363,8 +1505,15 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
             q->scan_grid = q->cus * std::max(1, std::min(nb_, 8));                                                     \
         }                                                                                                              \
         const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->scan_grid);                               \
-        hipLaunchKernelGGL(scan_dots_batch_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0,    \
-                           q->r1, q->dots32, q->ss.dots, pre);                                                         \
+        for (int j0 = 0; j0 < q->nb; j0 += QB) {                                                                       \
+            PreArgs pj = pre;                                                                                          \
+            pj.info = pre.info + j0;                                                                                   \
+            pj.infow = pre.infow + j0;                                                                                 \
+            pj.ckey = (void*)((float*)pre.ckey + (int64_t)j0 * CAND_CAP);                                              \
+            pj.cidx = pre.cidx + (int64_t)j0 * CAND_CAP;                                                               \
+            hipLaunchKernelGGL(scan_dots_batch_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32 + (int64_t)j0 * sp->dp, \
+                               sp->dp, q->r0, q->r1, q->dots32 + (int64_t)j0 * q->ss.dots, q->ss.dots, pj);             \
+        }                                                                                                              \
     } while (0)
             switch (nch) {
                 case 1: AS_BSCAN(1); break;
@@ -1664,6 +1813,7 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     }
     q->nwaves = 4096;
     if (const char* ev = getenv("ARROWSPACE_SCAN_VARIANT")) q->scan_variant = atoi(ev) & 3;
+    if (const char* ev = getenv("ARROWSPACE_GEMM_VARIANT")) q->gemm_variant = atoi(ev);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) q->cus = prop.multiProcessorCount;
