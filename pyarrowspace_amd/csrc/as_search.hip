@@ -80,7 +80,7 @@ struct as_query {
     int Mk = 32, Ms = 32;
     int nwaves = 0;
     int cap = 1;             // query slots (GQ for the batched workspace)
-    int gemm_variant = 0;    // batched MFMA scan shape: 0 = 8 waves x 2 slabs, 1 = 4 x 2, 2 = 4 x 3 (ARROWSPACE_GEMM_VARIANT)
+    int gemm_variant = 0;    // batched MFMA scan (ARROWSPACE_GEMM_VARIANT): 1 = ring of 3 slabs, 2 = default cache policy, 16 = no MFMA (timing only)
     int nb = 1;              // active slots of the current launch sequence
     as::SlotStride ss{};
     int cus = 256;
@@ -376,106 +376,191 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
 }
 
 // Batched scan as a GEMM (rows up to 768 floats): dots[GQ x rows] = Q . X^T on fp32 MFMA
-// (v_mfma_f32_32x32x2_f32, A = 32 queries, B = 32 item rows per wave).  The GQ queries stay in
-// LDS for the whole launch ([GQ][dp], 16-byte chunks XOR-swizzled by the query index so the
-// fragment reads are conflict-free without padding); every wave streams its own 32-row blocks
-// by LDS-DMA into a private ring of NBUF XOR-swizzled slabs (same image as knn_mfma_dma_kernel),
-// so the K loop needs no block barrier at all, only the wave's own vmcnt.  One HBM pass serves
-// GQ queries: 2*GQ*dp flops per row against dp*4 bytes -- still HBM-bound at GQ=32.
-template <int WAVES, int NBUF>
-__global__ __launch_bounds__(WAVES * 64) void scan_gemm_kernel(const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp,
-                                                               int64_t r0, int64_t r1, float* __restrict__ dots, int64_t sd, PreArgs pre,
-                                                               int nb) {
+// (v_mfma_f32_32x32x2_f32, A = 32 queries, B = 32 item rows).  A block is a team of 4 waves
+// that splits K: wave w keeps the Q fragments of its quarter of the columns in registers for the
+// whole launch (<= 6 slabs of 32 floats -> 96 VGPRs) and streams the matching quarter of every
+// 32-row block by LDS-DMA into a private ring of NBUF XOR-swizzled slabs (same image as
+// knn_mfma_dma_kernel) -- the K loop has no block barrier, only the wave's own vmcnt, and all
+// of LDS is staging (2 blocks per CU, ~100 KB of rows in flight per CU).  The four partial
+// 32x32 tiles meet in LDS once per row block; wave w then owns queries [8w, 8w+8) of the
+// epilogue (store + fused kNN prefilter).  One HBM pass serves GQ queries: 2*GQ*dp flops per
+// row against dp*4 bytes -- still HBM-bound at GQ=32.
+constexpr int GEMM_NSW = 6;   // slabs per wave: dp <= 4 * 6 * 32
+
+// LDS accesses of the MFMA scan go through inline asm: the compiler orders every LDS read it can see after
+// *all* outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain the prefetch ring at each slab.
+// Each asm block waits for its own reads before it ends, so no register the compiler may copy or reuse ever
+// holds data that is still in flight.
+__device__ __forceinline__ void lds_read4x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, f32x4& x0, f32x4& x1, f32x4& x2, f32x4& x3) {
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+        : "memory");
+}
+__device__ __forceinline__ void lds_read4x3(unsigned a0, unsigned a1, unsigned a2, f32x4& x0, f32x4& x1, f32x4& x2) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2)
+                 : "v"(a0), "v"(a1), "v"(a2)
+                 : "memory");
+}
+__device__ __forceinline__ float lds_read1(unsigned a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
+// s_nop: the hazard recogniser does not look inside asm, and an MFMA result may be the operand
+__device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
+    asm volatile("s_nop 15\n\ts_nop 3\n\tds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// AUX: cache policy of the row DMA (2 = nt: rows are read once per launch; measured 7-10 % faster than the default).
+// DIAG = 1 (measurement only, wrong results): no MFMA -- the memory side alone; fetching the same bytes as
+// 2 rows x 512 B or 1 row x 1 KiB per instruction instead of 8 rows x 128 B measured the same time.
+template <int NBUF, int DIAG = 0, int AUX = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
+    const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+    int64_t sd, PreArgs pre, int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
-    float* Qs = (float*)smem;                   // [GQ][dp], chunk c of query i at chunk (c & ~7) | ((c ^ i) & 7)
-    float* St = Qs + GQ * dp;                   // per wave: NBUF slabs x [32 rows][32 floats]
+    float* St = (float*)smem;   // per wave: NBUF slabs x [32 rows][32 floats]; Ex[owner wave][3 senders][64 lanes][4]; Ax[wave][64]
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ex0 = lds0 + 4 * NBUF * 4096, ax0 = ex0 + 4 * 3 * 64 * 16;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nc4 = (int)(dp / 4);
-    for (int i = tid; i < GQ * nc4; i += WAVES * 64) {
-        const int qi = i / nc4, c4 = i % nc4;
-        *(f32x4*)(Qs + (int64_t)qi * dp + (((c4 & ~7) | ((c4 ^ qi) & 7)) << 2)) = *(const f32x4*)(q32 + (int64_t)qi * dp + c4 * 4);
-    }
-    __syncthreads();
+    const int nslab = (int)(dp / 32), nsw = (nslab + 3) / 4;
+    const int ks0 = wu * nsw;
+    const int myns = max(0, min(nsw, nslab - ks0));
+    f32x4 qf[GEMM_NSW][4];
+#pragma unroll
+    for (int ks = 0; ks < GEMM_NSW; ++ks)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[ks][s] = ks < myns ? *(const f32x4*)(q32 + (int64_t)l31 * dp + (ks0 + ks) * 32 + (2 * s + h) * 4) : f32x4{0, 0, 0, 0};
+    // per-query constants of the prefilter, for the 4 queries this lane finishes: b = e + 8 wu + 4 h
+    float nqv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nqv[e] = pre.metric == AS_METRIC_L2 ? pre.info[e + 8 * wu + 4 * h].nq32 : pre.info[e + 8 * wu + 4 * h].inq32;
+    // the loads above complete here, once: otherwise the compiler has to assume they are still pending inside
+    // the loop and puts a vmcnt(0) -- which also waits for the whole prefetch ring -- in front of their first use
+#pragma unroll
+    for (int ks = 0; ks < GEMM_NSW; ++ks)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[ks][s]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(nqv[e]));
     float* my = St + wu * NBUF * 1024;
+    const unsigned my0 = lds0 + wu * NBUF * 4096;
     const int drow = lane >> 3;
     const int csw0 = (lane & 7) ^ ((lane >> 4) & 7), csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
     const unsigned lo0 = (unsigned)((drow * dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * dp + csw1 * 4) * 4);
-    int foff[4], qoff[4];
+    unsigned foff[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        foff[s] = (((2 * s + h) ^ ((l31 >> 1) & 7)) << 2);
-        qoff[s] = (((2 * s + h) ^ (l31 & 7)) << 2);
-    }
-    const int nslab = (int)(dp / 32);
+    for (int s = 0; s < 4; ++s) foff[s] = my0 + (unsigned)(l31 * 128 + (((2 * s + h) ^ ((l31 >> 1) & 7)) << 4));
     const int64_t nrb = (r1 - r0 + 31) / 32;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES + wu, NWV = (int64_t)gridDim.x * WAVES;
     const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
     // prefetch cursor: the wave's slab sequence (row block, k slab), NBUF-1 slabs ahead of the MFMAs
-    int64_t prb = gw;
+    int64_t prb = myns > 0 ? (int64_t)blockIdx.x : nrb;
     int pks = 0, pbuf = 0, inflight = 0;
     auto issue = [&]() {
         if (prb >= nrb) return;
         // 4 x 1 KiB pieces per 32-row slab: piece j = rows [8j, 8j+8)
-        const char* base = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + pks * 32);
+        const char* base = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + (ks0 + pks) * 32);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const char* src = base + (size_t)(8 * j) * dp * 4 + ((j & 1) ? lo1 : lo0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(my + pbuf * 1024 + 8 * j * 32), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(my + pbuf * 1024 + 8 * j * 32), 16, 0, AUX);
         }
         pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;
-        if (++pks == nslab) {
+        if (++pks == myns) {
             pks = 0;
-            prb += NWV;
+            prb += gridDim.x;
         }
         ++inflight;
     };
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) issue();
-    int cur = 0;
-    for (int64_t rb = gw; rb < nrb; rb += NWV) {
+    unsigned cur = 0;   // byte offset of the slab the MFMAs read next
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // the row's norm for the prefilter: issued before this block's slabs, so it is older than every DMA still in
+        // flight at the epilogue when the wave has at least NBUF-1 slabs per block
         const int64_t row = r0 + rb * 32 + l31;
-        for (int ks = 0; ks < nslab; ++ks) {
-            // slab `cur` has landed once at most inflight-1 newer slabs (4 DMA ops each) are outstanding;
-            // loads retire in order, so the count is conservative whatever else is in flight
-            if (NBUF >= 3 && inflight >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            --inflight;
-            issue();   // overwrites the slab read in the previous iteration (its ds_reads were consumed by MFMAs)
-            const float* Xr = my + cur * 1024 + l31 * 32;
-            const float* Qr = Qs + (int64_t)l31 * dp + ks * 32;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + row),   // padded arrays: readable
+                                         (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + wu * 64), 4, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x4 qf = *(const f32x4*)(Qr + qoff[s]);
-                const f32x4 xf = *(const f32x4*)(Xr + foff[s]);
+        for (int ks = 0; ks < GEMM_NSW; ++ks) {
+            if (ks < myns) {
+                // slab `cur` has landed once at most inflight-1 newer slabs (4 DMA ops each) are outstanding:
+                // loads retire in order, so the count is conservative whatever else is in flight
+                if (NBUF >= 4 && inflight >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (NBUF >= 3 && inflight == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                --inflight;
+                issue();   // overwrites the slab read in the previous iteration (its ds_reads were consumed by MFMAs)
+                f32x4 x0, x1, x2, x3;
+                lds_read4x4(foff[0] + cur, foff[1] + cur, foff[2] + cur, foff[3] + cur, x0, x1, x2, x3);
+                if (DIAG == 1) {
+                    acc[0] += x0[0] + x1[1] + x2[2] + x3[3];
+                    cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
+                    continue;
+                }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], xf[t], acc, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][0][t], x0[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][1][t], x1[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][2][t], x2[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][3][t], x3[t], acc, 0, 0, 0);
+                cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
             }
-            cur = cur + 1 == NBUF ? 0 : cur + 1;
         }
-        // C[i = query][j = row]: lane owns row l31 of the block, register r <-> query (r&3) + 8 (r>>2) + 4 h
+        // C[i = query][j = row]: register r <-> query (r&3) + 8 (r>>2) + 4 h, lane <-> row l31.  Wave o owns
+        // registers [4o, 4o+4) = queries 8o + {0..3} + 4h; the other three waves send it their partials.
+        // Raw barriers: __syncthreads() carries a vmcnt(0) fence that would drain the prefetch ring.
+        __builtin_amdgcn_s_barrier();   // the previous row block's exchange has been read (its reads were waited for)
+        f32x4 mine = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4 part = {acc[4 * o], acc[4 * o + 1], acc[4 * o + 2], acc[4 * o + 3]};
+            if (o != wu) lds_write4(ex0 + (unsigned)(((o * 3 + (wu < o ? wu : wu - 1)) * 64 + lane) * 16), part);
+            else mine = part;
+        }
+        AS_LDS_FENCE();
+        __builtin_amdgcn_s_barrier();
+        {
+            f32x4 p0, p1, p2;
+            const unsigned pa = ex0 + (unsigned)((wu * 3 * 64 + lane) * 16);
+            lds_read4x3(pa, pa + 1024, pa + 2048, p0, p1, p2);
+            mine += p0;
+            mine += p1;
+            mine += p2;
+        }
+        // aux: older than the slabs in flight when they were all issued inside this row block
+        if (myns >= NBUF - 1 && inflight == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (myns >= NBUF - 1 && inflight == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (myns >= NBUF - 1 && inflight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
         if (row < r1) {
             const bool pf = pre.enabled && row < pre.n && row != pre.exclude;
-            const float aux = pf ? auxv[row] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int e = 0; e < 4; ++e) {
+                const int b = e + 8 * wu + 4 * h;
                 if (b >= nb) continue;   // idle slot
-                const float dot = acc[r];
+                const float dot = mine[e];
                 dots[(int64_t)b * sd + row] = dot;
                 if (pf) {
                     float key, bound;
                     if (pre.metric == AS_METRIC_L2) {
-                        const float nq = pre.info[b].nq32;
-                        key = fmaf(-2.0f, dot, aux + nq);
-                        bound = ((float)pre.epskey + (float)pre.coef * (aux + nq)) * 1.000001f;
+                        key = fmaf(-2.0f, dot, aux + nqv[e]);
+                        bound = ((float)pre.epskey + (float)pre.coef * (aux + nqv[e])) * 1.000001f;
                     } else {
-                        key = 1.0f - fmaxf(0.0f, dot * aux * pre.info[b].inq32);
+                        key = 1.0f - fmaxf(0.0f, dot * aux * nqv[e]);
                         bound = ((float)pre.epskey + (float)pre.coef) * 1.000001f;
                     }
                     if (key <= bound) {
@@ -489,6 +574,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_gemm_kernel(const float* __re
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // generic width (dp > 2048): query re-read from L1 per chunk
@@ -1442,8 +1528,14 @@ static int list_width(int64_t k) {
     return -1;
 }
 
-static double coef_query(int64_t dp, bool exact) {
+// fp32/fp64 error coefficient of one dot product: (terms in the longest rounding chain + slack) * u.
+// Wave-per-row scans sum dp/64 fused terms per lane before a 6-level butterfly; the MFMA pass
+// accumulates a quarter of the columns in sequence (two roundings per term, in case the matrix
+// core rounds the products) and adds four partials.
+static double coef_query(const as_query* q, bool exact) {
     const double u = exact ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
+    const int64_t dp = q->sp->dp;
+    if (!exact && q->cap > 1 && dp <= 4 * GEMM_NSW * 32) return (double)(2 * (((dp / 32 + 3) / 4) * 32) + 3 + 24) * u;
     return (double)(dp / 64 + 24) * u;
 }
 
@@ -1454,7 +1546,7 @@ static PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) 
     p.ckey = q->ckey_k; p.cidx = q->cidx_k;
     p.metric = sp->opts.metric;
     p.epskey = p.metric == AS_METRIC_L2 ? eps * eps : eps;
-    p.coef = coef_query(sp->dp, q->exact != 0);
+    p.coef = coef_query(q, q->exact != 0);
     p.n = sp->n; p.exclude = exclude; p.enabled = enabled ? 1 : 0;
     return p;
 }
@@ -1471,26 +1563,25 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
                            q->r1, q->dots64, pre);
     } else {
         const int nch = (int)((sp->dp + 255) / 256);
-        if (q->cap > 1 && sp->dp <= 768) {
-            // batched pass, GEMM-shaped: GQ queries resident in LDS, fp32 MFMA
-            const int gv = q->gemm_variant;
-#define AS_GSCAN(W, NB_)                                                                                               \
+        if (q->cap > 1 && sp->dp <= 4 * GEMM_NSW * 32) {
+            // batched pass, GEMM-shaped: fp32 MFMA, K split over the 4 waves of a block, 2 blocks per CU
+#define AS_GSCAN(NB_, DG, AX)                                                                                                \
     do {                                                                                                               \
-        const size_t lds = sizeof(float) * ((size_t)GQ * sp->dp + (size_t)(W) * (NB_) * 1024);                         \
+        const size_t lds = sizeof(float) * ((size_t)4 * (NB_) * 1024 + 4 * 3 * 64 * 4 + 4 * 64);                       \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            AS_HIP(hipFuncSetAttribute((const void*)scan_gemm_kernel<W, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)(sizeof(float) * ((size_t)GQ * 768 + (size_t)(W) * (NB_) * 1024))));        \
+            AS_HIP(hipFuncSetAttribute((const void*)scan_gemm_kernel<NB_, DG, AX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr_set = true;                                                                                           \
         }                                                                                                              \
         const int64_t nrb = (rows + 31) / 32;                                                                          \
-        const unsigned grid = (unsigned)std::min<int64_t>((nrb + (W) - 1) / (W), q->cus);                              \
-        hipLaunchKernelGGL((scan_gemm_kernel<W, NB_>), dim3(grid), dim3((W) * 64), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
-                           q->r1, q->dots32, q->ss.dots, pre, q->nb);                                                  \
+        const unsigned grid = (unsigned)std::min<int64_t>(nrb, 2 * q->cus);                                            \
+        hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
+                           q->dots32, q->ss.dots, pre, q->nb);                                                         \
     } while (0)
-            if (gv == 1) AS_GSCAN(4, 2);
-            else if (gv == 2) AS_GSCAN(4, 3);
-            else AS_GSCAN(8, 2);
+            if (q->gemm_variant == 1) AS_GSCAN(3, 0, 2);
+            else if (q->gemm_variant == 2) AS_GSCAN(4, 0, 0);
+            else if (q->gemm_variant == 16) AS_GSCAN(4, 1, 2);
+            else AS_GSCAN(4, 0, 2);
 #undef AS_GSCAN
             AS_HIP(hipGetLastError());
             return AS_OK;
@@ -1619,7 +1710,7 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lamb
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? eps * eps : eps;
     FinishArgs f = make_finish(q);
-    f.M = q->Mk; f.epskey = epskey; f.coef = coef_query(sp->dp, q->exact != 0);
+    f.M = q->Mk; f.epskey = epskey; f.coef = coef_query(q, q->exact != 0);
     f.recs = o_idx ? nullptr : q->knn;
     f.o_idx = o_idx; f.o_key = o_key; f.o_dist = o_dist; f.o_gy = o_gy; f.o_cnt = o_cnt;
     f.fuse = fuse_lambda;
@@ -1655,7 +1746,7 @@ template <typename T, typename U, int PASSES>
 static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_final) {
     hipStream_t st = q->stream;
     f.M = q->Ms; f.hits = q->hits; f.fuse = fuse_final; f.hout = q->hout_dev; f.seq = q->seq;
-    const double coef_s = coef_query(q->sp->dp, sizeof(T) == 8);
+    const double coef_s = coef_query(q, sizeof(T) == 8);
     if (q->robust && q->Ms > MAX_LIST) {
         // wide lists: exact global selection, then the filter-path finish kernel on exactly M rows
         const int64_t rows = q->r1 - q->r0;

@@ -103,21 +103,22 @@ def test_non_fp32_representable_items_keep_fp64(oracle_lib):
     assert [i for i, _ in got] == [i for i, _ in want]
 
 
-@pytest.mark.parametrize("metric", ["l2", "cosine"])
-def test_search_batch_matches_single_and_oracle(oracle_lib, metric):
-    """as_search_batch: 8 query slots per pass over the items; chunks of 8, 8 and 3."""
+@pytest.mark.parametrize("metric,d", [("l2", 200), ("cosine", 200), ("l2", 24), ("cosine", 768), ("l2", 1000)])
+def test_search_batch_matches_single_and_oracle(oracle_lib, metric, d):
+    """as_search_batch: 32 query slots per pass over the items (MFMA pass up to 768 columns, K split over
+    4 waves: 7 slabs -> 2,2,2,1; 1 slab -> 1,0,0,0; 24 slabs -> 6 each; VALU pass above), chunks of 32 and 13."""
     import pyarrowspace_amd as asp
-    n, d, k, topk = 3000, 200, 9, 7
+    n, k, topk = 3000, 9, 7
     X = clustered(n, d, nclust=10, seed=13)
     gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": topk, "p": 2.0, "sigma": None, "metric": metric}
     aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
     ref = oracle_lib.OracleIndex(X, gp)
     rng = np.random.default_rng(17)
-    Q = np.stack([X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d) for _ in range(19)])
+    Q = np.stack([X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d) for _ in range(45)])
     for tau in (0.62, 1.0):
         got = aspace.search_batch(Q, gl, tau)
-        assert len(got) == 19
-        for b in range(19):
+        assert len(got) == 45
+        for b in range(45):
             want, _ = ref.search(Q[b], tau)
             assert [i for i, _ in got[b]] == [i for i, _ in want], (b, tau)
             np.testing.assert_allclose([s for _, s in got[b]], [s for _, s in want], rtol=RTOL)
