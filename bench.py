@@ -115,6 +115,15 @@ def main():
     Qd = X[qrows] + 0.05 * 0.5 * torch.randn((nq_total, d), generator=gq, device=device, dtype=torch.float32) / (d ** 0.5) * (d ** 0.5) / 31.0
     Q = (Qd / Qd.norm(dim=1, keepdim=True)).double().cpu().numpy()
     eps = args.eps if args.eps > 0 else calibrate_eps(X, args.k)
+    if dist is not None:
+        # every rank derives the same queries and eps from the same seeds; broadcast rank 0's anyway so that
+        # a bit-level difference between devices can never desynchronise the ranks' control flow
+        qt = torch.from_numpy(Q).to(device)
+        et = torch.tensor([eps], dtype=torch.float64, device=device)
+        dist.broadcast(qt, 0)
+        dist.broadcast(et, 0)
+        Q = qt.cpu().numpy()
+        eps = float(et.item())
     gp = {"eps": eps, "k": args.k, "topk": args.topk, "p": 2.0, "sigma": None}
 
     def barrier():

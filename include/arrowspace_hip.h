@@ -148,8 +148,12 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
                           double* out_score, int64_t* out_len, double* out_lambda_q);
 /* flags bit0: run the following scans in fp64 end to end (the fallback as_search takes when
  * the fp32 candidate lists are not provably exact); bit1: wavefront-list selection instead
- * of the filter buffers (taken when a buffer overflowed).  as_query_flags reports the last
- * finished search: bit0 = not provably exact, bit1 = a candidate buffer overflowed. */
+ * of the filter buffers (taken when a buffer overflowed); bit2: the next as_query_scan does
+ * not scan -- it re-derives the k-NN candidates of the SAME query and row range from the dot
+ * products the previous scan left in HBM (threshold selection; taken when only the k-NN
+ * buffer overflowed: more than 4096 rows inside eps).  as_query_flags reports the last
+ * finished search: bit0 = not provably exact, bit1 = this side's candidate buffer overflowed
+ * (knn_inexact: the k-NN buffer, score_inexact: the scorer's). */
 void as_query_set_exact(as_query* q, int32_t flags);
 as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact);
 /* HIP stream (hipStream_t) the query's kernels run on, for event timing / ordering;

@@ -53,8 +53,23 @@ struct QInfo {
     int nhit;
     int knn_cnt;      // filter path: appended k-NN candidates
     int sc_cnt;       // filter path: appended scorer candidates
-    int overflow;     // a candidate buffer overflowed -> rerun on the list path
+    int overflow;     // bit0: the k-NN candidate buffer overflowed (-> threshold repair over the kept dots), bit1: the scorer's (-> list path)
 };
+
+// everything a search writes into QInfo after the query itself was prepared (norms stay)
+__device__ __forceinline__ void reset_query_state(QInfo* info) {
+    info->lambda_q = 0.0;
+    info->status = AS_OK;
+    info->knn_inexact = 0;
+    info->score_inexact = 0;
+    info->knn_total = 0;
+    info->nhit = 0;
+    info->knn_cnt = 0;
+    info->sc_cnt = 0;
+    info->overflow = 0;
+    info->thr32 = 0.0f;
+    info->thr64 = 0.0;
+}
 
 struct HostOut {
     volatile int64_t seq;
@@ -79,6 +94,7 @@ struct as_query {
     int64_t k = 0, topk = 0;
     int Mk = 32, Ms = 32;
     int nwaves = 0;
+    int reuse = 0;           // staged path: the next scan call repairs the previous scan's overflow from its dots
     int cap = 1;             // query slots (GQ for the batched workspace)
     int gemm_variant = 0;    // batched MFMA scan (ARROWSPACE_GEMM_VARIANT): 1 = ring of 3 slabs, 2 = default cache policy, 16 = no MFMA (timing only)
     int nb = 1;              // active slots of the current launch sequence
@@ -166,18 +182,8 @@ __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int6
         info->inq = nq > 0.0 ? 1.0 / sqrt(nq) : 0.0;
         info->nq32 = (float)nq;
         info->inq32 = nq > 0.0 ? (float)(1.0 / sqrt(nq)) : 0.0f;
-        info->lambda_q = 0.0;
         info->tau = tau;
-        info->status = AS_OK;
-        info->knn_inexact = 0;
-        info->score_inexact = 0;
-        info->knn_total = 0;
-        info->nhit = 0;
-        info->knn_cnt = 0;
-        info->sc_cnt = 0;
-        info->overflow = 0;
-        info->thr32 = 0.0f;
-        info->thr64 = 0.0;
+        reset_query_state(info);
     }
 }
 
@@ -201,8 +207,10 @@ struct PreArgs {
 };
 
 // aux = n32[row] (L2) or inorm32[row] (cosine), loaded by the caller together with the row
-__device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, float dot, float aux, float nq32, float inq32) {
-    if (!p.enabled || row >= p.n || row == p.exclude) return;
+// full: set once this lane has seen the buffer overflow -- the counter only has to exceed CAND_CAP, and a
+// neighbourhood of most of the items would otherwise serialise a million atomics on one address
+__device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, float dot, float aux, float nq32, float inq32, int& full) {
+    if (!p.enabled || full || row >= p.n || row == p.exclude) return;
     float key, bound;
     if (p.metric == AS_METRIC_L2) {
         key = fmaf(-2.0f, dot, aux + nq32);
@@ -216,6 +224,8 @@ __device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, flo
         if (slot < CAND_CAP) {
             ((float*)p.ckey)[slot] = key;
             p.cidx[slot] = (int)row;
+        } else {
+            full = 1;
         }
     }
 }
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     const float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+    int full = 0;
     const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
     f32x4 qv[NCH];
     bool on[NCH];
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
         if (lane < 2) {
             const float dot = lane ? sb : sa;
             dots[myrow] = dot;
-            prefilter_f32(pre, myrow, dot, aux, nq32, inq32);
+            prefilter_f32(pre, myrow, dot, aux, nq32, inq32, full);
         }
     }
     if (row < r1) {
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
         sa = wave_sum(sa);
         if (lane == 0) {
             dots[ra] = sa;
-            prefilter_f32(pre, ra, sa, auxv[ra], nq32, inq32);
+            prefilter_f32(pre, ra, sa, auxv[ra], nq32, inq32, full);
         }
     }
 }
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
     const int myq = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     const bool owner = (lane & 7) == 0;
     const float nq32 = pre.info[myq].nq32, inq32 = pre.info[myq].inq32;
+    int full = 0;
     PreArgs mine = pre;
     mine.info = pre.info + myq;
     mine.infow = pre.infow + myq;
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
         k1 += __shfl_xor(k1, 1, 64);
         if (owner) {
             mydots[row] = k1;
-            prefilter_f32(mine, row, k1, aux, nq32, inq32);
+            prefilter_f32(mine, row, k1, aux, nq32, inq32, full);
         }
     }
 }
@@ -482,6 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) issue();
     unsigned cur = 0;   // byte offset of the slab the MFMAs read next
+    int full = 0;       // bit e: query e of this lane has overflowed its candidate buffer (see prefilter_f32)
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         f32x16 acc;
 #pragma unroll
@@ -554,7 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (b >= nb) continue;   // idle slot
                 const float dot = mine[e];
                 dots[(int64_t)b * sd + row] = dot;
-                if (pf) {
+                if (pf && !((full >> e) & 1)) {
                     float key, bound;
                     if (pre.metric == AS_METRIC_L2) {
                         key = fmaf(-2.0f, dot, aux + nqv[e]);
@@ -568,6 +581,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (slot < CAND_CAP) {
                             ((float*)pre.ckey)[(int64_t)b * CAND_CAP + slot] = key;
                             pre.cidx[(int64_t)b * CAND_CAP + slot] = (int)row;
+                        } else {
+                            full |= 1 << e;
                         }
                     }
                 }
@@ -585,6 +600,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_generic_kernel(const float*
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     const float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+    int full = 0;
     for (int64_t row = r0 + gw; row < r1; row += nw) {
         const float* pa = x32 + row * dp;
         float s = 0.0f;
@@ -597,7 +613,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_generic_kernel(const float*
         s = wave_sum(s);
         if (lane == 0) {
             dots[row] = s;
-            prefilter_f32(pre, row, s, (pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32)[row], nq32, inq32);
+            prefilter_f32(pre, row, s, (pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32)[row], nq32, inq32, full);
         }
     }
 }
@@ -610,6 +626,7 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     const double nq = pre.info->nq;
+    int full = 0;
     for (int64_t row = r0 + gw; row < r1; row += nw) {
         double s = 0.0;
         if (x64) {
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
         s = wave_sum(s);
         if (lane == 0) {
             dots[row] = s;
-            if (pre.enabled && row < pre.n && row != pre.exclude) {
+            if (pre.enabled && !full && row < pre.n && row != pre.exclude) {
                 const double ni = pre.n64[row];
                 double key, bound;
                 if (pre.metric == AS_METRIC_L2) {
@@ -639,6 +656,8 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
                     if (slot < CAND_CAP) {
                         ((double*)pre.ckey)[slot] = key;
                         pre.cidx[slot] = (int)row;
+                    } else {
+                        full = 1;
                     }
                 }
             }
@@ -723,21 +742,35 @@ __device__ __forceinline__ double knn_key<double>(const SelArgs<double>& a, int6
     return 1.0 - (c > 0.0 ? c : 0.0);
 }
 
-// ------------------------------------------------------------------ filter path, scorer side
-// (1) per-group minimum of the scorer key; one wave per group of G rows
-template <typename T>
+// ------------------------------------------------------------------ filter path
+// KEY = 0: the scorer key (-score) of every scanned row.  KEY = 1: the k-NN key of the rows inside the eps
+// bound, +inf elsewhere -- the second chance of a query whose neighbourhood overflowed the scan's candidate
+// buffer: the dots are still there, so the k nearest are found by threshold without a second scan.
+template <typename T, int KEY>
+__device__ __forceinline__ T sel_key(const SelArgs<T>& a, const ScoreCtx& c, int64_t row) {
+    if (KEY == 0) return score_key<T>(a, c, row);
+    if (row >= a.n || row == a.exclude) return key_traits<T>::inf();
+    const T key = knn_key<T>(a, row, a.dots[row], c.nq);
+    const double ni = sizeof(T) == 4 ? (double)a.n32[row] : a.n64[row];
+    const double bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + c.nq) : a.epskey + a.coef;
+    return (double)key <= bound * 1.000001 ? key : key_traits<T>::inf();
+}
+
+// (1) per-group minimum of the key; one wave per group of G rows
+template <typename T, int KEY>
 __global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G, int ngroups) {
     sel_slot(a);
     T* __restrict__ gmin = a.gmin;
     const int lane = lane_id();
     const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (KEY == 1 && g == 0 && lane == 0) reset_query_state(a.info_w);   // the search restarts behind the scan
     if (g >= ngroups) return;
     const ScoreCtx c = load_ctx(a.info, a.tau);
     const int64_t lo = a.r0 + g * G;
     const int64_t hi = lo + G < a.r1 ? lo + G : a.r1;
     T m = key_traits<T>::inf();
     for (int64_t row = lo + lane; row < hi; row += 64) {
-        const T k = score_key<T>(a, c, row);
+        const T k = sel_key<T, KEY>(a, c, row);
         m = k < m ? k : m;
     }
 #pragma unroll
@@ -839,21 +872,25 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
 }
 
 // (3) append every row whose key <= threshold
-template <typename T>
+template <typename T, int KEY>
 __global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a) {
     sel_slot(a);
     T* __restrict__ ckey = a.ckey;
     int* __restrict__ cidx = a.cidx;
+    int* counter = KEY ? &a.info_w->knn_cnt : &a.info_w->sc_cnt;
     const ScoreCtx c = load_ctx(a.info, a.tau);
     const T thr = sizeof(T) == 4 ? (T)a.info->thr32 : (T)a.info->thr64;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
-        const T k = score_key<T>(a, c, row);
-        if (k <= thr) {
-            const int slot = atomicAdd(&a.info_w->sc_cnt, 1);
+    bool full = false;   // mass ties at the threshold: the counter only has to exceed CAND_CAP
+    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1 && !full; row += stride) {
+        const T k = sel_key<T, KEY>(a, c, row);
+        if (k <= thr && (KEY == 0 || k < key_traits<T>::inf())) {
+            const int slot = atomicAdd(counter, 1);
             if (slot < CAND_CAP) {
                 ckey[slot] = k;
                 cidx[slot] = (int)row;
+            } else {
+                full = true;
             }
         }
     }
@@ -1148,6 +1185,7 @@ struct FinishArgs {
     SlotStride ss;
     int fuse;           // knn: compute lambda_q in the same launch; score: publish to hout
     int from_list;      // candidates come from the wavefront lists instead of the filter buffer
+    int thresholded;    // the buffer holds the rows under a selection threshold, not every row inside eps
     // build-fallback outputs (row-list form); null for searches
     int32_t* o_idx;
     double* o_key;
@@ -1219,7 +1257,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         total = a.info->knn_total;
     } else {
         const int raw = a.info->knn_cnt;
-        if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow = 1;
+        if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow |= 1;
         total = raw < CAND_CAP ? raw : CAND_CAP;
         select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
@@ -1305,7 +1343,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         if (a.o_cnt) *a.o_cnt = cnt;
         int bad = 0;
         a.info->knn_total = total;
-        if (total > a.M && Mp > 0) {
+        if ((total > a.M || a.thresholded) && Mp > 0) {
             const double B = npass >= a.k ? sk2[a.k - 1] : a.epskey;
             // dropped items' norms are unknown: bound them by the largest norm in the space
             const double e = a.metric == AS_METRIC_L2 ? a.coef * (a.nmax + nq) : a.coef;
@@ -1389,7 +1427,7 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
         total = (int)(a.nrows < 0x7fffffff ? a.nrows : 0x7fffffff);
     } else {
         const int raw = a.info->sc_cnt;
-        if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow = 1;
+        if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow |= 2;
         total = raw < CAND_CAP ? raw : CAND_CAP;
         select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
@@ -1450,7 +1488,7 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
             // trailing flag record: every rank sees every rank's flags after the all-gather
             as_hit_rec r;
             r.idx = -2;
-            r.score = (double)((a.info->knn_inexact ? 1 : 0) | (bad ? 2 : 0) | (a.info->overflow ? 4 : 0));
+            r.score = (double)((a.info->knn_inexact ? 1 : 0) | (bad ? 2 : 0) | ((a.info->overflow & 1) ? 4 : 0) | ((a.info->overflow & 2) ? 8 : 0));
             a.hits[a.topk] = r;
         }
         if (a.fuse && a.hout) {
@@ -1508,7 +1546,7 @@ __global__ __launch_bounds__(1024) void hits_final_kernel(const as_hit_rec* __re
         out->status = info->status;
         out->knn_inexact = (info->knn_inexact || (fl & 1)) ? 1 : 0;
         out->score_inexact = (info->score_inexact || (fl & 2)) ? 1 : 0;
-        out->overflow = (info->overflow || (fl & 4)) ? 1 : 0;
+        out->overflow = (info->overflow & 3) | ((fl & 4) ? 1 : 0) | ((fl & 8) ? 2 : 0);
         publish(out, seq);
     }
 }
@@ -1703,8 +1741,38 @@ static size_t finish_lds() {
 }
 
 // k-NN candidates of the scanned rows -> records (or row lists for the build fallback)
+// Second chance of a neighbourhood that overflowed the scan's candidate buffer (more than CAND_CAP rows inside
+// eps): the dots are still in HBM, so the candidates are re-derived by threshold -- the Mk-th smallest group
+// minimum of the k-NN key -- exactly as the scorer's filter path does, instead of scanning the items again.
+template <typename T, typename U, int PASSES>
+static void launch_knn_repair(as_query* q, const T* dots, double eps, int64_t exclude) {
+    hipStream_t st = q->stream;
+    const int64_t rows = q->r1 - q->r0;
+    int64_t G = (rows + CAND_CAP - 1) / CAND_CAP;
+    G = std::max<int64_t>(64, (G + 63) / 64 * 64);
+    const int ng = (int)((rows + G - 1) / G);
+    SelArgs<T> a = make_sel<T>(q, dots, q->Mk, exclude);
+    a.epskey = q->sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps;
+    a.coef = coef_query(q, sizeof(T) == 8);
+    a.ckey = (T*)q->ckey_k;
+    a.cidx = q->cidx_k;
+    const unsigned nb = (unsigned)q->nb;
+    hipLaunchKernelGGL((score_gmin_kernel<T, 1>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
+    hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Mk, q->info);
+    const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
+    hipLaunchKernelGGL((score_filter_kernel<T, 1>), dim3(fg, 1, nb), dim3(256), 0, st, a);
+}
+
+static as_status knn_repair(as_query* q, double eps, int64_t exclude) {
+    if (q->r1 - q->r0 <= 0) return AS_OK;
+    if (q->exact) launch_knn_repair<double, unsigned long long, 8>(q, q->dots64, eps, exclude);
+    else launch_knn_repair<float, unsigned int, 4>(q, q->dots32, eps, exclude);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
 static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lambda, int32_t* o_idx, double* o_key,
-                         double* o_dist, double* o_gy, int32_t* o_cnt) {
+                         double* o_dist, double* o_gy, int32_t* o_cnt, int thresholded = 0) {
     const as_space* sp = q->sp;
     hipStream_t st = q->stream;
     const int metric = sp->opts.metric;
@@ -1714,6 +1782,7 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lamb
     f.recs = o_idx ? nullptr : q->knn;
     f.o_idx = o_idx; f.o_key = o_key; f.o_dist = o_dist; f.o_gy = o_gy; f.o_cnt = o_cnt;
     f.fuse = fuse_lambda;
+    f.thresholded = thresholded;
     if (q->robust) {
         int nw = 0;
         const int grid = sel_grid(q, &nw);
@@ -1780,10 +1849,10 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
         a.tau = f.tau;
         const unsigned nb = (unsigned)q->nb;
-        hipLaunchKernelGGL(score_gmin_kernel<T>, dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
+        hipLaunchKernelGGL((score_gmin_kernel<T, 0>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
         hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
         const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
-        hipLaunchKernelGGL(score_filter_kernel<T>, dim3(fg, 1, nb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((score_filter_kernel<T, 0>), dim3(fg, 1, nb), dim3(256), 0, st, a);
         f.ck = q->ckey_s; f.ci = q->cidx_s;
         hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1, 1, nb), dim3(1024), score_lds<T>(), st, f, coef_s);
     }
@@ -2002,6 +2071,15 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
         set_err("as_query_scan: null argument");
         return AS_EINVAL;
     }
+    if (q->reuse && !q->robust) {
+        // same query again after a candidate-buffer overflow: threshold repair over the kept dots
+        if (row_begin != q->r0 || row_end != q->r1) {
+            set_err("as_query_scan: the repair pass must cover the rows of the scan it repairs");
+            return AS_EINVAL;
+        }
+        AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
+        return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
+    }
     AS_TRY(query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1));
     return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
@@ -2055,12 +2133,13 @@ void as_query_set_exact(as_query* q, int32_t flags) {
     if (!q) return;
     q->exact = (flags & 1) ? 1 : 0;
     q->robust = (flags & 2) ? 1 : 0;
+    q->reuse = (flags & 4) ? 1 : 0;
 }
 
 as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact) {
     if (!q) return AS_EINVAL;
-    if (knn_inexact) *knn_inexact = q->hout->knn_inexact | (q->hout->overflow ? 2 : 0);
-    if (score_inexact) *score_inexact = q->hout->score_inexact | (q->hout->overflow ? 2 : 0);
+    if (knn_inexact) *knn_inexact = q->hout->knn_inexact | ((q->hout->overflow & 1) ? 2 : 0);
+    if (score_inexact) *score_inexact = q->hout->score_inexact | ((q->hout->overflow & 2) ? 2 : 0);
     return AS_OK;
 }
 
@@ -2098,6 +2177,14 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     AS_TRY(run_score(q, tau, 1));
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
     AS_TRY(wait_published(q));
+    if (!q->robust && (q->hout->overflow & 1)) {
+        // more than CAND_CAP rows inside eps: re-derive the candidates from the kept dots, no second scan
+        AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
+        AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1));
+        q->seq += 1;
+        AS_TRY(run_score(q, tau, 1));
+        AS_TRY(wait_published(q));
+    }
     return collect(q, out_idx, out_score, out_len, out_lambda_q);
 }
 
@@ -2113,6 +2200,18 @@ as_status search_batch_once(as_query* q, const double* queries, int nb, int64_t 
     AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
     q->seq += 1;
     AS_TRY(run_score(q, tau, 1));
+    bool crowded = false;
+    for (int b = 0; b < nb; ++b) {
+        AS_TRY(wait_published(q, b));
+        crowded = crowded || (q->hout[b].overflow & 1);
+    }
+    if (crowded) {
+        // some neighbourhood overflowed its candidate buffer: threshold repair of every slot over the kept dots
+        AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
+        AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1));
+        q->seq += 1;
+        AS_TRY(run_score(q, tau, 1));
+    }
     for (int b = 0; b < nb; ++b) {
         AS_TRY(wait_published(q, b));
         const HostOut* h = q->hout + b;

@@ -31,6 +31,21 @@ def shard_bounds(n: int, world: int) -> list[int]:
     return b
 
 
+def next_mode(mode: int, inexact: bool, overflow: int):
+    """Escalation of one sharded search (every rank sees the same merged flags, so every rank takes the
+    same step).  mode bits as in as_query_set_exact: 1 = fp64 scans, 2 = wavefront-list selection,
+    4 = repair the k-NN candidates from the kept dots.  Returns None when the answer stands."""
+    if inexact and not mode & 1:
+        return (mode | 1) & ~4                    # fp64 from scratch (the fp32 dots cannot be reused)
+    if overflow & 1 and not mode & 6:
+        # more than CAND_CAP rows inside eps: threshold repair, no rescan (the scorer ran on a truncated
+        # neighbourhood, so its own overflow bit means nothing yet)
+        return mode | 4
+    if overflow:
+        return None if mode & 2 else (mode | 2) & ~4   # scorer buffer, or the repair itself overflowed: list path
+    return None
+
+
 class HipEngine:
     """Thin driver of the staged C ABI on this rank's GPU (torch tensors carry the pointers)."""
 
@@ -124,7 +139,7 @@ class HipEngine:
         ki, si = C.c_int32(0), C.c_int32(0)
         self.L.as_query_flags(self.q, C.byref(ki), C.byref(si))
         inexact = bool((ki.value & 1) or (si.value & 1))
-        overflow = bool((ki.value | si.value) & 2)
+        overflow = (1 if ki.value & 2 else 0) | (2 if si.value & 2 else 0)   # bit0: k-NN buffer, bit1: scorer buffer
         if st not in (self._lib.AS_OK, self._lib.AS_EZEROLAMBDA):
             self._check(st)
         hits = [(int(self._idx[t]), float(self._sc[t])) for t in range(ln.value)]
@@ -278,7 +293,7 @@ class ShardedIndex:
         ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
         mode = 0
         with ctx:
-            for _ in range(3):
+            for _ in range(4):
                 e.set_mode(mode)
                 e.query_scan(q, self.r0, self.r1)
                 knn_all = self._gather_fixed(e.knn_local)
@@ -286,10 +301,9 @@ class ShardedIndex:
                 e.query_score(tau)
                 hits_all = self._gather_fixed(e.hits_local)
                 hits, lq, zero, inexact, overflow = e.query_finish(hits_all)
-                nxt = mode | (2 if overflow else 0) | (1 if inexact else 0)
-                if nxt == mode:
+                mode = next_mode(mode, inexact, overflow)
+                if mode is None:
                     break
-                mode = nxt
         self.last_lambda_q = lq
         if zero:
             raise PanicException("The lambdas are zero, check the magnitude of items and eps.")

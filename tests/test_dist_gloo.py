@@ -192,3 +192,25 @@ def test_record_layouts_match_the_c_structs():
     import ctypes
     assert ctypes.sizeof(_lib.KnnRec) == 8 * KNN_REC_F64
     assert ctypes.sizeof(_lib.HitRec) == 8 * HIT_REC_F64
+
+
+def test_escalation_steps():
+    """pyarrowspace_amd.dist.next_mode: fp64 restart, threshold repair, list path -- and termination."""
+    from pyarrowspace_amd.dist import next_mode
+    assert next_mode(0, False, 0) is None
+    assert next_mode(0, False, 1) == 4            # crowded neighbourhood: repair from the kept dots
+    assert next_mode(4, False, 0) is None
+    assert next_mode(4, False, 1) == 2            # the repair overflowed as well (mass ties): list path
+    assert next_mode(0, False, 2) == 2            # scorer buffer overflowed
+    assert next_mode(0, False, 3) == 4            # the scorer's bit means nothing while the neighbourhood is truncated
+    assert next_mode(4, False, 2) == 2
+    assert next_mode(2, False, 3) is None         # nothing beyond the list path
+    assert next_mode(0, True, 0) == 1             # not provably exact in fp32
+    assert next_mode(4, True, 0) == 1             # fp32 dots are no use to the fp64 pass
+    assert next_mode(1, True, 0) is None
+    assert next_mode(1, False, 1) == 5
+    assert next_mode(5, False, 1) == 3
+    m, steps = 0, 0
+    while m is not None and steps < 10:           # worst case: every flag raised every time
+        m, steps = next_mode(m, True, 3), steps + 1
+    assert m is None and steps <= 4

@@ -43,6 +43,28 @@ def test_single_rank_staged_path_matches_oracle(oracle_lib):
     index.close()
 
 
+def test_staged_path_repairs_a_crowded_neighbourhood(oracle_lib):
+    """eps above the diameter: the scan's candidate buffer (4096) overflows, the staged host asks for the
+    threshold repair over the kept dots (set_exact bit2) instead of a second scan."""
+    import torch
+    from pyarrowspace_amd import dist as asdist
+    n, d = 5000, 64
+    X = clustered(n, d, nclust=6, noise=0.4, seed=23)
+    gp = {"eps": 10.0, "k": 25, "topk": 15, "p": 2.0, "sigma": None}
+    index = asdist.ShardedIndex.build(gp, torch.from_numpy(X).cuda())
+    ref = oracle_lib.OracleIndex(X, gp)
+    modes = []
+    real = index.engine.set_mode
+    index.engine.set_mode = lambda m: (modes.append(m), real(m))[1]
+    for q, tau in _queries(X, n, d)[:6]:
+        want, lq = ref.search(q, tau)
+        got = index.search(q, tau)
+        assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-9)
+        assert abs(index.last_lambda_q - lq) <= 1e-9 * abs(lq)
+    assert 4 in modes and 2 not in modes and 6 not in modes, modes
+    index.close()
+
+
 def _worker(rank, world, port, n, d, split, out):
     import torch
     import torch.distributed as dist

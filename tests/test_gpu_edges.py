@@ -107,6 +107,15 @@ def test_dense_neighbourhoods_prune_thousands_of_candidates(oracle_lib, mode):
     _compare(X, gp, oracle_lib, [X[5] * 1.01, X[n - 3] + 0.01 / np.sqrt(d)], taus=(0.62, 1.0))
 
 
+def test_every_pair_within_eps(oracle_lib):
+    """eps above the diameter (the reference harnesses' eps=10 on small-norm data, tests/test_3_beir.py:194-200):
+    the k cap alone decides the graph, and every query overflows the prefilter buffer into the robust path."""
+    n, d = 5000, 64
+    X = clustered(n, d, nclust=6, noise=0.4, seed=23)
+    gp = {"eps": 10.0, "k": 25, "topk": 15, "p": 2.0, "sigma": None}
+    _compare(X, gp, oracle_lib, [X[17] * 1.02, X[n - 1] + 0.02 / np.sqrt(d)], taus=(0.62, 1.0))
+
+
 @pytest.mark.parametrize("topk", [57, 100, 1000, 1024])
 def test_large_topk(oracle_lib, topk):
     """topk up to 1024 (candidate list = topk + margin, exact re-scoring in rounds of 64)."""
