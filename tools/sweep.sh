@@ -1,0 +1,24 @@
+#!/bin/bash
+# Headline-adjacent configurations (SURVEY 8d "config restatement" + width/topk/tau variations): one bench.py line each.
+set -e
+mkdir -p gpurun_out
+out=gpurun_out/sweep.jsonl
+: > $out
+run() { timeout -k 10 400 python bench.py --no-cpu-baseline --steps 100 --warmup 10 "$@" 2>/dev/null | grep '^{"metric"' >> $out; }
+run --n 400000 --d 384 --k 4 --topk 2
+run --n 200000 --d 768
+run --n 1000000 --d 768 --topk 100
+run --n 1000000 --d 768 --tau 1.0
+run --n 1000000 --d 768 --tau 0.0
+run --n 262144 --d 1024
+run --n 131072 --d 2048
+run --n 65536 --d 4096
+run --n 20000 --d 768
+python - <<'PY'
+import json
+for l in open("gpurun_out/sweep.jsonl"):
+    d = json.loads(l)
+    c = d["config"]
+    print(f"n={c['n']:>8} d={c['d']:>5} {c['workload'].split('fp32, ')[1].split(' eps')[0]:28s} q/s={d['value']:9.1f} scan={d['roofline']['frac']:.3f} query={d['roofline_query']['frac']:.3f} "
+          f"build={d['index_build_sec']:.2f}s mfma={d['roofline_build']['frac']:.3f} batched={d['batched_queries_per_sec'] or 0:.0f}")
+PY
