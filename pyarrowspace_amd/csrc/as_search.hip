@@ -421,14 +421,33 @@ __device__ __forceinline__ float lds_read1(unsigned a) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
     return v;
 }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate).  Only the counts the
+// slab ring produces get an exact wait; anything else waits for everything (always correct).  A 14-way switch
+// at every slab of the unrolled K loop pushed the kernel into scratch spills.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (n == 4 || n == 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// always issued (an exec-masked store the compiler may not branch around): the wave's count of outstanding
+// operations must never be smaller than the ring's bookkeeping assumes
+__device__ __forceinline__ void store_dword_issued(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
 // s_nop: the hazard recogniser does not look inside asm, and an MFMA result may be the operand
 __device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
     asm volatile("s_nop 15\n\ts_nop 3\n\tds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 // AUX: cache policy of the row DMA (2 = nt: rows are read once per launch; measured 7-10 % faster than the default).
-// DIAG = 1 (measurement only, wrong results): no MFMA -- the memory side alone; fetching the same bytes as
-// 2 rows x 512 B or 1 row x 1 KiB per instruction instead of 8 rows x 128 B measured the same time.
+// DIAG = 1 (measurement only, wrong results): no MFMA -- the memory side alone (0.59 ms of the kernel's 0.61).
+// Measured on that skeleton: fetching the same bytes as 2 rows x 512 B or 1 row x 1 KiB per instruction
+// instead of 8 rows x 128 B: no change; without the norm DMA: no change; without the 4 dot stores per row
+// block: 0.46 ms (7.0 TB/s); with nt stores: 0.52 ms -- but in the full kernel nt stores were slower (0.63 ms)
+// and cost the per-slot selection kernels their cache hits.
 template <int NBUF, int DIAG = 0, int AUX = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
     const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
@@ -474,25 +493,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // prefetch cursor: the wave's slab sequence (row block, k slab), NBUF-1 slabs ahead of the MFMAs
     int64_t prb = myns > 0 ? (int64_t)blockIdx.x : nrb;
     int pks = 0, pbuf = 0, inflight = 0;
-    auto issue = [&]() {
-        if (prb >= nrb) return;
-        // 4 x 1 KiB pieces per 32-row slab: piece j = rows [8j, 8j+8)
-        const char* base = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + (ks0 + pks) * 32);
+    // x0/x1/x2: vector-memory operations other than slab DMAs issued after the oldest / 2nd / 3rd slab in
+    // flight -- a lower bound: the norm DMA and the 4 dot stores of each row block (rare appends add more and
+    // only make the wait stricter).  Operations retire in issue order, so "oldest slab landed" == "at most
+    // 4 (inflight - 1) + x0 operations outstanding"; counting the stores keeps them off the critical path
+    // (waiting for them too cost 23 % of the launch).
+    int x0 = 0, x1 = 0, x2 = 0;
+    // (a macro, not a lambda: the by-reference closure of a lambda this size was left in scratch memory)
+#define AS_ISSUE_SLAB()                                                                                                   \
+    do {                                                                                                                  \
+        if (prb < nrb) {                                                                                                  \
+            /* 4 x 1 KiB pieces per 32-row slab: piece j = rows [8j, 8j+8) */                                             \
+            const char* base_ = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + (ks0 + pks) * 32);                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+                const char* src_ = base_ + (size_t)(8 * j) * dp * 4 + ((j & 1) ? lo1 : lo0);                              \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                     \
+                                                 (__attribute__((address_space(3))) void*)(my + pbuf * 1024 + 8 * j * 32), 16, 0, AUX); \
+            }                                                                                                             \
+            pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;                                                                       \
+            if (++pks == myns) {                                                                                          \
+                pks = 0;                                                                                                  \
+                prb += gridDim.x;                                                                                         \
+            }                                                                                                             \
+            if (inflight == 0) x0 = 0;                                                                                    \
+            else if (inflight == 1) x1 = 0;                                                                               \
+            else x2 = 0;                                                                                                  \
+            ++inflight;                                                                                                   \
+        }                                                                                                                 \
+    } while (0)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const char* src = base + (size_t)(8 * j) * dp * 4 + ((j & 1) ? lo1 : lo0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(my + pbuf * 1024 + 8 * j * 32), 16, 0, AUX);
-        }
-        pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;
-        if (++pks == myns) {
-            pks = 0;
-            prb += gridDim.x;
-        }
-        ++inflight;
-    };
-#pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i) issue();
+    for (int i = 0; i < NBUF - 1; ++i) AS_ISSUE_SLAB();
     unsigned cur = 0;   // byte offset of the slab the MFMAs read next
     int full = 0;       // bit e: query e of this lane has overflowed its candidate buffer (see prefilter_f32)
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
@@ -502,18 +532,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the row's norm for the prefilter: issued before this block's slabs, so it is older than every DMA still in
         // flight at the epilogue when the wave has at least NBUF-1 slabs per block
         const int64_t row = r0 + rb * 32 + l31;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + row),   // padded arrays: readable
-                                         (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + wu * 64), 4, 0, 0);
+        {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + row),   // padded arrays: readable
+                                             (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + wu * 64), 4, 0, 0);
+            x0 += 1;
+            x1 += 1;
+            x2 += 1;
+        }
 #pragma unroll
         for (int ks = 0; ks < GEMM_NSW; ++ks) {
             if (ks < myns) {
                 // slab `cur` has landed once at most inflight-1 newer slabs (4 DMA ops each) are outstanding:
                 // loads retire in order, so the count is conservative whatever else is in flight
-                if (NBUF >= 4 && inflight >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (NBUF >= 3 && inflight == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wait_vmcnt(4 * (inflight - 1) + (x0 >= 5 ? 5 : 0));
                 --inflight;
-                issue();   // overwrites the slab read in the previous iteration (its ds_reads were consumed by MFMAs)
+                x0 = x1;
+                x1 = x2;
+                AS_ISSUE_SLAB();   // overwrites the slab read in the previous iteration (its ds_reads were consumed by MFMAs)
                 f32x4 x0, x1, x2, x3;
                 lds_read4x4(foff[0] + cur, foff[1] + cur, foff[2] + cur, foff[3] + cur, x0, x1, x2, x3);
                 if (DIAG == 1) {
@@ -553,20 +588,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             mine += p1;
             mine += p2;
         }
-        // aux: older than the slabs in flight when they were all issued inside this row block
-        if (myns >= NBUF - 1 && inflight == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (myns >= NBUF - 1 && inflight == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (myns >= NBUF - 1 && inflight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the norms: older than the slabs in flight when those were all issued inside this row block
+        wait_vmcnt(myns >= NBUF - 1 ? 4 * inflight : 0);
         const float aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
-        if (row < r1) {
-            const bool pf = pre.enabled && row < pre.n && row != pre.exclude;
+        {
+            // all 4 stores are issued whatever the lane holds: rows past r1 land in the padding of the slot's
+            // buffer (stride np + ROW_TILE), idle slots have buffers of their own
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_dword_issued(dots + (int64_t)(e + 8 * wu + 4 * h) * sd + row, mine[e]);
+            x0 += 4;
+            x1 += 4;
+            x2 += 4;
+            const bool pf = pre.enabled && row < r1 && row < pre.n && row != pre.exclude;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int b = e + 8 * wu + 4 * h;
                 if (b >= nb) continue;   // idle slot
                 const float dot = mine[e];
-                dots[(int64_t)b * sd + row] = dot;
                 if (pf && !((full >> e) & 1)) {
                     float key, bound;
                     if (pre.metric == AS_METRIC_L2) {
@@ -590,6 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef AS_ISSUE_SLAB
 }
 
 // generic width (dp > 2048): query re-read from L1 per chunk
