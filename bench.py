@@ -207,12 +207,15 @@ def main():
     mfma_tf = bstats["mfma_flops"] / max(bstats["knn_mfma_s"], 1e-9) / 1e12
 
     # HBM-side traffic per launch from the committed PMC profile (only for the profiled workload)
-    traffic_scan = traffic_mfma = None
+    traffic_scan = traffic_mfma = traffic_batch = None
+    # rows up to 1024 floats take the LDS-DMA ring scan, wider rows the register-staged one
+    scan_kernel = "scan_dma_kernel" if d <= 1024 and os.environ.get("ARROWSPACE_SCAN_VARIANT", "0") in ("", "0") else "scan_dots_f32_kernel"
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if tj["workload"] == {"n": n, "d": d} and world == 1:
-            traffic_scan = tj["scan_dots_f32_kernel"]["bytes_per_launch"]
-            traffic_mfma = tj["knn_mfma_kernel"]["bytes_per_launch"]
+            traffic_scan = tj.get(scan_kernel, {}).get("bytes_per_launch")
+            traffic_mfma = tj.get("knn_mfma_kernel", {}).get("bytes_per_launch")
+            traffic_batch = tj.get("scan_gemm_kernel", {}).get("bytes_per_launch")
     except (OSError, KeyError, ValueError):
         pass
 
@@ -236,7 +239,7 @@ def main():
         "batched_queries_per_sec": batched_qps,
         "build_stages_sec": {k: bstats[k] for k in ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s")},
         "build_fallback_rows": bstats["fallback_rows"],
-        "roofline": {"kernel": "scan_dots_f32_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
                      "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes},
         "roofline_query": {"bound": "hbm", "achieved": query_bytes / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
@@ -246,6 +249,7 @@ def main():
             "kernel": "scan_gemm_kernel + per-slot selection", "bound": "hbm", "queries_per_pass": 32,
             "achieved": query_bytes / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": query_bytes / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
+            "traffic": traffic_batch,
             "note": "whole 32-query pass, host-visible; N*(D+2)*4 bytes per pass; fp32 MFMA work 2*32*N*D flops"},
         "roofline_build": {"kernel": "knn_mfma_kernel", "bound": "mfma", "achieved": mfma_tf, "peak": MFMA_F32_PEAK_TF,
                            "unit": "TFLOP/s", "frac": mfma_tf / MFMA_F32_PEAK_TF, "traffic": traffic_mfma,

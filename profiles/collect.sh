@@ -14,3 +14,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 2 "$@" > $OUT/pmc_$C.log 2>&1 || exit 1
   python3 profiles/summarise.py pmc $OUT/pmc_$C $C gpurun_out/${TAG}_pmc_$C.csv
 done
+python3 profiles/summarise.py traffic gpurun_out/${TAG}_pmc_FETCH_SIZE.csv gpurun_out/${TAG}_pmc_WRITE_SIZE.csv ${AS_PROFILE_N:-1000000} ${AS_PROFILE_D:-768} gpurun_out/${TAG}_traffic.json

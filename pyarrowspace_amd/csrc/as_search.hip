@@ -101,7 +101,7 @@ struct as_query {
     as::SlotStride ss{};
     int cus = 256;
     int scan_grid = 0;
-    int scan_variant = 0;    // bit0: alternate scan direction per query, bit1: temporal row loads
+    int scan_variant = 0;    // bit2: register-staged scan instead of the LDS-DMA ring; with it, bit0: alternate scan direction per query, bit1: temporal row loads
     int64_t scan_count = 0;
     int64_t r0 = 0, r1 = 0;
     int exact = 0;
@@ -629,6 +629,159 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef AS_ISSUE_SLAB
+}
+
+// Wave-wide sum on the DPP crossbar (6 VALU adds, no LDS round trips: a __shfl_xor butterfly is 6 dependent
+// ds_bpermute, ~600 cycles of latency per row): xor-1 and xor-2 inside quads, half-row and row mirrors, then
+// row_bcast15 / row_bcast31 carry the row sums up to lane 63.  Returns the total in every lane (readlane 63).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Single-query scan on the LDS-DMA ring (rows up to 1024 floats) -- the default.  The batched kernel's
+// skeleton streams at 7.0 TB/s where the register-staged scan above stops at 6.3: every wave keeps NSLOT-1
+// whole rows (NCH KiB each) in flight into a private LDS ring by `global_load_lds ... nt`, costs no VGPRs for
+// it, and consumes the oldest row behind a counted vmcnt.  Rows are handed out in chunks of 64 consecutive rows
+// per wave, round-robin over all waves (a moving window over the items), the remainder split evenly; lane r of
+// the wave ends up with the dot of the chunk's row r, so norms arrive by one 256-byte DMA per chunk, the dots
+// leave by one coalesced store and the k-NN prefilter runs lane-parallel.
+// All LDS reads and the store are inline asm (see scan_gemm_kernel): nothing the compiler can see may force
+// a vmcnt(0) inside the loop.
+template <int NCH, int NSLOT>
+__global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp,
+                                                       int64_t r0, int64_t r1, float* __restrict__ dots, PreArgs pre, int rounds,
+                                                       int tail_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RING = NSLOT * NCH * 1024;   // bytes per wave
+    constexpr int WAVE_LDS = RING + 256;       // + the chunk's 64 norms
+    constexpr int K1 = NCH * (NSLOT - 2);      // DMA operations younger than the oldest row of a full ring
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* myp = smem + wu * WAVE_LDS;
+    const unsigned my0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wu * WAVE_LDS;
+    const unsigned ax0 = my0 + RING;
+    // lanes past the end of a row never receive DMA data: they must read zeros, not stale bits
+    for (int i = lane; i < RING / 16; i += 64) *(f32x4*)(myp + i * 16) = f32x4{0, 0, 0, 0};
+    f32x4 qv[NCH];
+    bool on[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        on[u] = 4 * (lane + 64 * u) < dp;
+        qv[u] = on[u] ? *(const f32x4*)(q32 + 4 * (lane + 64 * u)) : f32x4{0, 0, 0, 0};
+    }
+    float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) asm volatile("" : "+v"(qv[u]));   // loads complete here, once (see scan_gemm_kernel)
+    asm volatile("" : "+v"(nq32), "+v"(inq32));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
+    const int64_t tail0 = r0 + (int64_t)rounds * NW * 64;
+    // chunk t of this wave: 64 rows for t < rounds, then its share of the remainder
+#define AS_CHUNK(t, base, cnt)                                                           \
+    do {                                                                                 \
+        if ((t) < rounds) {                                                              \
+            base = r0 + ((int64_t)(t) * NW + gw) * 64;                                    \
+            cnt = 64;                                                                    \
+        } else if ((t) == rounds) {                                                      \
+            base = tail0 + gw * tail_rows;                                               \
+            const int64_t left_ = r1 - base;                                             \
+            cnt = (int)(left_ < 0 ? 0 : (left_ < tail_rows ? left_ : tail_rows));        \
+        } else {                                                                         \
+            base = r1;                                                                   \
+            cnt = 0;                                                                     \
+        }                                                                                \
+    } while (0)
+    // prefetch cursor
+    int pt = 0, pr = 0, pcnt = 0, pslot = 0, inflight = 0;
+    int64_t pbase = 0;
+    AS_CHUNK(0, pbase, pcnt);
+#define AS_ISSUE_ROW()                                                                                                  \
+    do {                                                                                                                \
+        if (pcnt > 0) {                                                                                                 \
+            const float* src_ = x32 + (size_t)(pbase + pr) * dp + 4 * lane;                                             \
+            _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                                           \
+                if (on[u])                                                                                              \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + 256 * u),   \
+                                                     (__attribute__((address_space(3))) void*)(myp + (pslot * NCH + u) * 1024), 16, 0, 2); \
+            }                                                                                                           \
+            pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;                                                                 \
+            ++inflight;                                                                                                 \
+            if (++pr == pcnt) {                                                                                         \
+                pr = 0;                                                                                                 \
+                ++pt;                                                                                                   \
+                AS_CHUNK(pt, pbase, pcnt);                                                                              \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) AS_ISSUE_ROW();
+    unsigned cur = 0;    // byte offset of the oldest row in the ring
+    int marked = 0;      // rows in flight that have a chunk boundary's store + norm DMA behind them in the queue
+    int full = 0;
+    bool first = true;
+    for (int t = 0; t <= rounds; ++t) {
+        int64_t base;
+        int cnt;
+        AS_CHUNK(t, base, cnt);
+        if (cnt <= 0) continue;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),   // padded: readable
+                                         (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
+        marked = first ? 0 : inflight;   // the first chunk has only the norm DMA behind its rows: assume nothing
+        first = false;
+        float mydot = 0.0f;
+        for (int r = 0; r < cnt; ++r) {
+            // operations retire in issue order: the oldest row has landed once at most (rows behind it) * NCH
+            // (+ 2 for a chunk boundary behind it) operations are outstanding
+            if (inflight == NSLOT - 1) {
+                if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            marked = marked > 0 ? marked - 1 : 0;
+            --inflight;
+            AS_ISSUE_ROW();   // into the slot consumed one row ago
+            f32x4 xv[NCH];
+            const unsigned a0 = my0 + cur + lane * 16;
+            if (NCH == 1) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xv[0]) : "v"(a0) : "memory");
+            if (NCH == 2)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]) : "v"(a0) : "memory");
+            if (NCH == 3)
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]), "=&v"(xv[NCH > 2 ? 2 : 0]) : "v"(a0) : "memory");
+            if (NCH == 4)
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]), "=&v"(xv[NCH > 2 ? 2 : 0]), "=&v"(xv[NCH > 3 ? 3 : 0]) : "v"(a0) : "memory");
+            cur = cur + NCH * 1024 == RING ? 0 : cur + NCH * 1024;
+            float sacc = 0.0f;
+#pragma unroll
+            for (int u = 0; u < NCH; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc = fmaf(xv[u][e], qv[u][e], sacc);
+            sacc = wave_sum_dpp(sacc);
+            mydot = lane == r ? sacc : mydot;
+        }
+        // the norms are older than every row issued inside this chunk; one of those has been consumed once the
+        // chunk is at least as long as the ring
+        if (cnt < NSLOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float aux = lds_read1(ax0 + lane * 4);
+        const int64_t row = base + lane;
+        if (lane < cnt) {   // cnt >= 1: the store is always issued (the ring's bookkeeping counts it)
+            store_dword_issued(dots + row, mydot);
+            prefilter_f32(pre, row, mydot, aux, nq32, inq32, full);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef AS_ISSUE_ROW
+#undef AS_CHUNK
 }
 
 // generic width (dp > 2048): query re-read from L1 per chunk
@@ -1711,6 +1864,36 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
             hipLaunchKernelGGL((scan_dots_f32_kernel<N, true>), dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp,  \
                                q->r0, q->r1, q->dots32, pre, rev);                                                     \
     } while (0)
+        // default for rows up to 1024 floats: the LDS-DMA ring scan (ARROWSPACE_SCAN_VARIANT bit2 = register-staged scan)
+        if (nch <= 4 && !(q->scan_variant & 4)) {
+            const int64_t want = std::max<int64_t>(1, (rows + 63) / 64);                 // blocks that still get >= 16 rows per wave
+            // 2 blocks per CU, ring of 5 rows at 768 columns; rings of 4 or 6 rows and 3 blocks per CU measured the same or slower
+            const int64_t nblk = std::min<int64_t>(want, 2 * (int64_t)q->cus);
+            const int64_t NW = nblk * 4;
+            const int rounds = (int)(rows / (NW * 64));
+            const int64_t rem = rows - (int64_t)rounds * NW * 64;
+            const int tail_rows = (int)((rem + NW - 1) / NW);
+#define AS_DSCAN(N, S)                                                                                                 \
+    do {                                                                                                               \
+        const size_t lds = 4 * ((size_t)(S) * (N) * 1024 + 256);                                                       \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            AS_HIP(hipFuncSetAttribute((const void*)scan_dma_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
+                           q->r1, q->dots32, pre, rounds, tail_rows);                                                  \
+    } while (0)
+            switch (nch) {
+                case 1: AS_DSCAN(1, 8); break;
+                case 2: AS_DSCAN(2, 8); break;
+                case 3: AS_DSCAN(3, 5); break;
+                default: AS_DSCAN(4, 4); break;
+            }
+#undef AS_DSCAN
+            AS_HIP(hipGetLastError());
+            return AS_OK;
+        }
         switch (nch) {
             case 1: AS_SCAN(1); break;
             case 2: AS_SCAN(2); break;
@@ -2011,7 +2194,7 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
         return AS_EUNSUPPORTED;
     }
     q->nwaves = 4096;
-    if (const char* ev = getenv("ARROWSPACE_SCAN_VARIANT")) q->scan_variant = atoi(ev) & 3;
+    if (const char* ev = getenv("ARROWSPACE_SCAN_VARIANT")) q->scan_variant = atoi(ev) & 7;
     if (const char* ev = getenv("ARROWSPACE_GEMM_VARIANT")) q->gemm_variant = atoi(ev);
     {
         hipDeviceProp_t prop;
