@@ -31,7 +31,8 @@ constexpr int GQ = 32;          // queries per MFMA (GEMM-shaped) batched scan p
 // Batched searches run QB independent query "slots" side by side: every per-query buffer is
 // an array over slots and blockIdx.z selects the slot (z = 0 for single-query searches).
 struct SlotStride {
-    int64_t dots;   // elements between consecutive slots' dots arrays
+    int64_t dots;   // elements between consecutive slots' dots inside one 32-row tile (32: tile-major, batched workspace)
+    int64_t dots_ts; // elements between consecutive 32-row tiles (32 = plain row order, single slot; 32 * slots batched)
     int64_t q;      // dp
     int64_t qin;    // d
     int64_t knn;    // k records
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
 template <int NCH>
 __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
                                                               int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
-                                                              int64_t sd, PreArgs pre) {
+                                                              int64_t sd, int64_t ts, PreArgs pre) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
     mine.infow = pre.infow + myq;
     mine.ckey = (void*)((float*)pre.ckey + (int64_t)myq * CAND_CAP);
     mine.cidx = pre.cidx + (int64_t)myq * CAND_CAP;
-    float* __restrict__ mydots = dots + (int64_t)myq * sd;
+    float* __restrict__ mydots = dots + (int64_t)myq * sd;   // tile-major: [32-row tile][slot][32]
     for (int64_t row = r0 + gw; row < r1; row += nw) {
         const float* pa = x32 + row * dp + 4 * lane;
         f32x4 v[NCH];
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
         k1 += __shfl_xor(k1, 2, 64);
         k1 += __shfl_xor(k1, 1, 64);
         if (owner) {
-            mydots[row] = k1;
+            mydots[(row >> 5) * ts + (row & 31)] = k1;
             prefilter_f32(mine, row, k1, aux, nq32, inq32, full);
         }
     }
@@ -451,7 +452,7 @@ __device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
 template <int NBUF, int DIAG = 0, int AUX = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
     const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
-    int64_t sd, PreArgs pre, int nb) {
+    int64_t sd, int64_t ts, PreArgs pre, int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     float* St = (float*)smem;   // per wave: NBUF slabs x [32 rows][32 floats]; Ex[owner wave][3 senders][64 lanes][4]; Ax[wave][64]
@@ -592,10 +593,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wait_vmcnt(myns >= NBUF - 1 ? 4 * inflight : 0);
         const float aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
         {
-            // all 4 stores are issued whatever the lane holds: rows past r1 land in the padding of the slot's
-            // buffer (stride np + ROW_TILE), idle slots have buffers of their own
+            // all 4 stores are issued whatever the lane holds: rows past r1 land in the padding behind the last
+            // tile (np + ROW_TILE rows are allocated), idle slots have their places in every tile.  Tile-major
+            // dots: the wave's four stores fill 1 KiB of the row block's contiguous 4 KiB
+            float* const tile = dots + (row >> 5) * ts + (row & 31);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) store_dword_issued(dots + (int64_t)(e + 8 * wu + 4 * h) * sd + row, mine[e]);
+            for (int e = 0; e < 4; ++e) store_dword_issued(tile + (int64_t)(e + 8 * wu + 4 * h) * sd, mine[e]);
             x0 += 4;
             x1 += 4;
             x2 += 4;
@@ -876,8 +879,16 @@ struct SelArgs {
     T* gmin;      // filter path: group minima, candidate buffers (CAND_CAP per slot)
     T* ckey;
     int* cidx;
-    int64_t sd;   // dots stride between slots
+    int64_t sd;   // dots: elements between slots inside a 32-row tile
+    int64_t ts;   // dots: elements between 32-row tiles (32 = plain row order)
 };
+
+// The batched workspace keeps dots tile-major -- [32-row tile][slot][32 rows] -- so that the MFMA scan writes one
+// contiguous 4 KiB block per row block instead of 32 segments 4 MiB apart; with ts = 32 this is plain row order.
+template <typename T>
+__device__ __forceinline__ T dot_at(const SelArgs<T>& a, int64_t row) {
+    return a.dots[(row >> 5) * a.ts + (row & 31)];
+}
 
 template <typename T>
 __device__ __forceinline__ void sel_slot(SelArgs<T>& a) {
@@ -908,14 +919,14 @@ template <typename T>
 __device__ __forceinline__ T score_key(const SelArgs<T>& a, const ScoreCtx& c, int64_t row);
 template <>
 __device__ __forceinline__ float score_key<float>(const SelArgs<float>& a, const ScoreCtx& c, int64_t row) {
-    const float cs = a.dots[row] * a.inorm32[row] * c.inq32;
+    const float cs = dot_at(a, row) * a.inorm32[row] * c.inq32;
     const float term = 1.0f / (1.0f + fabsf(c.lq32 - a.lam32[row]));
     return -(c.tau32 * cs + (1.0f - c.tau32) * term);
 }
 template <>
 __device__ __forceinline__ double score_key<double>(const SelArgs<double>& a, const ScoreCtx& c, int64_t row) {
     const double den = sqrt(a.n64[row] * c.nq);
-    const double cs = den > 0.0 ? a.dots[row] / den : 0.0;
+    const double cs = den > 0.0 ? dot_at(a, row) / den : 0.0;
     return -(c.tau * cs + (1.0 - c.tau) / (1.0 + fabs(c.lq - a.lam64[row])));
 }
 
@@ -942,7 +953,7 @@ template <typename T, int KEY>
 __device__ __forceinline__ T sel_key(const SelArgs<T>& a, const ScoreCtx& c, int64_t row) {
     if (KEY == 0) return score_key<T>(a, c, row);
     if (row >= a.n || row == a.exclude) return key_traits<T>::inf();
-    const T key = knn_key<T>(a, row, a.dots[row], c.nq);
+    const T key = knn_key<T>(a, row, dot_at(a, row), c.nq);
     const double ni = sizeof(T) == 4 ? (double)a.n32[row] : a.n64[row];
     const double bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + c.nq) : a.epskey + a.coef;
     return (double)key <= bound * 1.000001 ? key : key_traits<T>::inf();
@@ -1189,7 +1200,7 @@ __global__ __launch_bounds__(256) void knn_partial_kernel(SelArgs<T> a) {
         bool valid = row < a.r1 && row < a.n && row != a.exclude;
         T key = key_traits<T>::inf();
         if (valid) {
-            key = knn_key<T>(a, row, a.dots[row], nq);
+            key = knn_key<T>(a, row, dot_at(a, row), nq);
             const double ni = sizeof(T) == 4 ? (double)a.n32[row] : a.n64[row];
             const double bound = a.metric == AS_METRIC_L2 ? a.epskey + a.coef * (ni + nq) : a.epskey + a.coef;
             valid = (double)key <= bound * 1.000001;
@@ -1806,7 +1817,7 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
         const int64_t nrb = (rows + 31) / 32;                                                                          \
         const unsigned grid = (unsigned)std::min<int64_t>(nrb, 2 * q->cus);                                            \
         hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
-                           q->dots32, q->ss.dots, pre, q->nb);                                                         \
+                           q->dots32, q->ss.dots, q->ss.dots_ts, pre, q->nb);                                                         \
     } while (0)
             if (q->gemm_variant == 1) AS_GSCAN(3, 0, 2);
             else if (q->gemm_variant == 2) AS_GSCAN(4, 0, 0);
@@ -1833,7 +1844,7 @@ static as_status launch_scan(as_query* q, const PreArgs& pre) {
             pj.ckey = (void*)((float*)pre.ckey + (int64_t)j0 * CAND_CAP);                                              \
             pj.cidx = pre.cidx + (int64_t)j0 * CAND_CAP;                                                               \
             hipLaunchKernelGGL(scan_dots_batch_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32 + (int64_t)j0 * sp->dp, \
-                               sp->dp, q->r0, q->r1, q->dots32 + (int64_t)j0 * q->ss.dots, q->ss.dots, pj);             \
+                               sp->dp, q->r0, q->r1, q->dots32 + (int64_t)j0 * q->ss.dots, q->ss.dots, q->ss.dots_ts, pj);             \
         }                                                                                                              \
     } while (0)
             switch (nch) {
@@ -1923,7 +1934,7 @@ static SelArgs<T> make_sel(as_query* q, const T* dots, int M, int64_t exclude) {
     a.M = M; a.metric = sp->opts.metric;
     a.epskey = 0; a.coef = 0; a.tau = 1.0;
     a.pkey = (T*)q->pkey; a.pidx = q->pidx;
-    a.gmin = (T*)q->gmin; a.ckey = (T*)q->ckey_s; a.cidx = q->cidx_s; a.sd = q->ss.dots;
+    a.gmin = (T*)q->gmin; a.ckey = (T*)q->ckey_s; a.cidx = q->cidx_s; a.sd = q->ss.dots; a.ts = q->ss.dots_ts;
     return a;
 }
 
@@ -2208,7 +2219,8 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp * C));
     AS_HIP(hipMalloc(&q->info, sizeof(QInfo) * C));
     AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE) * C));
-    q->ss.dots = sp->np + ROW_TILE;
+    q->ss.dots = C > 1 ? 32 : sp->np + ROW_TILE;
+    q->ss.dots_ts = C > 1 ? 32 * (int64_t)C : 32;
     q->ss.q = sp->dp;
     q->ss.qin = sp->d;
     q->ss.knn = std::max<int64_t>(q->k, 1);
