@@ -1,0 +1,146 @@
+// Internal declarations shared by the search translation units (as_scan.hip: the scan kernels of K7a;
+// as_search.hip: selection, finish kernels and the host side).  Not part of the C ABI.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+
+#include "as_common.hpp"
+
+namespace as {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CAND_CAP = 4096;  // candidate buffer of the filter path
+constexpr int REC_CAP = 512;    // k-NN records q_lambda accepts (ranks x k)
+constexpr int MAX_TOPK = 1024;  // largest topk
+constexpr int MS_MAX = MAX_TOPK + 64;  // widest scorer candidate list (topk + margin, rounded to 64)
+constexpr int HIT_CAP = 8 * (MAX_TOPK + 1) + 8;  // hit records hits_final accepts (ranks x (topk + 1))
+constexpr int QB = 8;           // queries per VALU batched scan launch (query fragments live in registers)
+constexpr int GQ = 32;          // queries per MFMA (GEMM-shaped) batched scan pass == slots of the batched workspace
+
+// Batched searches run GQ independent query "slots" side by side: every per-query buffer is
+// an array over slots and blockIdx.z selects the slot (z = 0 for single-query searches).
+struct SlotStride {
+    int64_t dots;   // elements between consecutive slots' dots inside one 32-row tile (32: tile-major, batched workspace)
+    int64_t dots_ts; // elements between consecutive 32-row tiles (32 = plain row order, single slot; 32 * slots batched)
+    int64_t q;      // dp
+    int64_t qin;    // d
+    int64_t knn;    // k records
+    int64_t hits;   // topk + 1 records
+};
+
+struct QInfo {
+    double nq;        // |q|^2
+    double lambda_q;
+    double tau;
+    double inq;       // 1/|q|
+    double thr64;     // scorer threshold key (fp64 mode)
+    float nq32, inq32;
+    float thr32;      // scorer threshold key (fp32 mode)
+    int status;       // as_status of the lambda step
+    int knn_inexact;  // a-posteriori check of the k-NN candidate list failed
+    int score_inexact;
+    int knn_total;    // candidates that passed the eps prefilter
+    int nhit;
+    int knn_cnt;      // filter path: appended k-NN candidates
+    int sc_cnt;       // filter path: appended scorer candidates
+    int overflow;     // bit0: the k-NN candidate buffer overflowed (-> threshold repair over the kept dots), bit1: the scorer's (-> list path)
+};
+
+// everything a search writes into QInfo after the query itself was prepared (norms stay)
+__device__ __forceinline__ void reset_query_state(QInfo* info) {
+    info->lambda_q = 0.0;
+    info->status = AS_OK;
+    info->knn_inexact = 0;
+    info->score_inexact = 0;
+    info->knn_total = 0;
+    info->nhit = 0;
+    info->knn_cnt = 0;
+    info->sc_cnt = 0;
+    info->overflow = 0;
+    info->thr32 = 0.0f;
+    info->thr64 = 0.0;
+}
+
+struct HostOut {
+    volatile int64_t seq;
+    int64_t len;
+    double lambda_q;
+    int status, knn_inexact, score_inexact, overflow;
+    int64_t idx[MAX_TOPK];
+    double score[MAX_TOPK];
+};
+
+struct RSel;
+
+}  // namespace as
+
+struct as_query {
+    const as_space* sp = nullptr;
+    const as_graph* gr = nullptr;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int own_records = 1;
+    int64_t k = 0, topk = 0;
+    int Mk = 32, Ms = 32;
+    int nwaves = 0;
+    int reuse = 0;           // staged path: the next scan call repairs the previous scan's overflow from its dots
+    int cap = 1;             // query slots (GQ for the batched workspace)
+    int gemm_variant = 0;    // batched MFMA scan (ARROWSPACE_GEMM_VARIANT): 1 = ring of 3 slabs, 2 = default cache policy, 16 = no MFMA (timing only)
+    int nb = 1;              // active slots of the current launch sequence
+    as::SlotStride ss{};
+    int cus = 256;
+    int scan_grid = 0;
+    int scan_variant = 0;    // bit2: register-staged scan instead of the LDS-DMA ring; with it, bit0: alternate scan direction per query, bit1: temporal row loads
+    int64_t scan_count = 0;
+    int64_t r0 = 0, r1 = 0;
+    int exact = 0;
+    int robust = 0;          // 1: wavefront-list path instead of the filter path
+    int64_t seq = 0;
+    double* hq = nullptr;    // pinned host staging of the query (device-readable)
+    double* hq_dev = nullptr;
+    double* q64 = nullptr;   // [dp] zero padded
+    float* q32 = nullptr;    // [dp]
+    as::QInfo* info = nullptr;
+    float* dots32 = nullptr; // [np]
+    double* dots64 = nullptr;
+    void* pkey = nullptr;    // list path: [nwaves][64] keys (sized for double)
+    int* pidx = nullptr;
+    void* ckey_k = nullptr;  // filter path candidate buffers (sized for double)
+    int* cidx_k = nullptr;
+    void* ckey_s = nullptr;
+    int* cidx_s = nullptr;
+    void* gmin = nullptr;    // group minima of the scorer key
+    as::RSel* rsel = nullptr; // state of the exact global selection
+    as_knn_rec* knn = nullptr;
+    as_hit_rec* hits = nullptr;
+    as::HostOut* hout = nullptr;  // pinned
+    as::HostOut* hout_dev = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int ev_valid = 0;
+    double stats[4] = {0, 0, 0, 0};
+};
+
+namespace as {
+
+// ---- as_scan.hip
+struct PreArgs {
+    const float* n32;
+    const float* inorm32;
+    const double* n64;
+    const QInfo* info;
+    QInfo* infow;
+    void* ckey;
+    int* cidx;
+    double epskey, coef;
+    int64_t n, exclude;
+    int metric, enabled;
+};
+
+constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats
+double coef_query(const as_query* q, bool exact);
+PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
+as_status launch_scan(as_query* q, const PreArgs& pre);
+
+}  // namespace as

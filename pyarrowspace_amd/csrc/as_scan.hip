@@ -1,0 +1,820 @@
+// K7a of the search chain on gfx950: dots[i] = x_i . q over the fp32 item matrix, with the k-NN prefilter fused
+// into the epilogue (DESIGN.md sections 5.4, 5.5).  One HBM pass per query (scan_dma_kernel, scan_dots_f32_kernel)
+// or per 32 queries (scan_gemm_kernel, fp32 MFMA).  Replaces the scan inside `search_lambda_aware` and
+// `prepare_query_item` (/root/reference/src/lib.rs:154,173).
+#include "as_query.hpp"
+
+namespace as {
+
+// ------------------------------------------------------------------ K7a scan: dots[i] = x_i . q  (+ k-NN prefilter)
+
+// aux = n32[row] (L2) or inorm32[row] (cosine), loaded by the caller together with the row
+// full: set once this lane has seen the buffer overflow -- the counter only has to exceed CAND_CAP, and a
+// neighbourhood of most of the items would otherwise serialise a million atomics on one address
+__device__ __forceinline__ void prefilter_f32(const PreArgs& p, int64_t row, float dot, float aux, float nq32, float inq32, int& full) {
+    if (!p.enabled || full || row >= p.n || row == p.exclude) return;
+    float key, bound;
+    if (p.metric == AS_METRIC_L2) {
+        key = fmaf(-2.0f, dot, aux + nq32);
+        bound = ((float)p.epskey + (float)p.coef * (aux + nq32)) * 1.000001f;
+    } else {
+        key = 1.0f - fmaxf(0.0f, dot * aux * inq32);
+        bound = ((float)p.epskey + (float)p.coef) * 1.000001f;
+    }
+    if (key <= bound) {
+        const int slot = atomicAdd(&p.infow->knn_cnt, 1);
+        if (slot < CAND_CAP) {
+            ((float*)p.ckey)[slot] = key;
+            p.cidx[slot] = (int)row;
+        } else {
+            full = 1;
+        }
+    }
+}
+
+// HBM-bound: one wave per row, 16 B per lane per load, query fragment in registers,
+// two rows in flight per wave.  NCH = ceil(dp / 256) chunks of 256 floats.
+// NT: non-temporal row loads.  rev: walk the rows from the end -- consecutive queries alternate
+// direction, so the tail of one scan (still in the 256 MiB Infinity Cache) is the head of the next.
+template <int NCH, bool NT>
+__global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
+                                                            int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                            PreArgs pre, int rev) {
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+    int full = 0;
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    f32x4 qv[NCH];
+    bool on[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int64_t c = 4 * (lane + 64 * u);
+        on[u] = c < dp;
+        qv[u] = on[u] ? *(const f32x4*)(q32 + c) : f32x4{0, 0, 0, 0};
+    }
+    auto ld = [&](const float* p) -> f32x4 { return NT ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p; };
+    const int64_t last = r0 + r1 - 1;   // rev: logical row t maps to physical row last - t
+    int64_t row = r0 + gw;
+    for (; row + nw < r1; row += 2 * nw) {
+        const int64_t ra = rev ? last - row : row, rb = rev ? last - (row + nw) : row + nw;
+        const float* pa = x32 + ra * dp + 4 * lane;
+        const float* pb = x32 + rb * dp + 4 * lane;
+        f32x4 va[NCH], vb[NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            va[u] = on[u] ? ld(pa + 256 * u) : f32x4{0, 0, 0, 0};
+            vb[u] = on[u] ? ld(pb + 256 * u) : f32x4{0, 0, 0, 0};
+        }
+        // lanes 0 / 1 own the two results; their aux value is in flight with the row loads
+        const int64_t myrow = (lane & 1) ? rb : ra;
+        const float aux = auxv[myrow];
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sa = fmaf(va[u][e], qv[u][e], sa);
+                sb = fmaf(vb[u][e], qv[u][e], sb);
+            }
+        }
+        sa = wave_sum(sa);
+        sb = wave_sum(sb);
+        if (lane < 2) {
+            const float dot = lane ? sb : sa;
+            dots[myrow] = dot;
+            prefilter_f32(pre, myrow, dot, aux, nq32, inq32, full);
+        }
+    }
+    if (row < r1) {
+        const int64_t ra = rev ? last - row : row;
+        const float* pa = x32 + ra * dp + 4 * lane;
+        float sa = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            if (on[u]) {
+                const f32x4 v = ld(pa + 256 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa = fmaf(v[e], qv[u][e], sa);
+            }
+        }
+        sa = wave_sum(sa);
+        if (lane == 0) {
+            dots[ra] = sa;
+            prefilter_f32(pre, ra, sa, auxv[ra], nq32, inq32, full);
+        }
+    }
+}
+
+// Batched scan (as_search_batch): QB query fragments live in registers, every row is read from
+// HBM once for QB queries.  The QB partial sums per lane are reduced with a halving butterfly
+// (4+2+1 exchanges, then 3 on the single survivor): lane L with (L & 7) == 0 ends up owning
+// query ((L>>5)&1)*4 + ((L>>4)&1)*2 + ((L>>3)&1).
+template <int NCH>
+__global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
+                                                              int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                              int64_t sd, int64_t ts, PreArgs pre) {
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    f32x4 qv[QB][NCH];
+    bool on[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int64_t c = 4 * (lane + 64 * u);
+        on[u] = c < dp;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) qv[b][u] = on[u] ? *(const f32x4*)(q32 + (int64_t)b * dp + c) : f32x4{0, 0, 0, 0};
+    }
+    const int myq = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    const bool owner = (lane & 7) == 0;
+    const float nq32 = pre.info[myq].nq32, inq32 = pre.info[myq].inq32;
+    int full = 0;
+    PreArgs mine = pre;
+    mine.info = pre.info + myq;
+    mine.infow = pre.infow + myq;
+    mine.ckey = (void*)((float*)pre.ckey + (int64_t)myq * CAND_CAP);
+    mine.cidx = pre.cidx + (int64_t)myq * CAND_CAP;
+    float* __restrict__ mydots = dots + (int64_t)myq * sd;   // tile-major: [32-row tile][slot][32]
+    for (int64_t row = r0 + gw; row < r1; row += nw) {
+        const float* pa = x32 + row * dp + 4 * lane;
+        f32x4 v[NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) v[u] = on[u] ? __builtin_nontemporal_load((const f32x4*)(pa + 256 * u)) : f32x4{0, 0, 0, 0};
+        const float aux = auxv[row];
+        float acc[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) acc[b] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < QB; ++b) acc[b] = fmaf(v[u][e], qv[b][u][e], acc[b]);
+        // halving butterfly: keep the half selected by this lane's bit, send the other half
+        float k4[4], k2[2], k1;
+        {
+            const bool hi = (lane >> 5) & 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float keep = hi ? acc[j + 4] : acc[j];
+                const float send = hi ? acc[j] : acc[j + 4];
+                k4[j] = keep + __shfl_xor(send, 32, 64);
+            }
+        }
+        {
+            const bool hi = (lane >> 4) & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float keep = hi ? k4[j + 2] : k4[j];
+                const float send = hi ? k4[j] : k4[j + 2];
+                k2[j] = keep + __shfl_xor(send, 16, 64);
+            }
+        }
+        {
+            const bool hi = (lane >> 3) & 1;
+            const float keep = hi ? k2[1] : k2[0];
+            const float send = hi ? k2[0] : k2[1];
+            k1 = keep + __shfl_xor(send, 8, 64);
+        }
+        k1 += __shfl_xor(k1, 4, 64);
+        k1 += __shfl_xor(k1, 2, 64);
+        k1 += __shfl_xor(k1, 1, 64);
+        if (owner) {
+            mydots[(row >> 5) * ts + (row & 31)] = k1;
+            prefilter_f32(mine, row, k1, aux, nq32, inq32, full);
+        }
+    }
+}
+
+// Batched scan as a GEMM (rows up to 768 floats): dots[GQ x rows] = Q . X^T on fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, A = 32 queries, B = 32 item rows).  A block is a team of 4 waves
+// that splits K: wave w keeps the Q fragments of its quarter of the columns in registers for the
+// whole launch (<= 6 slabs of 32 floats -> 96 VGPRs) and streams the matching quarter of every
+// 32-row block by LDS-DMA into a private ring of NBUF XOR-swizzled slabs (same image as
+// knn_mfma_dma_kernel) -- the K loop has no block barrier, only the wave's own vmcnt, and all
+// of LDS is staging (2 blocks per CU, ~100 KB of rows in flight per CU).  The four partial
+// 32x32 tiles meet in LDS once per row block; wave w then owns queries [8w, 8w+8) of the
+// epilogue (store + fused kNN prefilter).  One HBM pass serves GQ queries: 2*GQ*dp flops per
+// row against dp*4 bytes -- still HBM-bound at GQ=32.
+
+// LDS accesses of the MFMA scan go through inline asm: the compiler orders every LDS read it can see after
+// *all* outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain the prefetch ring at each slab.
+// Each asm block waits for its own reads before it ends, so no register the compiler may copy or reuse ever
+// holds data that is still in flight.
+__device__ __forceinline__ void lds_read4x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, f32x4& x0, f32x4& x1, f32x4& x2, f32x4& x3) {
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+        : "memory");
+}
+__device__ __forceinline__ void lds_read4x3(unsigned a0, unsigned a1, unsigned a2, f32x4& x0, f32x4& x1, f32x4& x2) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2)
+                 : "v"(a0), "v"(a1), "v"(a2)
+                 : "memory");
+}
+__device__ __forceinline__ float lds_read1(unsigned a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate).  Only the counts the
+// slab ring produces get an exact wait; anything else waits for everything (always correct).  A 14-way switch
+// at every slab of the unrolled K loop pushed the kernel into scratch spills.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (n == 4 || n == 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// always issued (an exec-masked store the compiler may not branch around): the wave's count of outstanding
+// operations must never be smaller than the ring's bookkeeping assumes
+__device__ __forceinline__ void store_dword_issued(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+// s_nop: the hazard recogniser does not look inside asm, and an MFMA result may be the operand
+__device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
+    asm volatile("s_nop 15\n\ts_nop 3\n\tds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// AUX: cache policy of the row DMA (2 = nt: rows are read once per launch; measured 7-10 % faster than the default).
+// DIAG = 1 (measurement only, wrong results): no MFMA -- the memory side alone (0.59 ms of the kernel's 0.61).
+// Measured on that skeleton: fetching the same bytes as 2 rows x 512 B or 1 row x 1 KiB per instruction
+// instead of 8 rows x 128 B: no change; without the norm DMA: no change; without the 4 dot stores per row
+// block: 0.46 ms (7.0 TB/s); with nt stores: 0.52 ms -- but in the full kernel nt stores were slower (0.63 ms)
+// and cost the per-slot selection kernels their cache hits.
+template <int NBUF, int DIAG = 0, int AUX = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
+    const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+    int64_t sd, int64_t ts, PreArgs pre, int nb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    float* St = (float*)smem;   // per wave: NBUF slabs x [32 rows][32 floats]; Ex[owner wave][3 senders][64 lanes][4]; Ax[wave][64]
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ex0 = lds0 + 4 * NBUF * 4096, ax0 = ex0 + 4 * 3 * 64 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nslab = (int)(dp / 32), nsw = (nslab + 3) / 4;
+    const int ks0 = wu * nsw;
+    const int myns = max(0, min(nsw, nslab - ks0));
+    f32x4 qf[GEMM_NSW][4];
+#pragma unroll
+    for (int ks = 0; ks < GEMM_NSW; ++ks)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[ks][s] = ks < myns ? *(const f32x4*)(q32 + (int64_t)l31 * dp + (ks0 + ks) * 32 + (2 * s + h) * 4) : f32x4{0, 0, 0, 0};
+    // per-query constants of the prefilter, for the 4 queries this lane finishes: b = e + 8 wu + 4 h
+    float nqv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nqv[e] = pre.metric == AS_METRIC_L2 ? pre.info[e + 8 * wu + 4 * h].nq32 : pre.info[e + 8 * wu + 4 * h].inq32;
+    // the loads above complete here, once: otherwise the compiler has to assume they are still pending inside
+    // the loop and puts a vmcnt(0) -- which also waits for the whole prefetch ring -- in front of their first use
+#pragma unroll
+    for (int ks = 0; ks < GEMM_NSW; ++ks)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[ks][s]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(nqv[e]));
+    float* my = St + wu * NBUF * 1024;
+    const unsigned my0 = lds0 + wu * NBUF * 4096;
+    const int drow = lane >> 3;
+    const int csw0 = (lane & 7) ^ ((lane >> 4) & 7), csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+    const unsigned lo0 = (unsigned)((drow * dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * dp + csw1 * 4) * 4);
+    unsigned foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = my0 + (unsigned)(l31 * 128 + (((2 * s + h) ^ ((l31 >> 1) & 7)) << 4));
+    const int64_t nrb = (r1 - r0 + 31) / 32;
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    // prefetch cursor: the wave's slab sequence (row block, k slab), NBUF-1 slabs ahead of the MFMAs
+    int64_t prb = myns > 0 ? (int64_t)blockIdx.x : nrb;
+    int pks = 0, pbuf = 0, inflight = 0;
+    // x0/x1/x2: vector-memory operations other than slab DMAs issued after the oldest / 2nd / 3rd slab in
+    // flight -- a lower bound: the norm DMA and the 4 dot stores of each row block (rare appends add more and
+    // only make the wait stricter).  Operations retire in issue order, so "oldest slab landed" == "at most
+    // 4 (inflight - 1) + x0 operations outstanding"; counting the stores keeps them off the critical path
+    // (waiting for them too cost 23 % of the launch).
+    int x0 = 0, x1 = 0, x2 = 0;
+    // (a macro, not a lambda: the by-reference closure of a lambda this size was left in scratch memory)
+#define AS_ISSUE_SLAB()                                                                                                   \
+    do {                                                                                                                  \
+        if (prb < nrb) {                                                                                                  \
+            /* 4 x 1 KiB pieces per 32-row slab: piece j = rows [8j, 8j+8) */                                             \
+            const char* base_ = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + (ks0 + pks) * 32);                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+                const char* src_ = base_ + (size_t)(8 * j) * dp * 4 + ((j & 1) ? lo1 : lo0);                              \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                     \
+                                                 (__attribute__((address_space(3))) void*)(my + pbuf * 1024 + 8 * j * 32), 16, 0, AUX); \
+            }                                                                                                             \
+            pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;                                                                       \
+            if (++pks == myns) {                                                                                          \
+                pks = 0;                                                                                                  \
+                prb += gridDim.x;                                                                                         \
+            }                                                                                                             \
+            if (inflight == 0) x0 = 0;                                                                                    \
+            else if (inflight == 1) x1 = 0;                                                                               \
+            else x2 = 0;                                                                                                  \
+            ++inflight;                                                                                                   \
+        }                                                                                                                 \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) AS_ISSUE_SLAB();
+    unsigned cur = 0;   // byte offset of the slab the MFMAs read next
+    int full = 0;       // bit e: query e of this lane has overflowed its candidate buffer (see prefilter_f32)
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // the row's norm for the prefilter: issued before this block's slabs, so it is older than every DMA still in
+        // flight at the epilogue when the wave has at least NBUF-1 slabs per block
+        const int64_t row = r0 + rb * 32 + l31;
+        {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + row),   // padded arrays: readable
+                                             (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + wu * 64), 4, 0, 0);
+            x0 += 1;
+            x1 += 1;
+            x2 += 1;
+        }
+#pragma unroll
+        for (int ks = 0; ks < GEMM_NSW; ++ks) {
+            if (ks < myns) {
+                // slab `cur` has landed once at most inflight-1 newer slabs (4 DMA ops each) are outstanding:
+                // loads retire in order, so the count is conservative whatever else is in flight
+                wait_vmcnt(4 * (inflight - 1) + (x0 >= 5 ? 5 : 0));
+                --inflight;
+                x0 = x1;
+                x1 = x2;
+                AS_ISSUE_SLAB();   // overwrites the slab read in the previous iteration (its ds_reads were consumed by MFMAs)
+                f32x4 x0, x1, x2, x3;
+                lds_read4x4(foff[0] + cur, foff[1] + cur, foff[2] + cur, foff[3] + cur, x0, x1, x2, x3);
+                if (DIAG == 1) {
+                    acc[0] += x0[0] + x1[1] + x2[2] + x3[3];
+                    cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
+                    continue;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][0][t], x0[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][1][t], x1[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][2][t], x2[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][3][t], x3[t], acc, 0, 0, 0);
+                cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
+            }
+        }
+        // C[i = query][j = row]: register r <-> query (r&3) + 8 (r>>2) + 4 h, lane <-> row l31.  Wave o owns
+        // registers [4o, 4o+4) = queries 8o + {0..3} + 4h; the other three waves send it their partials.
+        // Raw barriers: __syncthreads() carries a vmcnt(0) fence that would drain the prefetch ring.
+        __builtin_amdgcn_s_barrier();   // the previous row block's exchange has been read (its reads were waited for)
+        f32x4 mine = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4 part = {acc[4 * o], acc[4 * o + 1], acc[4 * o + 2], acc[4 * o + 3]};
+            if (o != wu) lds_write4(ex0 + (unsigned)(((o * 3 + (wu < o ? wu : wu - 1)) * 64 + lane) * 16), part);
+            else mine = part;
+        }
+        AS_LDS_FENCE();
+        __builtin_amdgcn_s_barrier();
+        {
+            f32x4 p0, p1, p2;
+            const unsigned pa = ex0 + (unsigned)((wu * 3 * 64 + lane) * 16);
+            lds_read4x3(pa, pa + 1024, pa + 2048, p0, p1, p2);
+            mine += p0;
+            mine += p1;
+            mine += p2;
+        }
+        // the norms: older than the slabs in flight when those were all issued inside this row block
+        wait_vmcnt(myns >= NBUF - 1 ? 4 * inflight : 0);
+        const float aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
+        {
+            // all 4 stores are issued whatever the lane holds: rows past r1 land in the padding behind the last
+            // tile (np + ROW_TILE rows are allocated), idle slots have their places in every tile.  Tile-major
+            // dots: the wave's four stores fill 1 KiB of the row block's contiguous 4 KiB
+            float* const tile = dots + (row >> 5) * ts + (row & 31);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_dword_issued(tile + (int64_t)(e + 8 * wu + 4 * h) * sd, mine[e]);
+            x0 += 4;
+            x1 += 4;
+            x2 += 4;
+            const bool pf = pre.enabled && row < r1 && row < pre.n && row != pre.exclude;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = e + 8 * wu + 4 * h;
+                if (b >= nb) continue;   // idle slot
+                const float dot = mine[e];
+                if (pf && !((full >> e) & 1)) {
+                    float key, bound;
+                    if (pre.metric == AS_METRIC_L2) {
+                        key = fmaf(-2.0f, dot, aux + nqv[e]);
+                        bound = ((float)pre.epskey + (float)pre.coef * (aux + nqv[e])) * 1.000001f;
+                    } else {
+                        key = 1.0f - fmaxf(0.0f, dot * aux * nqv[e]);
+                        bound = ((float)pre.epskey + (float)pre.coef) * 1.000001f;
+                    }
+                    if (key <= bound) {
+                        const int slot = atomicAdd(&pre.infow[b].knn_cnt, 1);
+                        if (slot < CAND_CAP) {
+                            ((float*)pre.ckey)[(int64_t)b * CAND_CAP + slot] = key;
+                            pre.cidx[(int64_t)b * CAND_CAP + slot] = (int)row;
+                        } else {
+                            full |= 1 << e;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef AS_ISSUE_SLAB
+}
+
+// Wave-wide sum on the DPP crossbar (6 VALU adds, no LDS round trips: a __shfl_xor butterfly is 6 dependent
+// ds_bpermute, ~600 cycles of latency per row): xor-1 and xor-2 inside quads, half-row and row mirrors, then
+// row_bcast15 / row_bcast31 carry the row sums up to lane 63.  Returns the total in every lane (readlane 63).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Single-query scan on the LDS-DMA ring (rows up to 1024 floats) -- the default.  The batched kernel's
+// skeleton streams at 7.0 TB/s where the register-staged scan above stops at 6.3: every wave keeps NSLOT-1
+// whole rows (NCH KiB each) in flight into a private LDS ring by `global_load_lds ... nt`, costs no VGPRs for
+// it, and consumes the oldest row behind a counted vmcnt.  Rows are handed out in chunks of 64 consecutive rows
+// per wave, round-robin over all waves (a moving window over the items), the remainder split evenly; lane r of
+// the wave ends up with the dot of the chunk's row r, so norms arrive by one 256-byte DMA per chunk, the dots
+// leave by one coalesced store and the k-NN prefilter runs lane-parallel.
+// All LDS reads and the store are inline asm (see scan_gemm_kernel): nothing the compiler can see may force
+// a vmcnt(0) inside the loop.
+template <int NCH, int NSLOT>
+__global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp,
+                                                       int64_t r0, int64_t r1, float* __restrict__ dots, PreArgs pre, int rounds,
+                                                       int tail_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RING = NSLOT * NCH * 1024;   // bytes per wave
+    constexpr int WAVE_LDS = RING + 256;       // + the chunk's 64 norms
+    constexpr int K1 = NCH * (NSLOT - 2);      // DMA operations younger than the oldest row of a full ring
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* myp = smem + wu * WAVE_LDS;
+    const unsigned my0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wu * WAVE_LDS;
+    const unsigned ax0 = my0 + RING;
+    // lanes past the end of a row never receive DMA data: they must read zeros, not stale bits
+    for (int i = lane; i < RING / 16; i += 64) *(f32x4*)(myp + i * 16) = f32x4{0, 0, 0, 0};
+    f32x4 qv[NCH];
+    bool on[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        on[u] = 4 * (lane + 64 * u) < dp;
+        qv[u] = on[u] ? *(const f32x4*)(q32 + 4 * (lane + 64 * u)) : f32x4{0, 0, 0, 0};
+    }
+    float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) asm volatile("" : "+v"(qv[u]));   // loads complete here, once (see scan_gemm_kernel)
+    asm volatile("" : "+v"(nq32), "+v"(inq32));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
+    const int64_t tail0 = r0 + (int64_t)rounds * NW * 64;
+    // chunk t of this wave: 64 rows for t < rounds, then its share of the remainder
+#define AS_CHUNK(t, base, cnt)                                                           \
+    do {                                                                                 \
+        if ((t) < rounds) {                                                              \
+            base = r0 + ((int64_t)(t) * NW + gw) * 64;                                    \
+            cnt = 64;                                                                    \
+        } else if ((t) == rounds) {                                                      \
+            base = tail0 + gw * tail_rows;                                               \
+            const int64_t left_ = r1 - base;                                             \
+            cnt = (int)(left_ < 0 ? 0 : (left_ < tail_rows ? left_ : tail_rows));        \
+        } else {                                                                         \
+            base = r1;                                                                   \
+            cnt = 0;                                                                     \
+        }                                                                                \
+    } while (0)
+    // prefetch cursor
+    int pt = 0, pr = 0, pcnt = 0, pslot = 0, inflight = 0;
+    int64_t pbase = 0;
+    AS_CHUNK(0, pbase, pcnt);
+#define AS_ISSUE_ROW()                                                                                                  \
+    do {                                                                                                                \
+        if (pcnt > 0) {                                                                                                 \
+            const float* src_ = x32 + (size_t)(pbase + pr) * dp + 4 * lane;                                             \
+            _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                                           \
+                if (on[u])                                                                                              \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + 256 * u),   \
+                                                     (__attribute__((address_space(3))) void*)(myp + (pslot * NCH + u) * 1024), 16, 0, 2); \
+            }                                                                                                           \
+            pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;                                                                 \
+            ++inflight;                                                                                                 \
+            if (++pr == pcnt) {                                                                                         \
+                pr = 0;                                                                                                 \
+                ++pt;                                                                                                   \
+                AS_CHUNK(pt, pbase, pcnt);                                                                              \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) AS_ISSUE_ROW();
+    unsigned cur = 0;    // byte offset of the oldest row in the ring
+    int marked = 0;      // rows in flight that have a chunk boundary's store + norm DMA behind them in the queue
+    int full = 0;
+    bool first = true;
+    for (int t = 0; t <= rounds; ++t) {
+        int64_t base;
+        int cnt;
+        AS_CHUNK(t, base, cnt);
+        if (cnt <= 0) continue;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),   // padded: readable
+                                         (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
+        marked = first ? 0 : inflight;   // the first chunk has only the norm DMA behind its rows: assume nothing
+        first = false;
+        float mydot = 0.0f;
+        for (int r = 0; r < cnt; ++r) {
+            // operations retire in issue order: the oldest row has landed once at most (rows behind it) * NCH
+            // (+ 2 for a chunk boundary behind it) operations are outstanding
+            if (inflight == NSLOT - 1) {
+                if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            marked = marked > 0 ? marked - 1 : 0;
+            --inflight;
+            AS_ISSUE_ROW();   // into the slot consumed one row ago
+            f32x4 xv[NCH];
+            const unsigned a0 = my0 + cur + lane * 16;
+            if (NCH == 1) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xv[0]) : "v"(a0) : "memory");
+            if (NCH == 2)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]) : "v"(a0) : "memory");
+            if (NCH == 3)
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]), "=&v"(xv[NCH > 2 ? 2 : 0]) : "v"(a0) : "memory");
+            if (NCH == 4)
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]), "=&v"(xv[NCH > 2 ? 2 : 0]), "=&v"(xv[NCH > 3 ? 3 : 0]) : "v"(a0) : "memory");
+            cur = cur + NCH * 1024 == RING ? 0 : cur + NCH * 1024;
+            float sacc = 0.0f;
+#pragma unroll
+            for (int u = 0; u < NCH; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc = fmaf(xv[u][e], qv[u][e], sacc);
+            sacc = wave_sum_dpp(sacc);
+            mydot = lane == r ? sacc : mydot;
+        }
+        // the norms are older than every row issued inside this chunk; one of those has been consumed once the
+        // chunk is at least as long as the ring
+        if (cnt < NSLOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float aux = lds_read1(ax0 + lane * 4);
+        const int64_t row = base + lane;
+        if (lane < cnt) {   // cnt >= 1: the store is always issued (the ring's bookkeeping counts it)
+            store_dword_issued(dots + row, mydot);
+            prefilter_f32(pre, row, mydot, aux, nq32, inq32, full);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef AS_ISSUE_ROW
+#undef AS_CHUNK
+}
+
+// generic width (dp > 2048): query re-read from L1 per chunk
+__global__ __launch_bounds__(256) void scan_dots_f32_generic_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
+                                                                    int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                                    PreArgs pre) {
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+    int full = 0;
+    for (int64_t row = r0 + gw; row < r1; row += nw) {
+        const float* pa = x32 + row * dp;
+        float s = 0.0f;
+        for (int64_t c = 4 * lane; c < dp; c += 256) {
+            const f32x4 v = *(const f32x4*)(pa + c);
+            const f32x4 q = *(const f32x4*)(q32 + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(v[e], q[e], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            dots[row] = s;
+            prefilter_f32(pre, row, s, (pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32)[row], nq32, inq32, full);
+        }
+    }
+}
+
+// exact mode: fp64 accumulation over the fp64 items (or the widened fp32 items when lossless)
+__global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restrict__ x32, const double* __restrict__ x64,
+                                                            const double* __restrict__ q64, int64_t d, int64_t dp, int64_t r0,
+                                                            int64_t r1, double* __restrict__ dots, PreArgs pre) {
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const double nq = pre.info->nq;
+    int full = 0;
+    for (int64_t row = r0 + gw; row < r1; row += nw) {
+        double s = 0.0;
+        if (x64) {
+            const double* p = x64 + row * d;
+            for (int64_t c = lane; c < d; c += 64) s += p[c] * q64[c];
+        } else {
+            const float* p = x32 + row * dp;
+            for (int64_t c = lane; c < d; c += 64) s += (double)p[c] * q64[c];
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            dots[row] = s;
+            if (pre.enabled && !full && row < pre.n && row != pre.exclude) {
+                const double ni = pre.n64[row];
+                double key, bound;
+                if (pre.metric == AS_METRIC_L2) {
+                    key = ni + nq - 2.0 * s;
+                    bound = pre.epskey + pre.coef * (ni + nq);
+                } else {
+                    const double den = sqrt(ni * nq);
+                    const double c = den > 0.0 ? s / den : 0.0;
+                    key = 1.0 - (c > 0.0 ? c : 0.0);
+                    bound = pre.epskey + pre.coef;
+                }
+                if (key <= bound) {
+                    const int slot = atomicAdd(&pre.infow->knn_cnt, 1);
+                    if (slot < CAND_CAP) {
+                        ((double*)pre.ckey)[slot] = key;
+                        pre.cidx[slot] = (int)row;
+                    } else {
+                        full = 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+// fp32/fp64 error coefficient of one dot product: (terms in the longest rounding chain + slack) * u.
+// Wave-per-row scans sum dp/64 fused terms per lane before a 6-level butterfly; the MFMA pass
+// accumulates a quarter of the columns in sequence (two roundings per term, in case the matrix
+// core rounds the products) and adds four partials.
+double coef_query(const as_query* q, bool exact) {
+    const double u = exact ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
+    const int64_t dp = q->sp->dp;
+    if (!exact && q->cap > 1 && dp <= 4 * GEMM_NSW * 32) return (double)(2 * (((dp / 32 + 3) / 4) * 32) + 3 + 24) * u;
+    return (double)(dp / 64 + 24) * u;
+}
+
+PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
+    const as_space* sp = q->sp;
+    PreArgs p;
+    p.n32 = sp->n32; p.inorm32 = sp->inorm32; p.n64 = sp->n64; p.info = q->info; p.infow = q->info;
+    p.ckey = q->ckey_k; p.cidx = q->cidx_k;
+    p.metric = sp->opts.metric;
+    p.epskey = p.metric == AS_METRIC_L2 ? eps * eps : eps;
+    p.coef = coef_query(q, q->exact != 0);
+    p.n = sp->n; p.exclude = exclude; p.enabled = enabled ? 1 : 0;
+    return p;
+}
+
+as_status launch_scan(as_query* q, const PreArgs& pre) {
+    const as_space* sp = q->sp;
+    const int64_t rows = q->r1 - q->r0;
+    if (rows <= 0) return AS_OK;
+    hipStream_t st = q->stream;
+    if (q->exact) {
+        if (!q->dots64) AS_HIP(hipMalloc(&q->dots64, sizeof(double) * (sp->np + ROW_TILE)));
+        const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, 4096);
+        hipLaunchKernelGGL(scan_dots_f64_kernel, dim3(grid), dim3(256), 0, st, sp->x32, sp->x64, q->q64, sp->d, sp->dp, q->r0,
+                           q->r1, q->dots64, pre);
+    } else {
+        const int nch = (int)((sp->dp + 255) / 256);
+        if (q->cap > 1 && sp->dp <= 4 * GEMM_NSW * 32) {
+            // batched pass, GEMM-shaped: fp32 MFMA, K split over the 4 waves of a block, 2 blocks per CU
+#define AS_GSCAN(NB_, DG, AX)                                                                                                \
+    do {                                                                                                               \
+        const size_t lds = sizeof(float) * ((size_t)4 * (NB_) * 1024 + 4 * 3 * 64 * 4 + 4 * 64);                       \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            AS_HIP(hipFuncSetAttribute((const void*)scan_gemm_kernel<NB_, DG, AX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        const int64_t nrb = (rows + 31) / 32;                                                                          \
+        const unsigned grid = (unsigned)std::min<int64_t>(nrb, 2 * q->cus);                                            \
+        hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
+                           q->dots32, q->ss.dots, q->ss.dots_ts, pre, q->nb);                                                         \
+    } while (0)
+            if (q->gemm_variant == 1) AS_GSCAN(3, 0, 2);
+            else if (q->gemm_variant == 2) AS_GSCAN(4, 0, 0);
+            else if (q->gemm_variant == 16) AS_GSCAN(4, 1, 2);
+            else AS_GSCAN(4, 0, 2);
+#undef AS_GSCAN
+            AS_HIP(hipGetLastError());
+            return AS_OK;
+        }
+        if (q->cap > 1) {
+            // batched pass on VALU FMAs: QB queries per launch (query fragments in registers); dp <= 1024 only
+#define AS_BSCAN(N)                                                                                                    \
+    do {                                                                                                               \
+        if (!q->scan_grid) {                                                                                           \
+            int nb_ = 0;                                                                                               \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, scan_dots_batch_kernel<N>, 256, 0) != hipSuccess) nb_ = 2; \
+            q->scan_grid = q->cus * std::max(1, std::min(nb_, 8));                                                     \
+        }                                                                                                              \
+        const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->scan_grid);                               \
+        for (int j0 = 0; j0 < q->nb; j0 += QB) {                                                                       \
+            PreArgs pj = pre;                                                                                          \
+            pj.info = pre.info + j0;                                                                                   \
+            pj.infow = pre.infow + j0;                                                                                 \
+            pj.ckey = (void*)((float*)pre.ckey + (int64_t)j0 * CAND_CAP);                                              \
+            pj.cidx = pre.cidx + (int64_t)j0 * CAND_CAP;                                                               \
+            hipLaunchKernelGGL(scan_dots_batch_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32 + (int64_t)j0 * sp->dp, \
+                               sp->dp, q->r0, q->r1, q->dots32 + (int64_t)j0 * q->ss.dots, q->ss.dots, q->ss.dots_ts, pj);             \
+        }                                                                                                              \
+    } while (0)
+            switch (nch) {
+                case 1: AS_BSCAN(1); break;
+                case 2: AS_BSCAN(2); break;
+                case 3: AS_BSCAN(3); break;
+                default: AS_BSCAN(4); break;
+            }
+#undef AS_BSCAN
+            AS_HIP(hipGetLastError());
+            return AS_OK;
+        }
+        const int rev = (q->scan_variant & 1) ? (int)(q->scan_count++ & 1) : 0;
+        // resident grid: every wave gets the same number of rows and all of them run at once
+        // (a grid one block over residency costs a whole extra round at 1/8 occupancy)
+#define AS_SCAN(N)                                                                                                     \
+    do {                                                                                                               \
+        if (!q->scan_grid) {                                                                                           \
+            int nb = 0;                                                                                                \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_dots_f32_kernel<N, true>, 256, 0) != hipSuccess) nb = 4; \
+            q->scan_grid = q->cus * std::max(1, std::min(nb, 8));                                                      \
+        }                                                                                                              \
+        const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->scan_grid);                               \
+        if (q->scan_variant & 2)                                                                                       \
+            hipLaunchKernelGGL((scan_dots_f32_kernel<N, false>), dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, \
+                               q->r0, q->r1, q->dots32, pre, rev);                                                     \
+        else                                                                                                           \
+            hipLaunchKernelGGL((scan_dots_f32_kernel<N, true>), dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp,  \
+                               q->r0, q->r1, q->dots32, pre, rev);                                                     \
+    } while (0)
+        // default for rows up to 1024 floats: the LDS-DMA ring scan (ARROWSPACE_SCAN_VARIANT bit2 = register-staged scan)
+        if (nch <= 4 && !(q->scan_variant & 4)) {
+            const int64_t want = std::max<int64_t>(1, (rows + 63) / 64);                 // blocks that still get >= 16 rows per wave
+            // 2 blocks per CU, ring of 5 rows at 768 columns; rings of 4 or 6 rows and 3 blocks per CU measured the same or slower
+            const int64_t nblk = std::min<int64_t>(want, 2 * (int64_t)q->cus);
+            const int64_t NW = nblk * 4;
+            const int rounds = (int)(rows / (NW * 64));
+            const int64_t rem = rows - (int64_t)rounds * NW * 64;
+            const int tail_rows = (int)((rem + NW - 1) / NW);
+#define AS_DSCAN(N, S)                                                                                                 \
+    do {                                                                                                               \
+        const size_t lds = 4 * ((size_t)(S) * (N) * 1024 + 256);                                                       \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            AS_HIP(hipFuncSetAttribute((const void*)scan_dma_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
+                           q->r1, q->dots32, pre, rounds, tail_rows);                                                  \
+    } while (0)
+            switch (nch) {
+                case 1: AS_DSCAN(1, 8); break;
+                case 2: AS_DSCAN(2, 8); break;
+                case 3: AS_DSCAN(3, 5); break;
+                default: AS_DSCAN(4, 4); break;
+            }
+#undef AS_DSCAN
+            AS_HIP(hipGetLastError());
+            return AS_OK;
+        }
+        switch (nch) {
+            case 1: AS_SCAN(1); break;
+            case 2: AS_SCAN(2); break;
+            case 3: AS_SCAN(3); break;
+            case 4: AS_SCAN(4); break;
+            case 5: AS_SCAN(5); break;
+            case 6: AS_SCAN(6); break;
+            case 7: AS_SCAN(7); break;
+            case 8: AS_SCAN(8); break;
+            default: {
+                const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, q->cus * 8);
+                hipLaunchKernelGGL(scan_dots_f32_generic_kernel, dim3(grid), dim3(256), 0, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, q->dots32, pre);
+            }
+        }
+#undef AS_SCAN
+    }
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+}  // namespace as
