@@ -157,6 +157,7 @@ class OracleSearchOnly:
             self._h = None
 
     search = OracleIndex.search
+    scores = OracleIndex.scores
     query_lambda = OracleIndex.query_lambda
 
 

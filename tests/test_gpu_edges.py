@@ -167,3 +167,33 @@ def test_save_and_load_round_trip(tmp_path, keep64):
             assert b.search(q, h, tau) == a.search(q, g, tau)
     with pytest.raises(ValueError):
         asp.ArrowSpaceBuilder.load(str(tmp_path / "missing.asidx"))
+
+
+@pytest.mark.parametrize("n,d", [(140037, 100), (135001, 300), (133333, 700), (132000, 1000)])
+def test_scan_rounds_and_remainder(oracle_lib, n, d):
+    """Sizes just above one full round of the LDS-DMA scan (2048 waves x 64 rows = 131072): every wave takes one
+    round-robin chunk plus its share of the remainder; rows of 1..4 KiB pick the four ring shapes.  The all-pairs
+    oracle build is out of reach at this size, so the CPU scorer runs over the GPU-built lambdas and degrees
+    (the graph itself is covered by the smaller cases) and checks the search end to end."""
+    import torch
+    import bench
+    import pyarrowspace_amd as asp
+    dev = torch.device("cuda", 0)
+    X = bench.make_data(n, d, 7, dev, nclust=256)
+    gp = {"eps": bench.calibrate_eps(X, 10), "k": 10, "topk": 8, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build_from_device(gp, X.data_ptr(), "float32", n, d, d)
+    Xh = X.double().cpu().numpy()
+    ref = oracle_lib.OracleSearchOnly(Xh, gp, gl.degrees(), aspace.lambdas(), gl.tau0)
+    rng = np.random.default_rng(3)
+    rows = [0, n - 1, 131071, 131072, int(rng.integers(0, n)), int(rng.integers(0, n))]
+    Q = np.stack([Xh[i] * 1.01 + 0.01 * rng.standard_normal(d) / np.sqrt(d) for i in rows])
+    for q in Q:
+        for tau in (0.62, 1.0):
+            want, lq = ref.search(q, tau)
+            got = aspace.search(np.ascontiguousarray(q), gl, tau)
+            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=RTOL)
+    if d <= 1024:
+        got = aspace.search_batch(Q, gl, 0.62)
+        for b, q in enumerate(Q):
+            want, lq = ref.search(q, 0.62)
+            assert_hits_match(got[b], want, ref.scores(q, 0.62, lq), rtol=RTOL)
