@@ -50,6 +50,31 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; if this
+    library pulled in the system copies first, a later `import torch` would bring up a second runtime that finds
+    no GPU ("No HIP GPUs are available").  When torch is installed (not necessarily imported -- importing it
+    costs seconds), its bundled runtime is loaded first, so either import order works; without torch the system
+    runtime is used as linked."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -58,6 +83,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950). "
             "pyarrowspace_amd has no CPU fallback.")
+    _preload_torch_hip_runtime()
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
