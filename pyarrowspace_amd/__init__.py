@@ -9,6 +9,7 @@ There is no CPU fallback: importing this package without the built library fails
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 
 import numpy as np
@@ -223,14 +224,19 @@ class ArrowSpace:
         if not isinstance(gl, GraphLaplacian):
             raise TypeError("argument 'gl': expected GraphLaplacian")
         q = self._query(item)
-        # per-(space, graph) call state: output buffers and ctypes arguments are built once
-        st_ = getattr(self, "_sstate", None)
+        # per-(thread, space, graph) call state: output buffers and ctypes arguments are built once.  Per thread,
+        # because ctypes drops the GIL during the call: the library serialises searches on a space, but shared
+        # output buffers would be overwritten by the next thread's call before this one has read them.
+        tls = self.__dict__.get("_tls")
+        if tls is None:
+            tls = self.__dict__.setdefault("_tls", threading.local())
+        st_ = getattr(tls, "s", None)
         if st_ is None or st_[0] is not gl:
             topk = max(min(int(gl.graph_params["topk"]), self.nitems), 1)
             idx = (C.c_int64 * topk)()
             sc = (C.c_double * topk)()
             ln, lq = C.c_int64(0), C.c_double(0.0)
-            st_ = self._sstate = (gl, idx, sc, ln, lq, C.byref(ln), C.byref(lq))
+            st_ = tls.s = (gl, idx, sc, ln, lq, C.byref(ln), C.byref(lq))
         _, idx, sc, ln, lq, pln, plq = st_
         st = _L.as_search(self._h, gl._h, q.ctypes.data, q.shape[0], tau, idx, sc, pln, plq)
         if st:

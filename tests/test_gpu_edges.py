@@ -197,3 +197,74 @@ def test_scan_rounds_and_remainder(oracle_lib, n, d):
         for b, q in enumerate(Q):
             want, lq = ref.search(q, 0.62)
             assert_hits_match(got[b], want, ref.scores(q, 0.62, lq), rtol=RTOL)
+
+
+def test_threads_share_a_space(oracle_lib):
+    """ctypes drops the GIL inside as_search: the library serialises per space, results must not cross threads
+    (the reference holds the GIL throughout, src/lib.rs:132-174)."""
+    import threading
+    import pyarrowspace_amd as asp
+    n, d = 4000, 96
+    X = clustered(n, d, nclust=8, seed=1)
+    gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    want = {i: ref.search(X[i] * 1.01, 0.62)[0] for i in range(16)}
+    errs = []
+
+    def worker(t):
+        try:
+            for s in range(50):
+                i = (t * 7 + s) % 16
+                got = aspace.search(X[i] * 1.01, gl, 0.62)
+                if [j for j, _ in got] != [j for j, _ in want[i]]:
+                    errs.append((t, i, got))
+        except BaseException as e:   # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs[:2]
+
+
+def test_two_indexes_alive(oracle_lib):
+    import pyarrowspace_amd as asp
+    X1 = clustered(3000, 64, nclust=5, seed=2)
+    X2 = clustered(2000, 48, nclust=4, seed=3)
+    gp1 = {"eps": calibrate_eps(X1, 5), "k": 5, "topk": 4, "p": 2.0, "sigma": None}
+    gp2 = {"eps": calibrate_eps(X2, 7), "k": 7, "topk": 5, "p": 2.0, "sigma": None, "metric": "cosine"}
+    a1, g1 = asp.ArrowSpaceBuilder.build(gp1, X1)
+    a2, g2 = asp.ArrowSpaceBuilder.build(gp2, X2)
+    r1, r2 = oracle_lib.OracleIndex(X1, gp1), oracle_lib.OracleIndex(X2, gp2)
+    for i in range(4):
+        assert [j for j, _ in a1.search(X1[i] * 1.01, g1, 0.62)] == [j for j, _ in r1.search(X1[i] * 1.01, 0.62)[0]]
+        assert [j for j, _ in a2.search(X2[i] * 1.01, g2, 0.62)] == [j for j, _ in r2.search(X2[i] * 1.01, 0.62)[0]]
+    with pytest.raises(ValueError):
+        a1.search(X1[0], g2, 0.62)           # a graph of another space
+    del a2, g2
+    assert [j for j, _ in a1.search(X1[9] * 1.01, g1, 0.62)] == [j for j, _ in r1.search(X1[9] * 1.01, 0.62)[0]]
+
+
+def test_non_finite_values_behave_like_the_oracle(oracle_lib):
+    """NaN/Inf are counted, not rejected (src/helpers.rs:36-43): a poisoned row drops out of every neighbourhood,
+    a poisoned or all-zero query has no neighbours -> the zero-lambda panic."""
+    import pyarrowspace_amd as asp
+    n, d = 3000, 64
+    X = clustered(n, d, nclust=6, seed=4)
+    gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 5, "p": 2.0, "sigma": None}
+    for bad, row in ((np.nan, 11), (np.inf, 12)):
+        Xb = X.copy()
+        Xb[row, 5] = bad
+        aspace, gl = asp.ArrowSpaceBuilder.build(gp, Xb)
+        ref = oracle_lib.OracleIndex(Xb, gp)
+        np.testing.assert_allclose(aspace.lambdas(), ref.lambdas, rtol=RTOL, atol=1e-300)
+        q = np.ascontiguousarray(X[3] * 1.01)
+        want, lq = ref.search(q, 0.62)
+        assert_hits_match(aspace.search(q, gl, 0.62), want, np.nan_to_num(ref.scores(q, 0.62, lq), nan=-np.inf, posinf=-np.inf), rtol=RTOL)
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    for q in (np.zeros(d), np.r_[np.nan, X[3, 1:]], np.r_[np.inf, X[3, 1:]]):
+        with pytest.raises(asp.PanicException):
+            aspace.search(np.ascontiguousarray(q), gl, 0.62)
