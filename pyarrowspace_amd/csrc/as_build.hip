@@ -28,7 +28,7 @@ double err_coef(int64_t dp) {
 template <typename T>
 __global__ void ingest_kernel(const T* __restrict__ src, int64_t ld, int64_t n, int64_t d, int64_t dp,
                               float* __restrict__ x32, double* __restrict__ n64, float* __restrict__ n32,
-                              float* __restrict__ inorm32, int* lossless, unsigned long long* nmax_bits) {
+                              float* __restrict__ inorm32, int* lossless, unsigned long long* nmax_bits, unsigned long long* nmin_bits) {
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (row >= n) return;
     const int lane = lane_id();
@@ -47,7 +47,9 @@ __global__ void ingest_kernel(const T* __restrict__ src, int64_t ld, int64_t n, 
         n64[row] = s;
         n32[row] = (float)s;
         inorm32[row] = s > 0.0 ? (float)(1.0 / sqrt(s)) : 0.0f;
+        // squared norms are >= 0: their bit patterns order like the values
         if (s == s) atomicMax(nmax_bits, (unsigned long long)__double_as_longlong(s));
+        if (s > 0.0 && s < 1.0e308) atomicMin(nmin_bits, (unsigned long long)__double_as_longlong(s));
     }
 }
 
@@ -75,21 +77,22 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
     AS_HIP(hipMemsetAsync(sp->lam64, 0, sizeof(double) * n, sp->stream));
     AS_HIP(hipMemsetAsync(sp->lam32, 0, sizeof(float) * rows_alloc, sp->stream));
     int* flags = nullptr;
-    AS_HIP(hipMalloc(&flags, 16));
-    int hinit[4] = {1, 0, 0, 0};
-    AS_HIP(hipMemcpyAsync(flags, hinit, 16, hipMemcpyHostToDevice, sp->stream));
+    AS_HIP(hipMalloc(&flags, 24));
+    int hinit[6] = {1, 0, 0, 0, -1, 0x7fefffff};   // lossless, pad, nmax bits = 0, nmin bits = DBL_MAX
+    AS_HIP(hipMemcpyAsync(flags, hinit, 24, hipMemcpyHostToDevice, sp->stream));
     unsigned long long* nmax_bits = (unsigned long long*)(flags + 2);
+    unsigned long long* nmin_bits = (unsigned long long*)(flags + 4);
     const int wpb = 4;
     const unsigned grid = (unsigned)((n + wpb - 1) / wpb);
     if (dtype == AS_DTYPE_F64)
         hipLaunchKernelGGL(ingest_kernel<double>, dim3(grid), dim3(64 * wpb), 0, sp->stream, (const double*)items_dev, ld,
-                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits);
+                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits, nmin_bits);
     else
         hipLaunchKernelGGL(ingest_kernel<float>, dim3(grid), dim3(64 * wpb), 0, sp->stream, (const float*)items_dev, ld,
-                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits);
+                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits, nmin_bits);
     AS_HIP(hipGetLastError());
-    int hout[4];
-    AS_HIP(hipMemcpyAsync(hout, flags, 16, hipMemcpyDeviceToHost, sp->stream));
+    int hout[6];
+    AS_HIP(hipMemcpyAsync(hout, flags, 24, hipMemcpyDeviceToHost, sp->stream));
     AS_HIP(hipStreamSynchronize(sp->stream));
     sp->lossless = hout[0];
     unsigned long long nb;
@@ -97,7 +100,18 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
     long long nbs = (long long)nb;
     memcpy(&sp->nmax, &nbs, 8);
     AS_HIP(hipFree(flags));
-    const bool keep = (dtype == AS_DTYPE_F64 && !sp->lossless) || sp->opts.keep_f64 == AS_KEEP_F64_ALWAYS;
+    double nmin;
+    memcpy(&nmin, &hout[4], 8);
+    // The fp32 prefilters need every squared norm (and sums of two) inside the normal fp32 range: items scaled
+    // by 1e20 overflow them, by 1e-22 flush them to zero, and a prefilter that sees inf/0 keys silently drops
+    // true neighbours.  Outside a generous safe band the whole index runs in fp64 end to end (slow, exact).
+    const double hi = 0x1p+120, lo = 0x1p-100;
+    const bool range_unsafe = (sp->nmax < 1.0e308 && sp->nmax > hi) || (nmin < lo);
+    if (range_unsafe && !sp->opts.force_exact) {
+        sp->opts.force_exact = 1;
+        dbg("ingest: squared norms span [%.3g, %.3g], outside the fp32-safe range: fp64 end to end", nmin, sp->nmax);
+    }
+    const bool keep = (dtype == AS_DTYPE_F64 && !sp->lossless) || sp->opts.keep_f64 == AS_KEEP_F64_ALWAYS || range_unsafe;
     if (keep) {
         AS_HIP(hipMalloc(&sp->x64, sizeof(double) * n * d));
         const int64_t tot = n * d;

@@ -1423,7 +1423,7 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
 
 void as_query_set_exact(as_query* q, int32_t flags) {
     if (!q) return;
-    q->exact = (flags & 1) ? 1 : 0;
+    q->exact = ((flags & 1) || q->sp->opts.force_exact) ? 1 : 0;   // force_exact: build option, or items outside the fp32-safe range
     q->robust = (flags & 2) ? 1 : 0;
     q->reuse = (flags & 4) ? 1 : 0;
 }

@@ -268,3 +268,14 @@ def test_non_finite_values_behave_like_the_oracle(oracle_lib):
     for q in (np.zeros(d), np.r_[np.nan, X[3, 1:]], np.r_[np.inf, X[3, 1:]]):
         with pytest.raises(asp.PanicException):
             aspace.search(np.ascontiguousarray(q), gl, 0.62)
+
+
+@pytest.mark.parametrize("scale", [1e-22, 1e-6, 1e6, 1e18, 1e20, 1e25])
+def test_item_magnitudes_outside_the_fp32_range(oracle_lib, scale):
+    """The reference computes in f64 (src/lib.rs:28); squared norms of items scaled by 1e20 overflow fp32 and by
+    1e-22 flush to zero, so such an index runs in fp64 end to end instead of trusting fp32 prefilters."""
+    n, d = 1500, 48
+    X = clustered(n, d, nclust=5, seed=8)
+    eps = calibrate_eps(X, 6)
+    gp = {"eps": eps * scale, "k": 6, "topk": 4, "p": 2.0, "sigma": None}
+    _compare(X * scale, gp, oracle_lib, [X[3] * scale * 1.01, X[n - 2] * scale * 0.99], taus=(0.62, 1.0))
