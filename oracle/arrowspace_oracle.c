@@ -67,6 +67,14 @@ static inline double dotp(const double *a, const double *b, int64_t d) {
     return g;
 }
 
+/* SPEC S7 edge energy a (A + B - 2C) of the expanded form: a value inside the rounding noise of its own terms is
+ * zero (identical vectors with equal degrees must not turn into a 1e-16 "energy" whose share of the sum is 1) */
+#define ASO_ENERGY_NOISE 0x1p-46
+static inline double edge_energy(double w, double A, double B, double C) {
+    double v = w * (A + B - 2.0 * C);
+    return v > w * ASO_ENERGY_NOISE * (A + B + 2.0 * fabs(C)) ? v : 0.0;
+}
+
 /* SPEC S2: key (eps test + ordering), dist, gy for the pair (a,b) */
 static inline void pair_q(const double *a, const double *b, int64_t d, double na, double nb, int metric,
                           double *key, double *dist, double *gy) {
@@ -80,7 +88,7 @@ static inline void pair_q(const double *a, const double *b, int64_t d, double na
         double g = dotp(a, b, d);
         double den = sqrt(na * nb);
         double c = den > 0.0 ? g / den : 0.0;
-        double dd = 1.0 - (c > 0.0 ? c : 0.0);
+        double dd = 1.0 - (c > 0.0 ? (c < 1.0 ? c : 1.0) : 0.0);   /* rounding can push a cosine past 1: no negative distances */
         *key = dd;
         *dist = dd;
         *gy = c;
@@ -231,8 +239,7 @@ aso_index *aso_build(const double *X, int64_t n, int64_t d, double eps, int64_t 
             int64_t j = ix->indices[e];
             double sdd = sqrt(ix->deg[i] * ix->deg[j]);
             ix->lap[e] = -ix->w[e] / sdd;
-            double v = ix->w[e] * (ix->ny[i] / ix->deg[i] + ix->ny[j] / ix->deg[j] - 2.0 * ix->gy[e] / sdd);
-            S += v > 0.0 ? v : 0.0;
+            S += edge_energy(ix->w[e], ix->ny[i] / ix->deg[i], ix->ny[j] / ix->deg[j], ix->gy[e] / sdd);
         }
         ix->E[i] = ix->ny[i] > 0.0 ? (0.5 * S) / ix->ny[i] : 0.0;
         if (S > 0.0) {
@@ -240,8 +247,7 @@ aso_index *aso_build(const double *X, int64_t n, int64_t d, double eps, int64_t 
             for (int64_t e = lo; e < hi; ++e) {
                 int64_t j = ix->indices[e];
                 double sdd = sqrt(ix->deg[i] * ix->deg[j]);
-                double v = ix->w[e] * (ix->ny[i] / ix->deg[i] + ix->ny[j] / ix->deg[j] - 2.0 * ix->gy[e] / sdd);
-                double r = (v > 0.0 ? v : 0.0) / S;
+                double r = edge_energy(ix->w[e], ix->ny[i] / ix->deg[i], ix->ny[j] / ix->deg[j], ix->gy[e] / sdd) / S;
                 g += r * r;
             }
             ix->G[i] = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
@@ -324,8 +330,7 @@ double aso_query_lambda(const aso_index *ix, const double *q) {
                 int64_t j = lst[t].j;
                 double dj = ix->deg[j] + a[t];
                 double sdd = sqrt(degq * dj);
-                double v = a[t] * (nyq / degq + ix->ny[j] / dj - 2.0 * lst[t].gy / sdd);
-                es[t] = v > 0.0 ? v : 0.0;
+                es[t] = edge_energy(a[t], nyq / degq, ix->ny[j] / dj, lst[t].gy / sdd);
                 S += es[t];
             }
             double Eq = 0.5 * S / nyq, Gq = 0.0;

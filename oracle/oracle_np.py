@@ -61,6 +61,16 @@ def _edge_weight(d, sigma, p, kernel):
     return 1.0 / (1.0 + u)
 
 
+ENERGY_NOISE = 2.0 ** -46
+
+
+def edge_energy(w, A, B, C):
+    """SPEC S7 edge energy a (A + B - 2C) of the expanded form; a value inside the rounding noise of its own terms
+    is zero (identical vectors with equal degrees must not become a 1e-16 "energy" whose share of the sum is 1)."""
+    v = w * (A + B - 2.0 * C)
+    return v if v > w * ENERGY_NOISE * (A + B + 2.0 * abs(C)) else 0.0
+
+
 def pair_quantities(xi, X, ni, n, metric):
     """SPEC S2 for one row xi against all rows of X.
     Returns (key, dist, gy): key = quantity the eps test / ordering uses
@@ -74,7 +84,7 @@ def pair_quantities(xi, X, ni, n, metric):
         g = X @ xi
         den = np.sqrt(ni * n)
         c = np.where(den > 0, g / np.where(den > 0, den, 1.0), 0.0)
-        dist = 1.0 - np.maximum(0.0, c)
+        dist = 1.0 - np.minimum(1.0, np.maximum(0.0, c))   # rounding can push a cosine past 1: no negative distances
         key = dist
         gy = c
     return key, dist, gy
@@ -156,8 +166,7 @@ def graph_from_lists(X, prm, n, lists) -> dict:
             j = indices[e]
             sdd = np.sqrt(deg[i] * deg[j])
             lap[e] = -w[e] / sdd
-            v = w[e] * (ny[i] / deg[i] + ny[j] / deg[j] - 2.0 * gy[e] / sdd)
-            eps_e[t] = v if v > 0.0 else 0.0
+            eps_e[t] = edge_energy(w[e], ny[i] / deg[i], ny[j] / deg[j], gy[e] / sdd)
         S = 0.0
         for v in eps_e:
             S += v
@@ -229,8 +238,7 @@ def lambda_from_neighbours(idx: dict, q, items, dist, gy, deg=None, ny=None) -> 
     for t in range(len(items)):
         dj = deg[t] + a[t]
         sdd = np.sqrt(degq * dj)
-        v = a[t] * (nyq / degq + ny[t] / dj - 2.0 * gy[t] / sdd)
-        es.append(v if v > 0 else 0.0)
+        es.append(edge_energy(a[t], nyq / degq, ny[t] / dj, gy[t] / sdd))
     S = 0.0
     for v in es:
         S += v

@@ -921,7 +921,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(RefineArgs a) {
             } else {
                 const double den = sqrt(ni * a.n64[j]);
                 const double c = den > 0.0 ? dot / den : 0.0;
-                const double dd = 1.0 - (c > 0.0 ? c : 0.0);
+                const double dd = cosine_distance(c);
                 ek[t] = dd;
                 ed[t] = dd;
                 eg[t] = c;
@@ -1285,8 +1285,7 @@ __global__ void energy_kernel(int64_t n, const int64_t* __restrict__ indptr, con
             const double nyj = metric == AS_METRIC_L2 ? n64[j] : (n64[j] > 0.0 ? 1.0 : 0.0);
             const double sdd = sqrt(di * deg[j]);
             lap[e] = -wgt[e] / sdd;
-            const double v = wgt[e] * (nyi / di + nyj / deg[j] - 2.0 * gy[e] / sdd);
-            S += v > 0.0 ? v : 0.0;
+            S += edge_energy(wgt[e], nyi / di, nyj / deg[j], gy[e] / sdd);
         }
         Ei = nyi > 0.0 ? (0.5 * S) / nyi : 0.0;
         if (S > 0.0) {
@@ -1295,8 +1294,7 @@ __global__ void energy_kernel(int64_t n, const int64_t* __restrict__ indptr, con
                 const int j = col[e];
                 const double nyj = metric == AS_METRIC_L2 ? n64[j] : (n64[j] > 0.0 ? 1.0 : 0.0);
                 const double sdd = sqrt(di * deg[j]);
-                const double v = wgt[e] * (nyi / di + nyj / deg[j] - 2.0 * gy[e] / sdd);
-                const double r = (v > 0.0 ? v : 0.0) / S;
+                const double r = edge_energy(wgt[e], nyi / di, nyj / deg[j], gy[e] / sdd) / S;
                 g += r * r;
             }
             Gi = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);

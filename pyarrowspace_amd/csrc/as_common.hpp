@@ -97,6 +97,17 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // order; wait for them and stop the compiler from caching LDS values across the point.
 #define AS_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// SPEC S7 edge energy a (A + B - 2C) of the expanded form; a value inside the rounding noise of its own terms is
+// zero: identical vectors with equal degrees must not become a 1e-16 "energy" whose share of the sum is 1
+// (DESIGN.md section 2, S7).
+__host__ __device__ __forceinline__ double edge_energy(double w, double A, double B, double C) {
+    const double v = w * (A + B - 2.0 * C);
+    return v > w * 0x1p-46 * (A + B + 2.0 * fabs(C)) ? v : 0.0;
+}
+// SPEC S2 cosine distance: rounding can push a cosine past 1 -- no negative distances (a fractional p would turn
+// them into NaN weights)
+__host__ __device__ __forceinline__ double cosine_distance(double c) { return 1.0 - (c > 0.0 ? (c < 1.0 ? c : 1.0) : 0.0); }
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

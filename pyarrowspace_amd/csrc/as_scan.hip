@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
                 } else {
                     const double den = sqrt(ni * nq);
                     const double c = den > 0.0 ? s / den : 0.0;
-                    key = 1.0 - (c > 0.0 ? c : 0.0);
+                    key = cosine_distance(c);
                     bound = pre.epskey + pre.coef;
                 }
                 if (key <= bound) {

@@ -157,7 +157,7 @@ __device__ __forceinline__ double knn_key<double>(const SelArgs<double>& a, int6
     if (a.metric == AS_METRIC_L2) return a.n64[row] + nq - 2.0 * dot;
     const double den = sqrt(a.n64[row] * nq);
     const double c = den > 0.0 ? dot / den : 0.0;
-    return 1.0 - (c > 0.0 ? c : 0.0);
+    return cosine_distance(c);
 }
 
 // ------------------------------------------------------------------ filter path
@@ -628,8 +628,7 @@ __device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist
         if (on) {
             const double dj = s_deg[lane] + at;
             const double sdd = sqrt(degq * dj);
-            const double v = at * (nyq / degq + s_ny[lane] / dj - 2.0 * s_gy[lane] / sdd);
-            ev = v > 0.0 ? v : 0.0;
+            ev = edge_energy(at, nyq / degq, s_ny[lane] / dj, s_gy[lane] / sdd);
         }
         const double S = wave_sum(ev);
         const double Eq = 0.5 * S / nyq;
@@ -690,7 +689,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         } else {
             const double den = sqrt(nq * a.n64[fi[t]]);
             const double c = den > 0.0 ? dot / den : 0.0;
-            const double dd = 1.0 - (c > 0.0 ? c : 0.0);
+            const double dd = cosine_distance(c);
             ek[t] = dd;
             ed[t] = dd;
             eg[t] = c;
