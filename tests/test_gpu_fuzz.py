@@ -18,3 +18,10 @@ def test_seeded_fuzz_against_the_oracle():
     rng = np.random.default_rng(20260101)
     for case in range(40):
         fz.one_case(np.random.default_rng(rng.integers(1 << 62)), case)
+
+
+def test_seeded_fuzz_of_the_staged_path():
+    import fuzz_parity as fz
+    rng = np.random.default_rng(20260102)
+    for case in range(40):
+        fz.one_case(np.random.default_rng(rng.integers(1 << 62)), case, sharded=True)

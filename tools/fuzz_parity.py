@@ -1,6 +1,7 @@
 """Randomised differential check of the GPU path against the oracle: python tools/fuzz_parity.py [cases] [seed].
 Shapes, graph parameters, metric / kernel, query kinds and tau are drawn at random; any mismatch is printed with the
-configuration that reproduces it."""
+configuration that reproduces it.  `python tools/fuzz_parity.py 100 5 - sharded` drives the staged C ABI
+(pyarrowspace_amd.dist.ShardedIndex, one rank) instead of the fused single-GPU entry points."""
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,9 +14,11 @@ from oracle import oracle_c
 LOOSE = []
 
 
-def one_case(rng, case):
-    n = int(rng.choice([2, 3, 5, 17, 64, 65, 200, 257, 700, 1500, 3000]))
-    d = int(rng.choice([1, 2, 3, 7, 24, 31, 32, 33, 64, 100, 257, 300]))
+def gen_case(rng, case):
+    n = int(rng.choice([2, 3, 5, 17, 64, 65, 200, 257, 700, 1500, 3000, 6000, 12000]))
+    d = int(rng.choice([1, 2, 3, 7, 24, 31, 32, 33, 64, 100, 257, 300, 768, 1000]))
+    if n * d > 3_000_000:
+        d = 64
     metric = str(rng.choice(["l2", "cosine"]))
     kernel = str(rng.choice(["gaussian", "rational"]))
     k = int(rng.integers(1, min(30, n) + 1))
@@ -32,6 +35,8 @@ def one_case(rng, case):
             X *= float(10 ** rng.uniform(-3, 3))
     if rng.random() < 0.2 and n > 4:
         X[int(rng.integers(n))] = X[int(rng.integers(n))]           # an exact duplicate
+    if rng.random() < 0.5:
+        X = X.astype(np.float32).astype(np.float64)                  # fp32-representable items: no fp64 copy is kept
     # eps: a random quantile of the pair distances of a sample
     m = min(n, 200)
     S = X[rng.choice(n, m, replace=False)]
@@ -45,6 +50,14 @@ def one_case(rng, case):
     sigma = None if rng.random() < 0.5 else eps * float(rng.uniform(0.2, 3.0))
     gp = {"eps": eps, "k": k, "topk": topk, "p": p, "sigma": sigma, "metric": metric, "kernel": kernel}
     cfg = dict(case=case, n=n, d=d, kind=str(kind), gp=gp)
+    return X, gp, cfg
+
+
+def one_case(rng, case, sharded=False):
+    X, gp, cfg = gen_case(rng, case)
+    n, d = X.shape
+    if sharded:
+        return sharded_case(rng, X, gp, cfg)
     aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
     ref = oracle_c.OracleIndex(X, gp)
     # north_star tolerance 1e-6; the suite's own 1e-9 holds on well-conditioned data, but 1 - cos of nearly collinear
@@ -76,15 +89,49 @@ def one_case(rng, case):
             assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-6)
         except AssertionError as e:
             raise AssertionError("%s q=%s row=%d tau=%s: %s" % (cfg, qk, r, tau, str(e)[:300]))
-        if d <= 300 and qi == 0:
-            gb = aspace.search_batch(np.stack([q, q]), gl, tau)
-            assert gb[0] == got and gb[1] == got, ("batch", cfg)
+        if qi == 0:
+            q2 = np.ascontiguousarray(X[int(rng.integers(n))] * 1.01)
+            try:
+                g2 = aspace.search(q2, gl, tau)
+            except asp.PanicException:
+                g2 = None
+            if g2 is not None:
+                gb = aspace.search_batch(np.stack([q, q2, q]), gl, tau)
+                assert gb[0] == got and gb[1] == g2 and gb[2] == got, ("batch", cfg)
+
+
+def sharded_case(rng, X, gp, cfg):
+    """The staged C ABI through pyarrowspace_amd.dist.ShardedIndex (one rank, no process group)."""
+    import torch
+    from pyarrowspace_amd.dist import ShardedIndex
+    n, d = X.shape
+    ref = oracle_c.OracleIndex(X, gp)
+    index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())
+    try:
+        np.testing.assert_allclose(index.lambdas(), ref.lambdas, rtol=1e-6, atol=1e-300, err_msg=str(cfg))
+        for qi in range(4):
+            r = int(rng.integers(n))
+            q = np.ascontiguousarray([X[r] * 1.01, X[r].copy(), rng.standard_normal(d) * (np.abs(X).mean() + 1e-9), X[r] * 50.0][qi])
+            tau = float(rng.choice([1.0, 0.62, 0.0]))
+            try:
+                want, lq = ref.search(q, tau)
+            except oracle_c.ZeroLambda:
+                try:
+                    index.search(q, tau)
+                    raise AssertionError("sharded path answered where the oracle panics: %s" % cfg)
+                except asp.PanicException:
+                    continue
+            got = index.search(q, tau)
+            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-6)
+    finally:
+        index.close()
 
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    only = set(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    only = set(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+    sharded = len(sys.argv) > 4 and sys.argv[4] == "sharded"
     rng = np.random.default_rng(seed)
     bad = 0
     t0 = time.time()
@@ -93,7 +140,7 @@ def main():
         if only is not None and c not in only:
             continue
         try:
-            one_case(sub, c)
+            one_case(sub, c, sharded)
         except BaseException as e:   # noqa: BLE001
             bad += 1
             print("FAIL case %d: %s: %s" % (c, type(e).__name__, str(e)[:600]), flush=True)
