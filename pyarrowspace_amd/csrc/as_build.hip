@@ -999,10 +999,9 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     AS_HIP(hipMemsetAsync(t_idx, 0xff, sizeof(int32_t) * rows * kk, st));
     AS_HIP(hipMemsetAsync(out_cnt, 0, sizeof(int32_t) * rows, st));
 
-    int* flag = nullptr;
-    int* nflag = nullptr;
-    AS_HIP(hipMalloc(&flag, sizeof(int) * (rows + 1)));
-    nflag = flag + rows;
+    dev_tmp<int> flag;
+    AS_HIP(flag.alloc(rows + 1));
+    int* nflag = flag + rows;
     AS_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (rows + 1), st));
     double t_mfma = 0, t_ref = 0, t_fb = 0, flops = 0;
     int nflagged = 0;
@@ -1029,13 +1028,13 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         }
         const int units = nrb * S;
         const int grid = std::min(units, dev_cus * 2);
-        float *bkey = nullptr, *ckey = nullptr;
-        int *bidx = nullptr, *cidx = nullptr, *ccnt = nullptr;
-        AS_HIP(hipMalloc(&bkey, sizeof(float) * (size_t)grid * BM * CAP));
-        AS_HIP(hipMalloc(&bidx, sizeof(int) * (size_t)grid * BM * CAP));
-        AS_HIP(hipMalloc(&ckey, sizeof(float) * (size_t)rows * S * M));
-        AS_HIP(hipMalloc(&cidx, sizeof(int) * (size_t)rows * S * M));
-        AS_HIP(hipMalloc(&ccnt, sizeof(int) * (size_t)rows * S));
+        dev_tmp<float> bkey, ckey;
+        dev_tmp<int> bidx, cidx, ccnt;
+        AS_HIP(bkey.alloc((size_t)grid * BM * CAP));
+        AS_HIP(bidx.alloc((size_t)grid * BM * CAP));
+        AS_HIP(ckey.alloc((size_t)rows * S * M));
+        AS_HIP(cidx.alloc((size_t)rows * S * M));
+        AS_HIP(ccnt.alloc((size_t)rows * S));
         KnnArgs ka;
         ka.x32 = sp->x32; ka.n32 = sp->n32; ka.inorm32 = sp->inorm32;
         ka.n = n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
@@ -1107,7 +1106,6 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         t_mfma = ms01 * 1e-3; t_ref = ms12 * 1e-3;
         flops = 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
         hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
-        hipFree(bkey); hipFree(bidx); hipFree(ckey); hipFree(cidx); hipFree(ccnt);
         dbg("knn_rows: rows=%lld S=%d M=%d grid=%d mfma=%.3fs (%.1f TF/s) refine=%.3fs flagged=%d", (long long)rows, S, M,
             grid, t_mfma, flops / std::max(t_mfma, 1e-9) * 1e-12, t_ref, nflagged);
     } else {
@@ -1125,10 +1123,9 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             fs = exact_row_knn(ws, gp, r0 + lr, t_idx + lr * kk, t_key + lr * kk, t_dist + lr * kk, t_gy + lr * kk, out_cnt + lr);
         }
         as_query_free(ws);  // synchronises the workspace stream
-        if (fs != AS_OK) { hipFree(flag); return fs; }
+        if (fs != AS_OK) return fs;
         t_fb = now_s() - tf0;
     }
-    hipFree(flag);
     if (stats) {
         stats[1] += t_mfma; stats[2] += t_ref; stats[3] += t_fb; stats[6] += nflagged; stats[7] += flops;
     }
@@ -1375,15 +1372,15 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
     gr->gp = *gp;
     gr->metric = sp->opts.metric;
     gr->kernel = sp->opts.kernel;
-    int* revcnt = nullptr;
-    int64_t *len = nullptr, *bsum = nullptr, *total_d = nullptr;
-    AS_HIP(hipMalloc(&revcnt, sizeof(int) * n * 2));
+    dev_tmp<int> revcnt;
+    dev_tmp<int64_t> len, bsum;
+    AS_HIP(revcnt.alloc(n * 2));
     int* cursor = revcnt + n;
     AS_HIP(hipMemsetAsync(revcnt, 0, sizeof(int) * n * 2, st));
-    AS_HIP(hipMalloc(&len, sizeof(int64_t) * n));
+    AS_HIP(len.alloc(n));
     const int64_t nb = (n + 1023) / 1024;
-    AS_HIP(hipMalloc(&bsum, sizeof(int64_t) * (nb + 1)));
-    total_d = bsum + nb;
+    AS_HIP(bsum.alloc(nb + 1));
+    int64_t* total_d = bsum + nb;
     AS_HIP(hipMalloc(&gr->indptr, sizeof(int64_t) * (n + 1)));
     const unsigned ge = (unsigned)((n * k + 255) / 256), gn = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(sym_count_kernel, dim3(ge), dim3(256), 0, st, idx, cnt, n, k, revcnt);
@@ -1398,11 +1395,11 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
     AS_HIP(hipMemcpyAsync(gr->indptr + n, &nnz, sizeof(int64_t), hipMemcpyHostToDevice, st));
     gr->nnz = nnz;
     const int64_t na = std::max<int64_t>(nnz, 1);
-    int32_t* t_col = nullptr;
-    double *t_dist = nullptr, *t_gy = nullptr;
-    AS_HIP(hipMalloc(&t_col, sizeof(int32_t) * na));
-    AS_HIP(hipMalloc(&t_dist, sizeof(double) * na));
-    AS_HIP(hipMalloc(&t_gy, sizeof(double) * na));
+    dev_tmp<int32_t> t_col;
+    dev_tmp<double> t_dist, t_gy;
+    AS_HIP(t_col.alloc(na));
+    AS_HIP(t_dist.alloc(na));
+    AS_HIP(t_gy.alloc(na));
     AS_HIP(hipMalloc(&gr->indices, sizeof(int32_t) * na));
     AS_HIP(hipMalloc(&gr->dist, sizeof(double) * na));
     AS_HIP(hipMalloc(&gr->gy, sizeof(double) * na));
@@ -1419,10 +1416,10 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
     hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->gy, gr->deg, sp->n64,
                        gr->metric, gr->ny, gr->lap, gr->E, gr->G);
     AS_HIP(hipGetLastError());
-    SelState* sel = nullptr;
-    AS_HIP(hipMalloc(&sel, sizeof(SelState) + sizeof(double)));
+    dev_tmp<SelState> sel;
+    AS_HIP(sel.alloc(2));   // the selection state, then the slot tau0 is written to
     double* tau_d = (double*)(sel + 1);
-    AS_HIP(hipMemsetAsync(sel, 0, sizeof(SelState) + sizeof(double), st));
+    AS_HIP(hipMemsetAsync(sel, 0, 2 * sizeof(SelState), st));
     const unsigned gh = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
     for (int pass = 0; pass < 8; ++pass) {
         hipLaunchKernelGGL(sel_hist_kernel, dim3(gh), dim3(256), 0, st, gr->E, n, pass, sel);
@@ -1432,7 +1429,6 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
     AS_HIP(hipGetLastError());
     AS_HIP(hipMemcpyAsync(&gr->tau0, tau_d, sizeof(double), hipMemcpyDeviceToHost, st));
     AS_HIP(hipStreamSynchronize(st));
-    hipFree(sel); hipFree(t_col); hipFree(t_dist); hipFree(t_gy); hipFree(revcnt); hipFree(len); hipFree(bsum);
     dbg("graph: nnz=%lld tau0=%.6g", (long long)nnz, gr->tau0);
     return AS_OK;
 }

@@ -97,6 +97,20 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // order; wait for them and stop the compiler from caching LDS values across the point.
 #define AS_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// Scratch device allocation of a host function: freed on every return path, error paths included.
+template <typename T>
+struct dev_tmp {
+    T* p = nullptr;
+    dev_tmp() = default;
+    dev_tmp(const dev_tmp&) = delete;
+    dev_tmp& operator=(const dev_tmp&) = delete;
+    ~dev_tmp() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t count) { return hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)); }
+    operator T*() const { return p; }
+};
+
 // SPEC S7 edge energy a (A + B - 2C) of the expanded form; a value inside the rounding noise of its own terms is
 // zero: identical vectors with equal degrees must not become a 1e-16 "energy" whose share of the sum is 1
 // (DESIGN.md section 2, S7).
