@@ -1241,6 +1241,8 @@ void as_enable_search_stats(int32_t enabled) { g_search_stats.store(enabled ? 1 
 }  // extern "C"
 
 namespace as {
+static as_status query_alloc(as_query* q);
+
 as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out) {
     if (!sp || !out) {
         set_err("as_query_create: null argument");
@@ -1249,7 +1251,6 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     AS_HIP(hipSetDevice(sp->device));
     as_query* q = new as_query();
     q->cap = cap;
-    const size_t C = (size_t)cap;
     q->sp = sp;
     q->gr = gr;
     q->k = gr ? gr->gp.k : 1;
@@ -1261,6 +1262,18 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
         delete q;
         return AS_EUNSUPPORTED;
     }
+    const as_status st_alloc = query_alloc(q);
+    if (st_alloc != AS_OK) {
+        as_query_free(q);   // tolerates a partially built workspace
+        return st_alloc;
+    }
+    *out = q;
+    return AS_OK;
+}
+
+static as_status query_alloc(as_query* q) {
+    const as_space* sp = q->sp;
+    const size_t C = (size_t)q->cap;
     q->nwaves = 4096;
     if (const char* ev = getenv("ARROWSPACE_SCAN_VARIANT")) q->scan_variant = atoi(ev) & 7;
     if (const char* ev = getenv("ARROWSPACE_GEMM_VARIANT")) q->gemm_variant = atoi(ev);
@@ -1302,7 +1315,6 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     AS_HIP(hipFuncSetAttribute((const void*)hits_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((sizeof(double) + sizeof(int)) * HIT_CAP)));
     q->r0 = 0;
     q->r1 = sp->n;
-    *out = q;
     return AS_OK;
 }
 }  // namespace as
@@ -1314,8 +1326,9 @@ as_status as_query_create(const as_space* sp, const as_graph* gr, as_query** out
 void as_query_free(as_query* q) {
     if (!q) return;
     hipSetDevice(q->sp->device);
-    hipStreamSynchronize(q->stream);
-    hipHostFree(q->hq); hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32);
+    if (q->stream) hipStreamSynchronize(q->stream);
+    if (q->hq) hipHostFree(q->hq);
+    hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32);
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
     hipFree(q->gmin);
@@ -1324,9 +1337,10 @@ void as_query_free(as_query* q) {
         hipFree(q->knn);
         hipFree(q->hits);
     }
-    hipHostFree(q->hout);
-    for (int i = 0; i < 3; ++i) hipEventDestroy(q->ev[i]);
-    hipStreamDestroy(q->own_stream);
+    if (q->hout) hipHostFree(q->hout);
+    for (int i = 0; i < 3; ++i)
+        if (q->ev[i]) hipEventDestroy(q->ev[i]);
+    if (q->own_stream) hipStreamDestroy(q->own_stream);
     delete q;
 }
 
