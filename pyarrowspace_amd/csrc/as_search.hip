@@ -501,7 +501,9 @@ __device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx
     const T* rk = sk;
     const int* ri = si;
     int R = C;
-    if (C > 512) {
+    // a list as wide as the candidate set (topk above the number of rows that passed) keeps everything: a k-th
+    // smallest beyond the set does not exist, and the radix select would return an arbitrary threshold
+    if (C > 512 && M < C) {
         U v[4];
         bool have[4];
 #pragma unroll

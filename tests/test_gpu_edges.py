@@ -279,3 +279,14 @@ def test_item_magnitudes_outside_the_fp32_range(oracle_lib, scale):
     eps = calibrate_eps(X, 6)
     gp = {"eps": eps * scale, "k": 6, "topk": 4, "p": 2.0, "sigma": None}
     _compare(X * scale, gp, oracle_lib, [X[3] * scale * 1.01, X[n - 2] * scale * 0.99], taus=(0.62, 1.0))
+
+
+def test_list_wider_than_the_candidate_set(oracle_lib):
+    """topk = 1024 over 700 items: every row is a candidate and the list (768 wide) is wider than the set, which is
+    itself above the 512-candidate limit where ranking switches to a radix prune -- there is no 768th smallest of 700
+    (found by tools/fuzz_parity.py: the prune returned an arbitrary threshold and the re-scoring read wild rows)."""
+    n, d = 700, 64
+    X = np.random.default_rng(12).standard_normal((n, d))
+    gp = {"eps": 12.8, "k": 20, "topk": 1024, "p": 0.5, "sigma": 4.6, "kernel": "rational"}
+    aspace, gl, ref = _compare(X, gp, oracle_lib, [X[5] * 1.01, np.random.default_rng(13).standard_normal(d)], taus=(0.62, 1.0))
+    assert len(aspace.search(X[5] * 1.01, gl, 0.62)) == n

@@ -21,8 +21,8 @@ def gen_case(rng, case):
         d = 64
     metric = str(rng.choice(["l2", "cosine"]))
     kernel = str(rng.choice(["gaussian", "rational"]))
-    k = int(rng.integers(1, min(30, n) + 1))
-    topk = int(rng.integers(1, 41))
+    k = int(rng.integers(1, min(30, n) + 1)) if rng.random() < 0.9 else int(min(56, n))
+    topk = int(rng.integers(1, 41)) if rng.random() < 0.9 else int(rng.choice([57, 100, 200, 1024]))
     p = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
     kind = rng.choice(["clustered", "gauss", "positive", "scaled"])
     if kind == "clustered":
