@@ -19,10 +19,18 @@ def gen_case(rng, case):
     d = int(rng.choice([1, 2, 3, 7, 24, 31, 32, 33, 64, 100, 257, 300, 768, 1000]))
     if n * d > 3_000_000:
         d = 64
+    edgy = os.environ.get("FUZZ_BOUNDARIES") and rng.random() < 0.8
+    if edgy:   # sizes around the selection code's limits (512 ranked candidates, 4096-entry buffers, 64-wide lists)
+        n = int(rng.choice([63, 64, 65, 500, 511, 512, 513, 600, 767, 768, 769, 1023, 1025, 1100, 4000, 4095, 4096, 4097, 4200]))
+        d = int(rng.choice([3, 16, 32, 64]))
     metric = str(rng.choice(["l2", "cosine"]))
     kernel = str(rng.choice(["gaussian", "rational"]))
     k = int(rng.integers(1, min(30, n) + 1)) if rng.random() < 0.9 else int(min(56, n))
     topk = int(rng.integers(1, 41)) if rng.random() < 0.9 else int(rng.choice([57, 100, 200, 1024]))
+    if edgy:
+        k = int(rng.choice([1, min(n - 1, 55), min(n, 56)])) if n > 1 else 1
+        topk = int(rng.choice([1, 56, 57, 64, 65, 511, 512, 513, n - 1, n, n + 1, 1023, 1024]))
+        topk = max(1, min(topk, 1024))
     p = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
     kind = rng.choice(["clustered", "gauss", "positive", "scaled"])
     if kind == "clustered":
@@ -47,6 +55,8 @@ def gen_case(rng, case):
         D = 1 - np.maximum(0, (S @ S.T) / np.outer(nn, nn))
     dv = D[np.triu_indices(m, 1)] if m > 1 else np.array([1.0])
     eps = float(np.quantile(dv, rng.uniform(0.0, 1.0))) * float(rng.uniform(0.9, 1.1)) + 1e-12
+    if edgy and rng.random() < 0.6:
+        eps = float(dv.max()) * 1.5 + 1e-12          # every pair inside eps
     sigma = None if rng.random() < 0.5 else eps * float(rng.uniform(0.2, 3.0))
     gp = {"eps": eps, "k": k, "topk": topk, "p": p, "sigma": sigma, "metric": metric, "kernel": kernel}
     cfg = dict(case=case, n=n, d=d, kind=str(kind), gp=gp)
