@@ -47,7 +47,7 @@ def oracle_lib():
     return oracle_c
 
 
-def assert_hits_match(got, want, all_scores=None, rtol=1e-9, tie=1e-12):
+def assert_hits_match(got, want, all_scores=None, rtol=1e-9, tie=1e-12, atol=0.0):
     """Returned (index, score) lists against the oracle's.  Indices must be identical except
     where the oracle's scores tie to rounding (|ds| <= tie*|s|): two implementations that sum
     in different orders cannot agree on the order of mathematically equal scores.  With
@@ -56,7 +56,7 @@ def assert_hits_match(got, want, all_scores=None, rtol=1e-9, tie=1e-12):
     gi, gs = [i for i, _ in got], np.array([s for _, s in got])
     wi, ws = [i for i, _ in want], np.array([s for _, s in want])
     assert len(gi) == len(wi)
-    np.testing.assert_allclose(gs, ws, rtol=rtol)
+    np.testing.assert_allclose(gs, ws, rtol=rtol, atol=atol)   # atol: scores are sums of O(1) terms and can cancel to ~0
     assert all(gs[t] >= gs[t + 1] for t in range(len(gs) - 1))
     if gi == wi:
         return

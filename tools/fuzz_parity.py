@@ -3,6 +3,7 @@ Shapes, graph parameters, metric / kernel, query kinds and tau are drawn at rand
 configuration that reproduces it.  `python tools/fuzz_parity.py 100 5 - sharded` drives the staged C ABI
 (pyarrowspace_amd.dist.ShardedIndex, one rank) instead of the fused single-GPU entry points."""
 import os, sys, time, traceback
+os.environ.setdefault("OMP_NUM_THREADS", "8")   # the checker's thread team: 128 threads on tiny loops cost 0.3 s per call
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -96,7 +97,7 @@ def one_case(rng, case, sharded=False):
                 continue
         got = aspace.search(q, gl, tau)
         try:
-            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-6)
+            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-6, atol=1e-9)
         except AssertionError as e:
             raise AssertionError("%s q=%s row=%d tau=%s: %s" % (cfg, qk, r, tau, str(e)[:300]))
         if qi == 0:
@@ -132,7 +133,7 @@ def sharded_case(rng, X, gp, cfg):
                 except asp.PanicException:
                     continue
             got = index.search(q, tau)
-            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-6)
+            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-6, atol=1e-9)
     finally:
         index.close()
 
