@@ -80,6 +80,8 @@ def one_case(rng, case, sharded=False):
     indptr, indices, values = gl.to_csr()
     rows = np.repeat(np.arange(n), np.diff(indptr))
     assert np.array_equal(indices[indices != rows], ref.indices), cfg
+    if rng.random() < 0.3:
+        batch_case(rng, aspace, gl, X, cfg)
     for qi in range(4):
         r = int(rng.integers(n))
         qk = rng.choice(["near", "item", "random", "far"])
@@ -109,6 +111,30 @@ def one_case(rng, case, sharded=False):
             if g2 is not None:
                 gb = aspace.search_batch(np.stack([q, q2, q]), gl, tau)
                 assert gb[0] == got and gb[1] == g2 and gb[2] == got, ("batch", cfg)
+
+
+def batch_case(rng, aspace, gl, X, cfg):
+    """40 mixed queries through as_search_batch (two passes of the 32-slot workspace) against the single-query path."""
+    n, d = X.shape
+    rows = rng.integers(0, n, 40)
+    kinds = rng.integers(0, 3, 40)
+    Q = np.stack([X[r] * 1.01 + (0.02 * rng.standard_normal(d) * (np.abs(X[r]).mean() + 1e-9) if kd == 0 else 0.0) if kd < 2
+                  else rng.standard_normal(d) * (np.abs(X).mean() + 1e-9) for r, kd in zip(rows, kinds)])
+    tau = float(rng.choice([1.0, 0.62, 0.3]))
+    singles, panics = [], False
+    for q in Q:
+        try:
+            singles.append(aspace.search(np.ascontiguousarray(q), gl, tau))
+        except asp.PanicException:
+            singles.append(None)
+            panics = True
+    try:
+        got = aspace.search_batch(Q, gl, tau)
+    except asp.PanicException:
+        assert panics, ("batch panicked, no single query did", cfg)
+        return
+    assert not panics, ("a single query panicked, the batch did not", cfg)
+    assert got == singles, ("batch != singles", cfg, [i for i in range(40) if got[i] != singles[i]][:5])
 
 
 def sharded_case(rng, X, gp, cfg):
