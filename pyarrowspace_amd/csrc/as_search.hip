@@ -561,14 +561,27 @@ __device__ __forceinline__ void exact_eval_all(const float* x32, const double* x
             }
         } else {
             const float* pj = x32 + j * dp;  // rows and the query are zero padded to dp
-            for (int64_t e = 4 * sub; e < dp; e += 64) {
-                const f32x4 v = *(const f32x4*)(pj + e);
+            // four 64-float chunks per trip, every load issued before the first use: one chunk per trip was a chain
+            // of dp/64 dependent HBM round trips (12 at D=768) and most of this kernel's time
+            for (int64_t e0 = 4 * sub; e0 < dp; e0 += 256) {
+                f32x4 v[4];
+                double a[4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double a = q64[e + u], b = (double)v[u], t = a - b;
-                    s += t * t;
-                    g += a * b;
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t e = e0 + 64 * c;
+                    const bool in = e < dp;
+                    v[c] = in ? *(const f32x4*)(pj + e) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[c][u] = in ? q64[e + u] : 0.0;
                 }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double b = (double)v[c][u], t = a[c][u] - b;
+                        s += t * t;
+                        g += a[c][u] * b;
+                    }
             }
         }
     }

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# the checker's OpenMP team: on a 128-core host the default team costs 0.3 s per call on these small problems
+# (set before the checker's library is loaded; bench.py's cpu_baseline leg does not come through here)
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
