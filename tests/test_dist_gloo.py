@@ -214,3 +214,42 @@ def test_escalation_steps():
     while m is not None and steps < 10:           # worst case: every flag raised every time
         m, steps = next_mode(m, True, 3), steps + 1
     assert m is None and steps <= 4
+
+
+def test_sharded_search_follows_the_escalation_ladder():
+    """ShardedIndex.search with an engine that raises flags on a script: crowded neighbourhood -> repair (mode 4),
+    repair overflows -> list path (2), not provably exact -> fp64 (3); the answer of the last pass is returned and
+    the loop ends within four passes."""
+    import torch
+    from pyarrowspace_amd.dist import ShardedIndex
+
+    class Scripted(OracleEngine):
+        script = []
+
+        def __init__(self, gp):
+            super().__init__(gp)
+            self.modes = []
+
+        def set_mode(self, mode):
+            self.modes.append(mode)
+            super().set_mode(mode)
+
+        def query_finish(self, hits_all):
+            hits, lq, zero, _, _ = super().query_finish(hits_all)
+            inexact, overflow = self.script[len(self.modes) - 1] if len(self.modes) <= len(self.script) else (False, 0)
+            return hits, lq, zero, inexact, overflow
+
+    X = np.random.default_rng(0).standard_normal((120, 16))
+    gp = {"eps": 6.0, "k": 4, "topk": 3, "p": 2.0, "sigma": None}
+    plain = ShardedIndex.build(gp, torch.from_numpy(X), engine=OracleEngine(gp))
+    want = plain.search(X[3] * 1.01, 0.62)
+    for script, modes in (([(False, 0)], [0]),
+                          ([(False, 1), (False, 0)], [0, 4]),
+                          ([(False, 3), (False, 1), (False, 0)], [0, 4, 2]),
+                          ([(False, 1), (False, 1), (True, 0), (False, 0)], [0, 4, 2, 3]),
+                          ([(True, 0), (False, 1), (False, 2)], [0, 1, 5, 3])):
+        eng = Scripted(gp)
+        eng.script = script
+        index = ShardedIndex.build(gp, torch.from_numpy(X), engine=eng)
+        assert index.search(X[3] * 1.01, 0.62) == want
+        assert eng.modes == modes, (script, eng.modes)
