@@ -290,3 +290,22 @@ def test_list_wider_than_the_candidate_set(oracle_lib):
     gp = {"eps": 12.8, "k": 20, "topk": 1024, "p": 0.5, "sigma": 4.6, "kernel": "rational"}
     aspace, gl, ref = _compare(X, gp, oracle_lib, [X[5] * 1.01, np.random.default_rng(13).standard_normal(d)], taus=(0.62, 1.0))
     assert len(aspace.search(X[5] * 1.01, gl, 0.62)) == n
+
+
+def test_power_of_two_scaling_changes_nothing():
+    """Scaling the items by 2^e (eps and sigma alike) scales every intermediate exactly, in fp32 and fp64: graph,
+    degrees and lambdas must come out bit-identical, and a scaled query must return the same hits."""
+    import pyarrowspace_amd as asp
+    n, d = 2500, 48
+    X = clustered(n, d, nclust=6, seed=21)
+    eps = calibrate_eps(X, 7)
+    gp = {"eps": eps, "k": 7, "topk": 5, "p": 2.0, "sigma": eps * 0.7}
+    a0, g0 = asp.ArrowSpaceBuilder.build(gp, X)
+    q = np.ascontiguousarray(X[5] * 1.01)
+    h0 = a0.search(q, g0, 0.62)
+    for e in (-9, 7, 20):
+        s = 2.0 ** e
+        a1, g1 = asp.ArrowSpaceBuilder.build(dict(gp, eps=eps * s, sigma=eps * 0.7 * s), X * s)
+        assert np.array_equal(a1.lambdas(), a0.lambdas()) and np.array_equal(g1.degrees(), g0.degrees())
+        assert np.array_equal(g1.to_csr()[1], g0.to_csr()[1]) and np.array_equal(g1.to_csr()[2], g0.to_csr()[2])
+        assert a1.search(np.ascontiguousarray(q * s), g1, 0.62) == h0

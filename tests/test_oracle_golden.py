@@ -126,3 +126,32 @@ def test_graph_params_contract():
     assert oracle_np.resolve_params({"eps": 0.5, "k": 3, "topk": 2, "p": 2.0})["sigma"] == 0.25
     assert oracle_np.resolve_params({"eps": 0.5, "k": 3, "topk": 2, "p": 2.0, "sigma": None})["sigma"] == 0.25
     assert oracle_np.resolve_params({"eps": 0.5, "k": 3, "topk": 2, "p": 2.0, "sigma": 0.7})["sigma"] == 0.7
+
+
+def test_spec_properties_scale_and_permutation():
+    """Properties the SPEC implies and any restatement must keep: (1) power-of-two scaling of the items with eps and
+    sigma scaled alike changes nothing (every intermediate scales exactly in binary floating point); (2) permuting the
+    items permutes degrees and lambdas; (3) under the cosine metric a positive multiple of a query is the same query."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((60, 12))
+    gp = {"eps": 4.0, "k": 5, "topk": 4, "p": 2.0, "sigma": 1.5}
+    base = onp.build(X, gp)
+    for e in (-20, 7, 30):
+        s = 2.0 ** e
+        idx = onp.build(X * s, dict(gp, eps=gp["eps"] * s, sigma=gp["sigma"] * s))
+        assert np.array_equal(idx["lambdas"], base["lambdas"]) and np.array_equal(idx["deg"], base["deg"])
+        assert np.array_equal(idx["indices"], base["indices"])
+        q = X[3] * 1.01
+        assert onp.query_lambda(idx, q * s) == onp.query_lambda(base, q)
+    perm = rng.permutation(60)
+    idx = onp.build(X[perm], gp)
+    np.testing.assert_allclose(idx["lambdas"], base["lambdas"][perm], rtol=1e-12)
+    np.testing.assert_allclose(idx["deg"], base["deg"][perm], rtol=1e-12)
+    gpc = {"eps": 0.6, "k": 5, "topk": 4, "p": 2.0, "sigma": None, "metric": "cosine"}
+    cidx = onp.build(X, gpc)
+    q = X[7] + 0.05 * rng.standard_normal(12)
+    l1, l2 = onp.query_lambda(cidx, q), onp.query_lambda(cidx, q * 37.0)
+    assert l1 > 0 and abs(l1 - l2) <= 1e-12 * l1
+    h1, h2 = onp.search(cidx, q, 0.62), onp.search(cidx, q * 37.0, 0.62)
+    assert [i for i, _ in h1[0]] == [i for i, _ in h2[0]]
