@@ -309,3 +309,25 @@ def test_power_of_two_scaling_changes_nothing():
         assert np.array_equal(a1.lambdas(), a0.lambdas()) and np.array_equal(g1.degrees(), g0.degrees())
         assert np.array_equal(g1.to_csr()[1], g0.to_csr()[1]) and np.array_equal(g1.to_csr()[2], g0.to_csr()[2])
         assert a1.search(np.ascontiguousarray(q * s), g1, 0.62) == h0
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_build_from_device_with_a_leading_dimension(oracle_lib, dtype):
+    """Items resident in HBM as a view of a wider matrix (ld > d), fp32 or fp64."""
+    import torch
+    import pyarrowspace_amd as asp
+    n, d, ld = 1800, 40, 56
+    X = clustered(n, d, nclust=5, seed=33)
+    if dtype == "float32":
+        X = X.astype(np.float32).astype(np.float64)
+    wide = torch.full((n, ld), float("nan"), dtype=getattr(torch, dtype), device="cuda")   # the padding must never be read
+    wide[:, :d] = torch.from_numpy(X).to(wide.dtype).cuda()
+    gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 4, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build_from_device(gp, wide.data_ptr(), dtype, n, d, ld)
+    ref = oracle_lib.OracleIndex(X, gp)
+    np.testing.assert_allclose(aspace.lambdas(), ref.lambdas, rtol=RTOL, atol=1e-300)
+    v, lam = aspace.get_item(17)
+    assert np.array_equal(v, X[17]) and lam == aspace.lambdas()[17]
+    q = np.ascontiguousarray(X[9] * 1.01)
+    want, lq = ref.search(q, 0.62)
+    assert_hits_match(aspace.search(q, gl, 0.62), want, ref.scores(q, 0.62, lq), rtol=RTOL)
