@@ -70,9 +70,18 @@ static inline double dotp(const double *a, const double *b, int64_t d) {
 /* SPEC S7 edge energy a (A + B - 2C) of the expanded form: a value inside the rounding noise of its own terms is
  * zero (identical vectors with equal degrees must not turn into a 1e-16 "energy" whose share of the sum is 1) */
 #define ASO_ENERGY_NOISE 0x1p-46
-static inline double edge_energy(double w, double A, double B, double C) {
-    double v = w * (A + B - 2.0 * C);
-    return v > w * ASO_ENERGY_NOISE * (A + B + 2.0 * fabs(C)) ? v : 0.0;
+/* no FMA contraction here: the numpy restatement rounds every operation, and tau = 0 rankings turn on the last bit */
+__attribute__((optimize("fp-contract=off"), noinline))
+static double edge_energy(double w, int metric, double dist, double g, double di, double dj, double nyi, double nyj) {
+    /* w ||y_i/sqrt(d_i) - y_j/sqrt(d_j)||^2 in the form that does not cancel for near-identical neighbours
+     * (oracle_np.edge_energy, same operation order) */
+    double alpha = 1.0 / sqrt(di), beta = 1.0 / sqrt(dj), core;
+    if (metric == ASO_L2) core = alpha * beta * (dist * dist) + (alpha - beta) * (alpha * nyi - beta * nyj);
+    else if (nyi > 0.0 && nyj > 0.0) core = (alpha - beta) * (alpha - beta) + 2.0 * alpha * beta * (1.0 - g);
+    else core = alpha * alpha * nyi + beta * beta * nyj;
+    double v = w * core;
+    double floor_ = w * ASO_ENERGY_NOISE * (alpha * alpha * nyi + beta * beta * nyj + 2.0 * alpha * beta * fabs(g));
+    return v > floor_ ? v : 0.0;
 }
 
 /* SPEC S2: key (eps test + ordering), dist, gy for the pair (a,b) */
@@ -239,15 +248,14 @@ aso_index *aso_build(const double *X, int64_t n, int64_t d, double eps, int64_t 
             int64_t j = ix->indices[e];
             double sdd = sqrt(ix->deg[i] * ix->deg[j]);
             ix->lap[e] = -ix->w[e] / sdd;
-            S += edge_energy(ix->w[e], ix->ny[i] / ix->deg[i], ix->ny[j] / ix->deg[j], ix->gy[e] / sdd);
+            S += edge_energy(ix->w[e], ix->metric, ix->dist[e], ix->gy[e], ix->deg[i], ix->deg[j], ix->ny[i], ix->ny[j]);
         }
         ix->E[i] = ix->ny[i] > 0.0 ? (0.5 * S) / ix->ny[i] : 0.0;
         if (S > 0.0) {
             double g = 0.0;
             for (int64_t e = lo; e < hi; ++e) {
                 int64_t j = ix->indices[e];
-                double sdd = sqrt(ix->deg[i] * ix->deg[j]);
-                double r = edge_energy(ix->w[e], ix->ny[i] / ix->deg[i], ix->ny[j] / ix->deg[j], ix->gy[e] / sdd) / S;
+                double r = edge_energy(ix->w[e], ix->metric, ix->dist[e], ix->gy[e], ix->deg[i], ix->deg[j], ix->ny[i], ix->ny[j]) / S;
                 g += r * r;
             }
             ix->G[i] = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
@@ -329,8 +337,7 @@ double aso_query_lambda(const aso_index *ix, const double *q) {
             for (int64_t t = 0; t < m; ++t) {
                 int64_t j = lst[t].j;
                 double dj = ix->deg[j] + a[t];
-                double sdd = sqrt(degq * dj);
-                es[t] = edge_energy(a[t], nyq / degq, ix->ny[j] / dj, lst[t].gy / sdd);
+                es[t] = edge_energy(a[t], ix->metric, lst[t].dist, lst[t].gy, degq, dj, nyq, ix->ny[j]);
                 S += es[t];
             }
             double Eq = 0.5 * S / nyq, Gq = 0.0;

@@ -64,11 +64,23 @@ def _edge_weight(d, sigma, p, kernel):
 ENERGY_NOISE = 2.0 ** -46
 
 
-def edge_energy(w, A, B, C):
-    """SPEC S7 edge energy a (A + B - 2C) of the expanded form; a value inside the rounding noise of its own terms
-    is zero (identical vectors with equal degrees must not become a 1e-16 "energy" whose share of the sum is 1)."""
-    v = w * (A + B - 2.0 * C)
-    return v if v > w * ENERGY_NOISE * (A + B + 2.0 * abs(C)) else 0.0
+def edge_energy(w, metric, dist, g, di, dj, nyi, nyj):
+    """SPEC S6 edge energy w ||y_i/sqrt(d_i) - y_j/sqrt(d_j)||^2 from the stored pair quantities, in the form that
+    does not cancel for near-identical neighbours: with alpha = d_i^-1/2, beta = d_j^-1/2,
+      l2:      alpha beta dist^2 + (alpha - beta)(alpha n_i - beta n_j)      (dist^2 = n_i + n_j - 2 g, summed as differences)
+      cosine:  (alpha - beta)^2 + 2 alpha beta (1 - c)                       (unit vectors; zero vectors: alpha^2 n_i + beta^2 n_j)
+    A value inside the rounding noise of the expanded form's terms is zero: a neighbour identical to the node must
+    not become a 1e-16 "energy" whose share of the sum is 1."""
+    alpha, beta = 1.0 / np.sqrt(di), 1.0 / np.sqrt(dj)
+    if metric == METRIC_L2:
+        core = alpha * beta * (dist * dist) + (alpha - beta) * (alpha * nyi - beta * nyj)
+    elif nyi > 0.0 and nyj > 0.0:
+        core = (alpha - beta) * (alpha - beta) + 2.0 * alpha * beta * (1.0 - g)
+    else:
+        core = alpha * alpha * nyi + beta * beta * nyj
+    v = w * core
+    floor = w * ENERGY_NOISE * (alpha * alpha * nyi + beta * beta * nyj + 2.0 * alpha * beta * abs(g))
+    return v if v > floor else 0.0
 
 
 def pair_quantities(xi, X, ni, n, metric):
@@ -166,7 +178,7 @@ def graph_from_lists(X, prm, n, lists) -> dict:
             j = indices[e]
             sdd = np.sqrt(deg[i] * deg[j])
             lap[e] = -w[e] / sdd
-            eps_e[t] = edge_energy(w[e], ny[i] / deg[i], ny[j] / deg[j], gy[e] / sdd)
+            eps_e[t] = edge_energy(w[e], prm["metric"], dist[e], gy[e], deg[i], deg[j], ny[i], ny[j])
         S = 0.0
         for v in eps_e:
             S += v
@@ -238,7 +250,7 @@ def lambda_from_neighbours(idx: dict, q, items, dist, gy, deg=None, ny=None) -> 
     for t in range(len(items)):
         dj = deg[t] + a[t]
         sdd = np.sqrt(degq * dj)
-        es.append(edge_energy(a[t], nyq / degq, ny[t] / dj, gy[t] / sdd))
+        es.append(edge_energy(a[t], prm["metric"], dist[t], gy[t], degq, dj, nyq, ny[t]))
     S = 0.0
     for v in es:
         S += v

@@ -1265,7 +1265,8 @@ __global__ void degree_kernel(int64_t n, const int64_t* __restrict__ indptr, con
 }
 
 __global__ void energy_kernel(int64_t n, const int64_t* __restrict__ indptr, const int32_t* __restrict__ col,
-                              const double* __restrict__ wgt, const double* __restrict__ gy, const double* __restrict__ deg,
+                              const double* __restrict__ wgt, const double* __restrict__ dist, const double* __restrict__ gy,
+                              const double* __restrict__ deg,
                               const double* __restrict__ n64, int metric, double* __restrict__ ny, double* __restrict__ lap,
                               double* __restrict__ E, double* __restrict__ G) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1282,7 +1283,7 @@ __global__ void energy_kernel(int64_t n, const int64_t* __restrict__ indptr, con
             const double nyj = metric == AS_METRIC_L2 ? n64[j] : (n64[j] > 0.0 ? 1.0 : 0.0);
             const double sdd = sqrt(di * deg[j]);
             lap[e] = -wgt[e] / sdd;
-            S += edge_energy(wgt[e], nyi / di, nyj / deg[j], gy[e] / sdd);
+            S += edge_energy(wgt[e], metric, dist[e], gy[e], di, deg[j], nyi, nyj);
         }
         Ei = nyi > 0.0 ? (0.5 * S) / nyi : 0.0;
         if (S > 0.0) {
@@ -1290,8 +1291,7 @@ __global__ void energy_kernel(int64_t n, const int64_t* __restrict__ indptr, con
             for (int64_t e = lo; e < hi; ++e) {
                 const int j = col[e];
                 const double nyj = metric == AS_METRIC_L2 ? n64[j] : (n64[j] > 0.0 ? 1.0 : 0.0);
-                const double sdd = sqrt(di * deg[j]);
-                const double r = edge_energy(wgt[e], nyi / di, nyj / deg[j], gy[e] / sdd) / S;
+                const double r = edge_energy(wgt[e], metric, dist[e], gy[e], di, deg[j], nyi, nyj) / S;
                 g += r * r;
             }
             Gi = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
@@ -1413,7 +1413,7 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
     hipLaunchKernelGGL(sym_sort_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, gr->indptr, t_col, t_dist, t_gy,
                        gr->indices, gr->dist, gr->gy, gr->w, gp->sigma, gp->p, gr->kernel);
     hipLaunchKernelGGL(degree_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->w, gr->deg);
-    hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->gy, gr->deg, sp->n64,
+    hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->dist, gr->gy, gr->deg, sp->n64,
                        gr->metric, gr->ny, gr->lap, gr->E, gr->G);
     AS_HIP(hipGetLastError());
     dev_tmp<SelState> sel;

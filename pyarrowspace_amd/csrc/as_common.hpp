@@ -111,12 +111,23 @@ struct dev_tmp {
     operator T*() const { return p; }
 };
 
-// SPEC S7 edge energy a (A + B - 2C) of the expanded form; a value inside the rounding noise of its own terms is
-// zero: identical vectors with equal degrees must not become a 1e-16 "energy" whose share of the sum is 1
+// SPEC S6 edge energy w ||y_i/sqrt(d_i) - y_j/sqrt(d_j)||^2 from the stored pair quantities; a value inside the rounding
+// noise of the expanded form's terms is zero: a neighbour identical to the node must not become a 1e-16 "energy"
+// whose share of the sum is 1
 // (DESIGN.md section 2, S7).
-__host__ __device__ __forceinline__ double edge_energy(double w, double A, double B, double C) {
-    const double v = w * (A + B - 2.0 * C);
-    return v > w * 0x1p-46 * (A + B + 2.0 * fabs(C)) ? v : 0.0;
+// The form does not cancel for near-identical neighbours (alpha = d_i^-1/2, beta = d_j^-1/2):
+//   l2:     alpha beta dist^2 + (alpha - beta)(alpha n_i - beta n_j)   (dist^2 summed as differences)
+//   cosine: (alpha - beta)^2 + 2 alpha beta (1 - c) for unit vectors, alpha^2 n_i + beta^2 n_j if one is zero
+__host__ __device__ __forceinline__ double edge_energy(double w, int metric, double dist, double g, double di, double dj,
+                                                        double nyi, double nyj) {
+    const double alpha = 1.0 / sqrt(di), beta = 1.0 / sqrt(dj);
+    double core;
+    if (metric == AS_METRIC_L2) core = alpha * beta * (dist * dist) + (alpha - beta) * (alpha * nyi - beta * nyj);
+    else if (nyi > 0.0 && nyj > 0.0) core = (alpha - beta) * (alpha - beta) + 2.0 * alpha * beta * (1.0 - g);
+    else core = alpha * alpha * nyi + beta * beta * nyj;
+    const double v = w * core;
+    const double floor_ = w * 0x1p-46 * (alpha * alpha * nyi + beta * beta * nyj + 2.0 * alpha * beta * fabs(g));
+    return v > floor_ ? v : 0.0;
 }
 // SPEC S2 cosine distance: rounding can push a cosine past 1 -- no negative distances (a fractional p would turn
 // them into NaN weights)

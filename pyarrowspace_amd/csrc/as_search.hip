@@ -642,8 +642,7 @@ __device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist
         double ev = 0.0;
         if (on) {
             const double dj = s_deg[lane] + at;
-            const double sdd = sqrt(degq * dj);
-            ev = edge_energy(at, nyq / degq, s_ny[lane] / dj, s_gy[lane] / sdd);
+            ev = edge_energy(at, metric, s_dist[lane], s_gy[lane], degq, dj, nyq, s_ny[lane]);
         }
         const double S = wave_sum(ev);
         const double Eq = 0.5 * S / nyq;

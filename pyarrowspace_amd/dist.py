@@ -34,15 +34,19 @@ def shard_bounds(n: int, world: int) -> list[int]:
 def next_mode(mode: int, inexact: bool, overflow: int):
     """Escalation of one sharded search (every rank sees the same merged flags, so every rank takes the
     same step).  mode bits as in as_query_set_exact: 1 = fp64 scans, 2 = wavefront-list selection,
-    4 = repair the k-NN candidates from the kept dots.  Returns None when the answer stands."""
+    4 = repair the k-NN candidates from the kept dots.  Returns None when the answer stands (or nothing
+    stronger exists: fp64 + list selection).  Every step is strictly stronger, so a search takes at most
+    four passes: 0 -> 4 -> 2 -> 3, or 0 -> 1 -> 5 -> 3."""
     if inexact and not mode & 1:
-        return (mode | 1) & ~4                    # fp64 from scratch (the fp32 dots cannot be reused)
+        # fp64 from scratch (the fp32 dots cannot be reused); a buffer that overflowed will overflow again,
+        # so take the list path along with it
+        return 3 if overflow or mode & 2 else 1
     if overflow & 1 and not mode & 6:
         # more than CAND_CAP rows inside eps: threshold repair, no rescan (the scorer ran on a truncated
         # neighbourhood, so its own overflow bit means nothing yet)
         return mode | 4
-    if overflow:
-        return None if mode & 2 else (mode | 2) & ~4   # scorer buffer, or the repair itself overflowed: list path
+    if overflow and not mode & 2:
+        return (mode | 2) & ~4                    # scorer buffer, or the repair itself overflowed: list path
     return None
 
 
@@ -293,7 +297,7 @@ class ShardedIndex:
         ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
         mode = 0
         with ctx:
-            for _ in range(4):
+            for _ in range(8):
                 e.set_mode(mode)
                 e.query_scan(q, self.r0, self.r1)
                 knn_all = self._gather_fixed(e.knn_local)
@@ -304,6 +308,8 @@ class ShardedIndex:
                 mode = next_mode(mode, inexact, overflow)
                 if mode is None:
                     break
+            else:   # next_mode is strictly increasing: unreachable, and never a silently wrong answer
+                raise RuntimeError("sharded search did not settle on an exact answer")
         self.last_lambda_q = lq
         if zero:
             raise PanicException("The lambdas are zero, check the magnitude of items and eps.")

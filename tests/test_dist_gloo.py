@@ -204,16 +204,28 @@ def test_escalation_steps():
     assert next_mode(0, False, 2) == 2            # scorer buffer overflowed
     assert next_mode(0, False, 3) == 4            # the scorer's bit means nothing while the neighbourhood is truncated
     assert next_mode(4, False, 2) == 2
-    assert next_mode(2, False, 3) is None         # nothing beyond the list path
+    assert next_mode(2, False, 3) is None         # nothing beyond the list path in fp32 ...
+    assert next_mode(2, True, 0) == 3             # ... except fp64
     assert next_mode(0, True, 0) == 1             # not provably exact in fp32
     assert next_mode(4, True, 0) == 1             # fp32 dots are no use to the fp64 pass
+    assert next_mode(4, True, 2) == 3             # fp64 and the list path in one step
     assert next_mode(1, True, 0) is None
     assert next_mode(1, False, 1) == 5
     assert next_mode(5, False, 1) == 3
-    m, steps = 0, 0
-    while m is not None and steps < 10:           # worst case: every flag raised every time
-        m, steps = next_mode(m, True, 3), steps + 1
-    assert m is None and steps <= 4
+    assert next_mode(3, True, 3) is None
+    # every chain ends within four passes whatever the flags
+    import itertools
+    for flags in itertools.product([(False, 0), (False, 1), (False, 2), (False, 3), (True, 0), (True, 1), (True, 2), (True, 3)], repeat=4):
+        m, steps, seen = 0, 0, []
+        for f in flags:
+            seen.append(m)
+            m = next_mode(m, *f)
+            steps += 1
+            if m is None:
+                break
+            assert m not in seen, (flags, seen, m)
+        else:
+            assert next_mode(m, True, 3) is None, (flags, m)
 
 
 def test_sharded_search_follows_the_escalation_ladder():
@@ -247,6 +259,7 @@ def test_sharded_search_follows_the_escalation_ladder():
                           ([(False, 1), (False, 0)], [0, 4]),
                           ([(False, 3), (False, 1), (False, 0)], [0, 4, 2]),
                           ([(False, 1), (False, 1), (True, 0), (False, 0)], [0, 4, 2, 3]),
+                          ([(False, 3), (True, 2), (False, 0)], [0, 4, 3]),
                           ([(True, 0), (False, 1), (False, 2)], [0, 1, 5, 3])):
         eng = Scripted(gp)
         eng.script = script

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import calibrate_eps, clustered
+from conftest import assert_hits_match, calibrate_eps, clustered
 from oracle import oracle_np
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -111,8 +111,10 @@ def test_c_oracle_reproduces_golden_vectors(oracle_lib, name):
     for a, q in enumerate(z["Q"]):
         for b, tau in enumerate(z["taus"]):
             hits, lq = ref.search(q, float(tau))
-            assert [i for i, _ in hits] == z["hits_idx"][a, b].tolist()
-            np.testing.assert_allclose([s for _, s in hits], z["hits_score"][a, b], rtol=1e-12)
+            # indices identical except inside a run of scores tied to rounding (mutually nearest items with the same
+            # lambda at tau = 0: C and numpy round the energies differently in the last bit)
+            want = list(zip(z["hits_idx"][a, b].tolist(), z["hits_score"][a, b].tolist()))
+            assert_hits_match(hits, want, rtol=1e-12)
             assert abs(lq - z["lambda_q"][a]) <= 1e-12 * abs(lq)
 
 
