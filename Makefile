@@ -2,11 +2,12 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := pyarrowspace_amd/csrc
-SRCS := $(CSRC)/as_api.hip $(CSRC)/as_build.hip $(CSRC)/as_scan.hip $(CSRC)/as_search.hip
+SRCS := $(CSRC)/as_api.hip $(CSRC)/as_build.hip $(CSRC)/as_feat.hip $(CSRC)/as_scan.hip $(CSRC)/as_search.hip
 HDRS := $(CSRC)/as_common.hpp $(CSRC)/as_query.hpp include/arrowspace_hip.h
 OBJS := $(SRCS:.hip=.o)
 LIB := pyarrowspace_amd/libarrowspace_hip.so
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value
+ABLATION ?= 0
+HIPFLAGS ?= $(if $(filter 1,$(ABLATION)),-DAS_ABLATION) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value
 
 all: $(LIB) oracle
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)

@@ -26,42 +26,78 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_F64_PEAK_TF = 78.6    # v_mfma_f64_16x16x4_f64: vendor fp64 matrix peak (half the fp32 rate; not in the guide's table)
 
 
 def make_data(n, d, seed, device, nclust=1024, noise=0.5):
-    """SURVEY section 8(d) recipe on the GPU: clustered Gaussians, rows L2-normalised, fp32."""
+    """SURVEY section 8(d) recipe, bit for bit and reproducible off the GPU: rng = np.random.default_rng(seed);
+    C = rng.standard_normal((nclust, d)); z = rng.integers(0, nclust, n); X = C[z] + noise * rng.standard_normal((n, d));
+    rows L2-normalised; cast fp32.  The noise is drawn in row chunks (the generator's stream is the same as for one
+    big call) so the host never holds more than one fp64 chunk."""
     import torch
 
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    C = torch.randn((nclust, d), generator=g, device=device, dtype=torch.float32)
-    g.manual_seed(seed + 1000)
-    z = torch.randint(0, nclust, (n,), generator=g, device=device)
+    rng = np.random.default_rng(seed)
+    C = rng.standard_normal((nclust, d))
+    z = rng.integers(0, nclust, n)
     X = torch.empty((n, d), device=device, dtype=torch.float32)
-    step = 1 << 17
+    step = 1 << 16
     for s in range(0, n, step):
         e = min(n, s + step)
-        X[s:e] = C[z[s:e]] + noise * torch.randn((e - s, d), generator=g, device=device, dtype=torch.float32)
-        X[s:e] /= X[s:e].norm(dim=1, keepdim=True)
+        blk = C[z[s:e]] + noise * rng.standard_normal((e - s, d))
+        blk /= np.linalg.norm(blk, axis=1, keepdims=True)
+        X[s:e] = torch.from_numpy(blk.astype(np.float32)).to(device)
     return X
 
 
-def calibrate_eps(X, k, target=2.0, sample=512, seed=5):
-    """eps with mean degree before the k-cap ~ target*k, L2 metric."""
+def make_queries(X, nq, seed, spread=0.02):
+    """Queries: perturbed items, rows picked and noise drawn from np.random.default_rng(seed) -- as
+    tests/test_0.py:24 queries with a scaled item -- so that every query has neighbours inside eps (a fresh
+    sample of the section-8(d) recipe has its own cluster centres: no item within eps, lambda_q = 0, and the
+    reference's assert, src/lib.rs:156-159, would end the run).  Recorded as a deviation in config.workload."""
+    rng = np.random.default_rng(seed)
+    n, d = X.shape
+    rows = rng.integers(0, n, nq)
+    Q = X[rows].double().cpu().numpy() + spread * rng.standard_normal((nq, d)) / np.sqrt(d)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    return Q
+
+
+def calibrate_eps(X, k, metric="l2", target=2.0, sample=512, seed=5):
+    """eps with mean degree before the k-cap ~ target*k; L2 distance or the rectified-cosine
+    distance of GRAPH_VARIABLES.md:7."""
     import torch
 
     n = X.shape[0]
     g = torch.Generator(device=X.device)
     g.manual_seed(seed)
     rows = torch.randperm(n, generator=g, device=X.device)[:sample]
-    A = X[rows].double()
     nn = (X.double() ** 2).sum(1) if n <= (1 << 18) else (X * X).sum(1).double()
-    G = A @ X.double().T if n <= (1 << 18) else (X[rows] @ X.T).double()
-    D2 = (nn[rows][:, None] + nn[None, :] - 2 * G).clamp_min(0)
+    G = X[rows].double() @ X.double().T if n <= (1 << 18) else (X[rows] @ X.T).double()
+    if metric == "l2":
+        D2 = (nn[rows][:, None] + nn[None, :] - 2 * G).clamp_min(0)
+    else:
+        D2 = 1.0 - (G / (nn[rows][:, None] * nn[None, :]).sqrt()).clamp(0, 1)
     D2[torch.arange(len(rows), device=X.device), rows] = float("inf")
     kth = int(min(target * k, n - 1))
     vals = torch.topk(D2, kth, dim=1, largest=False).values[:, -1]
-    return float(vals.median().sqrt().item())
+    v = float(vals.median().item())
+    return v ** 0.5 if metric == "l2" else v
+
+
+def calibrate_feature_eps(X, k, metric="cosine", target=2.0):
+    """Feature mode (SPEC F1-F3): eps with about target*k other columns inside it, from the fp64 Gram of a row sample."""
+    import torch
+
+    n, d = X.shape
+    Xs = X[:: max(1, n // 65536)].double()
+    G = Xs.T @ Xs
+    m = G.diagonal()
+    if metric == "l2":
+        D = (m[:, None] + m[None, :] - 2 * G).clamp_min(0).sqrt() * (n / Xs.shape[0]) ** 0.5
+    else:
+        D = 1.0 - (G / (m[:, None] * m[None, :]).sqrt()).clamp(0, 1)
+    off = D[~torch.eye(d, dtype=torch.bool, device=X.device)]
+    return float(torch.quantile(off[: 1 << 24], min(1.0, target * k / max(d - 1, 1))).item())
 
 
 def main():
@@ -75,9 +111,17 @@ def main():
     ap.add_argument("--topk", type=int, default=15)
     ap.add_argument("--tau", type=float, default=0.62)
     ap.add_argument("--eps", type=float, default=0.0, help="0 = calibrate to mean degree 2k")
+    ap.add_argument("--metric", choices=["l2", "cosine"], default="l2",
+                    help="graph distance: l2 (north_star default) or the rectified cosine of GRAPH_VARIABLES.md:7")
+    ap.add_argument("--kernel", choices=["gaussian", "rational"], default="gaussian",
+                    help="edge weight: gaussian (north_star default) or 1/(1+(d/sigma)^p) of GRAPH_VARIABLES.md:9")
+    ap.add_argument("--lambda-mode", choices=["item", "feature"], default="item",
+                    help="item: node energy on the N-node graph; feature: F x F feature Laplacian of TAUMODE.md:8,12-27")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=12)
-    ap.add_argument("--cpu-build-n", type=int, default=8192)
+    ap.add_argument("--cpu-queries", type=int, default=24)
+    ap.add_argument("--cpu-build-n", type=int, nargs="*", default=[20000, 100000],
+                    help="item counts the CPU all-pairs build is timed at (SURVEY section 8d: 20k and 100k)")
+    ap.add_argument("--cpu-build-budget", type=float, default=45.0, help="skip a CPU build size predicted to take longer (s)")
     args = ap.parse_args()
 
     import torch
@@ -107,14 +151,14 @@ def main():
 
     n, d = args.n, args.d
     X = make_data(n, d, 42, device)
-    # queries: perturbed items (as tests/test_0.py:24 does), so every query has neighbours within eps
     nq_total = max(args.steps + args.warmup, 64)
-    gq = torch.Generator(device=device)
-    gq.manual_seed(43)
-    qrows = torch.randint(0, n, (nq_total,), generator=gq, device=device)
-    Qd = X[qrows] + 0.05 * 0.5 * torch.randn((nq_total, d), generator=gq, device=device, dtype=torch.float32) / (d ** 0.5) * (d ** 0.5) / 31.0
-    Q = (Qd / Qd.norm(dim=1, keepdim=True)).double().cpu().numpy()
-    eps = args.eps if args.eps > 0 else calibrate_eps(X, args.k)
+    Q = make_queries(X, nq_total, 43)
+    if args.eps > 0:
+        eps = args.eps
+    elif args.lambda_mode == "feature":
+        eps = calibrate_feature_eps(X, args.k, args.metric)
+    else:
+        eps = calibrate_eps(X, args.k, args.metric)
     if dist is not None:
         # every rank derives the same queries and eps from the same seeds; broadcast rank 0's anyway so that
         # a bit-level difference between devices can never desynchronise the ranks' control flow
@@ -124,7 +168,9 @@ def main():
         dist.broadcast(et, 0)
         Q = qt.cpu().numpy()
         eps = float(et.item())
-    gp = {"eps": eps, "k": args.k, "topk": args.topk, "p": 2.0, "sigma": None}
+    gp = {"eps": eps, "k": args.k, "topk": args.topk, "p": 2.0, "sigma": None, "metric": args.metric, "kernel": args.kernel,
+          "lambda_mode": args.lambda_mode}
+    feature = args.lambda_mode == "feature"
 
     def barrier():
         if dist is not None:
@@ -205,14 +251,18 @@ def main():
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
     mfma_tf = bstats["mfma_flops"] / max(bstats["knn_mfma_s"], 1e-9) / 1e12
+    mfma_peak = MFMA_F64_PEAK_TF if feature else MFMA_F32_PEAK_TF
+    build_kernel = "gram_f64_kernel" if feature else "knn_mfma_dma8_kernel<%s>" % args.metric
 
-    # HBM-side traffic per launch from the committed PMC profile (only for the profiled workload)
+    # HBM-side traffic per launch: not measurable inside this process (PMC counters need rocprofv3 around it) --
+    # taken from the committed profile of the same workload, profiles/traffic.json (profiles/collect.sh), and
+    # labelled so; null for any other workload
     traffic_scan = traffic_mfma = traffic_batch = None
     # rows up to 1024 floats take the LDS-DMA ring scan, wider rows the register-staged one
     scan_kernel = "scan_dma_kernel" if d <= 1024 and os.environ.get("ARROWSPACE_SCAN_VARIANT", "0") in ("", "0") else "scan_dots_f32_kernel"
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if tj["workload"] == {"n": n, "d": d} and world == 1:
+        if tj["workload"] == {"n": n, "d": d} and world == 1 and args.metric == "l2" and not feature:
             traffic_scan = tj.get(scan_kernel, {}).get("bytes_per_launch")
             traffic_mfma = tj.get("knn_mfma_kernel", {}).get("bytes_per_launch")
             traffic_batch = tj.get("scan_gemm_kernel", {}).get("bytes_per_launch")
@@ -232,15 +282,20 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "synthetic clustered N=%d x D=%d fp32, k=%d topk=%d tau=%.2f eps=%.5f (mean degree ~2k), "
-                               "L2 metric + Gaussian weights; BASELINE.json headline config" % (n, d, args.k, args.topk, args.tau, eps),
-                   "n": n, "d": d, "parallelism": "row-shard x%d" % world},
+        "config": {"workload": "SURVEY 8(d) synthetic: np.random.default_rng(42) clustered N=%d x D=%d fp32 (1024 centres, noise 0.5, "
+                               "rows normalised), k=%d topk=%d tau=%.2f eps=%.5f (calibrated: mean degree ~2k), metric=%s kernel=%s "
+                               "lambda_mode=%s; queries = items perturbed by default_rng(43) noise (deviation from 8(d): a fresh "
+                               "sample of the recipe has no neighbour inside eps); BASELINE.json headline config"
+                               % (n, d, args.k, args.topk, args.tau, eps, args.metric, args.kernel, args.lambda_mode),
+                   "n": n, "d": d, "metric": args.metric, "kernel": args.kernel, "lambda_mode": args.lambda_mode,
+                   "parallelism": "row-shard x%d" % world},
         "index_build_sec": build_s,
         "batched_queries_per_sec": batched_qps,
         "build_stages_sec": {k: bstats[k] for k in ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s")},
         "build_fallback_rows": bstats["fallback_rows"],
         "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
+                     "traffic_source": None if traffic_scan is None else "profiles/traffic.json (rocprofv3 --pmc passes of this workload, profiles/collect.sh)",
                      "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes},
         "roofline_query": {"bound": "hbm", "achieved": query_bytes / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
@@ -251,9 +306,10 @@ def main():
             "frac": query_bytes / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
             "traffic": traffic_batch,
             "note": "whole 32-query pass, host-visible; N*(D+2)*4 bytes per pass; fp32 MFMA work 2*32*N*D flops"},
-        "roofline_build": {"kernel": "knn_mfma_kernel", "bound": "mfma", "achieved": mfma_tf, "peak": MFMA_F32_PEAK_TF,
-                           "unit": "TFLOP/s", "frac": mfma_tf / MFMA_F32_PEAK_TF, "traffic": traffic_mfma,
-                           "flops_issued": bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"]},
+        "roofline_build": {"kernel": build_kernel, "bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak,
+                           "unit": "TFLOP/s", "frac": mfma_tf / mfma_peak, "traffic": traffic_mfma,
+                           "flops_issued": bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"],
+                           "dtype": "f64" if feature else "f32"},
     }
 
     # ---------------- CPU baseline: the oracle (fp64 C/OpenMP restatement) on this box's host cores
@@ -262,23 +318,40 @@ def main():
 
         cores = oracle_c.threads()
         Xh = X.double().cpu().numpy()
-        ref = oracle_c.OracleSearchOnly(Xh, gp, gl.degrees(), aspace.lambdas(), gl.tau0)
         nq = args.cpu_queries
-        ref.search(Q[0], args.tau)
+        if feature:
+            # feature mode: the CPU build is N-linear (Gram + per-item energies) -- timed on the whole index
+            t0 = time.perf_counter()
+            ref = oracle_c.OracleIndex(Xh, gp)
+            cpu_build = [{"value": time.perf_counter() - t0, "unit": "s", "n": n, "sample": "full feature-mode build (fp64 Gram + energies)"}]
+        else:
+            ref = oracle_c.OracleSearchOnly(Xh, gp, gl.degrees(), aspace.lambdas(), gl.tau0)
+            cpu_build = None
+        ref.search(Q[0], args.tau, fused=True)
         t0 = time.perf_counter()
         for i in range(nq):
-            ref.search(Q[(args.warmup + i) % len(Q)], args.tau)
+            ref.search(Q[(args.warmup + i) % len(Q)], args.tau, fused=True)
         cpu_dt = time.perf_counter() - t0
-        nb = min(args.cpu_build_n, n)
-        t0 = time.perf_counter()
-        oracle_c.OracleIndex(Xh[:nb], gp)
-        cpu_build = time.perf_counter() - t0
+        del ref
+        if cpu_build is None:
+            # all-pairs fp64 build: N^2 work, timed at the sizes SURVEY 8(d) names, never extrapolated into `value`
+            cpu_build, per_pair = [], None
+            for nb in sorted(set(min(v, n) for v in args.cpu_build_n)):
+                if per_pair is not None and per_pair * nb * nb > args.cpu_build_budget:
+                    cpu_build.append({"value": None, "unit": "s", "n": nb, "sample": "skipped: predicted %.0f s from the smaller size"
+                                      % (per_pair * nb * nb)})
+                    continue
+                t0 = time.perf_counter()
+                oracle_c.OracleIndex(Xh[:nb], gp)
+                tb_ = time.perf_counter() - t0
+                per_pair = tb_ / (nb * nb)
+                cpu_build.append({"value": tb_, "unit": "s", "n": nb, "sample": "all-pairs fp64 build on the first %d rows" % nb})
         out["cpu_baseline"] = {
             "value": nq / cpu_dt, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": "%d single queries over the full N=%d x D=%d fp64 items (two fp64 scans per query: lambda_q k-NN + "
-                      "scorer), OpenMP over items" % (nq, n, d),
-            "index_build": {"value": cpu_build, "unit": "s", "n": nb,
-                            "sample": "all-pairs fp64 build on the first %d rows only (N^2 work: not extrapolated)" % nb},
+            "sample": "%d single queries over the full N=%d x D=%d fp64 items; one fused pass per query (neighbour search and "
+                      "cosines from the same read of the items, scorer over the kept cosines), OpenMP static over items, items "
+                      "first-touched by the threads that scan them; %.2f GB/s effective" % (nq, n, d, n * d * 8.0 * nq / cpu_dt / 1e9),
+            "index_build": cpu_build,
         }
     if rank == 0:
         print(json.dumps(out))

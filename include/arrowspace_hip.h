@@ -50,6 +50,13 @@ typedef struct {
 
 enum { AS_METRIC_L2 = 0, AS_METRIC_COSINE = 1 };
 enum { AS_KERNEL_GAUSSIAN = 0, AS_KERNEL_RATIONAL = 1 };
+/* Which lambda the index carries.  ITEM: node-local spectral energy on the N-node item graph (BASELINE.json
+ * north_star).  FEATURE: the synthetic index of the reference's notes -- a Rayleigh quotient and an edgewise
+ * dispersion on an F x F feature-space Laplacian whose nodes are the D columns of the item matrix
+ * (/root/reference/TAUMODE.md:8,12-27, GRAPH_VARIABLES.md:17); the GraphLaplacian is then that F x F object
+ * (nnodes == nfeatures), the one `prepare_query_item(&v, gl)` takes the query's quotient against
+ * (/root/reference/src/lib.rs:154). */
+enum { AS_LAMBDA_ITEM = 0, AS_LAMBDA_FEATURE = 1 };
 enum { AS_KEEP_F64_AUTO = 0, AS_KEEP_F64_ALWAYS = 1 };
 enum { AS_DTYPE_F32 = 0, AS_DTYPE_F64 = 1 };
 
@@ -62,7 +69,9 @@ typedef struct {
     int32_t keep_f64; /* AS_KEEP_F64_*: AUTO keeps an fp64 copy of the items only when
                          they are not exactly representable in fp32 */
     int32_t force_exact; /* 1: skip the fp32 fast paths (fp64 everywhere; for tests) */
-    int32_t reserved[3];
+    int32_t search_mode; /* test hook: start searches on a fallback path (bit0 fp64, bit1 wavefront-list selection) */
+    int32_t lambda_mode; /* AS_LAMBDA_* */
+    int32_t reserved;
 } as_opts;
 
 typedef struct as_space as_space; /* crate `ArrowSpace`      (src/lib.rs:64-67)  */
@@ -97,6 +106,23 @@ as_status as_knn_rows(const as_space* sp, const as_graph_params* gp, int64_t row
 as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx_dev,
                             const double* dist_dev, const double* gy_dev, const int32_t* cnt_dev,
                             as_graph** out_graph);
+
+/* ---- staged build, feature mode (AS_LAMBDA_FEATURE): what as_build composes when opts->lambda_mode selects
+ *      the F x F feature-space Laplacian; multi-GPU hosts call the steps with a row range per rank and exchange
+ *      the D x D Gram partials and the N energies in between ---- */
+
+/* step 2f: Gram of the columns over items [row_begin, row_end): out_gram_dev[a*d + b] = sum_i x_ia x_ib
+ * (fp64, d x d, symmetric, device).  Partial Grams of disjoint row ranges add up to the full one. */
+as_status as_feat_gram(const as_space* sp, int64_t row_begin, int64_t row_end, double* out_gram_dev);
+/* step 3f: feature graph (k-NN over the D columns, union symmetrisation, weights, degrees; L = D - W) from
+ * the complete Gram. */
+as_status as_feat_graph(const as_space* sp, const as_graph_params* gp, const double* gram_dev, as_graph** out_graph);
+/* step 4f: Rayleigh energy E and dispersion G of items [row_begin, row_end), written at those positions of
+ * the n-long device arrays. */
+as_status as_feat_energy(const as_space* sp, const as_graph* gr, int64_t row_begin, int64_t row_end,
+                         double* E_dev, double* G_dev);
+/* step 5f: tau0 = median of the positive E, lambdas of all n items into the space (E, G complete, device). */
+as_status as_feat_lambdas(as_space* sp, as_graph* gr, const double* E_dev, const double* G_dev);
 
 /* ---- search: replaces prepare_query_item + search_lambda_aware, src/lib.rs:154,173 ---- */
 
@@ -177,6 +203,7 @@ int64_t as_graph_nnz(const as_graph* gr); /* stored Laplacian entries incl. diag
 as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, double* values);
 as_status as_graph_degrees(const as_graph* gr, double* out);
 double as_graph_tau0(const as_graph* gr);
+int32_t as_graph_lambda_mode(const as_graph* gr); /* AS_LAMBDA_* */
 /* device pointer to the fp64 lambdas (n) -- for multi-GPU hosts */
 const double* as_lambdas_dev(const as_space* sp);
 

@@ -41,6 +41,13 @@ typedef struct {
     double tau0;
     int64_t *knn_idx; /* n*k directed lists (-1 padded) */
     int64_t *knn_cnt;
+    /* feature mode (SPEC F1-F7): the graph arrays above then describe the D-node feature graph */
+    int fmode;
+    int64_t nnodes;   /* n (item mode) or d (feature mode) */
+    int64_t ne;       /* edges a < b */
+    int64_t *ea, *eb;
+    double *ew;
+    double *colm;     /* d: squared column norms */
 } aso_index;
 
 static double edge_weight(double d, double sigma, double p, int kernel) {
@@ -140,6 +147,7 @@ void aso_free(aso_index *ix) {
     free(ix->X); free(ix->nrm); free(ix->ny); free(ix->indptr); free(ix->indices);
     free(ix->dist); free(ix->gy); free(ix->w); free(ix->lap); free(ix->deg);
     free(ix->E); free(ix->G); free(ix->lam); free(ix->knn_idx); free(ix->knn_cnt);
+    free(ix->ea); free(ix->eb); free(ix->ew); free(ix->colm);
     free(ix);
 }
 
@@ -149,7 +157,7 @@ aso_index *aso_build(const double *X, int64_t n, int64_t d, double eps, int64_t 
     if (n <= 0 || d <= 0 || k <= 0) return NULL;
     aso_index *ix = (aso_index *)calloc(1, sizeof(aso_index));
     ix->n = n; ix->d = d; ix->eps = eps; ix->k = k; ix->p = p; ix->sigma = sigma;
-    ix->metric = metric; ix->kernel = kernel;
+    ix->metric = metric; ix->kernel = kernel; ix->nnodes = n;
     ix->X = (double *)malloc(sizeof(double) * n * d);
     memcpy(ix->X, X, sizeof(double) * n * d);
     ix->nrm = (double *)malloc(sizeof(double) * n);
@@ -281,40 +289,189 @@ aso_index *aso_build(const double *X, int64_t n, int64_t d, double eps, int64_t 
     return ix;
 }
 
-/* SPEC S10: prepare_query_item (src/lib.rs:154) restated. */
-double aso_query_lambda(const aso_index *ix, const double *q) {
-    const int64_t n = ix->n, d = ix->d, k = ix->k;
-    const double nq = dotp(q, q, d);
-    const double epskey = ix->metric == ASO_L2 ? ix->eps * ix->eps : ix->eps;
-    int nth = 1;
-#ifdef _OPENMP
-    nth = omp_get_max_threads();
-#endif
-    cand_t *part = (cand_t *)malloc(sizeof(cand_t) * k * nth);
-    int64_t *pcnt = (int64_t *)calloc(nth, sizeof(int64_t));
-#pragma omp parallel
-    {
-        int t = 0;
-#ifdef _OPENMP
-        t = omp_get_thread_num();
-#endif
-        cand_t *lst = part + (int64_t)t * k;
-        int64_t m = 0;
-#pragma omp for schedule(static)
-        for (int64_t j = 0; j < n; ++j) {
-            cand_t c;
-            c.j = j;
-            pair_q(q, ix->X + j * d, d, nq, ix->nrm[j], ix->metric, &c.key, &c.dist, &c.gy);
-            if (c.key <= epskey) cand_insert(lst, &m, k, c);
-        }
-        pcnt[t] = m;
+/* ---------------------------------------------------------------------------------------------
+ * Feature mode (SPEC F1-F7, oracle_np.feature_graph / feature_energy): lambda = the synthetic index of
+ * TAUMODE.md:8,12-27 on the F x F feature-space Laplacian of GRAPH_VARIABLES.md:17, whose nodes are the
+ * D columns of the item matrix (same graph parameters, distance and kernel as GRAPH_VARIABLES.md:7-10). */
+
+/* SPEC F6: (E, G) of one vector over the edge list a < b */
+static void feature_energy(const aso_index *ix, const double *x, double *Eo, double *Go) {
+    double T = 0.0, nx = 0.0;
+    for (int64_t c = 0; c < ix->d; ++c) nx += x[c] * x[c];
+    for (int64_t e = 0; e < ix->ne; ++e) {
+        double t = x[ix->ea[e]] - x[ix->eb[e]];
+        T += ix->ew[e] * t * t;
     }
-    cand_t *lst = (cand_t *)malloc(sizeof(cand_t) * k);
-    int64_t m = 0;
-    for (int t = 0; t < nth; ++t)
-        for (int64_t s = 0; s < pcnt[t]; ++s) cand_insert(lst, &m, k, part[(int64_t)t * k + s]);
-    free(part);
-    free(pcnt);
+    double G = 0.0;
+    if (T > 0.0) {
+        for (int64_t e = 0; e < ix->ne; ++e) {
+            double t = x[ix->ea[e]] - x[ix->eb[e]];
+            double r = ix->ew[e] * t * t / T;
+            G += r * r;
+        }
+        G = G < 0.0 ? 0.0 : (G > 1.0 ? 1.0 : G);
+    }
+    *Eo = nx > 0.0 ? T / nx : 0.0;
+    *Go = G;
+}
+
+aso_index *aso_build_feature(const double *X, int64_t n, int64_t d, double eps, int64_t k, double p, double sigma,
+                             int metric, int kernel) {
+    if (n <= 0 || d <= 0 || k <= 0) return NULL;
+    aso_index *ix = (aso_index *)calloc(1, sizeof(aso_index));
+    ix->n = n; ix->d = d; ix->eps = eps; ix->k = k; ix->p = p; ix->sigma = sigma;
+    ix->metric = metric; ix->kernel = kernel; ix->fmode = 1; ix->nnodes = d;
+    ix->X = (double *)malloc(sizeof(double) * n * d);
+    memcpy(ix->X, X, sizeof(double) * n * d);
+    ix->nrm = (double *)malloc(sizeof(double) * n);
+    for (int64_t i = 0; i < n; ++i) ix->nrm[i] = dotp(X + i * d, X + i * d, d);
+    /* F1: Gram of the columns (row-major accumulation over the items, fixed order) */
+    double *gram = (double *)calloc((size_t)d * d, sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < d; ++a)
+        for (int64_t i = 0; i < n; ++i) {
+            const double xa = X[i * d + a];
+            const double *row = X + i * d;
+            double *g = gram + a * d;
+            for (int64_t b = a; b < d; ++b) g[b] += xa * row[b];
+        }
+    for (int64_t a = 0; a < d; ++a)
+        for (int64_t b = 0; b < a; ++b) gram[a * d + b] = gram[b * d + a];
+    ix->colm = (double *)malloc(sizeof(double) * d);
+    for (int64_t a = 0; a < d; ++a) ix->colm[a] = gram[a * d + a];
+    /* F2: key / dist per pair (stored in place of the Gram: key in gram, dist derived) */
+    const double epskey = metric == ASO_L2 ? eps * eps : eps;
+    cand_t *lists = (cand_t *)malloc(sizeof(cand_t) * d * k);
+    int64_t *cnt = (int64_t *)calloc(d, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t a = 0; a < d; ++a) {
+        cand_t *lst = lists + a * k;
+        int64_t m = 0;
+        for (int64_t b = 0; b < d; ++b) {
+            if (b == a) continue;
+            cand_t c;
+            c.j = b;
+            c.gy = 0.0;
+            const double g = gram[a * d + b], ma = ix->colm[a], mb = ix->colm[b];
+            if (metric == ASO_L2) {
+                double key = ma + mb - 2.0 * g;
+                c.key = key > 0.0 ? key : 0.0;
+                c.dist = sqrt(c.key);
+            } else {
+                double den = sqrt(ma * mb);
+                double cs = den > 0.0 ? g / den : 0.0;
+                c.key = 1.0 - (cs > 0.0 ? (cs < 1.0 ? cs : 1.0) : 0.0);
+                c.dist = c.key;
+            }
+            if (c.key <= epskey) cand_insert(lst, &m, k, c);   /* F3: (key asc, b asc), first k */
+        }
+        cnt[a] = m;
+    }
+    free(gram);
+    ix->knn_idx = (int64_t *)malloc(sizeof(int64_t) * d * k);
+    ix->knn_cnt = cnt;
+    for (int64_t a = 0; a < d; ++a)
+        for (int64_t t = 0; t < k; ++t) ix->knn_idx[a * k + t] = t < cnt[a] ? lists[a * k + t].j : -1;
+    /* F4: union symmetrisation (the pair's payload is symmetric: the Gram is) */
+    int64_t *rowlen = (int64_t *)calloc(d + 1, sizeof(int64_t));
+    for (int64_t a = 0; a < d; ++a) rowlen[a] = cnt[a];
+    for (int64_t a = 0; a < d; ++a)
+        for (int64_t t = 0; t < cnt[a]; ++t) {
+            int64_t b = lists[a * k + t].j;
+            int found = 0;
+            for (int64_t s = 0; s < cnt[b]; ++s)
+                if (lists[b * k + s].j == a) { found = 1; break; }
+            if (!found) rowlen[b] += 1;
+        }
+    ix->indptr = (int64_t *)malloc(sizeof(int64_t) * (d + 1));
+    ix->indptr[0] = 0;
+    for (int64_t a = 0; a < d; ++a) ix->indptr[a + 1] = ix->indptr[a] + rowlen[a];
+    const int64_t nnz = ix->indptr[d];
+    const size_t na = (size_t)(nnz ? nnz : 1);
+    ix->indices = (int64_t *)malloc(sizeof(int64_t) * na);
+    ix->dist = (double *)malloc(sizeof(double) * na);
+    ix->w = (double *)malloc(sizeof(double) * na);
+    ix->lap = (double *)malloc(sizeof(double) * na);
+    ix->gy = (double *)calloc(na, sizeof(double));
+    cand_t *ent = (cand_t *)malloc(sizeof(cand_t) * na);
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * d);
+    for (int64_t a = 0; a < d; ++a) cur[a] = ix->indptr[a];
+    for (int64_t a = 0; a < d; ++a)
+        for (int64_t t = 0; t < cnt[a]; ++t) ent[cur[a]++] = lists[a * k + t];
+    for (int64_t a = 0; a < d; ++a)
+        for (int64_t t = 0; t < cnt[a]; ++t) {
+            int64_t b = lists[a * k + t].j;
+            int found = 0;
+            for (int64_t s = 0; s < cnt[b]; ++s)
+                if (lists[b * k + s].j == a) { found = 1; break; }
+            if (!found) {
+                cand_t c = lists[a * k + t];
+                c.j = a;
+                ent[cur[b]++] = c;
+            }
+        }
+    free(cur);
+    free(rowlen);
+    free(lists);
+    /* sort rows by column (insertion sort: rows are short) and compute weights, degrees (F5) */
+    ix->deg = (double *)calloc(d, sizeof(double));
+    for (int64_t a = 0; a < d; ++a) {
+        int64_t lo = ix->indptr[a], hi = ix->indptr[a + 1];
+        for (int64_t u = lo + 1; u < hi; ++u) {
+            cand_t c = ent[u];
+            int64_t v = u;
+            while (v > lo && ent[v - 1].j > c.j) { ent[v] = ent[v - 1]; --v; }
+            ent[v] = c;
+        }
+        double s = 0.0;
+        for (int64_t e = lo; e < hi; ++e) {
+            ix->indices[e] = ent[e].j;
+            ix->dist[e] = ent[e].dist;
+            ix->w[e] = edge_weight(ent[e].dist, sigma, p, kernel);
+            ix->lap[e] = -ix->w[e];
+            s += ix->w[e];
+        }
+        ix->deg[a] = s;
+    }
+    free(ent);
+    ix->ne = 0;
+    ix->ea = (int64_t *)malloc(sizeof(int64_t) * na);
+    ix->eb = (int64_t *)malloc(sizeof(int64_t) * na);
+    ix->ew = (double *)malloc(sizeof(double) * na);
+    for (int64_t a = 0; a < d; ++a)
+        for (int64_t e = ix->indptr[a]; e < ix->indptr[a + 1]; ++e)
+            if (a < ix->indices[e]) {
+                ix->ea[ix->ne] = a;
+                ix->eb[ix->ne] = ix->indices[e];
+                ix->ew[ix->ne] = ix->w[e];
+                ix->ne += 1;
+            }
+    /* F6 per item, F7 */
+    ix->E = (double *)calloc(n, sizeof(double));
+    ix->G = (double *)calloc(n, sizeof(double));
+    ix->lam = (double *)calloc(n, sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) feature_energy(ix, X + i * d, &ix->E[i], &ix->G[i]);
+    double *pos = (double *)malloc(sizeof(double) * n);
+    int64_t np_ = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (ix->E[i] > 0.0) pos[np_++] = ix->E[i];
+    double tau0 = ASO_TAU_MIN;
+    if (np_ > 0) {
+        qsort(pos, (size_t)np_, sizeof(double), cmp_f64);
+        tau0 = pos[(np_ - 1) / 2];
+        if (tau0 < ASO_TAU_MIN) tau0 = ASO_TAU_MIN;
+        if (tau0 > 1.0) tau0 = 1.0;
+    }
+    free(pos);
+    ix->tau0 = tau0;
+    for (int64_t i = 0; i < n; ++i)
+        ix->lam[i] = tau0 * (ix->E[i] / (ix->E[i] + tau0)) + (1.0 - tau0) * ix->G[i];
+    return ix;
+}
+
+/* SPEC S10, second half: lambda of the query appended as a node with the m neighbours in lst (any order) */
+static double lambda_from_list(const aso_index *ix, cand_t *lst, int64_t m, double nq) {
     double lam = 0.0;
     if (m > 0) {
         /* ascending-j order for every sum */
@@ -350,6 +507,49 @@ double aso_query_lambda(const aso_index *ix, const double *q) {
         }
         free(a);
     }
+    return lam;
+}
+
+/* SPEC S10: prepare_query_item (src/lib.rs:154) restated. */
+double aso_query_lambda(const aso_index *ix, const double *q) {
+    if (ix->fmode) {
+        double E, G;
+        feature_energy(ix, q, &E, &G);
+        return ix->tau0 * (E / (E + ix->tau0)) + (1.0 - ix->tau0) * G;
+    }
+    const int64_t n = ix->n, d = ix->d, k = ix->k;
+    const double nq = dotp(q, q, d);
+    const double epskey = ix->metric == ASO_L2 ? ix->eps * ix->eps : ix->eps;
+    int nth = 1;
+#ifdef _OPENMP
+    nth = omp_get_max_threads();
+#endif
+    cand_t *part = (cand_t *)malloc(sizeof(cand_t) * k * nth);
+    int64_t *pcnt = (int64_t *)calloc(nth, sizeof(int64_t));
+#pragma omp parallel
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        cand_t *lst = part + (int64_t)t * k;
+        int64_t m = 0;
+#pragma omp for schedule(static)
+        for (int64_t j = 0; j < n; ++j) {
+            cand_t c;
+            c.j = j;
+            pair_q(q, ix->X + j * d, d, nq, ix->nrm[j], ix->metric, &c.key, &c.dist, &c.gy);
+            if (c.key <= epskey) cand_insert(lst, &m, k, c);
+        }
+        pcnt[t] = m;
+    }
+    cand_t *lst = (cand_t *)malloc(sizeof(cand_t) * k);
+    int64_t m = 0;
+    for (int t = 0; t < nth; ++t)
+        for (int64_t s = 0; s < pcnt[t]; ++s) cand_insert(lst, &m, k, part[(int64_t)t * k + s]);
+    free(part);
+    free(pcnt);
+    double lam = lambda_from_list(ix, lst, m, nq);
     free(lst);
     return lam;
 }
@@ -406,6 +606,93 @@ int64_t aso_search(const aso_index *ix, const double *q, double tau, int64_t top
     return aso_search_with_lambda(ix, q, tau, lq, topk, out_idx, out_score);
 }
 
+/* The same search in ONE pass over the items (what a tuned CPU implementation does; bench.py's cpu_baseline):
+ * the pass that finds the query's neighbours keeps every cosine, the scorer then runs over those N numbers.
+ * Bit-identical results to aso_search. */
+int64_t aso_search_fused(const aso_index *ix, const double *q, double tau, int64_t topk, int64_t *out_idx,
+                         double *out_score, double *out_lambda_q) {
+    if (ix->fmode) return aso_search(ix, q, tau, topk, out_idx, out_score, out_lambda_q);
+    const int64_t n = ix->n, d = ix->d, k = ix->k;
+    const double nq = dotp(q, q, d);
+    const double epskey = ix->metric == ASO_L2 ? ix->eps * ix->eps : ix->eps;
+    if (topk > n) topk = n;
+    int nth = 1;
+#ifdef _OPENMP
+    nth = omp_get_max_threads();
+#endif
+    double *cosv = (double *)malloc(sizeof(double) * n);
+    cand_t *part = (cand_t *)malloc(sizeof(cand_t) * k * nth);
+    int64_t *pcnt = (int64_t *)calloc(nth, sizeof(int64_t));
+#pragma omp parallel
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        cand_t *lst = part + (int64_t)t * k;
+        int64_t m = 0;
+#pragma omp for schedule(static)
+        for (int64_t j = 0; j < n; ++j) {
+            cand_t c;
+            c.j = j;
+            double g;
+            if (ix->metric == ASO_L2) {
+                pair_q(q, ix->X + j * d, d, nq, ix->nrm[j], ix->metric, &c.key, &c.dist, &c.gy);
+                g = c.gy;
+                double den = sqrt(ix->nrm[j] * nq);
+                cosv[j] = den > 0.0 ? g / den : 0.0;
+            } else {
+                g = dotp(q, ix->X + j * d, d);
+                double den = sqrt(nq * ix->nrm[j]);
+                double cs = den > 0.0 ? g / den : 0.0;
+                double den2 = sqrt(ix->nrm[j] * nq);
+                cosv[j] = den2 > 0.0 ? g / den2 : 0.0;
+                c.key = c.dist = 1.0 - (cs > 0.0 ? (cs < 1.0 ? cs : 1.0) : 0.0);
+                c.gy = cs;
+            }
+            if (c.key <= epskey) cand_insert(lst, &m, k, c);
+        }
+        pcnt[t] = m;
+    }
+    cand_t *lst = (cand_t *)malloc(sizeof(cand_t) * k);
+    int64_t m = 0;
+    for (int t = 0; t < nth; ++t)
+        for (int64_t s = 0; s < pcnt[t]; ++s) cand_insert(lst, &m, k, part[(int64_t)t * k + s]);
+    free(part);
+    const double lq = lambda_from_list(ix, lst, m, nq);
+    free(lst);
+    if (out_lambda_q) *out_lambda_q = lq;
+    if (lq == 0.0) {
+        free(cosv); free(pcnt);
+        return -1;
+    }
+    cand_t *tpart = (cand_t *)malloc(sizeof(cand_t) * topk * nth);
+#pragma omp parallel
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        cand_t *tl = tpart + (int64_t)t * topk;
+        int64_t mm = 0;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            double sc = tau * cosv[i] + (1.0 - tau) / (1.0 + fabs(lq - ix->lam[i]));
+            cand_t cd;
+            cd.key = -sc; cd.j = i; cd.dist = sc; cd.gy = 0.0;
+            cand_insert(tl, &mm, topk, cd);
+        }
+        pcnt[t] = mm;
+    }
+    cand_t *fl = (cand_t *)malloc(sizeof(cand_t) * topk);
+    int64_t fm = 0;
+    for (int t = 0; t < nth; ++t)
+        for (int64_t s2 = 0; s2 < pcnt[t]; ++s2) cand_insert(fl, &fm, topk, tpart[(int64_t)t * topk + s2]);
+    for (int64_t t = 0; t < fm; ++t) { out_idx[t] = fl[t].j; out_score[t] = fl[t].dist; }
+    free(tpart); free(pcnt); free(fl); free(cosv);
+    return fm;
+}
+
 /* all N scores (for parity checks of the scorer itself) */
 void aso_scores(const aso_index *ix, const double *q, double tau, double lambda_q, double *out) {
     const int64_t n = ix->n, d = ix->d;
@@ -422,7 +709,8 @@ void aso_scores(const aso_index *ix, const double *q, double tau, double lambda_
 /* accessors for the ctypes wrapper */
 int64_t aso_n(const aso_index *ix) { return ix->n; }
 int64_t aso_d(const aso_index *ix) { return ix->d; }
-int64_t aso_nnz(const aso_index *ix) { return ix->indptr[ix->n]; }
+int64_t aso_nnz(const aso_index *ix) { return ix->indptr[ix->nnodes]; }
+int64_t aso_nnodes(const aso_index *ix) { return ix->nnodes; }
 double aso_tau0(const aso_index *ix) { return ix->tau0; }
 const int64_t *aso_indptr(const aso_index *ix) { return ix->indptr; }
 const int64_t *aso_indices(const aso_index *ix) { return ix->indices; }
@@ -446,19 +734,21 @@ int aso_threads(void) {
 }
 
 /* Search-only index from precomputed parts (bench.py cpu_baseline: the CPU scorer is
- * timed at full N without paying for an all-pairs CPU build). X is borrowed, not copied. */
+ * timed at full N without paying for an all-pairs CPU build).  The items are copied with the same static
+ * schedule the scans use, so every thread first-touches (NUMA-places) the rows it will read. */
 aso_index *aso_from_parts(double *X, int64_t n, int64_t d, double eps, int64_t k, double p, double sigma, int metric,
                           int kernel, const double *deg, const double *lam, double tau0) {
     aso_index *ix = (aso_index *)calloc(1, sizeof(aso_index));
     ix->n = n; ix->d = d; ix->eps = eps; ix->k = k; ix->p = p; ix->sigma = sigma;
-    ix->metric = metric; ix->kernel = kernel; ix->tau0 = tau0;
-    ix->X = X;
+    ix->metric = metric; ix->kernel = kernel; ix->tau0 = tau0; ix->nnodes = n;
+    ix->X = (double *)malloc(sizeof(double) * n * d);
     ix->nrm = (double *)malloc(sizeof(double) * n);
     ix->ny = (double *)malloc(sizeof(double) * n);
     ix->deg = (double *)malloc(sizeof(double) * n);
     ix->lam = (double *)malloc(sizeof(double) * n);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
+        memcpy(ix->X + i * d, X + i * d, sizeof(double) * d);
         ix->nrm[i] = dotp(X + i * d, X + i * d, d);
         ix->ny[i] = metric == ASO_L2 ? ix->nrm[i] : (ix->nrm[i] > 0.0 ? 1.0 : 0.0);
         ix->deg[i] = deg[i];
@@ -466,8 +756,4 @@ aso_index *aso_from_parts(double *X, int64_t n, int64_t d, double eps, int64_t k
     }
     return ix;
 }
-void aso_free_parts(aso_index *ix) {
-    if (!ix) return;
-    ix->X = NULL;
-    aso_free(ix);
-}
+void aso_free_parts(aso_index *ix) { aso_free(ix); }

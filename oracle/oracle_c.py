@@ -34,15 +34,19 @@ def lib():
         pi64 = C.POINTER(C.c_int64)
         L.aso_build.restype = C.c_void_p
         L.aso_build.argtypes = [p64, C.c_int64, C.c_int64, C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.aso_build_feature.restype = C.c_void_p
+        L.aso_build_feature.argtypes = L.aso_build.argtypes
         L.aso_free.argtypes = [C.c_void_p]
         L.aso_query_lambda.restype = C.c_double
         L.aso_query_lambda.argtypes = [C.c_void_p, p64]
         L.aso_search.restype = C.c_int64
         L.aso_search.argtypes = [C.c_void_p, p64, C.c_double, C.c_int64, pi64, p64, p64]
+        L.aso_search_fused.restype = C.c_int64
+        L.aso_search_fused.argtypes = L.aso_search.argtypes
         L.aso_search_with_lambda.restype = C.c_int64
         L.aso_search_with_lambda.argtypes = [C.c_void_p, p64, C.c_double, C.c_double, C.c_int64, pi64, p64]
         L.aso_scores.argtypes = [C.c_void_p, p64, C.c_double, C.c_double, p64]
-        for name in ("aso_n", "aso_d", "aso_nnz"):
+        for name in ("aso_n", "aso_d", "aso_nnz", "aso_nnodes"):
             getattr(L, name).restype = C.c_int64
             getattr(L, name).argtypes = [C.c_void_p]
         L.aso_tau0.restype = C.c_double
@@ -81,18 +85,21 @@ class OracleIndex:
         self.prm = resolve_params(graph_params)
         self.X = X
         L = lib()
-        self._h = L.aso_build(_p64(X), X.shape[0], X.shape[1], self.prm["eps"], self.prm["k"], self.prm["p"],
-                              self.prm["sigma"], self.prm["metric"], self.prm["kernel"])
+        fn = L.aso_build_feature if self.prm["lambda_mode"] == 1 else L.aso_build
+        self._h = fn(_p64(X), X.shape[0], X.shape[1], self.prm["eps"], self.prm["k"], self.prm["p"],
+                     self.prm["sigma"], self.prm["metric"], self.prm["kernel"])
         if not self._h:
             raise ValueError("aso_build failed")
-        n = X.shape[0]
+        nitems = X.shape[0]
+        n = L.aso_nnodes(self._h)   # graph nodes: the items, or the D features in feature mode
         nnz = L.aso_nnz(self._h)
         k = self.prm["k"]
 
         def arr(ptr, m, dt):
             return np.ctypeslib.as_array(ptr, shape=(max(m, 1),))[:m].astype(dt, copy=True)
 
-        self.n = arr(L.aso_norms(self._h), n, np.float64)
+        self.nnodes = n
+        self.n = arr(L.aso_norms(self._h), nitems, np.float64)
         self.indptr = arr(L.aso_indptr(self._h), n + 1, np.int64)
         self.indices = arr(L.aso_indices(self._h), nnz, np.int64)
         self.dist = arr(L.aso_dist(self._h), nnz, np.float64)
@@ -100,9 +107,9 @@ class OracleIndex:
         self.w = arr(L.aso_w(self._h), nnz, np.float64)
         self.lap = arr(L.aso_lap(self._h), nnz, np.float64)
         self.deg = arr(L.aso_deg(self._h), n, np.float64)
-        self.E = arr(L.aso_E(self._h), n, np.float64)
-        self.G = arr(L.aso_G(self._h), n, np.float64)
-        self.lambdas = arr(L.aso_lambdas(self._h), n, np.float64)
+        self.E = arr(L.aso_E(self._h), nitems, np.float64)
+        self.G = arr(L.aso_G(self._h), nitems, np.float64)
+        self.lambdas = arr(L.aso_lambdas(self._h), nitems, np.float64)
         self.knn_idx = arr(L.aso_knn_idx(self._h), n * k, np.int64).reshape(n, k)
         self.knn_cnt = arr(L.aso_knn_cnt(self._h), n, np.int64)
         self.tau0 = L.aso_tau0(self._h)
@@ -122,7 +129,8 @@ class OracleIndex:
         lib().aso_scores(self._h, _p64(q), tau, lambda_q, _p64(out))
         return out
 
-    def search(self, q, tau, topk=None):
+    def search(self, q, tau, topk=None, fused=False):
+        """fused=True: the one-pass form (aso_search_fused), same results."""
         q = np.ascontiguousarray(q, dtype=np.float64)
         if q.ndim != 1 or q.shape[0] != self.X.shape[1]:
             raise ValueError(f"query length {q.shape[0]} must match nfeatures {self.X.shape[1]}")
@@ -131,7 +139,8 @@ class OracleIndex:
         idx = np.empty(kk, dtype=np.int64)
         sc = np.empty(kk)
         lq = C.c_double(0.0)
-        m = lib().aso_search(self._h, _p64(q), tau, kk, idx.ctypes.data_as(C.POINTER(C.c_int64)), _p64(sc), C.byref(lq))
+        fn = lib().aso_search_fused if fused else lib().aso_search
+        m = fn(self._h, _p64(q), tau, kk, idx.ctypes.data_as(C.POINTER(C.c_int64)), _p64(sc), C.byref(lq))
         if m < 0:
             raise ZeroLambda("The lambdas are zero, check the magnitude of items and eps.")
         return [(int(idx[t]), float(sc[t])) for t in range(m)], lq.value
@@ -143,7 +152,7 @@ class OracleSearchOnly:
     def __init__(self, X, graph_params, deg, lambdas, tau0):
         from .oracle_np import resolve_params
 
-        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        self.X = np.ascontiguousarray(X, dtype=np.float64)   # the library keeps its own, first-touched copy
         self.prm = resolve_params(graph_params)
         self._deg = np.ascontiguousarray(deg, dtype=np.float64)
         self._lam = np.ascontiguousarray(lambdas, dtype=np.float64)

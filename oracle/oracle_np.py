@@ -33,6 +33,8 @@ METRIC_L2 = 0
 METRIC_COSINE = 1
 KERNEL_GAUSSIAN = 0
 KERNEL_RATIONAL = 1
+LAMBDA_ITEM = 0      # lambda_i = node-local energy on the N-node item graph (SPEC S3-S9; north_star)
+LAMBDA_FEATURE = 1   # lambda_i = Rayleigh quotient on the F x F feature-space Laplacian (SPEC F1-F7; TAUMODE.md:8,12-27)
 
 
 def resolve_params(graph_params: dict) -> dict:
@@ -48,6 +50,8 @@ def resolve_params(graph_params: dict) -> dict:
     kernel = graph_params.get("kernel", "gaussian")
     out["metric"] = {"l2": METRIC_L2, "cosine": METRIC_COSINE}[metric] if isinstance(metric, str) else int(metric)
     out["kernel"] = {"gaussian": KERNEL_GAUSSIAN, "rational": KERNEL_RATIONAL}[kernel] if isinstance(kernel, str) else int(kernel)
+    mode = graph_params.get("lambda_mode", "item")
+    out["lambda_mode"] = {"item": LAMBDA_ITEM, "feature": LAMBDA_FEATURE}[mode] if isinstance(mode, str) else int(mode)
     return out
 
 
@@ -131,6 +135,8 @@ def build(X, graph_params: dict) -> dict:
     if X.ndim != 2 or X.shape[0] == 0 or X.shape[1] == 0:
         raise ValueError("items must be non-empty 2D array")
     prm = resolve_params(graph_params)
+    if prm["lambda_mode"] == LAMBDA_FEATURE:
+        return build_feature(X, prm)
     n, lists = knn_lists(X, prm)
     return graph_from_lists(X, prm, n, lists)
 
@@ -266,9 +272,113 @@ def lambda_from_neighbours(idx: dict, q, items, dist, gy, deg=None, ny=None) -> 
 
 
 def query_lambda(idx: dict, q) -> float:
-    """SPEC S10: prepare_query_item (src/lib.rs:154) restated: q appended as a node."""
+    """SPEC S10: prepare_query_item (src/lib.rs:154) restated: q appended as a node.
+    Feature mode (SPEC F6/F7): the same functional as the items', on the index's feature Laplacian."""
+    if idx["prm"]["lambda_mode"] == LAMBDA_FEATURE:
+        E, G = feature_energy(idx, np.asarray(q, dtype=np.float64))
+        return float(synth_lambda(E, G, idx["tau0"]))
     items, _, dist, gy = query_neighbours(idx, q)
     return lambda_from_neighbours(idx, q, items, dist, gy)
+
+
+# ---------------------------------------------------------------------------------------------
+# Feature mode: the lambda the reference's notes document (TAUMODE.md:8,12-27) -- a Rayleigh
+# quotient on an F x F feature-space Laplacian whose nodes are the D columns of the item matrix
+# (GRAPH_VARIABLES.md:17 `GraphFactory::build_spectral_laplacian`), built with the same graph
+# parameters and the same distance / kernel options as the item graph (GRAPH_VARIABLES.md:7-10).
+#   F1  column a of X is the feature vector f_a in R^N; m_a = sum_i x_ia^2; Gram g_ab = sum_i x_ia x_ib.
+#   F2  cosine: c = g_ab / sqrt(m_a m_b) (0 if a column is zero), key = dist = 1 - min(1, max(0, c));
+#       l2: key = max(0, m_a + m_b - 2 g_ab) (Gram form), dist = sqrt(key).
+#   F3  directed list of a: b != a with key <= eps (cosine) / eps^2 (l2), order (key asc, b asc), first k.
+#   F4  union symmetrisation, w_ab = kernel(dist_ab; sigma, p).
+#   F5  deg_a = sum_b w_ab (ascending b).  L = D - W: the combinatorial Laplacian, the one for which
+#       x^T L x = sum_{a<b} w_ab (x_a - x_b)^2 with w_ab = -L_ab (TAUMODE.md:18-19).
+#   F6  for a vector x in R^D (an item or a query): e_ab = w_ab (x_a - x_b)^2 over the edges a < b;
+#       T = sum e_ab;  E(x) = T / sum_c x_c^2 (0 for the zero vector);  G(x) = clip(sum (e_ab / T)^2, 0, 1)
+#       (0 if T = 0) -- e_raw and g_clamped of TAUMODE.md:12-27.
+#   F7  tau0 = lower median of the positive E_i (S8), lambda = tau0 E/(E+tau0) + (1-tau0) G (S9 = TAUMODE.md:8).
+#   Query: lambda_q = F6/F7 of the query with the index's tau0; 0 -> the zero-lambda assert (src/lib.rs:156-159).
+# GraphLaplacian is then the F x F object the query's Rayleigh quotient is taken against, as in
+# `prepare_query_item(&v, gl)` (src/lib.rs:154): nnodes = D.
+def feature_graph(X, prm) -> dict:
+    """SPEC F1-F5."""
+    N, D = X.shape
+    m = np.einsum("ia,ia->a", X, X)
+    gram = X.T @ X
+    if prm["metric"] == METRIC_COSINE:
+        den = np.sqrt(np.outer(m, m))
+        c = np.where(den > 0, gram / np.where(den > 0, den, 1.0), 0.0)
+        dist = 1.0 - np.minimum(1.0, np.maximum(0.0, c))
+        key = dist
+    else:
+        key = np.maximum(0.0, m[:, None] + m[None, :] - 2.0 * gram)
+        dist = np.sqrt(key)
+    ek = _eps_key(prm["eps"], prm["metric"])
+    adj = [dict() for _ in range(D)]
+    knn = []
+    for a in range(D):
+        ok = key[a] <= ek
+        ok[a] = False
+        idx = np.nonzero(ok)[0]
+        order = np.lexsort((idx, key[a][idx]))
+        idx = idx[order][: prm["k"]]
+        knn.append(idx)
+        for b in idx:
+            b = int(b)
+            dd = dist[a, b] if a < b else dist[b, a]      # one value per unordered pair
+            adj[a][b] = dd
+            adj[b][a] = dd
+    indptr = np.zeros(D + 1, dtype=np.int64)
+    cols, dists = [], []
+    for a in range(D):
+        js = sorted(adj[a].keys())
+        indptr[a + 1] = indptr[a] + len(js)
+        cols.extend(js)
+        dists.extend(adj[a][b] for b in js)
+    indices = np.asarray(cols, dtype=np.int64)
+    dist_e = np.asarray(dists, dtype=np.float64)
+    w = _edge_weight(dist_e, prm["sigma"], prm["p"], prm["kernel"]) if len(dist_e) else dist_e.copy()
+    deg = np.zeros(D)
+    for a in range(D):
+        s = 0.0
+        for e in range(indptr[a], indptr[a + 1]):
+            s += w[e]
+        deg[a] = s
+    rows = np.repeat(np.arange(D), np.diff(indptr))
+    up = rows < indices                                   # each edge once, ascending (a, b)
+    return dict(m=m, indptr=indptr, indices=indices, dist=dist_e, w=w, deg=deg, lap=-w,
+                ea=rows[up], eb=indices[up], ew=w[up], knn=knn)
+
+
+def feature_energy(idx: dict, x):
+    """SPEC F6 for one vector (or a [n, D] block of vectors): (E, G)."""
+    x = np.asarray(x, dtype=np.float64)
+    one = x.ndim == 1
+    x2 = x[None, :] if one else x
+    ea, eb, ew = idx["ea"], idx["eb"], idx["ew"]
+    diff = x2[:, ea] - x2[:, eb]
+    e = ew[None, :] * diff * diff
+    T = e.sum(axis=1)
+    nx = np.einsum("ic,ic->i", x2, x2)
+    E = np.where(nx > 0, T / np.where(nx > 0, nx, 1.0), 0.0)
+    r = e / np.where(T > 0, T, 1.0)[:, None]
+    G = np.where(T > 0, np.minimum(1.0, np.maximum(0.0, (r * r).sum(axis=1))), 0.0)
+    return (float(E[0]), float(G[0])) if one else (E, G)
+
+
+def build_feature(X, prm) -> dict:
+    """ArrowSpaceBuilder.build in feature mode: SPEC F1-F7."""
+    fg = feature_graph(X, prm)
+    n = np.einsum("ij,ij->i", X, X)
+    out = dict(prm=prm, X=X, n=n, **fg)
+    E = np.zeros(X.shape[0])
+    G = np.zeros(X.shape[0])
+    step = max(1, (1 << 22) // max(1, len(fg["ea"])))
+    for s in range(0, X.shape[0], step):
+        E[s:s + step], G[s:s + step] = feature_energy(out, X[s:s + step])
+    tau0 = median_tau(E)
+    out.update(E=E, G=G, tau0=tau0, lambdas=synth_lambda(E, G, tau0))
+    return out
 
 
 def scores(idx: dict, q, tau: float, lambda_q: float):

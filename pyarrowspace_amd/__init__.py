@@ -56,11 +56,13 @@ def enable_search_stats(enabled: bool) -> None:
 def _parse_graph_params(graph_params) -> tuple[GraphParams, Opts]:
     """src/helpers.rs:48-76.  eps,k,topk,p required; sigma missing/None -> eps*0.5.
     Keys the reference ignores select the documented variants: 'metric' in
-    {'l2','cosine'}, 'kernel' in {'gaussian','rational'}."""
+    {'l2','cosine'}, 'kernel' in {'gaussian','rational'}, 'lambda_mode' in {'item','feature'}
+    (env ARROWSPACE_METRIC / _KERNEL / _LAMBDA_MODE set the defaults)."""
     gp, op = GraphParams(), Opts()
     op.device = int(os.environ.get("ARROWSPACE_DEVICE", "-1"))
     metric = os.environ.get("ARROWSPACE_METRIC", "l2")
     kernel = os.environ.get("ARROWSPACE_KERNEL", "gaussian")
+    lmode = os.environ.get("ARROWSPACE_LAMBDA_MODE", "item")
     if graph_params is None:
         # builder defaults (GRAPH_VARIABLES.md:15: eps~1e-3, k~6, p=2, sigma:=eps)
         gp.eps, gp.k, gp.topk, gp.p, gp.sigma, gp.has_sigma = 1e-3, 6, 3, 2.0, 1e-3, 1
@@ -84,15 +86,18 @@ def _parse_graph_params(graph_params) -> tuple[GraphParams, Opts]:
             gp.sigma, gp.has_sigma = float(sigma), 1
         metric = graph_params.get("metric", metric)
         kernel = graph_params.get("kernel", kernel)
+        lmode = graph_params.get("lambda_mode", lmode)
         op.force_exact = 1 if graph_params.get("force_exact", False) else 0
         op.keep_f64 = 1 if graph_params.get("keep_f64", False) else 0
         # test hook: start searches on a fallback path (bit0 fp64, bit1 wavefront-list selection)
-        op.reserved[0] = int(graph_params.get("_search_mode", 0))
+        op.search_mode = int(graph_params.get("_search_mode", 0))
     if metric not in _lib.METRICS:
         raise ValueError(f"unknown metric {metric!r}; expected one of {sorted(_lib.METRICS)}")
     if kernel not in _lib.KERNELS:
         raise ValueError(f"unknown kernel {kernel!r}; expected one of {sorted(_lib.KERNELS)}")
-    op.metric, op.kernel = _lib.METRICS[metric], _lib.KERNELS[kernel]
+    if lmode not in _lib.LAMBDA_MODES:
+        raise ValueError(f"unknown lambda_mode {lmode!r}; expected one of {sorted(_lib.LAMBDA_MODES)}")
+    op.metric, op.kernel, op.lambda_mode = _lib.METRICS[metric], _lib.KERNELS[kernel], _lib.LAMBDA_MODES[lmode]
     return gp, op
 
 
@@ -136,6 +141,12 @@ class GraphLaplacian:
     def tau0(self) -> float:
         return float(_L.as_graph_tau0(self._h))
 
+    @property
+    def lambda_mode(self) -> str:
+        """'item': N-node item graph, normalised Laplacian.  'feature': the F x F feature-space
+        Laplacian L = D - W of TAUMODE.md:8,12-27 (nnodes == nfeatures)."""
+        return "feature" if _L.as_graph_lambda_mode(self._h) == 1 else "item"
+
     def degrees(self) -> np.ndarray:
         out = np.empty(self.nnodes, dtype=np.float64)
         st = _L.as_graph_degrees(self._h, out.ctypes.data_as(C.c_void_p))
@@ -144,7 +155,8 @@ class GraphLaplacian:
         return out
 
     def to_csr(self):
-        """(indptr, indices, values) of L = I - D^-1/2 W D^-1/2, columns ascending."""
+        """(indptr, indices, values), columns ascending: L = I - D^-1/2 W D^-1/2 of the item graph, or
+        L = D - W of the feature graph (lambda_mode 'feature')."""
         n, nnz = self.nnodes, int(_L.as_graph_nnz(self._h))
         indptr = np.empty(n + 1, dtype=np.int64)
         indices = np.empty(nnz, dtype=np.int64)

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libarrowspace_hip.so")
 AS_OK, AS_EINVAL, AS_EZEROLAMBDA, AS_EHIP, AS_EUNSUPPORTED, AS_ENOMEM = range(6)
 METRICS = {"l2": 0, "cosine": 1}
 KERNELS = {"gaussian": 0, "rational": 1}
+LAMBDA_MODES = {"item": 0, "feature": 1}
 DTYPE_F32, DTYPE_F64 = 0, 1
 
 
@@ -24,7 +25,7 @@ class GraphParams(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("metric", C.c_int32), ("kernel", C.c_int32), ("device", C.c_int32), ("keep_f64", C.c_int32),
-                ("force_exact", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("force_exact", C.c_int32), ("search_mode", C.c_int32), ("lambda_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class KnnRec(C.Structure):
@@ -38,7 +39,8 @@ class HitRec(C.Structure):
 
 # every symbol include/arrowspace_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "as_build", "as_build_dev", "as_space_create_dev", "as_knn_rows", "as_graph_from_knn", "as_search",
+    "as_build", "as_build_dev", "as_space_create_dev", "as_knn_rows", "as_graph_from_knn", "as_feat_gram", "as_feat_graph",
+    "as_feat_energy", "as_feat_lambdas", "as_graph_lambda_mode", "as_search",
     "as_search_batch", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
     "as_query_finish", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
@@ -97,6 +99,11 @@ def load():
         "as_space_create_dev": (i32, [vp, i32, i64, i64, i64, pop, pvp]),
         "as_knn_rows": (i32, [vp, pgp, i64, i64, vp, vp, vp, vp, vp]),
         "as_graph_from_knn": (i32, [vp, pgp, vp, vp, vp, vp, pvp]),
+        "as_feat_gram": (i32, [vp, i64, i64, vp]),
+        "as_feat_graph": (i32, [vp, pgp, vp, pvp]),
+        "as_feat_energy": (i32, [vp, vp, i64, i64, vp, vp]),
+        "as_feat_lambdas": (i32, [vp, vp, vp, vp]),
+        "as_graph_lambda_mode": (i32, [vp]),
         "as_search": (i32, [vp, vp, vp, i64, f64, vp, vp, C.POINTER(i64), C.POINTER(f64)]),
         "as_search_batch": (i32, [vp, vp, vp, i64, i64, f64, vp, vp, vp, vp, vp]),
         "as_query_create": (i32, [vp, vp, pvp]),

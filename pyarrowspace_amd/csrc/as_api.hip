@@ -1,8 +1,10 @@
 // C ABI glue (include/arrowspace_hip.h): argument validation with the reference shim's
 // error behaviour (/root/reference/src/helpers.rs:24-76, src/lib.rs:100-120,140-159),
 // handle lifetime, and the composition of the staged build / search entry points.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <new>
 #include <vector>
 
 #include "as_common.hpp"
@@ -57,6 +59,23 @@ as_status resolve_params(const as_graph_params* gp, as_graph_params* out) {
     return AS_OK;
 }
 
+// Hard limits of the selection kernels, checked before any upload or GPU work (the reference takes any usize,
+// src/helpers.rs:56-63; INTEGRATION.md lists the caps): k-NN candidate lists are one slot per lane of a wave
+// (k + 8 <= 64), scorer lists live in LDS (topk <= 1024).  Both are capped by the number of items first.
+as_status check_limits(const as_graph_params* r, int64_t n, int lambda_mode) {
+    const int64_t k = std::min<int64_t>(r->k, std::max<int64_t>(n - 1, 1));
+    const int64_t topk = std::min<int64_t>(r->topk, n);
+    if (k > 56 && lambda_mode != AS_LAMBDA_FEATURE) {   // the feature graph ranks whole columns: any k up to D - 1
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 56 for n=%lld", (long long)r->k, (long long)n);
+        return AS_EUNSUPPORTED;
+    }
+    if (topk > 1024) {
+        set_err("graph_params['topk']=%lld exceeds the supported maximum of 1024", (long long)r->topk);
+        return AS_EUNSUPPORTED;
+    }
+    return AS_OK;
+}
+
 static as_status pick_device(const as_opts* opts, int* dev) {
     int d = opts ? opts->device : -1;
     if (d < 0) AS_HIP(hipGetDevice(&d));
@@ -97,6 +116,7 @@ void as_free_graph(as_graph* gr) {
     hipSetDevice(gr->device);
     hipFree(gr->indptr); hipFree(gr->indices); hipFree(gr->dist); hipFree(gr->gy); hipFree(gr->w); hipFree(gr->lap);
     hipFree(gr->deg); hipFree(gr->ny); hipFree(gr->E); hipFree(gr->G);
+    hipFree(gr->ea); hipFree(gr->eb); hipFree(gr->ew); hipFree(gr->colm);
     delete gr;
 }
 
@@ -134,6 +154,11 @@ as_status as_space_create_dev(const void* items_dev, int32_t dtype, int64_t n, i
     }
     if (sp->opts.kernel != AS_KERNEL_GAUSSIAN && sp->opts.kernel != AS_KERNEL_RATIONAL) {
         set_err("unknown kernel %d", sp->opts.kernel);
+        delete sp;
+        return AS_EINVAL;
+    }
+    if (sp->opts.lambda_mode != AS_LAMBDA_ITEM && sp->opts.lambda_mode != AS_LAMBDA_FEATURE) {
+        set_err("unknown lambda_mode %d", sp->opts.lambda_mode);
         delete sp;
         return AS_EINVAL;
     }
@@ -196,6 +221,7 @@ as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t 
     *out_graph = nullptr;
     as_graph_params r;
     AS_TRY(resolve_params(gp, &r));
+    if (n > 0) AS_TRY(check_limits(&r, n, opts ? opts->lambda_mode : 0));
     const double t0 = now_s();
     as_space* sp = nullptr;
     AS_TRY(as_space_create_dev(items_dev, dtype, n, d, ld, opts, &sp));
@@ -204,6 +230,21 @@ as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t 
     double *key = nullptr, *dist = nullptr, *gy = nullptr;
     as_graph* gr = new as_graph();
     as_status s = AS_OK;
+    if (sp->opts.lambda_mode == AS_LAMBDA_FEATURE) {
+        // lambda on the F x F feature-space Laplacian: no N x N item graph at all
+        s = feat_build(sp, &r, gr);
+        if (s != AS_OK) {
+            as_free_graph(gr);
+            as_free_space(sp);
+            return s;
+        }
+        gr->stats[0] = t1 - t0;
+        gr->stats[5] = now_s() - t0;
+        dbg("built ArrowSpace: nitems=%lld, nfeatures=%lld, lambdas_len=%lld", (long long)n, (long long)d, (long long)n);
+        *out_space = sp;
+        *out_graph = gr;
+        return AS_OK;
+    }
     do {
         hipError_t e;
         if ((e = hipMalloc(&idx, sizeof(int32_t) * n * r.k)) != hipSuccess || (e = hipMalloc(&cnt, sizeof(int32_t) * n)) != hipSuccess ||
@@ -249,6 +290,7 @@ as_status as_build(const double* items, int64_t n, int64_t d, int64_t row_stride
     }
     as_graph_params r;
     AS_TRY(resolve_params(gp, &r));
+    AS_TRY(check_limits(&r, n, opts ? opts->lambda_mode : 0));   // before the upload
     int dev = 0;
     AS_TRY(pick_device(opts, &dev));
     dbg("items shape: (%lld, %lld)", (long long)n, (long long)d);  // src/helpers.rs:31
@@ -294,6 +336,17 @@ static as_status get_cached_query(const as_space* sp, const as_graph* gr, as_que
 static as_status search_single_locked(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
                                       int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
 
+// the graph handle belongs to this space: item graphs have one node per item, feature graphs one per column
+static as_status graph_matches(const as_space* sp, const as_graph* gr, const char* who) {
+    const bool ok = gr->lambda_mode == AS_LAMBDA_FEATURE ? (gr->n == sp->d && gr->nitems == sp->n) : gr->n == sp->n;
+    if (!ok) {
+        set_err("%s: the graph (%lld nodes) was not built for this space (%lld items x %lld features)", who, (long long)gr->n,
+                (long long)sp->n, (long long)sp->d);
+        return AS_EINVAL;
+    }
+    return AS_OK;
+}
+
 as_status as_search(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau, int64_t* out_idx,
                     double* out_score, int64_t* out_len, double* out_lambda_q) {
     if (!sp || !gr || !query || !out_idx || !out_score) {
@@ -304,10 +357,7 @@ as_status as_search(const as_space* sp, const as_graph* gr, const double* query,
         set_err("query length %lld must match nfeatures %lld", (long long)d, (long long)sp->d);
         return AS_EINVAL;
     }
-    if (gr->n != sp->n) {
-        set_err("as_search: graph has %lld nodes but the space has %lld items", (long long)gr->n, (long long)sp->n);
-        return AS_EINVAL;
-    }
+    AS_TRY(graph_matches(sp, gr, "as_search"));
     std::lock_guard<std::mutex> lock(sp->qmu);
     return search_single_locked(sp, gr, query, d, tau, out_idx, out_score, out_len, out_lambda_q);
 }
@@ -318,7 +368,7 @@ static as_status search_single_locked(const as_space* sp, const as_graph* gr, co
     as_query* q = nullptr;
     AS_TRY(get_cached_query(sp, gr, &q));
     // mode bit0: fp64 end to end, bit1: wavefront-list selection (candidate buffer overflowed)
-    int mode = sp->opts.reserved[0] & 3;  // tests start directly on a fallback path
+    int mode = sp->opts.search_mode & 3;  // tests start directly on a fallback path
     as_status s = AS_OK;
     for (int attempt = 0; attempt < 3; ++attempt) {
         s = search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
@@ -346,12 +396,13 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
         set_err("query length %lld must match nfeatures %lld", (long long)d, (long long)sp->d);
         return AS_EINVAL;
     }
+    AS_TRY(graph_matches(sp, gr, "as_search_batch"));
     const int64_t topk = std::min<int64_t>(gr->gp.topk, sp->n);
     std::lock_guard<std::mutex> lock(sp->qmu);
     AS_HIP(hipSetDevice(sp->device));
     // the batched pass serves QUERY_BATCH queries per read of the items (MFMA pass for rows up to 768 floats,
     // register-resident VALU pass up to 1024): fp32 fast path only
-    const bool batched = sp->dp <= 1024 && !sp->opts.force_exact && (sp->opts.reserved[0] & 3) == 0 && b > 1;
+    const bool batched = sp->dp <= 1024 && !sp->opts.force_exact && (sp->opts.search_mode & 3) == 0 && b > 1;
     if (batched) {
         if (sp->qcache_b && sp->qcache_b_gr != gr) {
             as_query_free(sp->qcache_b);
@@ -394,6 +445,7 @@ int64_t as_nfeatures(const as_space* sp) { return sp ? sp->d : 0; }
 int64_t as_nnodes(const as_graph* gr) { return gr ? gr->n : 0; }
 int64_t as_graph_nnz(const as_graph* gr) { return gr ? gr->nnz + gr->n : 0; }
 double as_graph_tau0(const as_graph* gr) { return gr ? gr->tau0 : 0.0; }
+int32_t as_graph_lambda_mode(const as_graph* gr) { return gr ? gr->lambda_mode : 0; }
 const double* as_lambdas_dev(const as_space* sp) { return sp ? sp->lam64 : nullptr; }
 
 as_status as_get_item(const as_space* sp, int64_t idx, double* out_vec, double* out_lambda) {
@@ -462,7 +514,9 @@ as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, do
         AS_HIP(hipMemcpy(lap.data(), gr->lap, sizeof(double) * nnz, hipMemcpyDeviceToHost));
     }
     AS_HIP(hipMemcpy(deg.data(), gr->deg, sizeof(double) * n, hipMemcpyDeviceToHost));
-    // insert the diagonal (1 for connected nodes, 0 for isolated ones) keeping columns ascending
+    // insert the diagonal keeping columns ascending: normalised Laplacian 1 for connected nodes, 0 for isolated
+    // ones; feature graph (L = D - W) the degree
+    const bool comb = gr->lambda_mode == AS_LAMBDA_FEATURE;
     int64_t w = 0;
     for (int64_t i = 0; i < n; ++i) {
         indptr[i] = w;
@@ -470,7 +524,7 @@ as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, do
         for (int64_t e = ip[i]; e < ip[i + 1]; ++e) {
             if (!placed && col[e] > i) {
                 indices[w] = i;
-                values[w++] = deg[i] > 0.0 ? 1.0 : 0.0;
+                values[w++] = comb ? deg[i] : (deg[i] > 0.0 ? 1.0 : 0.0);
                 placed = true;
             }
             indices[w] = col[e];
@@ -478,7 +532,7 @@ as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, do
         }
         if (!placed) {
             indices[w] = i;
-            values[w++] = deg[i] > 0.0 ? 1.0 : 0.0;
+            values[w++] = comb ? deg[i] : (deg[i] > 0.0 ? 1.0 : 0.0);
         }
     }
     indptr[n] = w;
@@ -508,14 +562,20 @@ as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {
 // One flat little-endian file: header, the items (fp64 when an fp64 copy is kept, else the exact
 // fp32 values), lambdas, and the graph arrays.  Loading re-ingests the items (norms and the padded
 // fp32 layout are recomputed deterministically) and uploads the rest; no k-NN work is redone.
+// The header carries its own size and a format version; the loader checks the file length against the
+// header-derived sizes before allocating anything and validates the CSR it is about to trust.
 namespace {
 struct IndexHeader {
-    char magic[8];      // "ASIDX01\0"
-    int64_t n, d, nnz;
-    int32_t has_f64, metric, kernel, pad;
+    char magic[8];           // "ASIDX02\0"
+    int32_t header_bytes;    // sizeof(IndexHeader) of the writer
+    int32_t version;         // 2
+    int64_t n, d, nnz;       // items, features, adjacency entries
+    int64_t nnodes;          // graph nodes: n (item mode) or d (feature mode)
+    int32_t has_f64, metric, kernel, lambda_mode;
     as_graph_params gp;
     double tau0;
 };
+constexpr int32_t INDEX_VERSION = 2;
 
 template <typename T>
 as_status dev_to_file(FILE* f, const T* dev, size_t count) {
@@ -528,15 +588,39 @@ as_status dev_to_file(FILE* f, const T* dev, size_t count) {
     return AS_OK;
 }
 template <typename T>
-as_status file_to_dev(FILE* f, T** dev, size_t count) {
-    std::vector<T> h(std::max<size_t>(count, 1));
+as_status file_to_host(FILE* f, std::vector<T>& h, size_t count) {
+    h.resize(std::max<size_t>(count, 1));
     if (count && fread(h.data(), sizeof(T), count, f) != count) {
         set_err("as_index_load: truncated file");
         return AS_EINVAL;
     }
+    return AS_OK;
+}
+template <typename T>
+as_status host_to_dev(const std::vector<T>& h, T** dev, size_t count) {
     AS_HIP(hipMalloc(dev, sizeof(T) * std::max<size_t>(count, 1)));
     if (count) AS_HIP(hipMemcpy(*dev, h.data(), sizeof(T) * count, hipMemcpyHostToDevice));
     return AS_OK;
+}
+template <typename T>
+as_status file_to_dev(FILE* f, T** dev, size_t count) {
+    std::vector<T> h;
+    AS_TRY(file_to_host(f, h, count));
+    return host_to_dev(h, dev, count);
+}
+// bytes the arrays behind the header occupy, or -1 when the header's sizes are not credible
+int64_t payload_bytes(const IndexHeader& h) {
+    const int64_t lim = (int64_t)1 << 46;
+    if (h.n <= 0 || h.d <= 0 || h.nnz < 0 || h.nnodes <= 0 || h.n >= ((int64_t)1 << 31) || h.d >= ((int64_t)1 << 31) ||
+        h.nnz > lim || h.n > lim / h.d)
+        return -1;
+    const int64_t item = h.has_f64 ? 8 : 4;
+    int64_t b = h.n * h.d * item + h.n * 8;                 // items, lambdas
+    b += (h.nnodes + 1) * 8 + h.nnz * 4 + h.nnz * 8 * 4;    // indptr, indices, dist gy w lap
+    b += h.nnodes * 8;                                      // deg
+    if (h.lambda_mode == AS_LAMBDA_FEATURE) b += h.n * 8 * 2 + h.d * 8;   // E, G, colm
+    else b += h.n * 8 * 3;                                  // ny, E, G
+    return b;
 }
 }  // namespace
 
@@ -555,35 +639,41 @@ as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path
     }
     IndexHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "ASIDX01", 8);
-    h.n = sp->n; h.d = sp->d; h.nnz = gr->nnz;
-    h.has_f64 = sp->x64 ? 1 : 0; h.metric = gr->metric; h.kernel = gr->kernel;
+    memcpy(h.magic, "ASIDX02", 8);
+    h.header_bytes = (int32_t)sizeof(IndexHeader);
+    h.version = INDEX_VERSION;
+    h.n = sp->n; h.d = sp->d; h.nnz = gr->nnz; h.nnodes = gr->n;
+    h.has_f64 = sp->x64 ? 1 : 0; h.metric = gr->metric; h.kernel = gr->kernel; h.lambda_mode = gr->lambda_mode;
     h.gp = gr->gp; h.tau0 = gr->tau0;
     as_status s = fwrite(&h, sizeof(h), 1, f) == 1 ? AS_OK : AS_EINVAL;
-    const size_t n = (size_t)sp->n, d = (size_t)sp->d, nnz = (size_t)gr->nnz;
+    const size_t n = (size_t)sp->n, d = (size_t)sp->d, nnz = (size_t)gr->nnz, nn = (size_t)gr->n;
     if (s == AS_OK) {
         if (sp->x64) {
             s = dev_to_file(f, sp->x64, n * d);
         } else {
-            std::vector<float> row(sp->dp), all(n * d);
-            std::vector<float> pad(n * (size_t)sp->dp);
-            hipError_t e = hipMemcpy(pad.data(), sp->x32, sizeof(float) * pad.size(), hipMemcpyDeviceToHost);
+            std::vector<float> all(n * d);
+            hipError_t e = hipMemcpy2D(all.data(), sizeof(float) * d, sp->x32, sizeof(float) * sp->dp, sizeof(float) * d, n, hipMemcpyDeviceToHost);
             if (e != hipSuccess) s = AS_EHIP;
-            for (size_t i = 0; i < n && s == AS_OK; ++i) memcpy(&all[i * d], &pad[i * sp->dp], sizeof(float) * d);
             if (s == AS_OK && fwrite(all.data(), sizeof(float), n * d, f) != n * d) s = AS_EINVAL;
         }
     }
     if (s == AS_OK) s = dev_to_file(f, sp->lam64, n);
-    if (s == AS_OK) s = dev_to_file(f, gr->indptr, n + 1);
+    if (s == AS_OK) s = dev_to_file(f, gr->indptr, nn + 1);
     if (s == AS_OK) s = dev_to_file(f, gr->indices, nnz);
     if (s == AS_OK) s = dev_to_file(f, gr->dist, nnz);
     if (s == AS_OK) s = dev_to_file(f, gr->gy, nnz);
     if (s == AS_OK) s = dev_to_file(f, gr->w, nnz);
     if (s == AS_OK) s = dev_to_file(f, gr->lap, nnz);
-    if (s == AS_OK) s = dev_to_file(f, gr->deg, n);
-    if (s == AS_OK) s = dev_to_file(f, gr->ny, n);
-    if (s == AS_OK) s = dev_to_file(f, gr->E, n);
-    if (s == AS_OK) s = dev_to_file(f, gr->G, n);
+    if (s == AS_OK) s = dev_to_file(f, gr->deg, nn);
+    if (gr->lambda_mode == AS_LAMBDA_FEATURE) {
+        if (s == AS_OK) s = dev_to_file(f, gr->E, n);
+        if (s == AS_OK) s = dev_to_file(f, gr->G, n);
+        if (s == AS_OK) s = dev_to_file(f, gr->colm, d);
+    } else {
+        if (s == AS_OK) s = dev_to_file(f, gr->ny, n);
+        if (s == AS_OK) s = dev_to_file(f, gr->E, n);
+        if (s == AS_OK) s = dev_to_file(f, gr->G, n);
+    }
     if (fclose(f) != 0 && s == AS_OK) s = AS_EINVAL;
     if (s != AS_OK && err_slot().empty()) set_err("as_index_save: write to %s failed", path);
     return s;
@@ -594,38 +684,51 @@ __global__ void lam32_kernel(int64_t n, const double* __restrict__ lam64, float*
     if (i < n) lam32[i] = (float)lam64[i];
 }
 
-as_status as_index_load(const char* path, const as_opts* opts, as_space** out_space, as_graph** out_graph) {
-    if (!path || !out_space || !out_graph) {
-        set_err("as_index_load: null argument");
-        return AS_EINVAL;
-    }
-    *out_space = nullptr;
-    *out_graph = nullptr;
-    FILE* f = fopen(path, "rb");
-    if (!f) {
-        set_err("as_index_load: cannot open %s", path);
-        return AS_EINVAL;
-    }
+static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts, as_space** out_space, as_graph** out_graph) {
     IndexHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ASIDX01", 8) != 0 || h.n <= 0 || h.d <= 0 || h.nnz < 0) {
-        fclose(f);
-        set_err("as_index_load: %s is not an arrowspace index file", path);
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ASIDX02", 8) != 0 || h.header_bytes != (int32_t)sizeof(IndexHeader) ||
+        h.version != INDEX_VERSION) {
+        set_err("as_index_load: %s is not an arrowspace index file of format %d", path, INDEX_VERSION);
         return AS_EINVAL;
+    }
+    const int64_t need = payload_bytes(h);
+    const bool modes_ok = (h.metric == AS_METRIC_L2 || h.metric == AS_METRIC_COSINE) &&
+                          (h.kernel == AS_KERNEL_GAUSSIAN || h.kernel == AS_KERNEL_RATIONAL) &&
+                          (h.lambda_mode == AS_LAMBDA_ITEM || h.lambda_mode == AS_LAMBDA_FEATURE) &&
+                          h.nnodes == (h.lambda_mode == AS_LAMBDA_FEATURE ? h.d : h.n);
+    as_graph_params gpr;
+    if (need < 0 || !modes_ok || resolve_params(&h.gp, &gpr) != AS_OK || !(h.tau0 >= 0.0) || !(h.tau0 <= 1.0)) {
+        set_err("as_index_load: %s has an inconsistent header", path);
+        return AS_EINVAL;
+    }
+    {   // the file must hold exactly the arrays the header announces
+        const long pos = ftell(f);
+        if (pos < 0 || fseek(f, 0, SEEK_END) != 0) {
+            set_err("as_index_load: cannot seek in %s", path);
+            return AS_EINVAL;
+        }
+        const long end = ftell(f);
+        if (fseek(f, pos, SEEK_SET) != 0 || (int64_t)(end - pos) != need) {
+            set_err("as_index_load: %s is truncated or has trailing bytes (%lld payload bytes, header implies %lld)", path,
+                    (long long)(end - pos), (long long)need);
+            return AS_EINVAL;
+        }
     }
     as_opts o{};
     if (opts) o = *opts;
     o.metric = h.metric;
     o.kernel = h.kernel;
+    o.lambda_mode = h.lambda_mode;
     o.keep_f64 = h.has_f64 ? AS_KEEP_F64_ALWAYS : AS_KEEP_F64_AUTO;
     int dev = 0;
-    as_status s = pick_device(&o, &dev);
+    AS_TRY(pick_device(&o, &dev));
+    o.device = dev;
     as_space* sp = nullptr;
     as_graph* gr = nullptr;
     void* items = nullptr;
-    const size_t n = (size_t)h.n, d = (size_t)h.d, nnz = (size_t)h.nnz;
+    const size_t n = (size_t)h.n, d = (size_t)h.d, nnz = (size_t)h.nnz, nn = (size_t)h.nnodes;
+    as_status s = AS_OK;
     do {
-        if (s != AS_OK) break;
-        o.device = dev;
         if (h.has_f64) {
             double* p = nullptr;
             s = file_to_dev(f, &p, n * d);
@@ -644,20 +747,41 @@ as_status as_index_load(const char* path, const as_opts* opts, as_space** out_sp
         if (s != AS_OK) break;
         hipLaunchKernelGGL(lam32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sp->stream, h.n, sp->lam64, sp->lam32);
         gr = new as_graph();
-        gr->device = dev; gr->n = h.n; gr->nnz = h.nnz; gr->gp = h.gp; gr->metric = h.metric; gr->kernel = h.kernel; gr->tau0 = h.tau0;
-        if ((s = file_to_dev(f, &gr->indptr, n + 1)) != AS_OK) break;
-        if ((s = file_to_dev(f, &gr->indices, nnz)) != AS_OK) break;
+        gr->device = dev; gr->n = h.nnodes; gr->nitems = h.n; gr->nnz = h.nnz; gr->gp = gpr; gr->metric = h.metric; gr->kernel = h.kernel;
+        gr->lambda_mode = h.lambda_mode; gr->tau0 = h.tau0;
+        {   // the CSR is walked on trust afterwards: monotone row pointers ending at nnz, columns inside the graph
+            std::vector<int64_t> ip;
+            std::vector<int32_t> col;
+            if ((s = file_to_host(f, ip, nn + 1)) != AS_OK) break;
+            if ((s = file_to_host(f, col, nnz)) != AS_OK) break;
+            bool ok = ip[0] == 0 && ip[nn] == h.nnz;
+            for (size_t i = 0; ok && i < nn; ++i) ok = ip[i] <= ip[i + 1];
+            for (size_t e = 0; ok && e < nnz; ++e) ok = col[e] >= 0 && (int64_t)col[e] < h.nnodes;
+            if (!ok) {
+                set_err("as_index_load: %s holds an inconsistent graph (row pointers or column indices out of range)", path);
+                s = AS_EINVAL;
+                break;
+            }
+            if ((s = host_to_dev(ip, &gr->indptr, nn + 1)) != AS_OK) break;
+            if ((s = host_to_dev(col, &gr->indices, nnz)) != AS_OK) break;
+        }
         if ((s = file_to_dev(f, &gr->dist, nnz)) != AS_OK) break;
         if ((s = file_to_dev(f, &gr->gy, nnz)) != AS_OK) break;
         if ((s = file_to_dev(f, &gr->w, nnz)) != AS_OK) break;
         if ((s = file_to_dev(f, &gr->lap, nnz)) != AS_OK) break;
-        if ((s = file_to_dev(f, &gr->deg, n)) != AS_OK) break;
-        if ((s = file_to_dev(f, &gr->ny, n)) != AS_OK) break;
-        if ((s = file_to_dev(f, &gr->E, n)) != AS_OK) break;
-        if ((s = file_to_dev(f, &gr->G, n)) != AS_OK) break;
+        if ((s = file_to_dev(f, &gr->deg, nn)) != AS_OK) break;
+        if (h.lambda_mode == AS_LAMBDA_FEATURE) {
+            if ((s = file_to_dev(f, &gr->E, n)) != AS_OK) break;
+            if ((s = file_to_dev(f, &gr->G, n)) != AS_OK) break;
+            if ((s = file_to_dev(f, &gr->colm, d)) != AS_OK) break;
+            if ((s = feat_edges_from_csr(gr, sp->stream)) != AS_OK) break;
+        } else {
+            if ((s = file_to_dev(f, &gr->ny, n)) != AS_OK) break;
+            if ((s = file_to_dev(f, &gr->E, n)) != AS_OK) break;
+            if ((s = file_to_dev(f, &gr->G, n)) != AS_OK) break;
+        }
         if (hipStreamSynchronize(sp->stream) != hipSuccess) s = AS_EHIP;
     } while (0);
-    fclose(f);
     if (items) hipFree(items);
     if (s != AS_OK) {
         if (gr) as_free_graph(gr);
@@ -667,6 +791,29 @@ as_status as_index_load(const char* path, const as_opts* opts, as_space** out_sp
     *out_space = sp;
     *out_graph = gr;
     return AS_OK;
+}
+
+as_status as_index_load(const char* path, const as_opts* opts, as_space** out_space, as_graph** out_graph) {
+    if (!path || !out_space || !out_graph) {
+        set_err("as_index_load: null argument");
+        return AS_EINVAL;
+    }
+    *out_space = nullptr;
+    *out_graph = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        set_err("as_index_load: cannot open %s", path);
+        return AS_EINVAL;
+    }
+    as_status s;
+    try {
+        s = index_load_impl(f, path, opts, out_space, out_graph);
+    } catch (const std::bad_alloc&) {   // nothing may unwind through the C ABI
+        set_err("as_index_load: out of host memory reading %s", path);
+        s = AS_ENOMEM;
+    }
+    fclose(f);
+    return s;
 }
 
 }  // extern "C"

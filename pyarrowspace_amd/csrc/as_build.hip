@@ -134,7 +134,7 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
 // the candidate bookkeeping of a row never crosses waves.  Candidates that beat the row's
 // running bound are appended to a per-row buffer in HBM scratch; a full buffer is compacted
 // to its M smallest (key, idx) and the bound tightened.
-constexpr int BM = 256, BN = 128, BK = 32, LROW = 36, CAP = 256;
+constexpr int BM = 256, BN = 128, BK = 32, CAP = 256;
 
 struct KnnArgs {
     const float* x32;
@@ -188,6 +188,11 @@ __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, f
     AS_CBAR();
 }
 
+constexpr int DROW = 32;                       // floats per row of a DMA slab (no padding)
+constexpr int DSLAB = (BM + BN) * DROW;        // floats per slab buffer: A rows then B rows
+
+#ifdef AS_ABLATION   // the A/B ladder of DESIGN.md 5.2 (tools/knn_variants.py); the product library holds one kernel per metric
+constexpr int LROW = 36;   // padded LDS row of the register-staged kernels
 // V bit0: XCD-grouped unit order (blocks that share an XCD's L2 work on the same few row
 // blocks across the column segments); bit1: double-buffered LDS slabs (one barrier per slab);
 // bit2: non-temporal loads for the streamed column operand.
@@ -417,8 +422,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // image (lane L -> base + 16 L), so rows cannot be padded; bank conflicts are avoided by an XOR
 // swizzle applied to the per-lane SOURCE address and to the fragment reads: 16-byte chunk c of
 // row r lives at chunk c ^ ((r >> 1) & 7) (any 16 rows distinct mod 16 then cover all 64 banks).
-constexpr int DROW = 32;                       // floats per row of a DMA slab (no padding)
-constexpr int DSLAB = (BM + BN) * DROW;        // floats per slab buffer: A rows then B rows
 
 template <bool INTERLEAVE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void knn_mfma_dma_kernel(KnnArgs a) {
@@ -623,6 +626,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
     }
 }
+
+#endif  // AS_ABLATION
 
 // ---- K2 (LDS-DMA, 8 waves).  Same tile and LDS image as knn_mfma_dma_kernel, but 512 threads:
 // two waves share every SIMD's matrix pipe (wave w owns rows [32w, 32w+32) as 1x4 accumulators),
@@ -1043,18 +1048,9 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
         ka.epskey = nextafterf(ka.epskey, INFINITY);
         ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-        const size_t lds = sizeof(float) * (BM + BN) * LROW * (((variant & 2) && !(variant & 16)) ? 2 : 1) + sizeof(float) * 4 * BM +
-                           (sizeof(float) + sizeof(int)) * 4 * CAP;
-        int lgrid = grid;
-        if ((variant & 1) && !(variant & 32)) lgrid = std::max(8, std::min(units, dev_cus) / 8 * 8);  // one resident block per CU, 8 XCD labels
-        hipEvent_t e0, e1, e2;
-        AS_HIP(hipEventCreate(&e0)); AS_HIP(hipEventCreate(&e1)); AS_HIP(hipEventCreate(&e2));
-#define AS_KNN_LAUNCH(VV)                                                                                              \
-    case VV:                                                                                                           \
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_kernel<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        AS_HIP(hipEventRecord(e0, st));                                                                                \
-        hipLaunchKernelGGL(knn_mfma_kernel<VV>, dim3(lgrid), dim3(256), lds, st, ka);                                  \
-        break;
+        dev_events<3> ev;
+        AS_HIP(ev.create());
+        hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
         if ((variant & 48) == 48) {
             const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
@@ -1064,23 +1060,40 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
                 hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
             else
                 hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-        } else if (variant & 32) {
-            const size_t ldsd = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
-            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
-            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
-            AS_HIP(hipEventRecord(e0, st));
-            if (variant & 1) hipLaunchKernelGGL(knn_mfma_dma_kernel<true>, dim3(grid), dim3(256), ldsd, st, ka);
-            else hipLaunchKernelGGL(knn_mfma_dma_kernel<false>, dim3(grid), dim3(256), ldsd, st, ka);
-        } else
-        switch (variant) {
-            AS_KNN_LAUNCH(0) AS_KNN_LAUNCH(1) AS_KNN_LAUNCH(2) AS_KNN_LAUNCH(3)
-            AS_KNN_LAUNCH(4) AS_KNN_LAUNCH(5) AS_KNN_LAUNCH(6) AS_KNN_LAUNCH(7)
-            AS_KNN_LAUNCH(8) AS_KNN_LAUNCH(16) AS_KNN_LAUNCH(24) AS_KNN_LAUNCH(10)
-            default:
-                set_err("unknown ARROWSPACE_KNN_VARIANT %d", variant);
-                return AS_EINVAL;
-        }
+        } else {
+#ifdef AS_ABLATION
+            const size_t lds = sizeof(float) * (BM + BN) * LROW * (((variant & 2) && !(variant & 16)) ? 2 : 1) + sizeof(float) * 4 * BM +
+                               (sizeof(float) + sizeof(int)) * 4 * CAP;
+            int lgrid = grid;
+            if ((variant & 1) && !(variant & 32)) lgrid = std::max(8, std::min(units, dev_cus) / 8 * 8);  // one resident block per CU, 8 XCD labels
+#define AS_KNN_LAUNCH(VV)                                                                                              \
+    case VV:                                                                                                           \
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_kernel<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        AS_HIP(hipEventRecord(e0, st));                                                                                \
+        hipLaunchKernelGGL(knn_mfma_kernel<VV>, dim3(lgrid), dim3(256), lds, st, ka);                                  \
+        break;
+            if (variant & 32) {
+                const size_t ldsd = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
+                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+                AS_HIP(hipEventRecord(e0, st));
+                if (variant & 1) hipLaunchKernelGGL(knn_mfma_dma_kernel<true>, dim3(grid), dim3(256), ldsd, st, ka);
+                else hipLaunchKernelGGL(knn_mfma_dma_kernel<false>, dim3(grid), dim3(256), ldsd, st, ka);
+            } else
+            switch (variant) {
+                AS_KNN_LAUNCH(0) AS_KNN_LAUNCH(1) AS_KNN_LAUNCH(2) AS_KNN_LAUNCH(3)
+                AS_KNN_LAUNCH(4) AS_KNN_LAUNCH(5) AS_KNN_LAUNCH(6) AS_KNN_LAUNCH(7)
+                AS_KNN_LAUNCH(8) AS_KNN_LAUNCH(16) AS_KNN_LAUNCH(24) AS_KNN_LAUNCH(10)
+                default:
+                    set_err("unknown ARROWSPACE_KNN_VARIANT %d", variant);
+                    return AS_EINVAL;
+            }
 #undef AS_KNN_LAUNCH
+#else
+            set_err("ARROWSPACE_KNN_VARIANT=%d selects an ablation kernel: rebuild with -DAS_ABLATION (make ABLATION=1)", variant);
+            return AS_EUNSUPPORTED;
+#endif
+        }
         AS_HIP(hipGetLastError());
         AS_HIP(hipEventRecord(e1, st));
         RefineArgs ra;
@@ -1105,7 +1118,6 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         AS_HIP(hipEventElapsedTime(&ms12, e1, e2));
         t_mfma = ms01 * 1e-3; t_ref = ms12 * 1e-3;
         flops = 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
-        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
         dbg("knn_rows: rows=%lld S=%d M=%d grid=%d mfma=%.3fs (%.1f TF/s) refine=%.3fs flagged=%d", (long long)rows, S, M,
             grid, t_mfma, flops / std::max(t_mfma, 1e-9) * 1e-12, t_ref, nflagged);
     } else {
@@ -1114,6 +1126,9 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     if (nflagged > 0) {
         const double tf0 = now_s();
         std::vector<int> hflag(rows, 1);
+        // the fallback workspace writes the output lists on its own (non-blocking) stream: everything queued on
+        // sp->stream -- the memsets of those lists above, the refine kernel -- has to be done first
+        AS_HIP(hipStreamSynchronize(st));
         if (!sp->opts.force_exact) AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
         as_query* ws = nullptr;
         AS_TRY(as_query_create(sp, nullptr, &ws));
@@ -1363,15 +1378,10 @@ __global__ void lambda_kernel(int64_t n, const double* __restrict__ E, const dou
     lam32[i] = (float)l;
 }
 
-as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx, const double* dist, const double* gy,
-                         const int32_t* cnt, as_graph* gr) {
-    const int64_t n = sp->n, k = gp->k;
-    hipStream_t st = sp->stream;
-    gr->n = n;
-    gr->device = sp->device;
-    gr->gp = *gp;
-    gr->metric = sp->opts.metric;
-    gr->kernel = sp->opts.kernel;
+// K3 + degrees: union symmetrisation of n x k directed lists into the CSR arrays of gr (indptr, indices, dist, gy, w,
+// deg; lap is allocated, not filled).  Shared by the item graph (n items) and the feature graph (n = D columns).
+as_status csr_from_knn(hipStream_t st, int64_t n, int64_t k, const int32_t* idx, const double* dist, const double* gy,
+                       const int32_t* cnt, double sigma, double p, int kernel, as_graph* gr) {
     dev_tmp<int> revcnt;
     dev_tmp<int64_t> len, bsum;
     AS_HIP(revcnt.alloc(n * 2));
@@ -1406,30 +1416,55 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
     AS_HIP(hipMalloc(&gr->w, sizeof(double) * na));
     AS_HIP(hipMalloc(&gr->lap, sizeof(double) * na));
     AS_HIP(hipMalloc(&gr->deg, sizeof(double) * n));
-    AS_HIP(hipMalloc(&gr->ny, sizeof(double) * n));
-    AS_HIP(hipMalloc(&gr->E, sizeof(double) * n));
-    AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
     hipLaunchKernelGGL(sym_fill_kernel, dim3(ge), dim3(256), 0, st, idx, dist, gy, cnt, n, k, gr->indptr, cursor, t_col, t_dist, t_gy);
     hipLaunchKernelGGL(sym_sort_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, gr->indptr, t_col, t_dist, t_gy,
-                       gr->indices, gr->dist, gr->gy, gr->w, gp->sigma, gp->p, gr->kernel);
+                       gr->indices, gr->dist, gr->gy, gr->w, sigma, p, kernel);
     hipLaunchKernelGGL(degree_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->w, gr->deg);
-    hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->dist, gr->gy, gr->deg, sp->n64,
-                       gr->metric, gr->ny, gr->lap, gr->E, gr->G);
     AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(st));   // the temporaries die with this frame
+    return AS_OK;
+}
+
+// S8 + S9: tau0 = lower median of the positive energies (8-pass radix select), lambdas into the space
+as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const double* G) {
+    const int64_t n = sp->n;
+    hipStream_t st = sp->stream;
+    const unsigned gn = (unsigned)((n + 255) / 256);
     dev_tmp<SelState> sel;
     AS_HIP(sel.alloc(2));   // the selection state, then the slot tau0 is written to
     double* tau_d = (double*)(sel + 1);
     AS_HIP(hipMemsetAsync(sel, 0, 2 * sizeof(SelState), st));
     const unsigned gh = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
     for (int pass = 0; pass < 8; ++pass) {
-        hipLaunchKernelGGL(sel_hist_kernel, dim3(gh), dim3(256), 0, st, gr->E, n, pass, sel);
+        hipLaunchKernelGGL(sel_hist_kernel, dim3(gh), dim3(256), 0, st, E, n, pass, sel);
         hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, sel);
     }
-    hipLaunchKernelGGL(lambda_kernel, dim3(gn), dim3(256), 0, st, n, gr->E, gr->G, sel, sp->lam64, sp->lam32, tau_d);
+    hipLaunchKernelGGL(lambda_kernel, dim3(gn), dim3(256), 0, st, n, E, G, sel, sp->lam64, sp->lam32, tau_d);
     AS_HIP(hipGetLastError());
     AS_HIP(hipMemcpyAsync(&gr->tau0, tau_d, sizeof(double), hipMemcpyDeviceToHost, st));
     AS_HIP(hipStreamSynchronize(st));
-    dbg("graph: nnz=%lld tau0=%.6g", (long long)nnz, gr->tau0);
+    return AS_OK;
+}
+
+as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx, const double* dist, const double* gy,
+                         const int32_t* cnt, as_graph* gr) {
+    const int64_t n = sp->n, k = gp->k;
+    hipStream_t st = sp->stream;
+    gr->n = n;
+    gr->device = sp->device;
+    gr->gp = *gp;
+    gr->metric = sp->opts.metric;
+    gr->kernel = sp->opts.kernel;
+    AS_TRY(csr_from_knn(st, n, k, idx, dist, gy, cnt, gp->sigma, gp->p, gr->kernel, gr));
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    AS_HIP(hipMalloc(&gr->ny, sizeof(double) * n));
+    AS_HIP(hipMalloc(&gr->E, sizeof(double) * n));
+    AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
+    hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->dist, gr->gy, gr->deg, sp->n64,
+                       gr->metric, gr->ny, gr->lap, gr->E, gr->G);
+    AS_HIP(hipGetLastError());
+    AS_TRY(median_lambda(sp, gr, gr->E, gr->G));
+    dbg("graph: nnz=%lld tau0=%.6g", (long long)gr->nnz, gr->tau0);
     return AS_OK;
 }
 

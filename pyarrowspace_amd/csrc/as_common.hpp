@@ -85,6 +85,15 @@ struct as_graph {
     double* G = nullptr;        // [n]
     double tau0 = 0.0;
     double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // feature mode (AS_LAMBDA_FEATURE): n == nfeatures, the CSR above is the feature graph (lap = -w, the
+    // off-diagonal of L = D - W), nitems the number of items E / G / the lambdas cover
+    int lambda_mode = 0;
+    int64_t nitems = 0;
+    int64_t ne = 0;             // edges a < b
+    int32_t* ea = nullptr;      // [ne]
+    int32_t* eb = nullptr;
+    double* ew = nullptr;
+    double* colm = nullptr;     // [n] squared column norms (the Gram's diagonal)
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -109,6 +118,26 @@ struct dev_tmp {
     }
     hipError_t alloc(size_t count) { return hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)); }
     operator T*() const { return p; }
+};
+
+// HIP events of a host function: destroyed on every return path, error paths included.
+template <int N>
+struct dev_events {
+    hipEvent_t e[N] = {};
+    dev_events() = default;
+    dev_events(const dev_events&) = delete;
+    dev_events& operator=(const dev_events&) = delete;
+    ~dev_events() {
+        for (int i = 0; i < N; ++i)
+            if (e[i]) (void)hipEventDestroy(e[i]);
+    }
+    hipError_t create() {
+        for (int i = 0; i < N; ++i) {
+            const hipError_t r = hipEventCreate(&e[i]);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    }
 };
 
 // SPEC S6 edge energy w ||y_i/sqrt(d_i) - y_j/sqrt(d_j)||^2 from the stored pair quantities; a value inside the rounding
@@ -236,6 +265,7 @@ namespace as {
 struct Scratch;  // growable device scratch owned by a call
 
 as_status resolve_params(const as_graph_params* gp, as_graph_params* out);
+as_status check_limits(const as_graph_params* resolved, int64_t n, int lambda_mode);
 // per-pair fp32 error coefficient: |key32 - key64| <= coef * (n_i + n_j) for L2,
 // <= coef for cosine
 double err_coef(int64_t dp);
@@ -246,6 +276,18 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
                    double* out_key, double* out_dist, double* out_gy, int32_t* out_cnt, double* stats);
 as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx, const double* dist,
                          const double* gy, const int32_t* cnt, as_graph* gr);
+as_status csr_from_knn(hipStream_t st, int64_t n, int64_t k, const int32_t* idx, const double* dist, const double* gy,
+                       const int32_t* cnt, double sigma, double p, int kernel, as_graph* gr);
+as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const double* G);
+
+// feature mode (as_feat.hip)
+as_status feat_gram(const as_space* sp, int64_t r0, int64_t r1, double* gram);
+as_status feat_graph(const as_space* sp, const as_graph_params* gp, const double* gram, as_graph* gr);
+as_status feat_energy(const as_space* sp, const as_graph* gr, int64_t r0, int64_t r1, double* E, double* G);
+as_status feat_build(as_space* sp, const as_graph_params* gp, as_graph* gr);
+as_status feat_edges_from_csr(as_graph* gr, hipStream_t st);   // rebuilds ea/eb/ew from the CSR (index load)
+struct QInfo;
+as_status feat_query_lambda(const as_graph* gr, const double* q64, int64_t dp, QInfo* info, int nslots, hipStream_t st);
 
 // query-as-row exact k-NN used by the build fallback (as_search.hip)
 as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, int32_t* out_idx,

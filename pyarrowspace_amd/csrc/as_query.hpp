@@ -142,5 +142,6 @@ constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows u
 double coef_query(const as_query* q, bool exact);
 PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
 as_status launch_scan(as_query* q, const PreArgs& pre);
+as_status set_scan_attrs();   // per-device dynamic-LDS opt-in of the scan kernels
 
 }  // namespace as

@@ -684,6 +684,25 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     return p;
 }
 
+static constexpr size_t gemm_lds(int nbuf) { return sizeof(float) * ((size_t)4 * nbuf * 1024 + 4 * 3 * 64 * 4 + 4 * 64); }
+static constexpr size_t dma_lds(int nch, int nslot) { return 4 * ((size_t)nslot * nch * 1024 + 256); }
+
+// The dynamic-LDS opt-in is a per-device attribute of a kernel: set it for every scan kernel on the device a
+// workspace is created on (query_alloc), not once per process -- a second device would never be opted in.
+as_status set_scan_attrs() {
+#define AS_ATTR(KERN, BYTES) AS_HIP(hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+    AS_ATTR((scan_gemm_kernel<3, 0, 2>), gemm_lds(3));
+    AS_ATTR((scan_gemm_kernel<4, 0, 0>), gemm_lds(4));
+    AS_ATTR((scan_gemm_kernel<4, 1, 2>), gemm_lds(4));
+    AS_ATTR((scan_gemm_kernel<4, 0, 2>), gemm_lds(4));
+    AS_ATTR((scan_dma_kernel<1, 8>), dma_lds(1, 8));
+    AS_ATTR((scan_dma_kernel<2, 8>), dma_lds(2, 8));
+    AS_ATTR((scan_dma_kernel<3, 5>), dma_lds(3, 5));
+    AS_ATTR((scan_dma_kernel<4, 4>), dma_lds(4, 4));
+#undef AS_ATTR
+    return AS_OK;
+}
+
 as_status launch_scan(as_query* q, const PreArgs& pre) {
     const as_space* sp = q->sp;
     const int64_t rows = q->r1 - q->r0;
@@ -700,12 +719,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             // batched pass, GEMM-shaped: fp32 MFMA, K split over the 4 waves of a block, 2 blocks per CU
 #define AS_GSCAN(NB_, DG, AX)                                                                                                \
     do {                                                                                                               \
-        const size_t lds = sizeof(float) * ((size_t)4 * (NB_) * 1024 + 4 * 3 * 64 * 4 + 4 * 64);                       \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
-            AS_HIP(hipFuncSetAttribute((const void*)scan_gemm_kernel<NB_, DG, AX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr_set = true;                                                                                           \
-        }                                                                                                              \
+        const size_t lds = gemm_lds(NB_);                                                                              \
         const int64_t nrb = (rows + 31) / 32;                                                                          \
         const unsigned grid = (unsigned)std::min<int64_t>(nrb, 2 * q->cus);                                            \
         hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
@@ -778,12 +792,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int tail_rows = (int)((rem + NW - 1) / NW);
 #define AS_DSCAN(N, S)                                                                                                 \
     do {                                                                                                               \
-        const size_t lds = 4 * ((size_t)(S) * (N) * 1024 + 256);                                                       \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
-            AS_HIP(hipFuncSetAttribute((const void*)scan_dma_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr_set = true;                                                                                           \
-        }                                                                                                              \
+        const size_t lds = dma_lds(N, S);                                                                              \
         hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
                            q->r1, q->dots32, pre, rounds, tail_rows);                                                  \
     } while (0)

@@ -1199,9 +1199,13 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     } else {
         hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->hq_dev);
     }
-    hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, q->cap > 1 ? q->cap : q->nb), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
+    const int nslots = q->cap > 1 ? q->cap : q->nb;
+    hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, nslots), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
+    const bool feature = q->gr && q->gr->lambda_mode == AS_LAMBDA_FEATURE;
+    // feature mode: lambda_q is a functional of the query alone (SPEC F6/F7) -- no neighbour search, no prefilter
+    if (feature) AS_TRY(feat_query_lambda(q->gr, q->q64, sp->dp, q->info, nslots, st));
     if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
-    const PreArgs pre = make_pre(q, eps, exclude, !q->robust);
+    const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !feature);
     AS_TRY(launch_scan(q, pre));
     if (stats) AS_HIP(hipEventRecord(q->ev[1], st));
     q->ev_valid = stats ? 1 : 0;
@@ -1267,7 +1271,8 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     q->cap = cap;
     q->sp = sp;
     q->gr = gr;
-    q->k = gr ? gr->gp.k : 1;
+    const bool feature = gr && gr->lambda_mode == AS_LAMBDA_FEATURE;
+    q->k = gr && !feature ? gr->gp.k : 1;   // feature mode: the query has no k-NN step
     q->topk = gr ? std::min<int64_t>(gr->gp.topk, sp->n) : 1;
     q->Mk = list_width(std::min<int64_t>(q->k, sp->n));
     q->Ms = score_width(q->topk);
@@ -1319,6 +1324,7 @@ static as_status query_alloc(as_query* q) {
     AS_HIP(hipMalloc(&q->rsel, sizeof(RSel)));
     AS_HIP(hipMalloc(&q->knn, sizeof(as_knn_rec) * q->ss.knn * C));
     AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * q->ss.hits * C));
+    AS_HIP(hipMemset(q->knn, 0xff, sizeof(as_knn_rec) * q->ss.knn * C));   // idx = -1: empty records
     AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut) * C, hipHostMallocMapped | hipHostMallocCoherent));
     AS_HIP(hipHostGetDevicePointer((void**)&q->hout_dev, q->hout, 0));
     memset(q->hout, 0, sizeof(HostOut) * C);
@@ -1327,6 +1333,7 @@ static as_status query_alloc(as_query* q) {
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<double>()));
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<float>()));
     AS_HIP(hipFuncSetAttribute((const void*)hits_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((sizeof(double) + sizeof(int)) * HIT_CAP)));
+    AS_TRY(set_scan_attrs());
     q->r0 = 0;
     q->r1 = sp->n;
     return AS_OK;
@@ -1390,7 +1397,7 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
         set_err("as_query_scan: null argument");
         return AS_EINVAL;
     }
-    if (q->reuse && !q->robust) {
+    if (q->reuse && !q->robust && q->gr->lambda_mode != AS_LAMBDA_FEATURE) {
         // same query again after a candidate-buffer overflow: threshold repair over the kept dots
         if (row_begin != q->r0 || row_end != q->r1) {
             set_err("as_query_scan: the repair pass must cover the rows of the scan it repairs");
@@ -1400,6 +1407,7 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
         return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
     }
     AS_TRY(query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1));
+    if (q->gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // lambda_q is already there; the k-NN records stay empty
     return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
@@ -1413,6 +1421,7 @@ as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {
         return AS_EUNSUPPORTED;
     }
     const as_graph* gr = q->gr;
+    if (gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // computed by as_query_scan, identically on every rank
     hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, q->stream, recs_dev, m, q->k, gr->metric, gr->kernel,
                        gr->gp.sigma, gr->gp.p, gr->tau0, q->info);
     AS_HIP(hipGetLastError());
@@ -1490,8 +1499,9 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
                       int64_t* out_len, double* out_lambda_q) {
     q->exact = (mode & 1) || q->sp->opts.force_exact;
     q->robust = (mode & 2) ? 1 : 0;
+    const bool feature = q->gr->lambda_mode == AS_LAMBDA_FEATURE;
     AS_TRY(query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1));
-    AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+    if (!feature) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
     q->seq += 1;
     AS_TRY(run_score(q, tau, 1));
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
@@ -1516,7 +1526,7 @@ as_status search_batch_once(as_query* q, const double* queries, int nb, int64_t 
     q->robust = 0;
     q->nb = nb;
     AS_TRY(query_begin(q, queries, -1, d, 0, q->sp->n, q->gr->gp.eps, -1));
-    AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+    if (q->gr->lambda_mode != AS_LAMBDA_FEATURE) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
     q->seq += 1;
     AS_TRY(run_score(q, tau, 1));
     bool crowded = false;

@@ -44,6 +44,21 @@ def calibrate_eps(X, k, metric="l2", target=2.0, sample=256, seed=1):
     return float(np.quantile(D[np.isfinite(D)], q))
 
 
+def calibrate_feature_eps(X, k, metric="cosine", target=2.0):
+    """Feature mode (SPEC F1-F3): eps such that a column has about target*k other columns inside it."""
+    m = np.einsum("ia,ia->a", X, X)
+    G = X.T @ X
+    if metric == "l2":
+        D = np.sqrt(np.maximum(m[:, None] + m[None, :] - 2 * G, 0.0))
+    else:
+        den = np.sqrt(np.outer(m, m))
+        D = 1.0 - np.minimum(1.0, np.maximum(0.0, np.where(den > 0, G / np.where(den > 0, den, 1.0), 0.0)))
+    d = X.shape[1]
+    off = D[~np.eye(d, dtype=bool)]
+    q = min(1.0, target * k / max(d - 1, 1))
+    return float(np.quantile(off, q))
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import oracle_c
