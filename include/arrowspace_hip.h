@@ -85,7 +85,8 @@ typedef struct as_query as_query; /* per-search device workspace (no reference c
 as_status as_build(const double* items, int64_t n, int64_t d, int64_t row_stride, int64_t col_stride,
                    const as_graph_params* gp, const as_opts* opts, as_space** out_space, as_graph** out_graph);
 
-/* Same, items already resident in HBM (row-major, leading dimension ld elements). */
+/* Same, items already resident in HBM (row-major, leading dimension ld elements).  Synchronises the device
+ * first: whatever stream produced the items, they are complete when the ingest reads them. */
 as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld,
                        const as_graph_params* gp, const as_opts* opts, as_space** out_space, as_graph** out_graph);
 
@@ -209,7 +210,10 @@ const double* as_lambdas_dev(const as_space* sp);
 
 /* per-stage seconds of the last build, and kernel-only seconds of the X.X^T block:
  * out[0]=ingest out[1]=knn_mfma out[2]=refine out[3]=fallback_exact out[4]=graph
- * out[5]=total out[6]=fallback_rows out[7]=mfma_flops_issued */
+ * out[5]=total out[6]=fallback_rows (rows recomputed by the row-serial fp64 path) out[7]=mfma_flops_issued
+ * out[8]=unproven_rows (fallback rows whose list could still not be proven exact: more near-ties at the k-th
+ * distance than the widest candidate list holds, inside fp64 rounding of one another) out[9]=band_rows (rows
+ * settled by the second, band-collecting pass) */
 as_status as_build_stats(const as_graph* gr, double* out, int32_t n);
 /* per-stage device microseconds of the last search on q (HIP events):
  * out[0]=scan out[1]=rest out[2]=exact_fallback_used */

@@ -168,9 +168,10 @@ class GraphLaplacian:
         return indptr, indices[: indptr[-1]], values[: indptr[-1]]
 
     def build_stats(self) -> dict:
-        out = np.zeros(8, dtype=np.float64)
-        _L.as_build_stats(self._h, out.ctypes.data_as(C.c_void_p), 8)
-        keys = ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s", "total_s", "fallback_rows", "mfma_flops")
+        out = np.zeros(10, dtype=np.float64)
+        _L.as_build_stats(self._h, out.ctypes.data_as(C.c_void_p), 10)
+        keys = ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s", "total_s", "fallback_rows", "mfma_flops",
+                "unproven_rows", "band_rows")
         return dict(zip(keys, out.tolist()))
 
 

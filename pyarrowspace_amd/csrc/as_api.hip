@@ -141,6 +141,9 @@ as_status as_space_create_dev(const void* items_dev, int32_t dtype, int64_t n, i
     }
     int dev = 0;
     AS_TRY(pick_device(opts, &dev));
+    // the items come from the caller's own stream(s), which a raw pointer does not name: everything queued on the
+    // device has to be finished before the ingest (on the space's private non-blocking stream) reads them
+    AS_HIP(hipDeviceSynchronize());
     as_space* sp = new as_space();
     sp->device = dev;
     sp->n = n;
@@ -205,7 +208,7 @@ as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32
         as_free_graph(gr);
         return s;
     }
-    for (int i = 0; i < 8; ++i) gr->stats[i] = sp->kstats[i];  // k-NN stage of this rank's rows
+    for (int i = 0; i < 10; ++i) gr->stats[i] = sp->kstats[i];  // k-NN stage of this rank's rows
     gr->stats[4] = now_s() - t0;
     *out_graph = gr;
     return AS_OK;
@@ -552,7 +555,7 @@ as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {
         set_err("as_build_stats: null argument");
         return AS_EINVAL;
     }
-    for (int i = 0; i < n && i < 8; ++i) out[i] = gr->stats[i];
+    for (int i = 0; i < n && i < 10; ++i) out[i] = gr->stats[i];
     return AS_OK;
 }
 

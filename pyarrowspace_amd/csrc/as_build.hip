@@ -6,11 +6,10 @@
 #include <chrono>
 #include <vector>
 
-#include "as_common.hpp"
+#include "as_query.hpp"
 
 namespace as {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline double now_s() {
@@ -148,7 +147,15 @@ struct KnnArgs {
     int* buf_idx;
     float* out_key;  // [(r1-r0)][S][M]
     int* out_idx;
-    int* out_cnt;    // [(r1-r0)][S]: count | dropped<<30
+    int* out_cnt;    // [(r1-r0)][S]: count | dropped<<30 | overflowed<<31 (collect mode)
+    // collect mode (second pass over the rows the first could not prove exact): the A rows are a gathered copy
+    // [r1][dp] of those rows (r0 = 0), with their own norms, global ids (self exclusion) and FIXED per-row
+    // thresholds -- every column whose fp32 key is inside the threshold is kept, nothing is compacted away
+    const float* xa;
+    const float* a_n32;
+    const float* a_inorm32;
+    const int* a_ids;
+    const float* a_thr;
 };
 
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
                 a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
             }
-            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = cnt | (s_drop[rl] << 30);
+            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = (int)((unsigned)cnt | ((unsigned)s_drop[rl] << 30));
         }
         __syncthreads();
     }
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
                 a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
             }
-            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = cnt | (s_drop[rl] << 30);
+            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = (int)((unsigned)cnt | ((unsigned)s_drop[rl] << 30));
         }
         __syncthreads();
     }
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // two waves share every SIMD's matrix pipe (wave w owns rows [32w, 32w+32) as 1x4 accumulators),
 // so one wave's DMA issue, fragment-read latency and epilogue run in the shadow of its
 // partner's MFMAs.  Waves 4-7 issue their DMA pieces mid-slab, waves 0-3 at the slab start.
-template <int METRIC>
+template <int METRIC, bool COLLECT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_mfma_dma8_kernel(KnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Sl = (float*)smem;                  // 2 slab buffers
@@ -642,6 +649,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int* s_drop = s_cur + BM;
     float* c_key = (float*)(s_drop + BM);
     int* c_idx = (int*)(c_key + 8 * CAP);
+    int* s_id = c_idx + 8 * CAP;               // collect mode: global item id of every A row
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -667,14 +675,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int t0 = (int)((int64_t)a.ntile * cs / a.S), t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
         if (tid < BM) {
             const int64_t rg = rowbase + tid;
-            const bool valid = rg < a.r1 && rg < a.n;
-            const float ni = valid ? a.n32[rg] : 0.0f;
-            const float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
-            s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f);
+            if (COLLECT) {
+                const bool valid = rg < a.r1;
+                s_ta[tid] = make_float2(valid ? a.a_thr[rg] : -finf, valid ? (METRIC == AS_METRIC_L2 ? a.a_n32[rg] : a.a_inorm32[rg]) : 0.0f);
+                s_id[tid] = valid ? a.a_ids[rg] : -1;
+            } else {
+                const bool valid = rg < a.r1 && rg < a.n;
+                const float ni = valid ? a.n32[rg] : 0.0f;
+                const float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+                s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f);
+            }
             s_cur[tid] = 0;
             s_drop[tid] = 0;
         }
-        const char* pa0 = (const char*)(a.x32 + (size_t)(rowbase + wu * 32) * a.dp);
+        const char* pa0 = (const char*)((COLLECT ? a.xa : a.x32) + (size_t)(rowbase + wu * 32) * a.dp);
         // 6 pieces per wave and slab: j < 4 -> A rows [8j, 8j+8) of this wave's 32, j >= 4 -> B rows of its 16
         auto dma_piece = [&](const char* srcA, const char* srcB, float* dst, int j) {
             if (j < 4) {
@@ -755,6 +769,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 AS_CBAR();
                 const int rl = w * 32 + l31;
                 unsigned long long need = __ballot(lane < 32 && s_cur[rl] > CAP - BN);
+                if (COLLECT) {
+                    // nothing may be dropped here: a row whose band does not fit stops collecting and is reported
+                    if (lane < 32 && s_cur[rl] > CAP - BN) {
+                        s_ta[rl].x = -finf;
+                        s_drop[rl] = 2;
+                    }
+                    need = 0;
+                }
                 while (need) {
                     const int r = __ffsll((long long)need) - 1;
                     const unsigned rr = w * 32 + r;
@@ -763,13 +785,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 AS_CBAR();
             }
-            const bool edge = colbase + BN > a.n || (colbase < rowbase + BM && colbase + BN > rowbase);
+            const bool edge = COLLECT || colbase + BN > a.n || (colbase < rowbase + BM && colbase + BN > rowbase);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float2 ta = s_ta[rl];
                 const float thr = ta.x, ai = ta.y;
-                const int rg = (int)(rowbase + rl);
+                const int rg = COLLECT ? s_id[rl] : (int)(rowbase + rl);
                 float key[4];
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
@@ -777,9 +799,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * ai * nj[nn]);
                 }
                 if (edge) {  // wave-uniform: only tiles on the diagonal or at the padded tail pay for the exclusions
+                    // collect mode: the band of a row may be unbounded (+inf: an item with an infinite norm makes
+                    // every error bound infinite) -- an excluded entry must fail `key <= thr` even then: NaN
+                    const float excl = COLLECT ? __int_as_float(0x7fc00000) : finf;
 #pragma unroll
                     for (int nn = 0; nn < 4; ++nn)
-                        if (cj[nn] >= (int)a.n || cj[nn] == rg) key[nn] = finf;
+                        if (cj[nn] >= (int)a.n || cj[nn] == rg) key[nn] = excl;
                 }
                 const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
                 if (__ballot(kmin <= thr)) {
@@ -805,8 +830,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int r = 0; r < 32; ++r) {
             const unsigned rl = w * 32 + r;
             const int64_t rg = rowbase + rl;
-            if (rg >= a.r1 || rg >= a.n) break;
-            if (s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
+            if (rg >= a.r1 || (!COLLECT && rg >= a.n)) break;
+            if (!COLLECT && s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int cnt = s_cur[rl];
             const size_t ob = ((size_t)(rg - a.r0) * a.S + cs) * a.M;
@@ -814,7 +839,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
                 a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
             }
-            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = cnt | (s_drop[rl] << 30);
+            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = (int)((unsigned)cnt | ((unsigned)s_drop[rl] << 30));
         }
         __syncthreads();
     }
@@ -843,6 +868,7 @@ struct RefineArgs {
     int32_t* out_cnt;
     int* flag;      // [(r1-r0)]
     int* nflag;     // counter
+    double* out_B;  // [(r1-r0)]: upper bound of the k-th exact key of a flagged row (the band of the second pass)
 };
 
 __device__ __forceinline__ void exact_pair(const float* x32, const double* x64, int64_t d, int64_t dp, int64_t i,
@@ -964,7 +990,144 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(RefineArgs a) {
             bad = !(T32 - e > B);
         }
         a.flag[lr] = bad;
-        if (bad) atomicAdd(a.nflag, 1);
+        if (bad) {
+            atomicAdd(a.nflag, 1);
+            a.out_B[lr] = npass >= a.k ? sk[a.k - 1] : a.epskey;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K2c second pass: complete band collection for rows the
+// first pass could not prove exact (ties / near-ties at the k-th distance: duplicate items, dense blobs).
+// A flagged row i has an upper bound B_i of its k-th exact key (from the first refinement); every true neighbour has
+// key64 <= B_i, hence key32 <= B_i + e_i.  The MFMA kernel runs again over a gathered copy of just those rows in
+// collect mode and keeps EVERY column inside that fixed band; knn_band_refine_kernel evaluates them all in fp64 and
+// takes the k smallest by (key64, index) -- exact by construction, no proof needed.  Only rows whose band does not
+// fit the collection buffers (thousands of ties) are left to the row-serial fp64 path.
+__global__ void band_gather_kernel(const float* __restrict__ x32, const float* __restrict__ n32, const float* __restrict__ inorm32,
+                                   const double* __restrict__ n64, int64_t dp, int64_t r0, const int* __restrict__ ids, int nf,
+                                   const double* __restrict__ B, int metric, double coef, double nmax, float* __restrict__ xa,
+                                   float* __restrict__ a_n32, float* __restrict__ a_inorm32, int* __restrict__ a_ids,
+                                   float* __restrict__ a_thr) {
+    const int f = blockIdx.x;
+    if (f >= nf) return;
+    const int lr = ids[f];
+    const int64_t row = r0 + lr;
+    for (int64_t c = threadIdx.x * 4; c < dp; c += blockDim.x * 4) *(f32x4*)(xa + (size_t)f * dp + c) = *(const f32x4*)(x32 + row * dp + c);
+    if (threadIdx.x == 0) {
+        a_n32[f] = n32[row];
+        a_inorm32[f] = inorm32[row];
+        a_ids[f] = (int)row;
+        const double e = metric == AS_METRIC_L2 ? coef * (n64[row] + nmax) : coef;
+        // rounded up twice over: the device-side comparison must never be tighter than the fp64 band
+        a_thr[f] = __double2float_ru((B[lr] + e) * 1.000001);
+    }
+}
+
+struct BandArgs {
+    const float* x32;
+    const double* x64;
+    const double* n64;
+    int64_t d, dp, r0;
+    int S, CW, metric, nf;
+    int64_t k;          // output stride and cap
+    double epskey;
+    const int* ids;     // [nf] local row of every flagged row
+    const float* c_key; // [nf][S][CW]
+    const int* c_idx;
+    const int* c_cnt;   // [nf][S]
+    int32_t* out_idx;
+    double* out_key;
+    double* out_dist;
+    double* out_gy;
+    int32_t* out_cnt;
+    int* flag;          // cleared for rows settled here
+};
+
+// one block (4 waves) per flagged row; up to BAND_MAX candidates in LDS.  A row whose band holds more (or whose
+// collection overflowed a segment buffer) stays flagged.
+constexpr int BAND_MAX = 4096;
+
+__global__ __launch_bounds__(256) void knn_band_refine_kernel(BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ek = (double*)smem;           // exact key
+    double* ed = ek + BAND_MAX;           // distance
+    double* eg = ed + BAND_MAX;           // gy
+    int* ci = (int*)(eg + BAND_MAX);
+    __shared__ int s_C, s_over, s_pass;
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int f = blockIdx.x;
+    const int lr = a.ids[f];
+    const int64_t row = a.r0 + lr;
+    if (threadIdx.x == 0) {
+        // segment offsets: a serial scan over S counts (S is at most a few hundred)
+        int C = 0, over = 0;
+        for (int cs = 0; cs < a.S; ++cs) {
+            const int cc = a.c_cnt[(size_t)f * a.S + cs];
+            over |= (cc >> 31) & 1;
+            C += cc & 0xffff;
+        }
+        s_C = C;
+        s_over = over || C > BAND_MAX;
+        s_pass = 0;
+    }
+    __syncthreads();
+    if (s_over) return;   // the band did not fit: the row stays flagged
+    const int C = s_C;
+    {
+        int off = 0;
+        for (int cs = 0; cs < a.S; ++cs) {
+            const int c = a.c_cnt[(size_t)f * a.S + cs] & 0xffff;
+            const size_t ob = ((size_t)f * a.S + cs) * a.CW;
+            for (int t = threadIdx.x; t < c; t += blockDim.x) ci[off + t] = a.c_idx[ob + t];
+            off += c;
+        }
+    }
+    __syncthreads();
+    const double ni = a.n64[row];
+    for (int t = w; t < C; t += 4) {
+        const int j = ci[t];
+        double sq, dot;
+        exact_pair(a.x32, a.x64, a.d, a.dp, row, j, sq, dot);
+        if (lane == 0) {
+            if (a.metric == AS_METRIC_L2) {
+                ek[t] = sq;
+                ed[t] = sqrt(sq);
+                eg[t] = dot;
+            } else {
+                const double den = sqrt(ni * a.n64[j]);
+                const double c = den > 0.0 ? dot / den : 0.0;
+                const double dd = cosine_distance(c);
+                ek[t] = dd;
+                ed[t] = dd;
+                eg[t] = c;
+            }
+        }
+    }
+    __syncthreads();
+    int npass_l = 0;
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+        const double kk = ek[t];
+        if (!(kk <= a.epskey)) continue;
+        npass_l += 1;
+        const int i = ci[t];
+        int rank = 0;
+        for (int s2 = 0; s2 < C; ++s2) rank += lex_less<double>(ek[s2], ci[s2], kk, i) ? 1 : 0;
+        if (rank < a.k) {
+            a.out_idx[(size_t)lr * a.k + rank] = i;
+            a.out_key[(size_t)lr * a.k + rank] = kk;
+            a.out_dist[(size_t)lr * a.k + rank] = ed[t];
+            a.out_gy[(size_t)lr * a.k + rank] = eg[t];
+        }
+    }
+    if (npass_l) atomicAdd(&s_pass, npass_l);
+    __syncthreads();
+    const int npass = s_pass;
+    const int cnt = npass < a.k ? npass : (int)a.k;
+    for (int64_t t = cnt + threadIdx.x; t < a.k; t += blockDim.x) a.out_idx[(size_t)lr * a.k + t] = -1;
+    if (threadIdx.x == 0) {
+        a.out_cnt[lr] = cnt;
+        a.flag[lr] = 0;
     }
 }
 
@@ -1008,8 +1171,10 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     AS_HIP(flag.alloc(rows + 1));
     int* nflag = flag + rows;
     AS_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (rows + 1), st));
+    dev_tmp<double> bandB;
+    AS_HIP(bandB.alloc(rows));
     double t_mfma = 0, t_ref = 0, t_fb = 0, flops = 0;
-    int nflagged = 0;
+    int nflagged = 0, unproven = 0, band_rows = 0;
 
     if (!sp->opts.force_exact) {
         const int nrb = (int)((rows + BM - 1) / BM);
@@ -1048,11 +1213,12 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
         ka.epskey = nextafterf(ka.epskey, INFINITY);
         ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
+        ka.xa = nullptr; ka.a_n32 = nullptr; ka.a_inorm32 = nullptr; ka.a_ids = nullptr; ka.a_thr = nullptr;
         dev_events<3> ev;
         AS_HIP(ev.create());
         hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
         if ((variant & 48) == 48) {
-            const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
+            const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             AS_HIP(hipEventRecord(e0, st));
@@ -1102,7 +1268,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         ra.epskey = epskey; ra.coef = coef; ra.nmax = sp->nmax;
         ra.c_key = ckey; ra.c_idx = cidx; ra.c_cnt = ccnt;
         ra.out_idx = t_idx; ra.out_key = t_key; ra.out_dist = t_dist; ra.out_gy = t_gy; ra.out_cnt = out_cnt;
-        ra.flag = flag; ra.nflag = nflag;
+        ra.flag = flag; ra.nflag = nflag; ra.out_B = bandB;
         // the refine kernel indexes outputs with stride a.k; use the caller stride kk
         ra.k = kk;  // stride == gp->k; rows with fewer than gp->k candidates are padded with -1
         const size_t per_wave = (sizeof(double) * 4 * M + sizeof(float) * ((size_t)S * M + M) + sizeof(int) * ((size_t)S * M + M) + 15) / 16 * 16;
@@ -1120,6 +1286,78 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         flops = 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
         dbg("knn_rows: rows=%lld S=%d M=%d grid=%d mfma=%.3fs (%.1f TF/s) refine=%.3fs flagged=%d", (long long)rows, S, M,
             grid, t_mfma, flops / std::max(t_mfma, 1e-9) * 1e-12, t_ref, nflagged);
+        if (nflagged > 0 && !getenv("ARROWSPACE_NO_BAND_PASS")) {
+            // ---- second pass: complete band collection for the flagged rows (K2c)
+            const double tb0 = now_s();
+            std::vector<int> hflag(rows);
+            AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
+            std::vector<int> ids;
+            ids.reserve(nflagged);
+            for (int64_t lr = 0; lr < rows; ++lr)
+                if (hflag[lr]) ids.push_back((int)lr);
+            const int nf = (int)ids.size();
+            const int64_t nfp = ((int64_t)nf + BM - 1) / BM * BM;
+            const int nrb2 = (int)(nfp / BM);
+            // column segments: as many as the collection buffers allow (2^27 entries, 1 GB) -- a segment buffer takes at
+            // least 128 columns before it overflows, so with one tile per segment (few flagged rows) no band can overflow
+            const int S2 = (int)std::max<int64_t>(1, std::min<int64_t>(ntile, ((int64_t)1 << 27) / (nfp * CAP)));
+            dev_tmp<int> d_ids, a_ids, c2idx, c2cnt;
+            dev_tmp<float> xa, a_n32, a_inorm, a_thr, c2key;
+            AS_HIP(d_ids.alloc(nf));
+            AS_HIP(a_ids.alloc(nfp));
+            AS_HIP(xa.alloc((size_t)(nfp + BM) * sp->dp));
+            AS_HIP(a_n32.alloc(nfp)); AS_HIP(a_inorm.alloc(nfp)); AS_HIP(a_thr.alloc(nfp));
+            AS_HIP(c2key.alloc((size_t)nfp * S2 * CAP));
+            AS_HIP(c2idx.alloc((size_t)nfp * S2 * CAP));
+            AS_HIP(c2cnt.alloc((size_t)nfp * S2));
+            AS_HIP(hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
+            AS_HIP(hipMemsetAsync(xa, 0, sizeof(float) * (size_t)(nfp + BM) * sp->dp, st));
+            hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, sp->x32, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
+                               (const int*)d_ids, nf, (const double*)bandB, metric, coef, sp->nmax, (float*)xa, (float*)a_n32, (float*)a_inorm,
+                               (int*)a_ids, (float*)a_thr);
+            AS_HIP(hipGetLastError());
+            KnnArgs kb = ka;
+            kb.r0 = 0; kb.r1 = nf; kb.nrb = nrb2; kb.S = S2; kb.M = CAP;
+            kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
+            kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr;
+            const size_t lds8c = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
+            const int g2 = std::min(nrb2 * S2, dev_cus);
+            // per-block append buffers: the first pass sized them for ITS grid
+            dev_tmp<float> bkey2;
+            dev_tmp<int> bidx2;
+            if (g2 > grid) {
+                AS_HIP(bkey2.alloc((size_t)g2 * BM * CAP));
+                AS_HIP(bidx2.alloc((size_t)g2 * BM * CAP));
+                kb.buf_key = bkey2;
+                kb.buf_idx = bidx2;
+            }
+            if (metric == AS_METRIC_L2) {
+                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8c));
+                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, true>), dim3(g2), dim3(512), lds8c, st, kb);
+            } else {
+                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8c));
+                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, true>), dim3(g2), dim3(512), lds8c, st, kb);
+            }
+            AS_HIP(hipGetLastError());
+            BandArgs ba;
+            ba.x32 = sp->x32; ba.x64 = sp->x64; ba.n64 = sp->n64; ba.d = sp->d; ba.dp = sp->dp; ba.r0 = r0;
+            ba.S = S2; ba.CW = CAP; ba.metric = metric; ba.nf = nf; ba.k = kk; ba.epskey = epskey;
+            ba.ids = d_ids; ba.c_key = c2key; ba.c_idx = c2idx; ba.c_cnt = c2cnt;
+            ba.out_idx = t_idx; ba.out_key = t_key; ba.out_dist = t_dist; ba.out_gy = t_gy; ba.out_cnt = out_cnt; ba.flag = flag;
+            const size_t ldsb = (sizeof(double) * 3 + sizeof(int)) * (size_t)BAND_MAX;
+            AS_HIP(hipFuncSetAttribute((const void*)knn_band_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(knn_band_refine_kernel, dim3((unsigned)nf), dim3(256), ldsb, st, ba);
+            AS_HIP(hipGetLastError());
+            AS_HIP(hipStreamSynchronize(st));
+            AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
+            int left = 0;
+            for (int64_t lr = 0; lr < rows; ++lr) left += hflag[lr] ? 1 : 0;
+            dbg("knn_rows: band pass over %d flagged rows (S=%d): %d left for the row-serial path, %.3fs", nf, S2, left, now_s() - tb0);
+            t_ref += now_s() - tb0;
+            flops += 2.0 * (double)nrb2 * BM * (double)ntile * BN * (double)sp->dp;
+            band_rows = nf - left;
+            nflagged = left;
+        }
     } else {
         nflagged = (int)rows;
     }
@@ -1132,6 +1370,9 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         if (!sp->opts.force_exact) AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
         as_query* ws = nullptr;
         AS_TRY(as_query_create(sp, nullptr, &ws));
+        AS_HIP(hipMemsetAsync(nflag, 0, sizeof(int), st));
+        AS_HIP(hipStreamSynchronize(st));
+        ws->unproven_dev = nflag;   // reused: counts the rows that not even the fp64 path can prove
         as_status fs = AS_OK;
         for (int64_t lr = 0; lr < rows && fs == AS_OK; ++lr) {
             if (!hflag[lr]) continue;
@@ -1139,10 +1380,13 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         }
         as_query_free(ws);  // synchronises the workspace stream
         if (fs != AS_OK) return fs;
+        AS_HIP(hipMemcpy(&unproven, nflag, sizeof(int), hipMemcpyDeviceToHost));
+        if (unproven) dbg("knn_rows: %d rows have more near-ties at the k-th distance than fp64 can order: lists unproven", unproven);
         t_fb = now_s() - tf0;
     }
     if (stats) {
         stats[1] += t_mfma; stats[2] += t_ref; stats[3] += t_fb; stats[6] += nflagged; stats[7] += flops;
+        stats[8] += unproven; stats[9] += band_rows;
     }
     return AS_OK;
 }

@@ -64,7 +64,7 @@ struct as_space {
     mutable as_query* qcache_b = nullptr;     // batched workspace (QUERY_BATCH slots), lazily created
     mutable const as_graph* qcache_b_gr = nullptr;
     mutable std::mutex qmu;
-    mutable double kstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // accumulated by as_knn_rows
+    mutable double kstats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // accumulated by as_knn_rows
 };
 
 struct as_graph {
@@ -84,7 +84,7 @@ struct as_graph {
     double* E = nullptr;        // [n]
     double* G = nullptr;        // [n]
     double tau0 = 0.0;
-    double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // feature mode (AS_LAMBDA_FEATURE): n == nfeatures, the CSR above is the feature graph (lap = -w, the
     // off-diagonal of L = D - W), nitems the number of items E / G / the lambdas cover
     int lambda_mode = 0;

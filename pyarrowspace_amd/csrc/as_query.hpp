@@ -120,6 +120,7 @@ struct as_query {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int ev_valid = 0;
     double stats[4] = {0, 0, 0, 0};
+    int* unproven_dev = nullptr;   // build fallback: device counter (caller-owned) of rows that stay unproven
 };
 
 namespace as {

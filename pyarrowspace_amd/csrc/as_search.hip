@@ -618,12 +618,14 @@ struct FinishArgs {
     int fuse;           // knn: compute lambda_q in the same launch; score: publish to hout
     int from_list;      // candidates come from the wavefront lists instead of the filter buffer
     int thresholded;    // the buffer holds the rows under a selection threshold, not every row inside eps
+    int exhaustive;     // evaluate EVERY buffered candidate in fp64 (near-ties at the k-th distance that fp32 cannot order)
     // build-fallback outputs (row-list form); null for searches
     int32_t* o_idx;
     double* o_key;
     double* o_dist;
     double* o_gy;
     int32_t* o_cnt;
+    int* unproven;      // build fallback: counts the rows whose list failed the a-posteriori check even in fp64
 };
 
 // SPEC S10 given the selected neighbours in ascending index order in LDS; one wave, lane t
@@ -691,8 +693,47 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         total = raw < CAND_CAP ? raw : CAND_CAP;
         select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
-    const int Mp = fcount;
     const double nq = a.info->nq;
+    bool complete = false;   // the list below was chosen among ALL candidates by their exact keys: nothing to prove
+    if (a.exhaustive && !a.from_list && !a.thresholded && a.info->knn_cnt <= CAND_CAP && total > a.M) {
+        // Every row inside the eps bound is in the buffer.  Evaluate them all exactly, 64 per round, and keep the
+        // (up to) 64 smallest by (key64, index): the answer cannot depend on how fp32 ordered near-ties.
+        double* xk = (double*)(pi + PRUNE_CAP);   // CAND_CAP exact keys
+        __shared__ double t_sq[64], t_dot[64];
+        __shared__ int s_npass;
+        if (threadIdx.x == 0) s_npass = 0;
+        for (int t = threadIdx.x; t < total; t += blockDim.x) si[t] = cidx[t];
+        __syncthreads();
+        for (int base = 0; base < total; base += 64) {
+            const int m = total - base < 64 ? total - base : 64;
+            exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, si + base, m, t_sq, t_dot);
+            __syncthreads();
+            if (threadIdx.x < m) {
+                double kk = t_sq[threadIdx.x];
+                if (a.metric != AS_METRIC_L2) {
+                    const double den = sqrt(nq * a.n64[si[base + threadIdx.x]]);
+                    kk = cosine_distance(den > 0.0 ? t_dot[threadIdx.x] / den : 0.0);
+                }
+                xk[base + threadIdx.x] = kk;
+            }
+            __syncthreads();
+        }
+        int np_l = 0;
+        for (int t = threadIdx.x; t < total; t += blockDim.x) {
+            const double kk = xk[t];
+            if (!(kk <= a.epskey)) continue;
+            np_l += 1;
+            int rank = 0;
+            for (int s2 = 0; s2 < total; ++s2) rank += lex_less<double>(xk[s2], si[s2], kk, si[t]) ? 1 : 0;
+            if (rank < 64) fi[rank] = si[t];
+        }
+        if (np_l) atomicAdd(&s_npass, np_l);
+        __syncthreads();
+        if (threadIdx.x == 0) fcount = s_npass < 64 ? s_npass : 64;
+        __syncthreads();
+        complete = true;
+    }
+    const int Mp = fcount;
     exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, fi, Mp, ek, eg);
     __syncthreads();
     if (threadIdx.x < Mp) {
@@ -773,7 +814,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         if (a.o_cnt) *a.o_cnt = cnt;
         int bad = 0;
         a.info->knn_total = total;
-        if ((total > a.M || a.thresholded) && Mp > 0) {
+        if ((total > a.M || a.thresholded) && Mp > 0 && !complete) {
             const double B = npass >= a.k ? sk2[a.k - 1] : a.epskey;
             // dropped items' norms are unknown: bound them by the largest norm in the space
             const double e = a.metric == AS_METRIC_L2 ? a.coef * (a.nmax + nq) : a.coef;
@@ -781,6 +822,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
             bad = !(Tm - e > B);
         }
         a.info->knn_inexact = bad;
+        if (bad && a.unproven) atomicAdd(a.unproven, 1);
     }
     if (a.fuse) lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, a.metric, a.kernel, a.sigma, a.p, a.tau0, a.info);
 }
@@ -1041,7 +1083,7 @@ static size_t score_lds() {
 
 template <typename T>
 static size_t finish_lds() {
-    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP);
+    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP) + sizeof(double) * CAND_CAP;   // + exact keys of the exhaustive pass
 }
 
 // k-NN candidates of the scanned rows -> records (or row lists for the build fallback)
@@ -1076,7 +1118,7 @@ static as_status knn_repair(as_query* q, double eps, int64_t exclude) {
 }
 
 static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lambda, int32_t* o_idx, double* o_key,
-                         double* o_dist, double* o_gy, int32_t* o_cnt, int thresholded = 0) {
+                         double* o_dist, double* o_gy, int32_t* o_cnt, int thresholded = 0, int exhaustive = 0) {
     const as_space* sp = q->sp;
     hipStream_t st = q->stream;
     const int metric = sp->opts.metric;
@@ -1087,6 +1129,8 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lamb
     f.o_idx = o_idx; f.o_key = o_key; f.o_dist = o_dist; f.o_gy = o_gy; f.o_cnt = o_cnt;
     f.fuse = fuse_lambda;
     f.thresholded = thresholded;
+    f.exhaustive = exhaustive;
+    f.unproven = o_idx ? q->unproven_dev : nullptr;
     if (q->robust) {
         int nw = 0;
         const int grid = sel_grid(q, &nw);
@@ -1330,6 +1374,7 @@ static as_status query_alloc(as_query* q) {
     memset(q->hout, 0, sizeof(HostOut) * C);
     for (int i = 0; i < 3; ++i) AS_HIP(hipEventCreate(&q->ev[i]));
     AS_HIP(hipFuncSetAttribute((const void*)knn_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<double>()));
+    AS_HIP(hipFuncSetAttribute((const void*)knn_finish_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds<float>()));
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<double>()));
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<float>()));
     AS_HIP(hipFuncSetAttribute((const void*)hits_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((sizeof(double) + sizeof(int)) * HIT_CAP)));
@@ -1506,6 +1551,15 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     AS_TRY(run_score(q, tau, 1));
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
     AS_TRY(wait_published(q));
+    if (!feature && !q->robust && q->hout->knn_inexact && !(q->hout->overflow & 1)) {
+        // near-ties at the k-th distance the fp32 keys cannot order (duplicates, near-duplicates): every row inside
+        // the eps bound is still in the candidate buffer -- evaluate them all exactly, no second scan
+        AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1));
+        AS_HIP(hipMemsetAsync(&q->info->sc_cnt, 0, sizeof(int), q->stream));
+        q->seq += 1;
+        AS_TRY(run_score(q, tau, 1));
+        AS_TRY(wait_published(q));
+    }
     if (!q->robust && (q->hout->overflow & 1)) {
         // more than CAND_CAP rows inside eps: re-derive the candidates from the kept dots, no second scan
         AS_TRY(knn_repair(q, q->gr->gp.eps, -1));

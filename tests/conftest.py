@@ -59,6 +59,46 @@ def calibrate_feature_eps(X, k, metric="cosine", target=2.0):
     return float(np.quantile(off, q))
 
 
+def gpu_clustered(n, d, seed, nclust=1024, noise=0.5, scale=1.0, device="cuda"):
+    """Full-size test data on the GPU (torch RNG: seconds instead of the minute numpy needs for 10^9 normals; the
+    bench keeps SURVEY 8(d)'s numpy recipe): clustered Gaussians, rows normalised, times `scale`, fp32."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    C = torch.randn((nclust, d), generator=g, device=device, dtype=torch.float32)
+    z = torch.randint(0, nclust, (n,), generator=g, device=device)
+    X = torch.empty((n, d), device=device, dtype=torch.float32)
+    step = 1 << 17
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        X[s:e] = C[z[s:e]] + noise * torch.randn((e - s, d), generator=g, device=device, dtype=torch.float32)
+        X[s:e] *= scale / X[s:e].norm(dim=1, keepdim=True)
+    return X
+
+
+def brute_keys(X, rows, metric):
+    """fp64 keys (squared L2 distance, or rectified-cosine distance) of the sampled rows against every item,
+    on the GPU, by the norm expansion (good to ~1e-12 relative to the norms): [len(rows), N] with the self
+    entries at +inf."""
+    import torch
+    n = X.shape[0]
+    r = torch.as_tensor(rows, device=X.device)
+    A = X[r].double()
+    na = (A * A).sum(1)
+    out = torch.empty((len(rows), n), dtype=torch.float64, device=X.device)
+    step = 1 << 16
+    for s in range(0, n, step):
+        B = X[s:s + step].double()
+        nb = (B * B).sum(1)
+        G = A @ B.T
+        if metric == "l2":
+            out[:, s:s + step] = (na[:, None] + nb[None, :] - 2 * G).clamp_min(0)
+        else:
+            out[:, s:s + step] = 1.0 - (G / (na[:, None] * nb[None, :]).sqrt()).clamp(0, 1)
+    out[torch.arange(len(rows), device=X.device), r] = float("inf")
+    return out
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import oracle_c

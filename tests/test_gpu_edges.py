@@ -81,6 +81,29 @@ def test_exact_duplicates_break_ties_by_index(oracle_lib):
     _compare(X, gp, oracle_lib, [base[2] + 0.01, base[5]])
 
 
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_duplicate_heavy_build_is_settled_by_the_band_pass(oracle_lib, metric):
+    """5 200 items, 3 000 of them exact copies in groups of 30, plus 200 near-copies that fp32 cannot tell apart: the
+    first k-NN pass cannot prove those rows exact (ties at the k-th distance); the second pass collects every
+    column inside the proven band and settles them on the device -- no row is left to the row-serial fp64 path."""
+    import pyarrowspace_amd as asp
+    rng = np.random.default_rng(8)
+    n, d, k = 5200, 96, 10
+    X = clustered(n, d, nclust=20, seed=8)
+    src = rng.choice(2000, 100, replace=False)
+    for g, s0 in enumerate(src):
+        X[2000 + 30 * g: 2000 + 30 * (g + 1)] = X[s0]
+    # near-copies fp32 cannot tell apart and fp64 can (1 - cos of vectors 1e-9 apart is below fp64's own resolution:
+    # the cosine case keeps them 1e-4 apart, 1 - cos ~ 5e-9 against an fp32 key error of 7e-6)
+    amp = 1e-9 if metric == "l2" else 1e-4
+    X[2000 + 3000: 2000 + 3000 + 200] = X[src[0]] + amp * rng.standard_normal((200, d)) / np.sqrt(d)
+    # eps reaches the copies and near-copies only (a quantile-calibrated eps is 0 here); everything else is isolated
+    gp = {"eps": 1e-6, "k": k, "topk": 8, "p": 2.0, "sigma": None, "metric": metric}
+    aspace, gl, ref = _compare(X, gp, oracle_lib, [X[src[3]], X[5100]], taus=(1.0, 0.62))
+    st = gl.build_stats()
+    assert st["fallback_rows"] == 0 and st["fallback_s"] == 0.0, st
+
+
 def test_unnormalised_scaled_items(oracle_lib):
     """The reference's harnesses feed x100-scaled, unnormalised embeddings (tests/test_3_beir.py:155-156,190)."""
     n, d = 500, 96
@@ -137,9 +160,8 @@ def test_limits_are_reported_as_value_errors():
     with pytest.raises(ValueError, match="k"):
         asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 80, "topk": 5, "p": 2.0}, X)
     Y = clustered(1500, 16, nclust=3, seed=1)
-    a2, g2 = asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 5, "topk": 1300, "p": 2.0}, Y)
-    with pytest.raises(ValueError, match="topk"):
-        a2.search(np.ascontiguousarray(Y[0]), g2, 1.0)
+    with pytest.raises(ValueError, match="topk"):   # refused before any upload or GPU work, not at the first search
+        asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 5, "topk": 1300, "p": 2.0}, Y)
 
 
 @pytest.mark.parametrize("keep64", [False, True])
