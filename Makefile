@@ -7,7 +7,8 @@ HDRS := $(CSRC)/as_common.hpp $(CSRC)/as_query.hpp include/arrowspace_hip.h
 OBJS := $(SRCS:.hip=.o)
 LIB := pyarrowspace_amd/libarrowspace_hip.so
 ABLATION ?= 0
-HIPFLAGS ?= $(if $(filter 1,$(ABLATION)),-DAS_ABLATION) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value
+STAMPS ?= 0
+HIPFLAGS ?= $(if $(filter 1,$(ABLATION)),-DAS_ABLATION) $(if $(filter 1,$(STAMPS)),-DAS_STAMPS) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value
 
 all: $(LIB) oracle
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)

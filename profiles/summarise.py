@@ -4,6 +4,7 @@ summaries committed under profiles/.  Usage:
     python profiles/summarise.py stats <dir> <out.csv>
     python profiles/summarise.py pmc <dir> <counter> <out.csv>
     python profiles/summarise.py traffic <fetch.csv> <write.csv> <n> <d> <out.json>
+    python profiles/summarise.py timeline <dir> <out.csv>
 """
 import csv
 import glob
@@ -47,6 +48,45 @@ def pmc(d, counter, out):
     print(open(out).read())
 
 
+def timeline(d, out):
+    """Single-query search chain from the kernel trace: per kernel of the chain its average duration and the
+    average idle gap in front of it (previous kernel's end -> its start), and the gap between two queries
+    (last kernel's end -> next query's first kernel): where the whole-query time beyond the scan goes."""
+    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[0]
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), int(r.get("Grid_Size_Z", r.get("Grid_Size_z", 1)) or 1))
+            for r in csv.DictReader(open(f)) if "as::" in r["Kernel_Name"]]
+    rows.sort()
+    # a query = q_prepare (one slot) ... up to the next q_prepare
+    chains, cur = [], None
+    for st, en, name, gz in rows:
+        if name.startswith("as::q_prepare_kernel"):
+            if cur:
+                chains.append(cur)
+            cur = [(st, en, name, gz)]
+        elif cur is not None:
+            cur.append((st, en, name, gz))
+    if cur:
+        chains.append(cur)
+    single = [c for c in chains if all(g == 1 for _, _, _, g in c) and any("scan_d" in n for _, _, n, _ in c)]
+    from collections import Counter
+    shape = Counter(tuple(n for _, _, n, _ in c) for c in single).most_common(1)[0][0]
+    sel = [c for c in single if tuple(n for _, _, n, _ in c) == shape]
+    with open(out, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["position", "kernel", "avg_us", "avg_gap_before_us", "queries"])
+        tot = 0.0
+        for i, name in enumerate(shape):
+            dur = sum(c[i][1] - c[i][0] for c in sel) / len(sel) / 1e3
+            gap = sum((c[i][0] - c[i - 1][1]) for c in sel) / len(sel) / 1e3 if i else 0.0
+            tot += dur + gap
+            w.writerow([i, name, "%.2f" % dur, "%.2f" % gap, len(sel)])
+        inter = [b[0][0] - a[-1][1] for a, b in zip(sel, sel[1:]) if 0 < b[0][0] - a[-1][1] < 5e6]
+        span = sum(c[-1][1] - c[0][0] for c in sel) / len(sel) / 1e3
+        w.writerow(["", "device span of one query (first start -> last end)", "%.2f" % span, "", len(sel)])
+        w.writerow(["", "idle between queries (host turnaround)", "%.2f" % (sum(inter) / max(len(inter), 1) / 1e3), "", len(inter)])
+    print(open(out).read())
+
+
 def traffic(fetch_csv, write_csv, n, d, out):
     """HBM-side bytes per launch of the roofline kernels, corrected as MI355X_MICROARCH.md prescribes for
     gfx950: FETCH_SIZE (KiB) x 2 for 16-B-per-lane streaming reads, WRITE_SIZE (KiB) as read."""
@@ -78,5 +118,7 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "traffic":
         traffic(*sys.argv[2:7])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -16,6 +16,18 @@ namespace as {
 
 static std::atomic<int> g_search_stats{0};
 
+// In-kernel phase stamps of the two single-block finish kernels (diagnostic build only: make STAMPS=1; no stamp
+// executes in the product library).  100 MHz wall clock; slots 0..15 knn_finish, 16..31 score_finish.
+#ifdef AS_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define AS_STAMP(i)                                                           \
+    do {                                                                      \
+        if (threadIdx.x == 0 && blockIdx.z == 0) g_stamps[i] = wall_clock64(); \
+    } while (0)
+#else
+#define AS_STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ unsigned int ord_bits(float v) {
     const unsigned int b = (unsigned int)__float_as_int(v);
@@ -256,36 +268,122 @@ __device__ __forceinline__ U block_kth(const U (&v)[4], const bool (&have)[4], i
     return *s_prefix;
 }
 
-// (2) threshold = M-th smallest group minimum (radix select over the ordered bit pattern).
-// At least M rows have key <= threshold, so the M best rows all pass the filter.
-template <typename T, typename U, int PASSES>
+// (2) threshold: a value T with at least M group minima <= T (then at least M rows pass the filter, so the M best rows
+// all do).  One pass: 1024 linear bins between the smallest and the largest finite minimum, the bin b in which the
+// cumulative count reaches M, and T = the LARGEST minimum that fell into bins <= b -- valid by construction whatever
+// the rounding of the bin arithmetic, and within one bin width of the exact M-th minimum (the 4-pass radix select it
+// replaces took 7.7 us of every query).  Non-finite minima (NaN / inf keys of poisoned rows) are left out of the
+// range and counted last.
+template <typename T>
 __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gmin, int ng, int M, QInfo* info) {
-    __shared__ unsigned int hist[256];
-    __shared__ U s_prefix;
-    __shared__ int s_rank;
+    __shared__ unsigned int lhist[1024];
+    __shared__ double s_lo[16], s_hi[16];
+    __shared__ int s_bin, s_nfin[16];
     gmin += (int64_t)blockIdx.z * CAND_CAP;
     info += blockIdx.z;
-    const int tid = threadIdx.x;
-    if (ng <= M) {
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const double big = 1.0e300;
+    T v[4];
+    bool fin[4];
+    double lo = big, hi = -big;
+    int nfin = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * 1024;
+        v[q] = i < ng ? gmin[i] : key_traits<T>::inf();
+        fin[q] = i < ng && (double)v[q] > -big && (double)v[q] < big;
+        if (fin[q]) {
+            lo = (double)v[q] < lo ? (double)v[q] : lo;
+            hi = (double)v[q] > hi ? (double)v[q] : hi;
+            nfin += 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        nfin += __shfl_xor(nfin, o, 64);
+    }
+    if (lane == 0) {
+        s_lo[w] = lo;
+        s_hi[w] = hi;
+        s_nfin[w] = nfin;
+    }
+    lhist[tid] = 0;
+    __syncthreads();
+    lo = s_lo[0];
+    hi = s_hi[0];
+    nfin = s_nfin[0];
+    for (int w2 = 1; w2 < 16; ++w2) {
+        lo = s_lo[w2] < lo ? s_lo[w2] : lo;
+        hi = s_hi[w2] > hi ? s_hi[w2] : hi;
+        nfin += s_nfin[w2];
+    }
+    if (nfin < M) {
+        // fewer finite minima than the list is wide: no finite threshold is provable -- everything passes
         if (tid == 0) {
             if (sizeof(T) == 4) info->thr32 = key_traits<float>::inf();
             else info->thr64 = key_traits<double>::inf();
         }
         return;
     }
-    U v[4];
-    bool have[4];
+    const double scale = hi > lo ? 1024.0 / (hi - lo) : 0.0;
+    int bin[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int i = tid + q * 1024;
-        have[q] = i < ng;
-        v[q] = have[q] ? ord_bits(gmin[i]) : (U)0;
+        bin[q] = 1 << 20;
+        if (fin[q]) {
+            const int b = (int)(((double)v[q] - lo) * scale);
+            bin[q] = b < 0 ? 0 : (b > 1023 ? 1023 : b);
+            atomicAdd(&lhist[bin[q]], 1u);
+        }
     }
-    const U kth = block_kth<U, PASSES>(v, have, M - 1, hist, &s_prefix, &s_rank);
+    __syncthreads();
+    if (tid < 64) {
+        unsigned int h[16], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            h[j] = lhist[16 * tid + j];
+            tot += h[j];
+        }
+        unsigned int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t2 = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += t2;
+        }
+        const unsigned int excl = incl - tot;
+        if (excl < (unsigned)M && incl >= (unsigned)M) {
+            unsigned int run = excl;
+            int b = 16 * tid;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                run += h[j];
+                if (run >= (unsigned)M) break;
+                b += 1;
+            }
+            s_bin = b;
+        }
+    }
+    __syncthreads();
+    const int bsel = s_bin;
+    double mx = -big;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (fin[q] && bin[q] <= bsel) mx = (double)v[q] > mx ? (double)v[q] : mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_xor(mx, o, 64);
+        mx = m2 > mx ? m2 : mx;
+    }
+    __syncthreads();   // s_hi has been read by everybody
+    if (lane == 0) s_hi[w] = mx;
+    __syncthreads();
     if (tid == 0) {
-        const T thr = from_ord(kth);
-        if (sizeof(T) == 4) info->thr32 = (float)thr;
-        else info->thr64 = (double)thr;
+        for (int w2 = 1; w2 < 16; ++w2) mx = s_hi[w2] > mx ? s_hi[w2] : mx;
+        if (sizeof(T) == 4) info->thr32 = (float)mx;   // mx is one of the (float) minima: exact
+        else info->thr64 = mx;
     }
 }
 
@@ -478,6 +576,7 @@ __device__ __forceinline__ void merge_partials(const T* pkey, const int* pidx, i
 }
 
 constexpr int PRUNE_CAP = 2048;  // compact list of the radix-pruned candidates
+constexpr int Q_LDS_MAX = 2048;  // widest query (padded floats) the finish kernels keep in LDS
 
 // rank-select the M smallest (key, idx) of the C buffered candidates into (fk, fi), sorted.
 // Large C (dense neighbourhoods) is first pruned to the candidates at or below the M-th
@@ -502,8 +601,112 @@ __device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx
     const int* ri = si;
     int R = C;
     // a list as wide as the candidate set (topk above the number of rows that passed) keeps everything: a k-th
-    // smallest beyond the set does not exist, and the radix select would return an arbitrary threshold
-    if (C > 512 && M < C) {
+    // smallest beyond the set does not exist, and a select would return an arbitrary threshold
+    if (C > 128 && M < C) {
+        // One-pass prune: 1024 linear bins between the smallest and the largest key; the bin in which the cumulative
+        // count reaches M bounds the M smallest (monotone binning), and the quadratic ranking below only sees that
+        // prefix -- about M entries unless the keys pile up in one bin, which the radix select then handles.
+        // (The ranking over all C was 2.5 us at C = 500, the 4-pass radix select 8 us: most of knn_finish.)
+        __shared__ unsigned int lhist[1024];
+        __shared__ double s_mm[2][16];
+        __shared__ int s_bin;
+        T v[4];
+        bool have[4];
+        double lo = 1.0e300, hi = -1.0e300;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + q * 1024;
+            have[q] = i < C;
+            v[q] = have[q] ? sk[i] : (T)0;
+            if (have[q]) {
+                lo = (double)v[q] < lo ? (double)v[q] : lo;
+                hi = (double)v[q] > hi ? (double)v[q] : hi;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane_id() == 0) {
+            s_mm[0][threadIdx.x >> 6] = lo;
+            s_mm[1][threadIdx.x >> 6] = hi;
+        }
+        lhist[threadIdx.x] = 0;
+        __syncthreads();
+        {
+            const int nwv = blockDim.x >> 6;
+            lo = s_mm[0][0];
+            hi = s_mm[1][0];
+            for (int w2 = 1; w2 < nwv; ++w2) {
+                lo = s_mm[0][w2] < lo ? s_mm[0][w2] : lo;
+                hi = s_mm[1][w2] > hi ? s_mm[1][w2] : hi;
+            }
+        }
+        const double scale = hi > lo ? 1024.0 / (hi - lo) : 0.0;
+        int bin[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bin[q] = 0;
+            if (have[q]) {
+                const int b = (int)(((double)v[q] - lo) * scale);
+                bin[q] = b < 0 ? 0 : (b > 1023 ? 1023 : b);
+                atomicAdd(&lhist[bin[q]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // wave 0: 16 bins per lane, inclusive scan over lanes, the lane whose range reaches M finishes
+            unsigned int h[16], tot = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                h[j] = lhist[16 * threadIdx.x + j];
+                tot += h[j];
+            }
+            unsigned int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t2 = __shfl_up(incl, o, 64);
+                if ((int)threadIdx.x >= o) incl += t2;
+            }
+            const unsigned int excl = incl - tot;
+            if (excl < (unsigned)M && incl >= (unsigned)M) {
+                unsigned int run = excl;
+                int b = 16 * threadIdx.x;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    run += h[j];
+                    if (run >= (unsigned)M) break;
+                    b += 1;
+                }
+                s_bin = b;
+            }
+        }
+        __syncthreads();
+        const int bsel = s_bin;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (have[q] && bin[q] <= bsel) {
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < PRUNE_CAP) {
+                    const int i = threadIdx.x + q * 1024;
+                    pk[slot] = v[q];
+                    pi[slot] = si[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (s_cnt <= PRUNE_CAP) {
+            rk = pk;
+            ri = pi;
+            R = s_cnt;
+        }
+        __syncthreads();   // everybody has read s_cnt before it is reused
+    }
+    if (R > PRUNE_CAP && M < C) {
+        // the linear bins did not separate the keys (mass ties, outliers): exact radix select
+        if (threadIdx.x == 0) s_cnt = 0;
         U v[4];
         bool have[4];
 #pragma unroll
@@ -561,27 +764,27 @@ __device__ __forceinline__ void exact_eval_all(const float* x32, const double* x
             }
         } else {
             const float* pj = x32 + j * dp;  // rows and the query are zero padded to dp
-            // four 64-float chunks per trip, every load issued before the first use: one chunk per trip was a chain
-            // of dp/64 dependent HBM round trips (12 at D=768) and most of this kernel's time
-            for (int64_t e0 = 4 * sub; e0 < dp; e0 += 256) {
-                f32x4 v[4];
-                double a[4][4];
+            // twelve 64-float chunks (a whole 768-float row) per trip, every load issued before the first use: one
+            // chunk per trip was a chain of dp/64 dependent HBM round trips and most of these kernels' time
+            for (int64_t e0 = 4 * sub; e0 < dp; e0 += 768) {
+                f32x4 v[12];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int64_t e = e0 + 64 * c;
-                    const bool in = e < dp;
-                    v[c] = in ? *(const f32x4*)(pj + e) : f32x4{0, 0, 0, 0};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) a[c][u] = in ? q64[e + u] : 0.0;
+                for (int u = 0; u < 12; ++u) {
+                    const int64_t e = e0 + 64 * u;
+                    v[u] = e < dp ? *(const f32x4*)(pj + e) : f32x4{0, 0, 0, 0};
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int u = 0; u < 12; ++u) {
+                    const int64_t e = e0 + 64 * u;
+                    if (e < dp) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double b = (double)v[c][u], t = a[c][u] - b;
-                        s += t * t;
-                        g += a[c][u] * b;
+                        for (int t = 0; t < 4; ++t) {
+                            const double a = q64[e + t], b = (double)v[u][t], df = a - b;
+                            s += df * df;
+                            g += a * b;
+                        }
                     }
+                }
             }
         }
     }
@@ -628,7 +831,7 @@ struct FinishArgs {
     int* unproven;      // build fallback: counts the rows whose list failed the a-posteriori check even in fp64
 };
 
-// SPEC S10 given the selected neighbours in ascending index order in LDS; one wave, lane t
+// SPEC S10 given the selected neighbours in LDS in (key, index) rank order; one wave, lane t
 // owns neighbour t, sums are fixed-order butterflies (deterministic).
 __device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist, const double* s_gy, const double* s_deg,
                                                    const double* s_ny, int metric, int kernel, double sigma, double p,
@@ -667,6 +870,7 @@ __device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist
 template <typename T>
 __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    AS_STAMP(0);
     const int z = blockIdx.z;
     const T* ckey = (const T*)a.ck + (int64_t)z * CAND_CAP;
     const int* cidx = a.ci + (int64_t)z * CAND_CAP;
@@ -677,6 +881,14 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     int* si = (int*)(sk + CAND_CAP);
     T* pk = (T*)(si + CAND_CAP);            // PRUNE_CAP pruned candidates
     int* pi = (int*)(pk + PRUNE_CAP);
+    // the query, read dozens of times by the exact evaluation: once from HBM into LDS (visible behind the barriers
+    // of the candidate selection)
+    const double* qx = a.q64;
+    if (a.dp <= Q_LDS_MAX) {
+        double* qs = (double*)(pi + PRUNE_CAP) + CAND_CAP;
+        for (int64_t c = threadIdx.x; c < a.dp; c += blockDim.x) qs[c] = a.q64[c];
+        qx = qs;
+    }
     __shared__ T fk[64];
     __shared__ int fi[64];
     __shared__ double ek[64], ed[64], eg[64], sk2[64];
@@ -693,6 +905,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         total = raw < CAND_CAP ? raw : CAND_CAP;
         select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
+    AS_STAMP(1);
     const double nq = a.info->nq;
     bool complete = false;   // the list below was chosen among ALL candidates by their exact keys: nothing to prove
     if (a.exhaustive && !a.from_list && !a.thresholded && a.info->knn_cnt <= CAND_CAP && total > a.M) {
@@ -706,7 +919,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         __syncthreads();
         for (int base = 0; base < total; base += 64) {
             const int m = total - base < 64 ? total - base : 64;
-            exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, si + base, m, t_sq, t_dot);
+            exact_eval_all(a.x32, a.x64, qx, a.d, a.dp, si + base, m, t_sq, t_dot);
             __syncthreads();
             if (threadIdx.x < m) {
                 double kk = t_sq[threadIdx.x];
@@ -734,8 +947,15 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         complete = true;
     }
     const int Mp = fcount;
-    exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, fi, Mp, ek, eg);
+    // the selected candidates' degrees / norms: in flight under the exact evaluation instead of behind it
+    double pre_deg = 0.0, pre_ny = 0.0;
+    if (w == 0 && lane < Mp) {
+        pre_deg = a.deg ? a.deg[fi[lane]] : 0.0;
+        pre_ny = a.ny ? a.ny[fi[lane]] : 0.0;
+    }
+    exact_eval_all(a.x32, a.x64, qx, a.d, a.dp, fi, Mp, ek, eg);
     __syncthreads();
+    AS_STAMP(2);
     if (threadIdx.x < Mp) {
         const int t = threadIdx.x;
         const double sq = ek[t], dot = eg[t];
@@ -752,6 +972,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     }
     __syncthreads();
     if (w != 0) return;
+    AS_STAMP(3);
     // rank by (key64, idx): one candidate per lane
     const bool have = lane < Mp;
     const double myk = have ? ek[lane] : 0.0;
@@ -774,8 +995,8 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     }
     if (a.o_idx)
         for (int64_t t = lane; t < a.k; t += 64) a.o_idx[t] = -1;
-    const double mydeg = sel && a.deg ? a.deg[myi] : 0.0;
-    const double myny = sel && a.ny ? a.ny[myi] : 0.0;
+    const double mydeg = sel ? pre_deg : 0.0;
+    const double myny = sel ? pre_ny : 0.0;
     if (sel) {
         if (a.recs) {
             as_knn_rec r;
@@ -794,20 +1015,14 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
             a.o_gy[rank] = eg[lane];
         }
     }
-    if (a.fuse) {
-        // ascending-index order of the selected neighbours
-        int irank = 0;
-        for (int s = 0; s < 64; ++s) {
-            const int oi = bcast_lane(myi, s);
-            const bool osel = (__ballot(sel) >> s) & 1ull;
-            irank += (osel && oi < myi) ? 1 : 0;
-        }
-        if (sel) {
-            l_dist[irank] = ed[lane];
-            l_gy[irank] = eg[lane];
-            l_deg[irank] = mydeg;
-            l_ny[irank] = myny;
-        }
+    AS_STAMP(4);
+    if (a.fuse && sel) {
+        // lane order of the sums below = (key64, index) rank: fixed by the data alone, like the ascending-index order
+        // it replaces (64 readlane/ballot rounds, 2.3 us), and the same in q_lambda_kernel
+        l_dist[rank] = ed[lane];
+        l_gy[rank] = eg[lane];
+        l_deg[rank] = mydeg;
+        l_ny[rank] = myny;
     }
     AS_LDS_FENCE();
     if (lane == 0) {
@@ -824,7 +1039,9 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         a.info->knn_inexact = bad;
         if (bad && a.unproven) atomicAdd(a.unproven, 1);
     }
+    AS_STAMP(5);
     if (a.fuse) lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, a.metric, a.kernel, a.sigma, a.p, a.tau0, a.info);
+    AS_STAMP(6);
 }
 
 // SPEC S10 from m candidate records (this shard's, or all shards' all-gathered)
@@ -855,15 +1072,13 @@ __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restri
     }
     const int cnt = wave_sum(cnt_l);
     AS_LDS_FENCE();
-    // ascending-index order
+    // lane order = (key, index) rank, as in knn_finish_kernel
     if (lane < cnt) {
         const int t = l_pos[lane];
-        int irank = 0;
-        for (int s = 0; s < cnt; ++s) irank += r_idx[l_pos[s]] < r_idx[t] ? 1 : 0;
-        l_dist[irank] = recs[t].dist;
-        l_gy[irank] = recs[t].gy;
-        l_deg[irank] = recs[t].deg;
-        l_ny[irank] = recs[t].ny;
+        l_dist[lane] = recs[t].dist;
+        l_gy[lane] = recs[t].gy;
+        l_deg[lane] = recs[t].deg;
+        l_ny[lane] = recs[t].ny;
     }
     AS_LDS_FENCE();
     lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
@@ -877,6 +1092,7 @@ __device__ __forceinline__ void publish(HostOut* out, int64_t seq) {
 template <typename T>
 __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double coef_s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    AS_STAMP(16);
     const int z = blockIdx.z;
     const T* ckey = (const T*)a.ck + (int64_t)z * CAND_CAP;
     const int* cidx = a.ci + (int64_t)z * CAND_CAP;
@@ -892,6 +1108,12 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
     double* sk2 = es + MS_MAX;                 // MS_MAX: scratch, then scores in rank order
     T* fk = (T*)(sk2 + MS_MAX);               // MS_MAX best fp32 keys, sorted
     int* fi = (int*)(fk + MS_MAX);
+    const double* qx = a.q64;
+    if (a.dp <= Q_LDS_MAX) {
+        double* qs = (double*)(fi + MS_MAX);
+        for (int64_t c = threadIdx.x; c < a.dp; c += blockDim.x) qs[c] = a.q64[c];
+        qx = qs;
+    }
     __shared__ int fcount;
     int total;
     if (a.from_list) {
@@ -904,17 +1126,26 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
         select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
     const int Mp = fcount;
+    AS_STAMP(17);
     const double nq = a.info->nq, tau = a.tau, lq = a.info->lambda_q;
+    // norms and lambdas of the candidates this thread scores afterwards: in flight under the exact evaluation
+    double pre_n = 0.0, pre_l = 0.0;
+    if ((int)threadIdx.x < Mp) {
+        pre_n = a.n64[fi[threadIdx.x]];
+        pre_l = a.lam64[fi[threadIdx.x]];
+    }
     for (int base = 0; base < Mp; base += 64)   // 64 candidates per round, 16 lanes each
-        exact_eval_all(a.x32, a.x64, a.q64, a.d, a.dp, fi + base, Mp - base < 64 ? Mp - base : 64, sk2 + base, es + base);
+        exact_eval_all(a.x32, a.x64, qx, a.d, a.dp, fi + base, Mp - base < 64 ? Mp - base : 64, sk2 + base, es + base);
     __syncthreads();
     for (int t = threadIdx.x; t < Mp; t += blockDim.x) {
         const int j = fi[t];
-        const double den = sqrt(a.n64[j] * nq);
+        const double nj = t < (int)blockDim.x ? pre_n : a.n64[j], lj = t < (int)blockDim.x ? pre_l : a.lam64[j];
+        const double den = sqrt(nj * nq);
         const double c = den > 0.0 ? es[t] / den : 0.0;
-        es[t] = tau * c + (1.0 - tau) / (1.0 + fabs(lq - a.lam64[j]));
+        es[t] = tau * c + (1.0 - tau) / (1.0 + fabs(lq - lj));
     }
     __syncthreads();
+    AS_STAMP(18);
     const int64_t want = a.topk < a.nrows ? a.topk : a.nrows;
     const int nhit = (int)(Mp < want ? Mp : want);
     if (a.hits) {
@@ -946,6 +1177,7 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    AS_STAMP(19);
     if (threadIdx.x == 0) {
         int bad = 0;
         if (a.nrows > a.M && Mp > 0) {
@@ -973,6 +1205,7 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
             publish(a.hout, a.seq);
         }
     }
+    AS_STAMP(20);
 }
 
 // merge m hit records (own or all-gathered) -> final topk, written to pinned host memory
@@ -1078,12 +1311,13 @@ static FinishArgs make_finish(as_query* q) {
 
 template <typename T>
 static size_t score_lds() {
-    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP + MS_MAX) + 2 * sizeof(double) * MS_MAX;
+    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP + MS_MAX) + 2 * sizeof(double) * MS_MAX + sizeof(double) * Q_LDS_MAX;
 }
 
 template <typename T>
 static size_t finish_lds() {
-    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP) + sizeof(double) * CAND_CAP;   // + exact keys of the exhaustive pass
+    // candidates + pruned candidates + exact keys of the exhaustive pass + the query
+    return (sizeof(T) + sizeof(int)) * (size_t)(CAND_CAP + PRUNE_CAP) + sizeof(double) * CAND_CAP + sizeof(double) * Q_LDS_MAX;
 }
 
 // k-NN candidates of the scanned rows -> records (or row lists for the build fallback)
@@ -1104,7 +1338,7 @@ static void launch_knn_repair(as_query* q, const T* dots, double eps, int64_t ex
     a.cidx = q->cidx_k;
     const unsigned nb = (unsigned)q->nb;
     hipLaunchKernelGGL((score_gmin_kernel<T, 1>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
-    hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Mk, q->info);
+    hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Mk, q->info);
     const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
     hipLaunchKernelGGL((score_filter_kernel<T, 1>), dim3(fg, 1, nb), dim3(256), 0, st, a);
 }
@@ -1198,7 +1432,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         a.tau = f.tau;
         const unsigned nb = (unsigned)q->nb;
         hipLaunchKernelGGL((score_gmin_kernel<T, 0>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
-        hipLaunchKernelGGL((pick_thr_kernel<T, U, PASSES>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
+        hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
         const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
         hipLaunchKernelGGL((score_filter_kernel<T, 0>), dim3(fg, 1, nb), dim3(256), 0, st, a);
         f.ck = q->ckey_s; f.ci = q->cidx_s;
@@ -1299,6 +1533,13 @@ using namespace as;
 extern "C" {
 
 void as_enable_search_stats(int32_t enabled) { g_search_stats.store(enabled ? 1 : 0, std::memory_order_relaxed); }
+
+#ifdef AS_STAMPS
+// diagnostic build only (not declared in the public header): the raw stamps of the last finish kernels
+int as_debug_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(as::g_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // extern "C"
 
