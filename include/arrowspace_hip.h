@@ -108,6 +108,37 @@ as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32
                             const double* dist_dev, const double* gy_dev, const int32_t* cnt_dev,
                             as_graph** out_graph);
 
+/* ---- staged build without replication (row-sharded multi-GPU): a rank's space holds only ITS rows;
+ *      the other ranks' shards visit one at a time as temporary spaces (ring send/recv in the host).  Per visiting
+ *      block as_knn_block fills that block's slice of the partial lists (M = as_knn_list_width(k) exact entries per
+ *      row, ids global); as_knn_merge ranks the slices of all blocks, applies eps and k and flags the rows for which
+ *      something a block dropped could still belong to the answer; those rows go round once more through
+ *      as_knn_block_band (complete collection inside the proven band), then as_knn_merge again.  Partial arrays are
+ *      device memory, caller-allocated: key / dist / gy fp64 and idx int32 [nblocks][rows][M], cnt int32 and t32 fp32
+ *      [nblocks][rows]; the pointers passed to as_knn_block / _band are those of ONE block's slice. ---- */
+int32_t as_knn_list_width(int64_t k);                 /* M; < 0 when k is not supported */
+double as_space_nmax(const as_space* sp);             /* largest squared norm (error bound of a block's dropped candidates) */
+as_status as_space_norms(const as_space* sp, double* out_dev); /* fp64 squared norms of the space's rows, device to device */
+int64_t as_space_row_offset(const as_space* sp);      /* global index of row 0 (set by as_graph_from_knn_global) */
+as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                       int64_t row_goff, int64_t col_goff, double* p_key_dev, double* p_dist_dev, double* p_gy_dev,
+                       int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev);
+as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t nblocks,
+                       const double* p_key_dev, const double* p_dist_dev, const double* p_gy_dev, const int32_t* p_idx_dev,
+                       const int32_t* p_cnt_dev, const float* p_t32_dev, const double* block_nmax_host, int32_t* out_idx_dev,
+                       double* out_key_dev, double* out_dist_dev, double* out_gy_dev, int32_t* out_cnt_dev,
+                       int32_t* out_flag_dev, double* out_band_dev, int64_t* out_nflagged);
+as_status as_knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin,
+                            int64_t row_end, int64_t row_goff, int64_t col_goff, const int32_t* flag_dev,
+                            const double* band_dev, double* p_key_dev, double* p_dist_dev, double* p_gy_dev,
+                            int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev, int64_t* out_overflowed);
+/* step 3 over the lists of ALL n_global items for a space that holds the rows [row_offset, row_offset + nitems):
+ * global graph, Laplacian, energies, tau0; this shard's lambdas into the space.  n64_global_dev: fp64 squared norms
+ * of all items (device).  Searches on the space then report global item ids. */
+as_status as_graph_from_knn_global(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset,
+                                   const int32_t* idx_dev, const double* dist_dev, const double* gy_dev,
+                                   const int32_t* cnt_dev, const double* n64_global_dev, as_graph** out_graph);
+
 /* ---- staged build, feature mode (AS_LAMBDA_FEATURE): what as_build composes when opts->lambda_mode selects
  *      the F x F feature-space Laplacian; multi-GPU hosts call the steps with a row range per rank and exchange
  *      the D x D Gram partials and the N energies in between ---- */

@@ -40,7 +40,8 @@ class HitRec(C.Structure):
 # every symbol include/arrowspace_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "as_build", "as_build_dev", "as_space_create_dev", "as_knn_rows", "as_graph_from_knn", "as_feat_gram", "as_feat_graph",
-    "as_feat_energy", "as_feat_lambdas", "as_graph_lambda_mode", "as_search",
+    "as_feat_energy", "as_feat_lambdas", "as_graph_lambda_mode", "as_knn_list_width", "as_space_nmax", "as_space_norms",
+    "as_space_row_offset", "as_knn_block", "as_knn_merge", "as_knn_block_band", "as_graph_from_knn_global", "as_search",
     "as_search_batch", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
     "as_query_finish", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
@@ -99,6 +100,14 @@ def load():
         "as_space_create_dev": (i32, [vp, i32, i64, i64, i64, pop, pvp]),
         "as_knn_rows": (i32, [vp, pgp, i64, i64, vp, vp, vp, vp, vp]),
         "as_graph_from_knn": (i32, [vp, pgp, vp, vp, vp, vp, pvp]),
+        "as_knn_list_width": (i32, [i64]),
+        "as_space_nmax": (f64, [vp]),
+        "as_space_norms": (i32, [vp, vp]),
+        "as_space_row_offset": (i64, [vp]),
+        "as_knn_block": (i32, [vp, vp, pgp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
+        "as_knn_merge": (i32, [vp, pgp, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
+        "as_knn_block_band": (i32, [vp, vp, pgp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
+        "as_graph_from_knn_global": (i32, [vp, pgp, i64, i64, vp, vp, vp, vp, vp, pvp]),
         "as_feat_gram": (i32, [vp, i64, i64, vp]),
         "as_feat_graph": (i32, [vp, pgp, vp, pvp]),
         "as_feat_energy": (i32, [vp, vp, i64, i64, vp, vp]),

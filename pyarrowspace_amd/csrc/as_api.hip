@@ -214,6 +214,105 @@ as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32
     return AS_OK;
 }
 
+as_status as_graph_from_knn_global(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx_dev,
+                                   const double* dist_dev, const double* gy_dev, const int32_t* cnt_dev, const double* n64_global_dev,
+                                   as_graph** out_graph) {
+    if (!sp || !idx_dev || !dist_dev || !gy_dev || !cnt_dev || !n64_global_dev || !out_graph) {
+        set_err("as_graph_from_knn_global: null argument");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    as_graph* gr = new as_graph();
+    const double t0 = now_s();
+    as_status s = graph_from_knn_global(sp, &r, n_global, row_offset, idx_dev, dist_dev, gy_dev, cnt_dev, n64_global_dev, gr);
+    if (s != AS_OK) {
+        as_free_graph(gr);
+        return s;
+    }
+    for (int i = 0; i < 10; ++i) gr->stats[i] = sp->kstats[i];
+    gr->stats[4] = now_s() - t0;
+    *out_graph = gr;
+    return AS_OK;
+}
+
+int32_t as_knn_list_width(int64_t k) { return knn_list_width(k); }
+double as_space_nmax(const as_space* sp) { return sp ? sp->nmax : 0.0; }
+as_status as_space_norms(const as_space* sp, double* out_dev) {
+    if (!sp || !out_dev) {
+        set_err("as_space_norms: null argument");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    AS_HIP(hipMemcpy(out_dev, sp->n64, sizeof(double) * sp->n, hipMemcpyDeviceToDevice));
+    return AS_OK;
+}
+int64_t as_space_row_offset(const as_space* sp) { return sp ? sp->row_offset : 0; }
+
+as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                       int64_t row_goff, int64_t col_goff, double* p_key_dev, double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev,
+                       int32_t* p_cnt_dev, float* p_t32_dev) {
+    if (!sp || !cols || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev) {
+        set_err("as_knn_block: null argument");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    const int M = knn_list_width(r.k);
+    if (M < 0) {
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 56", (long long)r.k);
+        return AS_EUNSUPPORTED;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    const double t0 = now_s();
+    const as_status s = knn_block(sp, cols, &r, row_begin, row_end, row_goff, col_goff, M, p_key_dev, p_dist_dev, p_gy_dev, p_idx_dev,
+                                  p_cnt_dev, p_t32_dev);
+    sp->kstats[1] += now_s() - t0;
+    return s;
+}
+
+as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t nblocks,
+                       const double* p_key_dev, const double* p_dist_dev, const double* p_gy_dev, const int32_t* p_idx_dev,
+                       const int32_t* p_cnt_dev, const float* p_t32_dev, const double* block_nmax_host, int32_t* out_idx_dev,
+                       double* out_key_dev, double* out_dist_dev, double* out_gy_dev, int32_t* out_cnt_dev, int32_t* out_flag_dev,
+                       double* out_band_dev, int64_t* out_nflagged) {
+    if (!sp || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev || !block_nmax_host || !out_idx_dev ||
+        !out_key_dev || !out_dist_dev || !out_gy_dev || !out_cnt_dev || !out_flag_dev || !out_band_dev || !out_nflagged || nblocks < 1) {
+        set_err("as_knn_merge: null argument");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    const double t0 = now_s();
+    const as_status s = knn_merge(sp, &r, row_begin, row_end, nblocks, knn_list_width(r.k), p_key_dev, p_dist_dev, p_gy_dev, p_idx_dev,
+                                  p_cnt_dev, p_t32_dev, block_nmax_host, out_idx_dev, out_key_dev, out_dist_dev, out_gy_dev, out_cnt_dev,
+                                  out_flag_dev, out_band_dev, out_nflagged);
+    sp->kstats[2] += now_s() - t0;
+    return s;
+}
+
+as_status as_knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                            int64_t row_goff, int64_t col_goff, const int32_t* flag_dev, const double* band_dev, double* p_key_dev,
+                            double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev,
+                            int64_t* out_overflowed) {
+    if (!sp || !cols || !flag_dev || !band_dev || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev ||
+        !out_overflowed) {
+        set_err("as_knn_block_band: null argument");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    const double t0 = now_s();
+    const as_status s = knn_block_band(sp, cols, &r, row_begin, row_end, row_goff, col_goff, knn_list_width(r.k), flag_dev, band_dev,
+                                       p_key_dev, p_dist_dev, p_gy_dev, p_idx_dev, p_cnt_dev, p_t32_dev, out_overflowed);
+    sp->kstats[2] += now_s() - t0;
+    if (s == AS_OK) sp->kstats[8] += (double)*out_overflowed;
+    return s;
+}
+
 as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_graph_params* gp,
                        const as_opts* opts, as_space** out_space, as_graph** out_graph) {
     if (!out_space || !out_graph) {
@@ -341,7 +440,8 @@ static as_status search_single_locked(const as_space* sp, const as_graph* gr, co
 
 // the graph handle belongs to this space: item graphs have one node per item, feature graphs one per column
 static as_status graph_matches(const as_space* sp, const as_graph* gr, const char* who) {
-    const bool ok = gr->lambda_mode == AS_LAMBDA_FEATURE ? (gr->n == sp->d && gr->nitems == sp->n) : gr->n == sp->n;
+    // a shard of a row-sharded index searches against the graph of all items
+    const bool ok = gr->lambda_mode == AS_LAMBDA_FEATURE ? (gr->n == sp->d && gr->nitems == sp->n) : gr->n >= sp->row_offset + sp->n;
     if (!ok) {
         set_err("%s: the graph (%lld nodes) was not built for this space (%lld items x %lld features)", who, (long long)gr->n,
                 (long long)sp->n, (long long)sp->d);

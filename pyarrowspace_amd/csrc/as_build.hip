@@ -148,12 +148,16 @@ struct KnnArgs {
     float* out_key;  // [(r1-r0)][S][M]
     int* out_idx;
     int* out_cnt;    // [(r1-r0)][S]: count | dropped<<30 | overflowed<<31 (collect mode)
-    // collect mode (second pass over the rows the first could not prove exact): the A rows are a gathered copy
-    // [r1][dp] of those rows (r0 = 0), with their own norms, global ids (self exclusion) and FIXED per-row
-    // thresholds -- every column whose fp32 key is inside the threshold is kept, nothing is compacted away
+    // Row side (A operand) and column side (B operand = x32 / n32 / inorm32 / n above) are separate: the same space
+    // for a single-GPU build, this rank's shard against a visiting shard on the ring.  Item ids
+    // are global: row id = row_goff + row, stored column id = col_goff + column.
     const float* xa;
     const float* a_n32;
     const float* a_inorm32;
+    int64_t row_goff, col_goff;
+    // collect mode (second pass over the rows the first could not prove exact): the A rows are a gathered copy
+    // [r1][dp] of those rows (r0 = 0), with their own norms, global ids (self exclusion) and FIXED per-row
+    // thresholds -- every column whose fp32 key is inside the threshold is kept, nothing is compacted away
     const int* a_ids;
     const float* a_thr;
 };
@@ -680,15 +684,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 s_ta[tid] = make_float2(valid ? a.a_thr[rg] : -finf, valid ? (METRIC == AS_METRIC_L2 ? a.a_n32[rg] : a.a_inorm32[rg]) : 0.0f);
                 s_id[tid] = valid ? a.a_ids[rg] : -1;
             } else {
-                const bool valid = rg < a.r1 && rg < a.n;
-                const float ni = valid ? a.n32[rg] : 0.0f;
+                const bool valid = rg < a.r1;
+                const float ni = valid ? a.a_n32[rg] : 0.0f;
                 const float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
-                s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.inorm32[rg]) : 0.0f);
+                s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.a_inorm32[rg]) : 0.0f);
             }
             s_cur[tid] = 0;
             s_drop[tid] = 0;
         }
-        const char* pa0 = (const char*)((COLLECT ? a.xa : a.x32) + (size_t)(rowbase + wu * 32) * a.dp);
+        const char* pa0 = (const char*)(a.xa + (size_t)(rowbase + wu * 32) * a.dp);
         // 6 pieces per wave and slab: j < 4 -> A rows [8j, 8j+8) of this wave's 32, j >= 4 -> B rows of its 16
         auto dma_piece = [&](const char* srcA, const char* srcB, float* dst, int j) {
             if (j < 4) {
@@ -785,13 +789,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 AS_CBAR();
             }
-            const bool edge = COLLECT || colbase + BN > a.n || (colbase < rowbase + BM && colbase + BN > rowbase);
+            const int64_t colg = a.col_goff + colbase, rowg = a.row_goff + rowbase;   // global ids of the tile's corner
+            const bool edge = COLLECT || colbase + BN > a.n || (colg < rowg + BM && colg + BN > rowg);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float2 ta = s_ta[rl];
                 const float thr = ta.x, ai = ta.y;
-                const int rg = COLLECT ? s_id[rl] : (int)(rowbase + rl);
+                const int rg = COLLECT ? s_id[rl] : (int)(rowg + rl);
                 float key[4];
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float excl = COLLECT ? __int_as_float(0x7fc00000) : finf;
 #pragma unroll
                     for (int nn = 0; nn < 4; ++nn)
-                        if (cj[nn] >= (int)a.n || cj[nn] == rg) key[nn] = excl;
+                        if (cj[nn] >= (int)a.n || cj[nn] + (int)a.col_goff == rg) key[nn] = excl;
                 }
                 const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
                 if (__ballot(kmin <= thr)) {
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (p) {
                             const unsigned slot = (unsigned)rl * CAP + base + __popc(hm & ((1u << l31) - 1u));
                             bkey[slot] = key[nn];
-                            bidx[slot] = cj[nn];
+                            bidx[slot] = cj[nn] + (int)a.col_goff;
                         }
                         s_cur[rl] = base + __popc(hm);
                     }
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int r = 0; r < 32; ++r) {
             const unsigned rl = w * 32 + r;
             const int64_t rg = rowbase + rl;
-            if (rg >= a.r1 || (!COLLECT && rg >= a.n)) break;
+            if (rg >= a.r1) break;
             if (!COLLECT && s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int cnt = s_cur[rl];
@@ -1008,7 +1013,7 @@ __global__ void band_gather_kernel(const float* __restrict__ x32, const float* _
                                    const double* __restrict__ n64, int64_t dp, int64_t r0, const int* __restrict__ ids, int nf,
                                    const double* __restrict__ B, int metric, double coef, double nmax, float* __restrict__ xa,
                                    float* __restrict__ a_n32, float* __restrict__ a_inorm32, int* __restrict__ a_ids,
-                                   float* __restrict__ a_thr) {
+                                   float* __restrict__ a_thr, int64_t goff) {
     const int f = blockIdx.x;
     if (f >= nf) return;
     const int lr = ids[f];
@@ -1017,7 +1022,7 @@ __global__ void band_gather_kernel(const float* __restrict__ x32, const float* _
     if (threadIdx.x == 0) {
         a_n32[f] = n32[row];
         a_inorm32[f] = inorm32[row];
-        a_ids[f] = (int)row;
+        a_ids[f] = (int)(goff + row);   // global item id (self exclusion against global column ids)
         const double e = metric == AS_METRIC_L2 ? coef * (n64[row] + nmax) : coef;
         // rounded up twice over: the device-side comparison must never be tighter than the fp64 band
         a_thr[f] = __double2float_ru((B[lr] + e) * 1.000001);
@@ -1138,6 +1143,7 @@ static int pick_list_width(int64_t k) {
     if (need <= 64) return 64;
     return -1;
 }
+int knn_list_width(int64_t k) { return pick_list_width(k); }
 
 as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int32_t* out_idx,
                    double* out_key, double* out_dist, double* out_gy, int32_t* out_cnt, double* stats) {
@@ -1213,7 +1219,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
         ka.epskey = nextafterf(ka.epskey, INFINITY);
         ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-        ka.xa = nullptr; ka.a_n32 = nullptr; ka.a_inorm32 = nullptr; ka.a_ids = nullptr; ka.a_thr = nullptr;
+        ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = 0; ka.col_goff = 0; ka.a_ids = nullptr; ka.a_thr = nullptr;
         dev_events<3> ev;
         AS_HIP(ev.create());
         hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
@@ -1314,7 +1320,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             AS_HIP(hipMemsetAsync(xa, 0, sizeof(float) * (size_t)(nfp + BM) * sp->dp, st));
             hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, sp->x32, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
                                (const int*)d_ids, nf, (const double*)bandB, metric, coef, sp->nmax, (float*)xa, (float*)a_n32, (float*)a_inorm,
-                               (int*)a_ids, (float*)a_thr);
+                               (int*)a_ids, (float*)a_thr, (int64_t)0);
             AS_HIP(hipGetLastError());
             KnnArgs kb = ka;
             kb.r0 = 0; kb.r1 = nf; kb.nrb = nrb2; kb.S = S2; kb.M = CAP;
@@ -1388,6 +1394,486 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         stats[1] += t_mfma; stats[2] += t_ref; stats[3] += t_fb; stats[6] += nflagged; stats[7] += flops;
         stats[8] += unproven; stats[9] += band_rows;
     }
+    return AS_OK;
+}
+
+// ------------------------------------------------------------------ K2 over visiting column blocks (multi-GPU ring)
+// A rank holds only ITS rows.  The other shards visit one at a time (ring send/recv in the host):
+// per visiting block the same fused MFMA kernel runs with A = own rows, B = the block, and a block refinement turns
+// its fp32 candidate lists into M exact (key64, global id) entries per row plus the largest kept fp32 key (what was
+// dropped from that block is provably beyond it).  After the last block knn_merge_kernel ranks the nblocks * M exact
+// entries of every row, applies eps and k, and checks block by block that nothing dropped could belong to the answer;
+// rows that fail go round the ring once more in collect mode (K2c per block).  The item matrix is never replicated.
+__device__ __forceinline__ void exact_pair2(const float* xa32, const double* xa64, const float* xb32, const double* xb64, int64_t d,
+                                            int64_t dp, int64_t i, int64_t j, double& sq, double& dot) {
+    const int lane = lane_id();
+    double s = 0.0, g = 0.0;
+    // the same lane-strided order as exact_pair: a pair gives the same bits whichever path evaluated it
+    for (int64_t c = lane; c < d; c += 64) {
+        const double a = xa64 ? xa64[i * d + c] : (double)xa32[i * dp + c];
+        const double b = xb64 ? xb64[j * d + c] : (double)xb32[j * dp + c];
+        const double t = a - b;
+        s += t * t;
+        g += a * b;
+    }
+    sq = wave_sum(s);
+    dot = wave_sum(g);
+}
+
+struct BlockRefineArgs {
+    const float *xa32, *xb32;
+    const double *xa64, *xb64, *na64, *nb64;
+    int64_t d, dp, r0, r1, col_goff;
+    int S, M, metric;
+    const float* c_key;
+    const int* c_idx;
+    const int* c_cnt;
+    // partial lists of this block: [rows][M] sorted by (key64, global id), count | dropped << 30, largest kept fp32 key
+    double *p_key, *p_dist, *p_gy;
+    int32_t* p_idx;
+    int32_t* p_cnt;
+    float* p_t32;
+};
+
+__global__ __launch_bounds__(256) void knn_block_refine_kernel(BlockRefineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int SM = a.S * a.M;
+    const size_t per_wave = sizeof(double) * 3 * a.M + sizeof(float) * (SM + a.M) + sizeof(int) * (SM + a.M);
+    char* base = smem + (size_t)w * ((per_wave + 15) / 16 * 16);
+    double* ek = (double*)base;
+    double* eg = ek + a.M;
+    double* ed = eg + a.M;
+    float* ck = (float*)(ed + a.M);
+    float* lk = ck + SM;
+    int* ci = (int*)(lk + a.M);
+    int* li = ci + SM;
+    const int64_t row = a.r0 + (int64_t)blockIdx.x * 4 + w;
+    if (row >= a.r1) return;
+    const int64_t lr = row - a.r0;
+    int C = 0, anyfull = 0;
+    for (int cs = 0; cs < a.S; ++cs) {
+        const int cc = a.c_cnt[lr * a.S + cs];
+        const int c = cc & 0xffff;
+        anyfull |= (cc >> 30) & 1;
+        const size_t ob = ((size_t)lr * a.S + cs) * a.M;
+        for (int t = lane; t < c; t += 64) {
+            ck[C + t] = a.c_key[ob + t];
+            ci[C + t] = a.c_idx[ob + t];
+        }
+        C += c;
+    }
+    if (C > a.M) anyfull = 1;
+    const int Mp = C < a.M ? C : a.M;
+    AS_LDS_FENCE();
+    for (int t = lane; t < C; t += 64) {
+        const float k = ck[t];
+        const int i = ci[t];
+        int rank = 0;
+        for (int s2 = 0; s2 < C; ++s2) rank += lex_less<float>(ck[s2], ci[s2], k, i) ? 1 : 0;
+        if (rank < a.M) {
+            lk[rank] = k;
+            li[rank] = i;
+        }
+    }
+    AS_LDS_FENCE();
+    const double ni = a.na64[row];
+    for (int t = 0; t < Mp; ++t) {
+        const int64_t j = (int64_t)li[t] - a.col_goff;
+        double sq, dot;
+        exact_pair2(a.xa32, a.xa64, a.xb32, a.xb64, a.d, a.dp, row, j, sq, dot);
+        if (lane == 0) {
+            if (a.metric == AS_METRIC_L2) {
+                ek[t] = sq;
+                ed[t] = sqrt(sq);
+                eg[t] = dot;
+            } else {
+                const double den = sqrt(ni * a.nb64[j]);
+                const double c = den > 0.0 ? dot / den : 0.0;
+                const double dd = cosine_distance(c);
+                ek[t] = dd;
+                ed[t] = dd;
+                eg[t] = c;
+            }
+        }
+    }
+    AS_LDS_FENCE();
+    for (int t = lane; t < Mp; t += 64) {
+        const double k = ek[t];
+        const int i = li[t];
+        int rank = 0;
+        for (int s2 = 0; s2 < Mp; ++s2) rank += lex_less<double>(ek[s2], li[s2], k, i) ? 1 : 0;
+        const size_t o = (size_t)lr * a.M + rank;
+        a.p_key[o] = k;
+        a.p_dist[o] = ed[t];
+        a.p_gy[o] = eg[t];
+        a.p_idx[o] = i;
+    }
+    if (lane == 0) {
+        a.p_cnt[lr] = Mp | (anyfull << 30);
+        a.p_t32[lr] = Mp > 0 ? lk[Mp - 1] : 0.0f;
+    }
+}
+
+struct MergeArgs {
+    int64_t rows, k;          // k: cap and output stride
+    int nblocks, M, metric;
+    double epskey, coef;
+    const double* na64;       // own rows' squared norms, [r0 + lr]
+    int64_t r0;
+    const double *p_key, *p_dist, *p_gy;   // [nblocks][rows][M]
+    const int32_t* p_idx;
+    const int32_t* p_cnt;     // [nblocks][rows]
+    const float* p_t32;
+    const double* nmax;       // [nblocks]: largest squared norm of the block (error bound of what it dropped)
+    int32_t* out_idx;
+    double *out_key, *out_dist, *out_gy;
+    int32_t* out_cnt;
+    int* flag;
+    int* nflag;
+    double* out_B;
+};
+
+// one wave per row
+__global__ __launch_bounds__(256) void knn_merge_kernel(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int cap = a.nblocks * a.M;
+    char* base = smem + (size_t)w * ((sizeof(double) + sizeof(int) * 2) * cap);
+    double* mk = (double*)base;
+    int* mi = (int*)(mk + cap);
+    int* mp = mi + cap;          // position in the partial arrays
+    const int64_t lr = (int64_t)blockIdx.x * 4 + w;
+    if (lr >= a.rows) return;
+    int C = 0;
+    for (int b = 0; b < a.nblocks; ++b) {
+        const int c = a.p_cnt[(size_t)b * a.rows + lr] & 0xffff;
+        const size_t ob = ((size_t)b * a.rows + lr) * a.M;
+        for (int t = lane; t < c; t += 64) {
+            mk[C + t] = a.p_key[ob + t];
+            mi[C + t] = a.p_idx[ob + t];
+            mp[C + t] = (int)(ob + t - (size_t)lr * a.M);   // relative: fits an int
+        }
+        C += c;
+    }
+    AS_LDS_FENCE();
+    int npass_l = 0;
+    double kth_l = -1.0;
+    for (int t = lane; t < C; t += 64) {
+        const double kk = mk[t];
+        if (!(kk <= a.epskey)) continue;
+        npass_l += 1;
+        int rank = 0;
+        for (int s2 = 0; s2 < C; ++s2) rank += lex_less<double>(mk[s2], mi[s2], kk, mi[t]) ? 1 : 0;
+        if (rank < a.k) {
+            const size_t src = (size_t)lr * a.M + (size_t)mp[t];
+            a.out_idx[lr * a.k + rank] = mi[t];
+            a.out_key[lr * a.k + rank] = kk;
+            a.out_dist[lr * a.k + rank] = a.p_dist[src];
+            a.out_gy[lr * a.k + rank] = a.p_gy[src];
+            if (rank == a.k - 1) kth_l = kk;
+        }
+    }
+    const int npass = wave_sum(npass_l);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(kth_l, o, 64);
+        kth_l = other > kth_l ? other : kth_l;
+    }
+    const int cnt = npass < a.k ? npass : (int)a.k;
+    for (int64_t t = cnt + lane; t < a.k; t += 64) a.out_idx[lr * a.k + t] = -1;
+    if (lane == 0) {
+        a.out_cnt[lr] = cnt;
+        const double B = npass >= a.k ? kth_l : a.epskey;
+        const double ni = a.na64[a.r0 + lr];
+        int bad = 0;
+        for (int b = 0; b < a.nblocks; ++b) {
+            const int cc = a.p_cnt[(size_t)b * a.rows + lr];
+            if (!((cc >> 30) & 1) || (cc & 0xffff) == 0) continue;   // nothing was dropped from this block
+            const double e = a.metric == AS_METRIC_L2 ? a.coef * (ni + a.nmax[b]) : a.coef;
+            if (!((double)a.p_t32[(size_t)b * a.rows + lr] - e > B)) bad = 1;
+        }
+        a.flag[lr] = bad;
+        if (bad) {
+            atomicAdd(a.nflag, 1);
+            a.out_B[lr] = B;
+        }
+    }
+}
+
+// band pass of one visiting block for the flagged rows: exact evaluation of everything the collect-mode kernel
+// kept, the M smallest (key64, id) of THIS block into the row's partial list (nothing dropped: count without flag)
+struct BlockBandArgs {
+    const float *xa32, *xb32;
+    const double *xa64, *xb64, *na64, *nb64;
+    int64_t d, dp, r0, col_goff;
+    int S, CW, M, metric, nf;
+    const int* ids;
+    const int* c_idx;
+    const int* c_cnt;
+    double *p_key, *p_dist, *p_gy;
+    int32_t* p_idx;
+    int32_t* p_cnt;
+    float* p_t32;
+    int* overflow;   // counts rows whose band did not fit
+};
+
+__global__ __launch_bounds__(256) void knn_block_band_kernel(BlockBandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ek = (double*)smem;
+    double* ed = ek + BAND_MAX;
+    double* eg = ed + BAND_MAX;
+    int* ci = (int*)(eg + BAND_MAX);
+    __shared__ int s_C, s_over;
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int f = blockIdx.x;
+    const int lr = a.ids[f];
+    const int64_t row = a.r0 + lr;
+    if (threadIdx.x == 0) {
+        int C = 0, over = 0;
+        for (int cs = 0; cs < a.S; ++cs) {
+            const int cc = a.c_cnt[(size_t)f * a.S + cs];
+            over |= (cc >> 31) & 1;
+            C += cc & 0xffff;
+        }
+        s_C = C;
+        s_over = over || C > BAND_MAX;
+    }
+    __syncthreads();
+    if (s_over) {
+        if (threadIdx.x == 0) atomicAdd(a.overflow, 1);   // the first pass's (unproven) list of this block stands
+        return;
+    }
+    const int C = s_C;
+    {
+        int off = 0;
+        for (int cs = 0; cs < a.S; ++cs) {
+            const int c = a.c_cnt[(size_t)f * a.S + cs] & 0xffff;
+            const size_t ob = ((size_t)f * a.S + cs) * a.CW;
+            for (int t = threadIdx.x; t < c; t += blockDim.x) ci[off + t] = a.c_idx[ob + t];
+            off += c;
+        }
+    }
+    __syncthreads();
+    const double ni = a.na64[row];
+    for (int t = w; t < C; t += 4) {
+        const int64_t j = (int64_t)ci[t] - a.col_goff;
+        double sq, dot;
+        exact_pair2(a.xa32, a.xa64, a.xb32, a.xb64, a.d, a.dp, row, j, sq, dot);
+        if (lane == 0) {
+            if (a.metric == AS_METRIC_L2) {
+                ek[t] = sq;
+                ed[t] = sqrt(sq);
+                eg[t] = dot;
+            } else {
+                const double den = sqrt(ni * a.nb64[j]);
+                const double c = den > 0.0 ? dot / den : 0.0;
+                const double dd = cosine_distance(c);
+                ek[t] = dd;
+                ed[t] = dd;
+                eg[t] = c;
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+        const double kk = ek[t];
+        int rank = 0;
+        for (int s2 = 0; s2 < C; ++s2) rank += lex_less<double>(ek[s2], ci[s2], kk, ci[t]) ? 1 : 0;
+        if (rank < a.M) {
+            const size_t o = (size_t)lr * a.M + rank;
+            a.p_key[o] = kk;
+            a.p_dist[o] = ed[t];
+            a.p_gy[o] = eg[t];
+            a.p_idx[o] = ci[t];
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.p_cnt[lr] = C < a.M ? C : a.M;   // complete inside the band: no "dropped" flag
+        a.p_t32[lr] = 0.0f;
+    }
+}
+
+// the fused MFMA kernel on (rows of sp) x (columns of cols), normal or collect mode
+static as_status launch_k2(const KnnArgs& ka, int metric, bool collect, int grid, hipStream_t st) {
+    const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
+#define AS_K2(MM, CC)                                                                                                   \
+    do {                                                                                                                \
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<MM, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); \
+        hipLaunchKernelGGL((knn_mfma_dma8_kernel<MM, CC>), dim3(grid), dim3(512), lds8, st, ka);                        \
+    } while (0)
+    if (metric == AS_METRIC_L2 && !collect) AS_K2(AS_METRIC_L2, false);
+    else if (metric == AS_METRIC_L2) AS_K2(AS_METRIC_L2, true);
+    else if (!collect) AS_K2(AS_METRIC_COSINE, false);
+    else AS_K2(AS_METRIC_COSINE, true);
+#undef AS_K2
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+static int device_cus(int device) {
+    hipDeviceProp_t prop;
+    return hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+}
+
+static as_status block_check(const as_space* sp, const as_space* cols, int64_t r0, int64_t r1, const char* who) {
+    if (!sp || !cols || cols->d != sp->d || cols->dp != sp->dp || cols->device != sp->device || cols->opts.metric != sp->opts.metric) {
+        set_err("%s: the column block does not match the space (features, device or metric)", who);
+        return AS_EINVAL;
+    }
+    if (r0 < 0 || r1 > sp->n || r0 > r1) {
+        set_err("%s: bad row range [%lld,%lld) for n=%lld", who, (long long)r0, (long long)r1, (long long)sp->n);
+        return AS_EINVAL;
+    }
+    if (sp->opts.force_exact || cols->opts.force_exact) {
+        set_err("%s: items outside the fp32-safe range (force_exact) are not supported on the ring path", who);
+        return AS_EUNSUPPORTED;
+    }
+    return AS_OK;
+}
+
+// first pass of one visiting block: fused MFMA kernel + block refinement -> the block's slice of the partial lists
+as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
+                    int64_t col_goff, int M, double* p_key, double* p_dist, double* p_gy, int32_t* p_idx, int32_t* p_cnt,
+                    float* p_t32) {
+    AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block"));
+    const int64_t rows = r1 - r0;
+    if (rows == 0) return AS_OK;
+    hipStream_t st = sp->stream;
+    const int metric = sp->opts.metric;
+    const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
+    const double coef = err_coef(sp->dp);
+    const int dev_cus = device_cus(sp->device);
+    const int nrb = (int)((rows + BM - 1) / BM);
+    const int ntile = (int)(cols->np / BN);
+    int S = 1;
+    while (S < 8 && nrb * S < dev_cus * 16 && ntile / (S * 2) >= 8) S *= 2;
+    const int units = nrb * S, grid = std::min(units, dev_cus);
+    dev_tmp<float> bkey, ckey;
+    dev_tmp<int> bidx, cidx, ccnt;
+    AS_HIP(bkey.alloc((size_t)grid * BM * CAP));
+    AS_HIP(bidx.alloc((size_t)grid * BM * CAP));
+    AS_HIP(ckey.alloc((size_t)rows * S * M));
+    AS_HIP(cidx.alloc((size_t)rows * S * M));
+    AS_HIP(ccnt.alloc((size_t)rows * S));
+    const double nmax = std::max(sp->nmax, cols->nmax);
+    KnnArgs ka;
+    ka.x32 = cols->x32; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+    ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
+    ka.epskey = nextafterf((float)epskey, INFINITY); ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(nmax * 1.0000002);
+    ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
+    ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff + 0; ka.col_goff = col_goff;
+    ka.a_ids = nullptr; ka.a_thr = nullptr;
+    AS_TRY(launch_k2(ka, metric, false, grid, st));
+    BlockRefineArgs ra;
+    ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = cols->x32; ra.xb64 = cols->x64; ra.na64 = sp->n64; ra.nb64 = cols->n64;
+    ra.d = sp->d; ra.dp = sp->dp; ra.r0 = r0; ra.r1 = r1; ra.col_goff = col_goff; ra.S = S; ra.M = M; ra.metric = metric;
+    ra.c_key = ckey; ra.c_idx = cidx; ra.c_cnt = ccnt;
+    ra.p_key = p_key; ra.p_dist = p_dist; ra.p_gy = p_gy; ra.p_idx = p_idx; ra.p_cnt = p_cnt; ra.p_t32 = p_t32;
+    const size_t per_wave = (sizeof(double) * 3 * M + sizeof(float) * ((size_t)S * M + M) + sizeof(int) * ((size_t)S * M + M) + 15) / 16 * 16;
+    AS_HIP(hipFuncSetAttribute((const void*)knn_block_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_wave * 4)));
+    hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), per_wave * 4, st, ra);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(st));   // the scratch dies with this frame; the block may be freed by the caller
+    sp->kstats[7] += 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
+    return AS_OK;
+}
+
+as_status knn_merge(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int nblocks, int M, const double* p_key,
+                    const double* p_dist, const double* p_gy, const int32_t* p_idx, const int32_t* p_cnt, const float* p_t32,
+                    const double* block_nmax_host, int32_t* out_idx, double* out_key, double* out_dist, double* out_gy,
+                    int32_t* out_cnt, int32_t* flag, double* out_B, int64_t* nflagged) {
+    const int64_t rows = r1 - r0;
+    *nflagged = 0;
+    if (rows == 0) return AS_OK;
+    hipStream_t st = sp->stream;
+    dev_tmp<double> nmax;
+    dev_tmp<int> nflag;
+    AS_HIP(nmax.alloc(nblocks));
+    AS_HIP(nflag.alloc(1));
+    AS_HIP(hipMemcpyAsync(nmax, block_nmax_host, sizeof(double) * nblocks, hipMemcpyHostToDevice, st));
+    AS_HIP(hipMemsetAsync(nflag, 0, sizeof(int), st));
+    MergeArgs ma;
+    ma.rows = rows; ma.k = gp->k; ma.nblocks = nblocks; ma.M = M; ma.metric = sp->opts.metric;
+    ma.epskey = ma.metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps; ma.coef = err_coef(sp->dp);
+    ma.na64 = sp->n64; ma.r0 = r0;
+    ma.p_key = p_key; ma.p_dist = p_dist; ma.p_gy = p_gy; ma.p_idx = p_idx; ma.p_cnt = p_cnt; ma.p_t32 = p_t32; ma.nmax = nmax;
+    ma.out_idx = out_idx; ma.out_key = out_key; ma.out_dist = out_dist; ma.out_gy = out_gy; ma.out_cnt = out_cnt;
+    ma.flag = flag; ma.nflag = nflag; ma.out_B = out_B;
+    const size_t lds = 4 * (sizeof(double) + sizeof(int) * 2) * (size_t)nblocks * M;
+    if (lds > 150 * 1024) {
+        set_err("as_knn_merge: %d blocks x list width %d exceed the merge kernel's LDS", nblocks, M);
+        return AS_EUNSUPPORTED;
+    }
+    AS_HIP(hipFuncSetAttribute((const void*)knn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), lds, st, ma);
+    AS_HIP(hipGetLastError());
+    int nf = 0;
+    AS_HIP(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+    AS_HIP(hipStreamSynchronize(st));
+    *nflagged = nf;
+    return AS_OK;
+}
+
+// second pass of one visiting block, for the rows the merge flagged: collect mode + exact evaluation of the band
+as_status knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
+                         int64_t col_goff, int M, const int32_t* flag, const double* B, double* p_key, double* p_dist, double* p_gy,
+                         int32_t* p_idx, int32_t* p_cnt, float* p_t32, int64_t* overflowed) {
+    AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block_band"));
+    const int64_t rows = r1 - r0;
+    *overflowed = 0;
+    if (rows == 0) return AS_OK;
+    hipStream_t st = sp->stream;
+    const int metric = sp->opts.metric;
+    const double coef = err_coef(sp->dp);
+    std::vector<int> hflag(rows);
+    AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
+    std::vector<int> ids;
+    for (int64_t lr = 0; lr < rows; ++lr)
+        if (hflag[lr]) ids.push_back((int)lr);
+    const int nf = (int)ids.size();
+    if (nf == 0) return AS_OK;
+    const int dev_cus = device_cus(sp->device);
+    const int64_t nfp = ((int64_t)nf + BM - 1) / BM * BM;
+    const int nrb2 = (int)(nfp / BM);
+    const int ntile = (int)(cols->np / BN);
+    const int S2 = (int)std::max<int64_t>(1, std::min<int64_t>(ntile, ((int64_t)1 << 27) / (nfp * CAP)));
+    dev_tmp<int> d_ids, a_ids, c2idx, c2cnt, over, bidx;
+    dev_tmp<float> xa, a_n32, a_inorm, a_thr, c2key, bkey;
+    AS_HIP(d_ids.alloc(nf)); AS_HIP(a_ids.alloc(nfp)); AS_HIP(over.alloc(1));
+    AS_HIP(xa.alloc((size_t)(nfp + BM) * sp->dp));
+    AS_HIP(a_n32.alloc(nfp)); AS_HIP(a_inorm.alloc(nfp)); AS_HIP(a_thr.alloc(nfp));
+    AS_HIP(c2key.alloc((size_t)nfp * S2 * CAP)); AS_HIP(c2idx.alloc((size_t)nfp * S2 * CAP)); AS_HIP(c2cnt.alloc((size_t)nfp * S2));
+    const int g2 = std::min(nrb2 * S2, dev_cus);
+    AS_HIP(bkey.alloc((size_t)g2 * BM * CAP)); AS_HIP(bidx.alloc((size_t)g2 * BM * CAP));
+    AS_HIP(hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
+    AS_HIP(hipMemsetAsync(xa, 0, sizeof(float) * (size_t)(nfp + BM) * sp->dp, st));
+    AS_HIP(hipMemsetAsync(over, 0, sizeof(int), st));
+    const double nmax = std::max(sp->nmax, cols->nmax);
+    hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, sp->x32, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
+                       (const int*)d_ids, nf, B, metric, coef, nmax, (float*)xa, (float*)a_n32, (float*)a_inorm, (int*)a_ids, (float*)a_thr,
+                       row_goff);
+    AS_HIP(hipGetLastError());
+    KnnArgs kb;
+    kb.x32 = cols->x32; kb.n32 = cols->n32; kb.inorm32 = cols->inorm32; kb.n = cols->n; kb.dp = sp->dp; kb.r0 = 0; kb.r1 = nf;
+    kb.nrb = nrb2; kb.S = S2; kb.ntile = ntile; kb.M = CAP; kb.metric = metric;
+    kb.epskey = 0; kb.coef = 0; kb.nmax = 0;
+    kb.buf_key = bkey; kb.buf_idx = bidx; kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
+    kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr; kb.row_goff = 0; kb.col_goff = col_goff;
+    AS_TRY(launch_k2(kb, metric, true, g2, st));
+    BlockBandArgs ba;
+    ba.xa32 = sp->x32; ba.xa64 = sp->x64; ba.xb32 = cols->x32; ba.xb64 = cols->x64; ba.na64 = sp->n64; ba.nb64 = cols->n64;
+    ba.d = sp->d; ba.dp = sp->dp; ba.r0 = r0; ba.col_goff = col_goff; ba.S = S2; ba.CW = CAP; ba.M = M; ba.metric = metric; ba.nf = nf;
+    ba.ids = d_ids; ba.c_idx = c2idx; ba.c_cnt = c2cnt;
+    ba.p_key = p_key; ba.p_dist = p_dist; ba.p_gy = p_gy; ba.p_idx = p_idx; ba.p_cnt = p_cnt; ba.p_t32 = p_t32; ba.overflow = over;
+    const size_t ldsb = (sizeof(double) * 3 + sizeof(int)) * (size_t)BAND_MAX;
+    AS_HIP(hipFuncSetAttribute((const void*)knn_block_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL(knn_block_band_kernel, dim3((unsigned)nf), dim3(256), ldsb, st, ba);
+    AS_HIP(hipGetLastError());
+    int hov = 0;
+    AS_HIP(hipMemcpyAsync(&hov, over, sizeof(int), hipMemcpyDeviceToHost, st));
+    AS_HIP(hipStreamSynchronize(st));
+    *overflowed = hov;
     return AS_OK;
 }
 
@@ -1619,7 +2105,7 @@ __global__ void lambda_kernel(int64_t n, const double* __restrict__ E, const dou
     if (i >= n) return;
     const double l = tau0 * (E[i] / (E[i] + tau0)) + (1.0 - tau0) * G[i];
     lam64[i] = l;
-    lam32[i] = (float)l;
+    if (lam32) lam32[i] = (float)l;
 }
 
 // K3 + degrees: union symmetrisation of n x k directed lists into the CSR arrays of gr (indptr, indices, dist, gy, w,
@@ -1669,10 +2155,8 @@ as_status csr_from_knn(hipStream_t st, int64_t n, int64_t k, const int32_t* idx,
     return AS_OK;
 }
 
-// S8 + S9: tau0 = lower median of the positive energies (8-pass radix select), lambdas into the space
-as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const double* G) {
-    const int64_t n = sp->n;
-    hipStream_t st = sp->stream;
+// S8 + S9: tau0 = lower median of the positive energies (8-pass radix select), lambdas of n nodes
+as_status median_lambda_n(hipStream_t st, int64_t n, const double* E, const double* G, double* lam64, float* lam32, double* tau0_out) {
     const unsigned gn = (unsigned)((n + 255) / 256);
     dev_tmp<SelState> sel;
     AS_HIP(sel.alloc(2));   // the selection state, then the slot tau0 is written to
@@ -1683,10 +2167,58 @@ as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const doubl
         hipLaunchKernelGGL(sel_hist_kernel, dim3(gh), dim3(256), 0, st, E, n, pass, sel);
         hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, sel);
     }
-    hipLaunchKernelGGL(lambda_kernel, dim3(gn), dim3(256), 0, st, n, E, G, sel, sp->lam64, sp->lam32, tau_d);
+    hipLaunchKernelGGL(lambda_kernel, dim3(gn), dim3(256), 0, st, n, E, G, sel, lam64, lam32, tau_d);
     AS_HIP(hipGetLastError());
-    AS_HIP(hipMemcpyAsync(&gr->tau0, tau_d, sizeof(double), hipMemcpyDeviceToHost, st));
+    AS_HIP(hipMemcpyAsync(tau0_out, tau_d, sizeof(double), hipMemcpyDeviceToHost, st));
     AS_HIP(hipStreamSynchronize(st));
+    return AS_OK;
+}
+as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const double* G) {
+    return median_lambda_n(sp->stream, sp->n, E, G, sp->lam64, sp->lam32, &gr->tau0);
+}
+
+__global__ void lam_slice_kernel(int64_t n, const double* __restrict__ src, double* __restrict__ lam64, float* __restrict__ lam32) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    lam64[i] = src[i];
+    lam32[i] = (float)src[i];
+}
+
+// Graph stage over the lists of ALL n_global items (all-gathered by the host) for a space that holds only the rows
+// [row_offset, row_offset + sp->n): symmetrisation, Laplacian, energies and tau0 over the global graph, this
+// shard's slice of the lambdas into the space.
+as_status graph_from_knn_global(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx,
+                                const double* dist, const double* gy, const int32_t* cnt, const double* n64_global, as_graph* gr) {
+    const int64_t n = n_global, k = gp->k;
+    hipStream_t st = sp->stream;
+    if (row_offset < 0 || row_offset + sp->n > n_global) {
+        set_err("as_graph_from_knn_global: rows [%lld, %lld) are outside the %lld items", (long long)row_offset,
+                (long long)(row_offset + sp->n), (long long)n_global);
+        return AS_EINVAL;
+    }
+    gr->n = n;
+    gr->device = sp->device;
+    gr->gp = *gp;
+    gr->metric = sp->opts.metric;
+    gr->kernel = sp->opts.kernel;
+    AS_TRY(csr_from_knn(st, n, k, idx, dist, gy, cnt, gp->sigma, gp->p, gr->kernel, gr));
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    AS_HIP(hipMalloc(&gr->ny, sizeof(double) * n));
+    AS_HIP(hipMalloc(&gr->E, sizeof(double) * n));
+    AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
+    hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->dist, gr->gy, gr->deg, n64_global,
+                       gr->metric, gr->ny, gr->lap, gr->E, gr->G);
+    AS_HIP(hipGetLastError());
+    dev_tmp<double> lam;
+    AS_HIP(lam.alloc(n));
+    AS_TRY(median_lambda_n(st, n, gr->E, gr->G, lam, nullptr, &gr->tau0));
+    hipLaunchKernelGGL(lam_slice_kernel, dim3((unsigned)((sp->n + 255) / 256)), dim3(256), 0, st, sp->n, (const double*)lam + row_offset,
+                       sp->lam64, sp->lam32);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(st));
+    sp->row_offset = row_offset;
+    dbg("graph (global, %lld nodes; this shard rows [%lld, %lld)): nnz=%lld tau0=%.6g", (long long)n, (long long)row_offset,
+        (long long)(row_offset + sp->n), (long long)gr->nnz, gr->tau0);
     return AS_OK;
 }
 

@@ -55,6 +55,7 @@ struct as_space {
     float* inorm32 = nullptr; // [np] 1/|x| (0 for zero rows / pad rows)
     double* lam64 = nullptr;  // [n] lambdas (written by as_graph_from_knn)
     float* lam32 = nullptr;   // [np]
+    int64_t row_offset = 0;   // global index of row 0 (a rank's shard of a row-sharded index); 0 for a whole index
     double nmax = 0.0;        // max squared norm
     int lossless = 0;         // items exactly representable in fp32
     as_opts opts{};
@@ -279,6 +280,19 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
 as_status csr_from_knn(hipStream_t st, int64_t n, int64_t k, const int32_t* idx, const double* dist, const double* gy,
                        const int32_t* cnt, double sigma, double p, int kernel, as_graph* gr);
 as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const double* G);
+as_status graph_from_knn_global(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx,
+                                const double* dist, const double* gy, const int32_t* cnt, const double* n64_global, as_graph* gr);
+// k-NN over visiting column blocks (multi-GPU ring, as_build.hip)
+as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
+                    int64_t col_goff, int M, double* p_key, double* p_dist, double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32);
+as_status knn_merge(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int nblocks, int M, const double* p_key,
+                    const double* p_dist, const double* p_gy, const int32_t* p_idx, const int32_t* p_cnt, const float* p_t32,
+                    const double* block_nmax_host, int32_t* out_idx, double* out_key, double* out_dist, double* out_gy,
+                    int32_t* out_cnt, int32_t* flag, double* out_B, int64_t* nflagged);
+as_status knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
+                         int64_t col_goff, int M, const int32_t* flag, const double* B, double* p_key, double* p_dist, double* p_gy,
+                         int32_t* p_idx, int32_t* p_cnt, float* p_t32, int64_t* overflowed);
+int knn_list_width(int64_t k);
 
 // feature mode (as_feat.hip)
 as_status feat_gram(const as_space* sp, int64_t r0, int64_t r1, double* gram);

@@ -821,6 +821,7 @@ struct FinishArgs {
     int fuse;           // knn: compute lambda_q in the same launch; score: publish to hout
     int from_list;      // candidates come from the wavefront lists instead of the filter buffer
     int thresholded;    // the buffer holds the rows under a selection threshold, not every row inside eps
+    int64_t goff;       // global id of local row 0 (a shard of a row-sharded index); graph arrays and records use global ids
     int exhaustive;     // evaluate EVERY buffered candidate in fp64 (near-ties at the k-th distance that fp32 cannot order)
     // build-fallback outputs (row-list form); null for searches
     int32_t* o_idx;
@@ -950,8 +951,8 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     // the selected candidates' degrees / norms: in flight under the exact evaluation instead of behind it
     double pre_deg = 0.0, pre_ny = 0.0;
     if (w == 0 && lane < Mp) {
-        pre_deg = a.deg ? a.deg[fi[lane]] : 0.0;
-        pre_ny = a.ny ? a.ny[fi[lane]] : 0.0;
+        pre_deg = a.deg ? a.deg[fi[lane] + a.goff] : 0.0;
+        pre_ny = a.ny ? a.ny[fi[lane] + a.goff] : 0.0;
     }
     exact_eval_all(a.x32, a.x64, qx, a.d, a.dp, fi, Mp, ek, eg);
     __syncthreads();
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     if (sel) {
         if (a.recs) {
             as_knn_rec r;
-            r.idx = myi;
+            r.idx = myi + a.goff;
             r.key = myk;
             r.dist = ed[lane];
             r.gy = eg[lane];
@@ -1166,12 +1167,12 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
         sk2[rank] = es[t];
         if (a.hits && rank < a.topk) {
             as_hit_rec r;
-            r.idx = myi;
+            r.idx = myi + a.goff;
             r.score = es[t];
             a.hits[rank] = r;
         }
         if (a.fuse && a.hout && rank < nhit) {
-            a.hout->idx[rank] = myi;
+            a.hout->idx[rank] = myi + a.goff;
             a.hout->score[rank] = es[t];
         }
     }
@@ -1300,7 +1301,7 @@ static FinishArgs make_finish(as_query* q) {
     f.x32 = sp->x32; f.x64 = sp->x64; f.n64 = sp->n64; f.q64 = q->q64; f.lam64 = sp->lam64;
     f.deg = q->gr ? q->gr->deg : nullptr; f.ny = q->gr ? q->gr->ny : nullptr;
     f.info = q->info; f.n = sp->n; f.d = sp->d; f.dp = sp->dp; f.k = q->k; f.topk = q->topk; f.nrows = q->r1 - q->r0;
-    f.metric = sp->opts.metric; f.kernel = sp->opts.kernel; f.nmax = sp->nmax;
+    f.metric = sp->opts.metric; f.kernel = sp->opts.kernel; f.nmax = sp->nmax; f.goff = sp->row_offset;
     if (q->gr) {
         f.sigma = q->gr->gp.sigma; f.p = q->gr->gp.p; f.tau0 = q->gr->tau0;
     }

@@ -1,10 +1,13 @@
 """Row-sharded multi-GPU build and search: one process per GPU, torch.distributed
 (backend "nccl" = RCCL over xGMI) for the exchange steps, the C ABI for every kernel.
 
-Build   (DESIGN.md section 6): all-gather of the item shards (each rank ends with the full
-        fp32 item matrix in HBM) -> every rank runs the fused X.X^T k-NN kernel for ITS rows
-        against all columns -> all-gather of the exact k-NN lists -> the O(N k) graph /
-        Laplacian / lambda stage is computed redundantly on every rank (milliseconds).
+Build   (DESIGN.md section 6): a rank keeps only ITS rows.  The raw shards travel round a ring (send to
+        rank+1, receive from rank-1, double-buffered against the compute): per visiting shard the fused
+        X.X^T k-NN kernel runs own rows x visiting columns and leaves M exact candidates per row; after the
+        last shard they are merged into the exact k-NN lists (rows not provably exact go round once more in
+        collect mode) -> all-gather of the lists and of the squared norms -> the O(N k) graph / Laplacian /
+        lambda stage is computed redundantly on every rank.  `replicate=True` keeps the round-1 form
+        (all-gather of the whole item matrix, every rank holds all of it).
 Search: every rank scans its own rows, the k nearest-neighbour records and the top-k hit
         records (fixed-size structs of include/arrowspace_hip.h) are all-gathered and merged
         identically on every rank; two collectives of a few KB per query.
@@ -105,6 +108,96 @@ class HipEngine:
                                              C.c_void_p(dist.data_ptr()), C.c_void_p(gy.data_ptr()),
                                              C.c_void_p(cnt.data_ptr()), C.byref(self.gr)))
 
+    # ---- build without replication: visiting column blocks (ring)
+    def ring_begin(self, nblocks):
+        torch = self.torch
+        self.M = int(self.L.as_knn_list_width(int(self.gp.k)))
+        if self.M < 0:
+            raise ValueError(f"graph_params['k']={int(self.gp.k)} exceeds the supported maximum of 56")
+        dev = torch.device("cuda", self.op.device)
+        rows, M = max(self.n, 1), self.M
+        self.p_key = torch.zeros((nblocks, rows, M), dtype=torch.float64, device=dev)
+        self.p_dist = torch.zeros_like(self.p_key)
+        self.p_gy = torch.zeros_like(self.p_key)
+        self.p_idx = torch.full((nblocks, rows, M), -1, dtype=torch.int32, device=dev)
+        self.p_cnt = torch.zeros((nblocks, rows), dtype=torch.int32, device=dev)
+        self.p_t32 = torch.zeros((nblocks, rows), dtype=torch.float32, device=dev)
+        self.nblocks = nblocks
+
+    def open_block(self, X):
+        """A visiting shard as a temporary space (ingested into the HBM layout the kernels read)."""
+        torch = self.torch
+        dt = self._lib.DTYPE_F32 if X.dtype == torch.float32 else self._lib.DTYPE_F64
+        h = C.c_void_p()
+        self._check(self.L.as_space_create_dev(C.c_void_p(X.data_ptr()), dt, X.shape[0], X.shape[1], X.shape[1],
+                                               C.byref(self.op), C.byref(h)))
+        return h
+
+    def close_block(self, h):
+        self.L.as_free_space(h)
+
+    def own_block(self):
+        return self.sp
+
+    def block_nmax(self, h):
+        return float(self.L.as_space_nmax(h))
+
+    def _slice(self, b):
+        return [C.c_void_p(t[b].data_ptr()) for t in (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
+
+    def knn_block(self, h, b, row_goff, col_goff):
+        if self.n > 0:
+            self._check(self.L.as_knn_block(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff, *self._slice(b)))
+
+    def knn_merge(self, nmax):
+        torch = self.torch
+        k, rows = int(self.gp.k), self.n
+        dev = torch.device("cuda", self.op.device)
+        self.l_idx = torch.full((max(rows, 1), k), -1, dtype=torch.int32, device=dev)
+        self.l_key = torch.zeros((max(rows, 1), k), dtype=torch.float64, device=dev)
+        self.l_dist = torch.zeros_like(self.l_key)
+        self.l_gy = torch.zeros_like(self.l_key)
+        self.l_cnt = torch.zeros((max(rows, 1),), dtype=torch.int32, device=dev)
+        self.l_flag = torch.zeros((max(rows, 1),), dtype=torch.int32, device=dev)
+        self.l_band = torch.zeros((max(rows, 1),), dtype=torch.float64, device=dev)
+        nm = np.ascontiguousarray(nmax, dtype=np.float64)
+        nf = C.c_int64(0)
+        torch.cuda.synchronize()
+        if rows > 0:
+            self._check(self.L.as_knn_merge(self.sp, C.byref(self.gp), 0, rows, self.nblocks, *[C.c_void_p(t.data_ptr()) for t in
+                                            (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)],
+                                            nm.ctypes.data_as(C.c_void_p), *[C.c_void_p(t.data_ptr()) for t in
+                                            (self.l_idx, self.l_key, self.l_dist, self.l_gy, self.l_cnt, self.l_flag, self.l_band)],
+                                            C.byref(nf)))
+        return int(nf.value)
+
+    def knn_block_band(self, h, b, row_goff, col_goff):
+        ov = C.c_int64(0)
+        if self.n > 0:
+            self._check(self.L.as_knn_block_band(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff,
+                                                 C.c_void_p(self.l_flag.data_ptr()), C.c_void_p(self.l_band.data_ptr()),
+                                                 *self._slice(b), C.byref(ov)))
+        return int(ov.value)
+
+    def lists(self):
+        rows = self.n
+        return self.l_idx[:rows], self.l_dist[:rows], self.l_gy[:rows], self.l_cnt[:rows]
+
+    def norms(self):
+        """fp64 squared norms of the own rows (device tensor, copied out of the space)."""
+        torch = self.torch
+        out = torch.empty((max(self.n, 1),), dtype=torch.float64, device=torch.device("cuda", self.op.device))
+        if self.n > 0:
+            self._check(self.L.as_space_norms(self.sp, C.c_void_p(out.data_ptr())))
+        return out[: self.n]
+
+    def graph_from_knn_global(self, n_global, row_offset, idx, dist, gy, cnt, n64):
+        self.torch.cuda.synchronize()
+        self._check(self.L.as_graph_from_knn_global(self.sp, C.byref(self.gp), n_global, row_offset, C.c_void_p(idx.data_ptr()),
+                                                    C.c_void_p(dist.data_ptr()), C.c_void_p(gy.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                    C.c_void_p(n64.data_ptr()), C.byref(self.gr)))
+        del self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32
+
     # ---- search
     def query_open(self):
         torch = self.torch
@@ -155,9 +248,10 @@ class HipEngine:
         return out
 
     def stats(self):
-        out = np.zeros(8, dtype=np.float64)
-        self.L.as_build_stats(self.gr, out.ctypes.data_as(C.c_void_p), 8)
-        keys = ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s", "total_s", "fallback_rows", "mfma_flops")
+        out = np.zeros(10, dtype=np.float64)
+        self.L.as_build_stats(self.gr, out.ctypes.data_as(C.c_void_p), 10)
+        keys = ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s", "total_s", "fallback_rows", "mfma_flops",
+                "unproven_rows", "band_rows")
         return dict(zip(keys, out.tolist()))
 
     def tau0(self):
@@ -217,6 +311,16 @@ class ShardedIndex:
             parts = [full[r][: counts[r]] for r in range(world)]
         return torch.cat(parts, dim=0)
 
+    def _exchange_start(self, send, recv, nxt_rank, prv_rank):
+        """One ring hop: `send` goes to the next rank, `recv` is filled by the previous one (RCCL send/recv)."""
+        dist = self.dist
+        return dist.batch_isend_irecv([dist.P2POp(dist.isend, send, nxt_rank, group=self.group),
+                                       dist.P2POp(dist.irecv, recv, prv_rank, group=self.group)])
+
+    def _exchange_wait(self, reqs):
+        for r in reqs:
+            r.wait()
+
     def _gather_fixed(self, t):
         torch = self.torch
         if not self._collective():
@@ -235,9 +339,10 @@ class ShardedIndex:
         return torch.cat(parts, dim=0)
 
     @classmethod
-    def build(cls, graph_params, X_shard, dist=None, group=None, engine=None, force_collectives=False):
+    def build(cls, graph_params, X_shard, dist=None, group=None, engine=None, force_collectives=False, replicate=False):
         """X_shard: this rank's contiguous block of rows (torch tensor on this rank's device,
-        fp32 or fp64).  Ranks hold consecutive blocks in rank order."""
+        fp32 or fp64).  Ranks hold consecutive blocks in rank order.  replicate=True: all-gather the
+        whole item matrix onto every rank first (round-1 form; twice the HBM)."""
         import contextlib
 
         import torch
@@ -248,6 +353,7 @@ class ShardedIndex:
         self.rank = dist.get_rank(group) if dist is not None else 0
         self.force_collectives = bool(force_collectives) and dist is not None
         self.engine = engine if engine is not None else HipEngine(graph_params)
+        self.replicated = bool(replicate) or not hasattr(self.engine, "knn_block")
         # CUDA: kernels and RCCL collectives are ordered on ONE dedicated, non-default stream
         # (the legacy default stream has handle 0 and cannot be handed to the library)
         self.stream = torch.cuda.Stream() if X_shard.is_cuda else None
@@ -269,19 +375,93 @@ class ShardedIndex:
                 self.bounds.append(self.bounds[-1] + v)
             self.n = self.bounds[-1]
             self.r0, self.r1 = self.bounds[self.rank], self.bounds[self.rank + 1]
-            X_full = self._gather_rows(X_shard.contiguous(), counts).contiguous()
-            self._sync()
-            self.engine.create_space(X_full)
-            del X_full
-            idx, dst, gy, cnt = self.engine.knn_rows(self.r0, self.r1)
+            if min(counts) == 0 and isinstance(self.engine, HipEngine):
+                self.replicated = True      # a rank without rows has no space of its own to scan: keep the all-gather form
+            if self.replicated:
+                X_full = self._gather_rows(X_shard.contiguous(), counts).contiguous()
+                self._sync()
+                self.engine.create_space(X_full)
+                del X_full
+                idx, dst, gy, cnt = self.engine.knn_rows(self.r0, self.r1)
+                self.scan_rows = (self.r0, self.r1)      # the space holds every item: this rank scans its slice
+            else:
+                X_shard = X_shard.contiguous()
+                self._sync()
+                self.engine.create_space(X_shard)
+                idx, dst, gy, cnt = self._ring_knn(X_shard)
+                self.scan_rows = (0, rows)               # the space holds this rank's rows only; ids come out global
             idx = self._gather_rows(idx, counts).contiguous()
             dst = self._gather_rows(dst, counts).contiguous()
             gy = self._gather_rows(gy, counts).contiguous()
             cnt = self._gather_rows(cnt, counts).contiguous()
-            self._sync()
-            self.engine.graph_from_knn(idx, dst, gy, cnt)
+            if self.replicated:
+                self._sync()
+                self.engine.graph_from_knn(idx, dst, gy, cnt)
+            else:
+                n64 = self._gather_rows(self.engine.norms(), counts).contiguous()
+                self._sync()
+                self.engine.graph_from_knn_global(self.n, self.r0, idx, dst, gy, cnt, n64)
             self.engine.query_open()
         return self
+
+    def _ring_knn(self, X_shard):
+        """Exact k-NN lists of this rank's rows against all items, the shards visiting one at a time.
+        Step s works on the shard of rank (rank - s) mod world while the transfer for step s+1 is in flight."""
+        torch, dist, e = self.torch, self.dist, self.engine
+        world, rank, counts, bounds = self.world, self.rank, self.counts, self.bounds
+        ring = world > 1
+        e.ring_begin(world)
+        mx = max(max(counts), 1)
+        if ring:
+            nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+            bufs = [torch.zeros((mx,) + tuple(X_shard.shape[1:]), dtype=X_shard.dtype, device=X_shard.device) for _ in range(2)]
+            bufs[0][: X_shard.shape[0]] = X_shard
+        nmax_local = torch.tensor([e.block_nmax(e.own_block())], dtype=torch.float64, device=X_shard.device)
+        if ring:
+            parts = [torch.zeros_like(nmax_local) for _ in range(world)]
+            dist.all_gather(parts, nmax_local, group=self.group)
+            nmax = [float(p.item()) for p in parts]
+        else:
+            nmax = [float(nmax_local.item())]
+
+        def one_round(step_fn):
+            cur = 0
+            for s in range(world):
+                src = (rank - s) % world
+                if s == 0:
+                    h, own = e.own_block(), True
+                else:
+                    self._sync()
+                    h, own = e.open_block(bufs[cur][: counts[src]]), False
+                pending = None
+                if ring and s + 1 < world:
+                    # the shard just worked on goes on to the next rank while it is worked on here
+                    pending = self._exchange_start(bufs[cur], bufs[cur ^ 1], nxt_rank, prv_rank)
+                step_fn(h, src, bounds[rank], bounds[src])
+                if not own:
+                    e.close_block(h)
+                if pending is not None:
+                    self._exchange_wait(pending)
+                cur ^= 1
+
+        one_round(lambda h, b, rg, cg: e.knn_block(h, b, rg, cg))
+        nflag = e.knn_merge(nmax)
+        if ring:
+            t = torch.tensor([nflag], dtype=torch.int64, device=X_shard.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            anyflag = int(t.item())
+        else:
+            anyflag = nflag
+        self.ring_flagged = nflag
+        if anyflag:
+            # rows not provably exact somewhere: every rank sends its shard round once more (the ring is collective);
+            # ranks without flagged rows just pass the blocks on
+            if ring:
+                bufs[0].zero_()
+                bufs[0][: X_shard.shape[0]] = X_shard
+            one_round(lambda h, b, rg, cg: e.knn_block_band(h, b, rg, cg))
+            e.knn_merge(nmax)
+        return e.lists()
 
     def _sync(self):
         if self.stream is not None:
@@ -299,7 +479,7 @@ class ShardedIndex:
         with ctx:
             for _ in range(8):
                 e.set_mode(mode)
-                e.query_scan(q, self.r0, self.r1)
+                e.query_scan(q, *self.scan_rows)
                 knn_all = self._gather_fixed(e.knn_local)
                 e.query_lambda(knn_all)
                 e.query_score(tau)
@@ -316,7 +496,14 @@ class ShardedIndex:
         return hits
 
     def lambdas(self):
-        return self.engine.lambdas()
+        """lambdas of ALL items, in item order (ring build: every rank holds its own rows' -- gathered here)."""
+        lam = self.engine.lambdas()
+        if self.replicated or not self._collective():
+            return lam
+        torch = self.torch
+        dev = self.engine.knn_local.device
+        t = torch.from_numpy(np.ascontiguousarray(lam[: self.counts[self.rank]])).to(dev)
+        return self._gather_rows(t, self.counts).cpu().numpy()
 
     def last_scan_us(self):
         return self.engine.scan_us()

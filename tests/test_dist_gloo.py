@@ -53,7 +53,75 @@ class OracleEngine:
             cnt[i - r0] = len(c)
         return torch.from_numpy(idx), torch.from_numpy(dist), torch.from_numpy(gy), torch.from_numpy(cnt)
 
+    # ---- ring build (no replication): the same steps as HipEngine's, on numpy
+    def ring_begin(self, nblocks):
+        self.parts, self.off = {}, 0
+
+    def open_block(self, X):
+        return X.double().numpy().copy()
+
+    def close_block(self, h):
+        pass
+
+    def own_block(self):
+        return self.X
+
+    def block_nmax(self, h):
+        return float(np.einsum("ij,ij->i", h, h).max()) if len(h) else 0.0
+
+    def knn_block(self, h, b, row_goff, col_goff):
+        k, ek = self.prm["k"], self.o._eps_key(self.prm["eps"], self.prm["metric"])
+        nh = np.einsum("ij,ij->i", h, h)
+        out = []
+        for i in range(self.n):
+            if len(h) == 0:
+                out.append([])
+                continue
+            key, dd, gg = self.o.pair_quantities(self.X[i], h, self.nn[i], nh, self.prm["metric"])
+            ok = key <= ek
+            if col_goff <= row_goff + i < col_goff + len(h):
+                ok[row_goff + i - col_goff] = False
+            c = np.nonzero(ok)[0]
+            c = c[np.lexsort((c, key[c]))][:k]
+            out.append([(key[j], col_goff + j, dd[j], gg[j]) for j in c])
+        self.parts[b] = out
+        self.off = row_goff
+
+    def knn_block_band(self, h, b, row_goff, col_goff):
+        return 0
+
+    def knn_merge(self, nmax):
+        import torch
+        k = self.prm["k"]
+        idx = np.full((self.n, k), -1, dtype=np.int32)
+        dist = np.zeros((self.n, k))
+        gy = np.zeros((self.n, k))
+        cnt = np.zeros(self.n, dtype=np.int32)
+        for i in range(self.n):
+            allc = sorted(c for b in self.parts for c in self.parts[b][i])[:k]
+            for t, (kk, j, dd, gg) in enumerate(allc):
+                idx[i, t], dist[i, t], gy[i, t] = j, dd, gg
+            cnt[i] = len(allc)
+        self._lists = tuple(torch.from_numpy(a) for a in (idx, dist, gy, cnt))
+        return 0
+
+    def lists(self):
+        return self._lists
+
+    def norms(self):
+        return __import__("torch").from_numpy(self.nn.copy())
+
+    def graph_from_knn_global(self, n_global, row_offset, idx, dist, gy, cnt, n64):
+        idx, dist, gy, cnt, n64 = idx.numpy(), dist.numpy(), gy.numpy(), cnt.numpy(), n64.numpy()
+        lists = [(idx[i, : cnt[i]].astype(np.int64), dist[i, : cnt[i]], dist[i, : cnt[i]], gy[i, : cnt[i]]) for i in range(n_global)]
+        Xg = np.zeros((n_global, self.d))
+        Xg[row_offset : row_offset + self.n] = self.X          # only this rank's rows are ever read (scans are local)
+        self.index = self.o.graph_from_lists(Xg, self.prm, n64, lists)
+        self.off, self.nlocal = row_offset, self.n
+        self.n = n_global
+
     def graph_from_knn(self, idx, dist, gy, cnt):
+        self.off = 0
         idx, dist, gy, cnt = idx.numpy(), dist.numpy(), gy.numpy(), cnt.numpy()
         lists = [(idx[i, : cnt[i]].astype(np.int64), None, dist[i, : cnt[i]], gy[i, : cnt[i]]) for i in range(self.n)]
         lists = [(a, d, d, g) for a, _, d, g in lists]
@@ -70,6 +138,7 @@ class OracleEngine:
 
     def query_scan(self, q, r0, r1):
         self.q = np.asarray(q, dtype=np.float64)
+        r0, r1 = r0 + self.off, r1 + self.off                  # local rows of a shard-only space -> item ids
         self.r0, self.r1 = r0, r1
         items, key, dist, gy = self.o.query_neighbours(self.index, self.q, r0, r1)
         rec = np.zeros((self.k, 6))
@@ -113,7 +182,8 @@ class OracleEngine:
         return hits, self.lq, self.lq == 0.0, False, False
 
     def lambdas(self):
-        return self.index["lambdas"]
+        lam = self.index["lambdas"]
+        return lam[self.off : self.off + self.nlocal] if getattr(self, "nlocal", None) is not None and self.off + self.nlocal <= len(lam) and hasattr(self, "parts") else lam
 
     def close(self):
         pass
@@ -127,7 +197,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, d, split, out):
+def _worker(rank, world, port, n, d, split, out, replicate=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -139,8 +209,8 @@ def _worker(rank, world, port, n, d, split, out):
         gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
         bounds = [0, split, n] if world == 2 else [0, n]
         shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy())
-        index = ShardedIndex.build(gp, shard, dist, engine=OracleEngine(gp))
-        assert (index.r0, index.r1) == (bounds[rank], bounds[rank + 1]) and index.n == n
+        index = ShardedIndex.build(gp, shard, dist, engine=OracleEngine(gp), replicate=replicate)
+        assert (index.r0, index.r1) == (bounds[rank], bounds[rank + 1]) and index.n == n and index.replicated == replicate
         rng = np.random.default_rng(5)
         res = []
         for _ in range(4):
@@ -152,14 +222,17 @@ def _worker(rank, world, port, n, d, split, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("replicate", [False, True], ids=["ring", "replicated"])
 @pytest.mark.parametrize("split", [97, 150, 0])
-def test_two_rank_sharded_index_matches_single_process(split):
+def test_two_rank_sharded_index_matches_single_process(split, replicate):
+    """ring: every rank keeps only its rows, the shards visit over send/recv (uneven and EMPTY shards included);
+    replicated: the round-1 all-gather form."""
     import torch.multiprocessing as mp
     from oracle import oracle_np
     n, d, world = 300, 24, 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, d, split, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, d, split, out, replicate), nprocs=world, join=True)
     X = clustered(n, d, nclust=6, seed=21)
     gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
     ref = oracle_np.build(X, gp)

@@ -64,7 +64,7 @@ def test_staged_path_repairs_a_crowded_neighbourhood(oracle_lib):
     index.close()
 
 
-def _worker(rank, world, port, n, d, split, out):
+def _worker(rank, world, port, n, d, split, out, replicate=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -81,11 +81,23 @@ def _worker(rank, world, port, n, d, split, out):
                 torch.cuda.synchronize()
                 return super()._gather_fixed(t.cpu()).cuda()
 
+            def _exchange_start(self, send, recv, nxt_rank, prv_rank):   # the ring hop, staged through the CPU as well
+                torch.cuda.synchronize()
+                hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+                return (super()._exchange_start(hs, hr, nxt_rank, prv_rank), hr, recv, hs)
+
+            def _exchange_wait(self, pending):
+                reqs, hr, recv, _ = pending
+                super()._exchange_wait(reqs)
+                recv.copy_(hr)
+                torch.cuda.synchronize()
+
         X = clustered(n, d, nclust=8, seed=31)
         gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
         bounds = [0, split, n]
         shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy()).cuda()
-        index = CpuStaged.build(gp, shard, dist)
+        index = CpuStaged.build(gp, shard, dist, replicate=replicate)
+        assert index.replicated == replicate
         res = [(index.search(q, tau), index.last_lambda_q) for q, tau in _queries(X, n, d)]
         out[rank] = (index.lambdas().copy(), res)
         index.close()
@@ -93,7 +105,9 @@ def _worker(rank, world, port, n, d, split, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_oracle(oracle_lib):
+@pytest.mark.parametrize("replicate", [False, True], ids=["ring", "replicated"])
+def test_two_ranks_one_gpu_match_oracle(oracle_lib, replicate):
+    """ring: each rank ingests only its rows, the other shard visits by send/recv; replicated: round-1 form."""
     import torch.multiprocessing as mp
     n, d, world, split = 1200, 64, 2, 500
     s = socket.socket()
@@ -102,7 +116,7 @@ def test_two_ranks_one_gpu_match_oracle(oracle_lib):
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, n, d, split, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, d, split, out, replicate), nprocs=world, join=True)
     X = clustered(n, d, nclust=8, seed=31)
     gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
     ref = oracle_lib.OracleIndex(X, gp)

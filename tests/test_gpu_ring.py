@@ -1,0 +1,99 @@
+"""GPU: k-NN over visiting column blocks (the multi-GPU ring's per-rank work) on one device -- the items cut into
+uneven blocks, every block a temporary space, as_knn_block per block, as_knn_merge, and the collect-mode second round
+for rows the merge cannot prove exact -- against as_knn_rows on one space holding everything (bit-identical lists)
+and against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import calibrate_eps, clustered
+
+pytestmark = pytest.mark.gpu
+
+
+def _ring_lists(X, gp, cuts, own):
+    """Lists of the rows of block `own` against all blocks, through HipEngine's ring methods."""
+    import torch
+
+    from pyarrowspace_amd.dist import HipEngine
+    e = HipEngine(gp)
+    lo, hi = cuts[own], cuts[own + 1]
+    e.create_space(torch.from_numpy(X[lo:hi].copy()).cuda())
+    e.ring_begin(len(cuts) - 1)
+    blocks = [torch.from_numpy(X[cuts[b]:cuts[b + 1]].copy()).cuda() for b in range(len(cuts) - 1)]
+    nmax = []
+
+    def round_(fn):
+        for b, Xb in enumerate(blocks):
+            h = e.own_block() if b == own else e.open_block(Xb)
+            if len(nmax) < len(blocks):
+                nmax.append(e.block_nmax(h))
+            fn(h, b, lo, cuts[b])
+            if b != own:
+                e.close_block(h)
+
+    round_(e.knn_block)
+    nflag = e.knn_merge(nmax)
+    over = 0
+    if nflag:
+        res = []
+        round_(lambda h, b, rg, cg: res.append(e.knn_block_band(h, b, rg, cg)))
+        over = sum(res)
+        e.knn_merge(nmax)
+    idx, dist, gy, cnt = [t.cpu().numpy() for t in e.lists()]
+    key = e.l_key[: hi - lo].cpu().numpy()
+    e.close()
+    return idx, key, dist, gy, cnt, nflag, over
+
+
+def _single_lists(X, gp, lo, hi):
+    import torch
+
+    from pyarrowspace_amd.dist import HipEngine
+    e = HipEngine(gp)
+    e.create_space(torch.from_numpy(X).cuda())
+    idx, dist, gy, cnt = [t.cpu().numpy() for t in e.knn_rows(lo, hi)]
+    e.close()
+    return idx, dist, gy, cnt
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("n,d,k,cuts", [(3000, 96, 10, [0, 700, 1900, 3000]), (5000, 768, 25, [0, 2500, 5000]), (900, 40, 6, [0, 100, 101, 600, 900])])
+def test_blockwise_lists_equal_the_single_space_lists(oracle_lib, metric, n, d, k, cuts):
+    X = clustered(n, d, nclust=max(4, n // 200), seed=n + k)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
+    ref = oracle_lib.OracleIndex(X, gp)
+    for own in range(len(cuts) - 1):
+        lo, hi = cuts[own], cuts[own + 1]
+        idx, key, dist, gy, cnt, nflag, over = _ring_lists(X, gp, cuts, own)
+        sidx, sdist, sgy, scnt = _single_lists(X, gp, lo, hi)
+        assert over == 0
+        np.testing.assert_array_equal(cnt, scnt)
+        np.testing.assert_array_equal(idx, sidx)             # global ids, same order
+        np.testing.assert_array_equal(dist, sdist)           # exact keys are evaluated the same way: same bits
+        np.testing.assert_array_equal(gy, sgy)
+        np.testing.assert_array_equal(cnt, ref.knn_cnt[lo:hi])
+        np.testing.assert_array_equal(idx, ref.knn_idx[lo:hi])
+
+
+def test_blockwise_second_round_settles_duplicate_groups(oracle_lib):
+    """Groups of 150 identical rows spread over the blocks (more per block than a candidate list is wide): the merge
+    flags them (ties at the k-th distance), the second round collects each block's band, and the lists equal the
+    oracle's (ties by global index)."""
+    rng = np.random.default_rng(3)
+    n, d, k = 2400, 64, 8
+    X = clustered(n, d, nclust=12, seed=17)
+    for g in range(6):
+        rows = rng.choice(n, 150, replace=False)
+        X[rows] = X[rows[0]]
+    gp = {"eps": calibrate_eps(clustered(n, d, nclust=12, seed=17), k), "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_lib.OracleIndex(X, gp)
+    cuts = [0, 800, 1700, 2400]
+    flagged = 0
+    for own in range(3):
+        lo, hi = cuts[own], cuts[own + 1]
+        idx, key, dist, gy, cnt, nflag, over = _ring_lists(X, gp, cuts, own)
+        flagged += nflag
+        assert over == 0
+        np.testing.assert_array_equal(cnt, ref.knn_cnt[lo:hi])
+        np.testing.assert_array_equal(idx, ref.knn_idx[lo:hi])
+    assert flagged > 0          # the second round did run
