@@ -204,6 +204,17 @@ int64_t as_query_hit_capacity(const as_query* q);
 /* merge m hit records (own or all-gathered), copy to host; synchronises. */
 as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, int64_t* out_idx,
                           double* out_score, int64_t* out_len, double* out_lambda_q);
+/* Batched staged search (extension: 32 query slots per pass over this rank's rows, GEMM-shaped scan; the two
+ * record exchanges of a pass are amortised over the slots).  Record buffers: [slot][k] as_knn_rec and
+ * [slot][topk + 1] as_hit_rec (as_query_bind_records); the all-gathered buffers handed back are
+ * [rank][slot][...].  out_status[b]: AS_OK / AS_EZEROLAMBDA, or -1 = rerun query b through the single-query steps. */
+as_status as_query_create_batch(const as_space* sp, const as_graph* gr, as_query** out);
+int32_t as_query_slots(const as_query* q);
+as_status as_query_scan_batch(as_query* q, const double* queries_host, int32_t nb, int64_t d, int64_t row_begin, int64_t row_end);
+as_status as_query_lambda_batch(as_query* q, const as_knn_rec* recs_dev, int32_t nranks);
+as_status as_query_score_batch(as_query* q, double tau);
+as_status as_query_finish_batch(as_query* q, const as_hit_rec* hits_dev, int32_t nranks, int64_t* out_idx, double* out_score,
+                                int64_t* out_len, double* out_lambda_q, int32_t* out_status);
 /* flags bit0: run the following scans in fp64 end to end (the fallback as_search takes when
  * the fp32 candidate lists are not provably exact); bit1: wavefront-list selection instead
  * of the filter buffers (taken when a buffer overflowed); bit2: the next as_query_scan does

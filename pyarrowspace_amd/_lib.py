@@ -44,7 +44,8 @@ SYMBOLS = [
     "as_space_row_offset", "as_knn_block", "as_knn_merge", "as_knn_block_band", "as_graph_from_knn_global", "as_search",
     "as_search_batch", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
-    "as_query_finish", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
+    "as_query_finish", "as_query_create_batch", "as_query_slots", "as_query_scan_batch", "as_query_lambda_batch",
+    "as_query_score_batch", "as_query_finish_batch", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
     "as_get_item", "as_lambdas", "as_nnodes", "as_get_graph_params", "as_graph_nnz", "as_graph_csr",
     "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_last_search_stats", "as_enable_search_stats", "as_index_save", "as_index_load", "as_free_space",
     "as_free_graph", "as_set_debug", "as_last_error", "as_device_count", "as_version",
@@ -125,6 +126,12 @@ def load():
         "as_query_hit_records": (vp, [vp]),
         "as_query_hit_capacity": (i64, [vp]),
         "as_query_finish": (i32, [vp, vp, i64, vp, vp, C.POINTER(i64), C.POINTER(f64)]),
+        "as_query_create_batch": (i32, [vp, vp, pvp]),
+        "as_query_slots": (i32, [vp]),
+        "as_query_scan_batch": (i32, [vp, vp, i32, i64, i64, i64]),
+        "as_query_lambda_batch": (i32, [vp, vp, i32]),
+        "as_query_score_batch": (i32, [vp, f64]),
+        "as_query_finish_batch": (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
         "as_query_set_exact": (None, [vp, i32]),
         "as_query_flags": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "as_query_stream": (vp, [vp]),

@@ -1045,9 +1045,13 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     AS_STAMP(6);
 }
 
-// SPEC S10 from m candidate records (this shard's, or all shards' all-gathered)
-__global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs, int64_t m, int64_t k, int metric,
-                                                      int kernel, double sigma, double p, double tau0, QInfo* info) {
+// SPEC S10 from m candidate records (this shard's, or all shards' all-gathered).  blockIdx.x = query slot: the
+// all-gathered buffer is [rank][slot][per] records, a slot's m records are `per` from every rank, `rstride` apart.
+__global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs_all, int64_t m, int64_t per, int64_t rstride,
+                                                      int64_t k, int metric, int kernel, double sigma, double p, double tau0, QInfo* info) {
+    info += blockIdx.x;
+    const as_knn_rec* __restrict__ recs0 = recs_all + (int64_t)blockIdx.x * per;
+#define recs_at(t) recs0[((t) / per) * rstride + ((t) % per)]
     __shared__ double r_key[REC_CAP];
     __shared__ int r_idx[REC_CAP];
     __shared__ double l_dist[64], l_gy[64], l_deg[64], l_ny[64];
@@ -1055,9 +1059,10 @@ __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restri
     const int lane = lane_id();
     const int mm = (int)(m < REC_CAP ? m : REC_CAP);
     for (int t = lane; t < mm; t += 64) {
-        const bool valid = recs[t].idx >= 0;
-        r_key[t] = valid ? recs[t].key : key_traits<double>::inf();
-        r_idx[t] = valid ? (int)recs[t].idx : 0x7fffffff;
+        const as_knn_rec r = recs_at(t);
+        const bool valid = r.idx >= 0;
+        r_key[t] = valid ? r.key : key_traits<double>::inf();
+        r_idx[t] = valid ? (int)r.idx : 0x7fffffff;
     }
     AS_LDS_FENCE();
     // rank every record by (key, idx); the k best valid ones are the neighbours
@@ -1075,12 +1080,13 @@ __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restri
     AS_LDS_FENCE();
     // lane order = (key, index) rank, as in knn_finish_kernel
     if (lane < cnt) {
-        const int t = l_pos[lane];
-        l_dist[lane] = recs[t].dist;
-        l_gy[lane] = recs[t].gy;
-        l_deg[lane] = recs[t].deg;
-        l_ny[lane] = recs[t].ny;
+        const as_knn_rec r = recs_at(l_pos[lane]);
+        l_dist[lane] = r.dist;
+        l_gy[lane] = r.gy;
+        l_deg[lane] = r.deg;
+        l_ny[lane] = r.ny;
     }
+#undef recs_at
     AS_LDS_FENCE();
     lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
 }
@@ -1210,9 +1216,14 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
 }
 
 // merge m hit records (own or all-gathered) -> final topk, written to pinned host memory
-__global__ __launch_bounds__(1024) void hits_final_kernel(const as_hit_rec* __restrict__ hits, int64_t m, int64_t topk,
-                                                          const QInfo* info, HostOut* out, int64_t seq) {
+// blockIdx.x = query slot; [rank][slot][per] layout as in q_lambda_kernel
+__global__ __launch_bounds__(1024) void hits_final_kernel(const as_hit_rec* __restrict__ hits_all, int64_t m, int64_t per, int64_t rstride,
+                                                          int64_t topk, const QInfo* info, HostOut* out, int64_t seq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    info += blockIdx.x;
+    out += blockIdx.x;
+    const as_hit_rec* __restrict__ hits0 = hits_all + (int64_t)blockIdx.x * per;
+#define hits_at(t) hits0[((t) / per) * rstride + ((t) % per)]
     double* r_key = (double*)smem;           // mm
     int* r_idx = (int*)(r_key + HIT_CAP);
     __shared__ int s_flags, s_cnt;
@@ -1224,11 +1235,13 @@ __global__ __launch_bounds__(1024) void hits_final_kernel(const as_hit_rec* __re
     __syncthreads();
     int flags_l = 0;
     for (int t = threadIdx.x; t < mm; t += blockDim.x) {
-        const bool valid = hits[t].idx >= 0;
-        if (hits[t].idx == -2) flags_l |= (int)hits[t].score;
-        r_key[t] = valid ? -hits[t].score : key_traits<double>::inf();
-        r_idx[t] = valid ? (int)hits[t].idx : 0x7fffffff;
+        const as_hit_rec r = hits_at(t);
+        const bool valid = r.idx >= 0;
+        if (r.idx == -2) flags_l |= (int)r.score;
+        r_key[t] = valid ? -r.score : key_traits<double>::inf();
+        r_idx[t] = valid ? (int)r.idx : 0x7fffffff;
     }
+#undef hits_at
     if (flags_l) atomicOr(&s_flags, flags_l);
     __syncthreads();
     int cnt_l = 0;
@@ -1709,7 +1722,7 @@ as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {
     }
     const as_graph* gr = q->gr;
     if (gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // computed by as_query_scan, identically on every rank
-    hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, q->stream, recs_dev, m, q->k, gr->metric, gr->kernel,
+    hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, q->stream, recs_dev, m, m, m, q->k, gr->metric, gr->kernel,
                        gr->gp.sigma, gr->gp.p, gr->tau0, q->info);
     AS_HIP(hipGetLastError());
     return AS_OK;
@@ -1736,12 +1749,108 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
     hipStream_t st = q->stream;
     const int64_t topk = std::min<int64_t>(q->gr->gp.topk, q->sp->n);
     q->seq += 1;
-    hipLaunchKernelGGL(hits_final_kernel, dim3(1), dim3(1024), (sizeof(double) + sizeof(int)) * HIT_CAP, st, hits_dev, m, topk, q->info,
-                       q->hout_dev, q->seq);
+    hipLaunchKernelGGL(hits_final_kernel, dim3(1), dim3(1024), (sizeof(double) + sizeof(int)) * HIT_CAP, st, hits_dev, m, m, m, topk,
+                       q->info, q->hout_dev, q->seq);
     AS_HIP(hipGetLastError());
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], st));
     AS_TRY(wait_published(q));
     return collect(q, out_idx, out_score, out_len, out_lambda_q);
+}
+
+// ---- batched staged search: up to as_query_slots(q) queries per pass over this rank's rows; the record buffers hold
+// [slot][k] / [slot][topk + 1] records, the all-gathered ones [rank][slot][...] (one collective per step and pass)
+as_status as_query_create_batch(const as_space* sp, const as_graph* gr, as_query** out) {
+    if (sp && sp->dp > 1024) {
+        set_err("as_query_create_batch: rows wider than 1024 floats are searched query by query");
+        return AS_EUNSUPPORTED;
+    }
+    return query_create(sp, gr, QUERY_BATCH, out);
+}
+int32_t as_query_slots(const as_query* q) { return q ? q->cap : 0; }
+
+as_status as_query_scan_batch(as_query* q, const double* queries_host, int32_t nb, int64_t d, int64_t row_begin, int64_t row_end) {
+    if (!q || !queries_host || !q->gr || nb < 1 || nb > q->cap) {
+        set_err("as_query_scan_batch: null argument or more queries than slots");
+        return AS_EINVAL;
+    }
+    q->exact = q->sp->opts.force_exact ? 1 : 0;
+    q->robust = 0;
+    q->reuse = 0;
+    if (q->exact) {
+        set_err("as_query_scan_batch: the batched pass is the fp32 fast path only");
+        return AS_EUNSUPPORTED;
+    }
+    q->nb = nb;
+    AS_TRY(query_begin(q, queries_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1));
+    if (q->gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;
+    q->nb = q->cap;   // idle slots get empty records too: the gathered buffers are read slot by slot
+    const as_status s = run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    q->nb = nb;
+    return s;
+}
+
+as_status as_query_lambda_batch(as_query* q, const as_knn_rec* recs_dev, int32_t nranks) {
+    if (!q || !q->gr || !recs_dev || nranks < 1) {
+        set_err("as_query_lambda_batch: null argument");
+        return AS_EINVAL;
+    }
+    const as_graph* gr = q->gr;
+    if (gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;
+    const int64_t per = q->ss.knn, m = per * nranks;
+    if (m > REC_CAP) {
+        set_err("as_query_lambda_batch: %lld records per query exceed the supported %d", (long long)m, REC_CAP);
+        return AS_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(q_lambda_kernel, dim3((unsigned)q->cap), dim3(64), 0, q->stream, recs_dev, m, per, per * q->cap, q->k, gr->metric,
+                       gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, q->info);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+as_status as_query_score_batch(as_query* q, double tau) {
+    if (!q || !q->gr) {
+        set_err("as_query_score_batch: null argument");
+        return AS_EINVAL;
+    }
+    const int nb = q->nb;
+    q->nb = q->cap;
+    const as_status s = run_score(q, tau, 0);
+    q->nb = nb;
+    return s;
+}
+
+// out_idx / out_score: [nb][topk]; out_status[b]: AS_OK, AS_EZEROLAMBDA, or -1 = not provably exact on the batched fast
+// path (a candidate buffer overflowed, an a-posteriori check failed): rerun that query on the single-query path
+as_status as_query_finish_batch(as_query* q, const as_hit_rec* hits_dev, int32_t nranks, int64_t* out_idx, double* out_score,
+                                int64_t* out_len, double* out_lambda_q, int32_t* out_status) {
+    if (!q || !hits_dev || !out_idx || !out_score || !out_len || !out_status || nranks < 1) {
+        set_err("as_query_finish_batch: null argument");
+        return AS_EINVAL;
+    }
+    const int64_t per = q->ss.hits, m = per * nranks;
+    if (m > HIT_CAP) {
+        set_err("as_query_finish_batch: %lld records per query exceed the supported %d", (long long)m, HIT_CAP);
+        return AS_EUNSUPPORTED;
+    }
+    hipStream_t st = q->stream;
+    const int64_t topk = std::min<int64_t>(q->gr->gp.topk, q->gr->lambda_mode == AS_LAMBDA_FEATURE ? q->gr->nitems : q->gr->n);
+    q->seq += 1;
+    hipLaunchKernelGGL(hits_final_kernel, dim3((unsigned)q->nb), dim3(1024), (sizeof(double) + sizeof(int)) * HIT_CAP, st, hits_dev, m, per,
+                       per * q->cap, topk, q->info, q->hout_dev, q->seq);
+    AS_HIP(hipGetLastError());
+    for (int b = 0; b < q->nb; ++b) {
+        AS_TRY(wait_published(q, b));
+        const HostOut* h = q->hout + b;
+        if (h->overflow || h->knn_inexact || h->score_inexact) {
+            out_status[b] = -1;
+            out_len[b] = 0;
+            continue;
+        }
+        const as_status s1 = collect(q, out_idx + (int64_t)b * topk, out_score + (int64_t)b * topk, out_len + b,
+                                     out_lambda_q ? out_lambda_q + b : nullptr, b);
+        out_status[b] = (int32_t)s1;
+    }
+    return AS_OK;
 }
 
 void as_query_set_exact(as_query* q, int32_t flags) {

@@ -242,6 +242,49 @@ class HipEngine:
         hits = [(int(self._idx[t]), float(self._sc[t])) for t in range(ln.value)]
         return hits, float(lq.value), st == self._lib.AS_EZEROLAMBDA, inexact, overflow
 
+    # ---- batched staged search (32 slots per pass)
+    def batch_open(self):
+        torch = self.torch
+        self.qb = C.c_void_p()
+        self._check(self.L.as_query_create_batch(self.sp, self.gr, C.byref(self.qb)))
+        self.cap = int(self.L.as_query_slots(self.qb))
+        dev = torch.device("cuda", self.op.device)
+        self.knn_local_b = torch.zeros((self.cap, self.k, KNN_REC_F64), dtype=torch.float64, device=dev)
+        self.hits_local_b = torch.zeros((self.cap, self.hcap, HIT_REC_F64), dtype=torch.float64, device=dev)
+        self._check(self.L.as_query_bind_records(self.qb, C.c_void_p(self.knn_local_b.data_ptr()),
+                                                 C.c_void_p(self.hits_local_b.data_ptr())))
+        self.L.as_query_set_stream(self.qb, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self._bidx = np.empty((self.cap, max(self.topk, 1)), dtype=np.int64)
+        self._bsc = np.empty((self.cap, max(self.topk, 1)), dtype=np.float64)
+        return self.cap
+
+    def query_scan_batch(self, Q, r0, r1):
+        self._qb = np.ascontiguousarray(Q, dtype=np.float64)
+        self._check(self.L.as_query_scan_batch(self.qb, self._qb.ctypes.data_as(C.c_void_p), self._qb.shape[0], self._qb.shape[1], r0, r1))
+
+    def query_lambda_batch(self, knn_all, nranks):
+        self._check(self.L.as_query_lambda_batch(self.qb, C.c_void_p(knn_all.data_ptr()), nranks))
+
+    def query_score_batch(self, tau):
+        self._check(self.L.as_query_score_batch(self.qb, float(tau)))
+
+    def query_finish_batch(self, hits_all, nranks, nb):
+        """-> per query (hits | None when it has to be rerun query by query, lambda_q, zero_lambda)."""
+        ln = np.zeros(self.cap, dtype=np.int64)
+        lq = np.zeros(self.cap, dtype=np.float64)
+        st = np.zeros(self.cap, dtype=np.int32)
+        self._check(self.L.as_query_finish_batch(self.qb, C.c_void_p(hits_all.data_ptr()), nranks, self._bidx.ctypes.data_as(C.c_void_p),
+                                                 self._bsc.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p),
+                                                 lq.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)))
+        out = []
+        for b in range(nb):
+            if st[b] == -1:
+                out.append((None, 0.0, False))
+            else:
+                out.append(([(int(self._bidx[b, t]), float(self._bsc[b, t])) for t in range(ln[b])], float(lq[b]),
+                            st[b] == self._lib.AS_EZEROLAMBDA))
+        return out
+
     def lambdas(self):
         out = np.empty(self.n, dtype=np.float64)
         self._check(self.L.as_lambdas(self.sp, out.ctypes.data_as(C.c_void_p)))
@@ -263,6 +306,9 @@ class HipEngine:
         return float(out[0])
 
     def close(self):
+        if getattr(self, "qb", None):
+            self.L.as_query_free(self.qb)
+            self.qb = C.c_void_p()
         if self.q:
             self.L.as_query_free(self.q)
             self.q = C.c_void_p()
@@ -494,6 +540,46 @@ class ShardedIndex:
         if zero:
             raise PanicException("The lambdas are zero, check the magnitude of items and eps.")
         return hits
+
+    def search_batch(self, Q, tau):
+        """B queries [B, D] -> list of B hit lists: 32 query slots per pass over every rank's rows, the two record
+        exchanges of a pass shared by its slots.  A query the batched fast path cannot prove exact is rerun through
+        search() -- every rank sees the same merged flags, so every rank reruns the same ones."""
+        import contextlib
+
+        from . import PanicException
+
+        e = self.engine
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        if Q.ndim != 2:
+            raise TypeError("items must be a 2-D float64 array")
+        if not hasattr(e, "query_scan_batch") or getattr(e, "d", 0) > 1024:
+            return [self.search(np.ascontiguousarray(q), tau) for q in Q]
+        nranks = self.world if self._collective() else 1
+        ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        out, zero_any = [], False
+        with ctx:
+            if not getattr(self, "_batch_cap", 0):
+                self._batch_cap = e.batch_open()
+            cap = self._batch_cap
+            for i0 in range(0, Q.shape[0], cap):
+                chunk = Q[i0 : i0 + cap]
+                e.query_scan_batch(chunk, *self.scan_rows)
+                knn_all = self._gather_fixed(e.knn_local_b)
+                e.query_lambda_batch(knn_all, nranks)
+                e.query_score_batch(tau)
+                hits_all = self._gather_fixed(e.hits_local_b)
+                for b, (hits, lq, zero) in enumerate(e.query_finish_batch(hits_all, nranks, chunk.shape[0])):
+                    if hits is None:
+                        try:
+                            hits = self.search(np.ascontiguousarray(chunk[b]), tau)
+                        except PanicException:
+                            zero, hits = True, []
+                    zero_any = zero_any or zero
+                    out.append(hits)
+        if zero_any:
+            raise PanicException("The lambdas are zero, check the magnitude of items and eps.")
+        return out
 
     def lambdas(self):
         """lambdas of ALL items, in item order (ring build: every rank holds its own rows' -- gathered here)."""

@@ -181,6 +181,50 @@ class OracleEngine:
         hits = [(int(ids[t]), float(sc[t])) for t in o]
         return hits, self.lq, self.lq == 0.0, False, False
 
+    # ---- batched staged search: the single-query steps slot by slot, in the [slot][...] record layout
+    def batch_open(self):
+        import torch
+        self.cap = 4
+        self.knn_local_b = torch.zeros((self.cap, self.k, 6), dtype=torch.float64)
+        self.hits_local_b = torch.zeros((self.cap, self.topk + 1, 2), dtype=torch.float64)
+        return self.cap
+
+    def query_scan_batch(self, Q, r0, r1):
+        self.bq, self.brange = [np.asarray(q, dtype=np.float64) for q in Q], (r0, r1)
+        empty = np.zeros((self.k, 6))
+        empty[:, 0] = np.array([-1], dtype=np.int64).view(np.float64)[0]
+        empty[:, 1] = np.inf
+        for b in range(self.cap):
+            if b < len(self.bq):
+                self.query_scan(self.bq[b], r0, r1)
+                self.knn_local_b[b].copy_(self.knn_local)
+            else:
+                self.knn_local_b[b].copy_(__import__("torch").from_numpy(empty))
+
+    def query_lambda_batch(self, knn_all, nranks):
+        r = knn_all.reshape(nranks, self.cap, self.k, 6)
+        self.blq = []
+        for b in range(len(self.bq)):
+            self.q = self.bq[b]
+            self.query_lambda(r[:, b].reshape(nranks * self.k, 6))
+            self.blq.append(self.lq)
+
+    def query_score_batch(self, tau):
+        for b in range(len(self.bq)):
+            self.q, self.lq = self.bq[b], self.blq[b]
+            self.r0, self.r1 = self.brange[0] + self.off, self.brange[1] + self.off
+            self.query_score(tau)
+            self.hits_local_b[b].copy_(self.hits_local)
+
+    def query_finish_batch(self, hits_all, nranks, nb):
+        r = hits_all.reshape(nranks, self.cap, self.topk + 1, 2)
+        out = []
+        for b in range(nb):
+            self.lq = self.blq[b]
+            hits, lq, zero, _, _ = self.query_finish(r[:, b].reshape(nranks * (self.topk + 1), 2))
+            out.append((hits, lq, zero))
+        return out
+
     def lambdas(self):
         lam = self.index["lambdas"]
         return lam[self.off : self.off + self.nlocal] if getattr(self, "nlocal", None) is not None and self.off + self.nlocal <= len(lam) and hasattr(self, "parts") else lam
@@ -217,6 +261,10 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
             q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
             for tau in (1.0, 0.62, 0.0):
                 res.append((index.search(q, tau), index.last_lambda_q))
+        # batched search: 4 slots per pass in the test engine, 9 queries = 3 passes, one partly filled
+        rng = np.random.default_rng(6)
+        Qb = np.stack([X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d) for _ in range(9)])
+        assert index.search_batch(Qb, 0.62) == [index.search(q, 0.62) for q in Qb]
         out[rank] = (index.lambdas().copy(), res)
     finally:
         dist.destroy_process_group()

@@ -39,6 +39,12 @@ def test_single_rank_staged_path_matches_oracle(oracle_lib):
         got = index.search(q, tau)
         assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-9)   # ties to rounding (tau = 0) may swap
         assert abs(index.last_lambda_q - lq) <= 1e-9 * abs(lq)
+    Qb = np.stack([q for q, _ in _queries(X, n, d)] * 4)               # 48 queries: two passes of 32 slots
+    for tau in (0.62, 0.0):
+        got = index.search_batch(Qb, tau)
+        for b in range(len(Qb)):
+            want, lq = ref.search(Qb[b], tau)
+            assert_hits_match(got[b], want, ref.scores(Qb[b], tau, lq), rtol=1e-9)
     index.close()
 
 
@@ -99,6 +105,10 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
         index = CpuStaged.build(gp, shard, dist, replicate=replicate)
         assert index.replicated == replicate
         res = [(index.search(q, tau), index.last_lambda_q) for q, tau in _queries(X, n, d)]
+        rng = np.random.default_rng(6)
+        Qb = np.stack([X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d) for _ in range(45)])
+        for tau in (0.62, 1.0):   # two passes of 32 slots, the second partly filled
+            assert index.search_batch(Qb, tau) == [index.search(np.ascontiguousarray(q), tau) for q in Qb]
         out[rank] = (index.lambdas().copy(), res)
         index.close()
     finally:
