@@ -669,16 +669,18 @@ as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {
 // header-derived sizes before allocating anything and validates the CSR it is about to trust.
 namespace {
 struct IndexHeader {
-    char magic[8];           // "ASIDX02\0"
+    char magic[8];           // "ASIDX03\0"
     int32_t header_bytes;    // sizeof(IndexHeader) of the writer
-    int32_t version;         // 2
-    int64_t n, d, nnz;       // items, features, adjacency entries
-    int64_t nnodes;          // graph nodes: n (item mode) or d (feature mode)
+    int32_t version;         // 3
+    int64_t n, d, nnz;       // items held by this file, features, adjacency entries
+    int64_t nnodes;          // graph nodes: all items of the index (item mode; > n for one rank's shard of a
+                             // row-sharded index) or d (feature mode)
+    int64_t row_offset;      // global index of this file's first item (0 for a whole index)
     int32_t has_f64, metric, kernel, lambda_mode;
     as_graph_params gp;
     double tau0;
 };
-constexpr int32_t INDEX_VERSION = 2;
+constexpr int32_t INDEX_VERSION = 3;
 
 template <typename T>
 as_status dev_to_file(FILE* f, const T* dev, size_t count) {
@@ -722,7 +724,7 @@ int64_t payload_bytes(const IndexHeader& h) {
     b += (h.nnodes + 1) * 8 + h.nnz * 4 + h.nnz * 8 * 4;    // indptr, indices, dist gy w lap
     b += h.nnodes * 8;                                      // deg
     if (h.lambda_mode == AS_LAMBDA_FEATURE) b += h.n * 8 * 2 + h.d * 8;   // E, G, colm
-    else b += h.n * 8 * 3;                                  // ny, E, G
+    else b += h.nnodes * 8 * 3;                             // ny, E, G of every graph node
     return b;
 }
 }  // namespace
@@ -742,10 +744,10 @@ as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path
     }
     IndexHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "ASIDX02", 8);
+    memcpy(h.magic, "ASIDX03", 8);
     h.header_bytes = (int32_t)sizeof(IndexHeader);
     h.version = INDEX_VERSION;
-    h.n = sp->n; h.d = sp->d; h.nnz = gr->nnz; h.nnodes = gr->n;
+    h.n = sp->n; h.d = sp->d; h.nnz = gr->nnz; h.nnodes = gr->n; h.row_offset = sp->row_offset;
     h.has_f64 = sp->x64 ? 1 : 0; h.metric = gr->metric; h.kernel = gr->kernel; h.lambda_mode = gr->lambda_mode;
     h.gp = gr->gp; h.tau0 = gr->tau0;
     as_status s = fwrite(&h, sizeof(h), 1, f) == 1 ? AS_OK : AS_EINVAL;
@@ -773,9 +775,9 @@ as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path
         if (s == AS_OK) s = dev_to_file(f, gr->G, n);
         if (s == AS_OK) s = dev_to_file(f, gr->colm, d);
     } else {
-        if (s == AS_OK) s = dev_to_file(f, gr->ny, n);
-        if (s == AS_OK) s = dev_to_file(f, gr->E, n);
-        if (s == AS_OK) s = dev_to_file(f, gr->G, n);
+        if (s == AS_OK) s = dev_to_file(f, gr->ny, nn);
+        if (s == AS_OK) s = dev_to_file(f, gr->E, nn);
+        if (s == AS_OK) s = dev_to_file(f, gr->G, nn);
     }
     if (fclose(f) != 0 && s == AS_OK) s = AS_EINVAL;
     if (s != AS_OK && err_slot().empty()) set_err("as_index_save: write to %s failed", path);
@@ -789,7 +791,7 @@ __global__ void lam32_kernel(int64_t n, const double* __restrict__ lam64, float*
 
 static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts, as_space** out_space, as_graph** out_graph) {
     IndexHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ASIDX02", 8) != 0 || h.header_bytes != (int32_t)sizeof(IndexHeader) ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ASIDX03", 8) != 0 || h.header_bytes != (int32_t)sizeof(IndexHeader) ||
         h.version != INDEX_VERSION) {
         set_err("as_index_load: %s is not an arrowspace index file of format %d", path, INDEX_VERSION);
         return AS_EINVAL;
@@ -798,7 +800,8 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
     const bool modes_ok = (h.metric == AS_METRIC_L2 || h.metric == AS_METRIC_COSINE) &&
                           (h.kernel == AS_KERNEL_GAUSSIAN || h.kernel == AS_KERNEL_RATIONAL) &&
                           (h.lambda_mode == AS_LAMBDA_ITEM || h.lambda_mode == AS_LAMBDA_FEATURE) &&
-                          h.nnodes == (h.lambda_mode == AS_LAMBDA_FEATURE ? h.d : h.n);
+                          (h.lambda_mode == AS_LAMBDA_FEATURE ? (h.nnodes == h.d && h.row_offset == 0)
+                                                              : (h.row_offset >= 0 && h.nnodes >= h.row_offset + h.n));
     as_graph_params gpr;
     if (need < 0 || !modes_ok || resolve_params(&h.gp, &gpr) != AS_OK || !(h.tau0 >= 0.0) || !(h.tau0 <= 1.0)) {
         set_err("as_index_load: %s has an inconsistent header", path);
@@ -879,9 +882,10 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
             if ((s = file_to_dev(f, &gr->colm, d)) != AS_OK) break;
             if ((s = feat_edges_from_csr(gr, sp->stream)) != AS_OK) break;
         } else {
-            if ((s = file_to_dev(f, &gr->ny, n)) != AS_OK) break;
-            if ((s = file_to_dev(f, &gr->E, n)) != AS_OK) break;
-            if ((s = file_to_dev(f, &gr->G, n)) != AS_OK) break;
+            if ((s = file_to_dev(f, &gr->ny, nn)) != AS_OK) break;
+            if ((s = file_to_dev(f, &gr->E, nn)) != AS_OK) break;
+            if ((s = file_to_dev(f, &gr->G, nn)) != AS_OK) break;
+            sp->row_offset = h.row_offset;
         }
         if (hipStreamSynchronize(sp->stream) != hipSuccess) s = AS_EHIP;
     } while (0);

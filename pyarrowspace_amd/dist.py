@@ -242,6 +242,17 @@ class HipEngine:
         hits = [(int(self._idx[t]), float(self._sc[t])) for t in range(ln.value)]
         return hits, float(lq.value), st == self._lib.AS_EZEROLAMBDA, inexact, overflow
 
+    # ---- persistence: this rank's shard + the graph, one file per rank
+    def save(self, path):
+        import os
+        self._check(self.L.as_index_save(self.sp, self.gr, os.fsencode(path)))
+
+    def load(self, path):
+        import os
+        self._check(self.L.as_index_load(os.fsencode(path), C.byref(self.op), C.byref(self.sp), C.byref(self.gr)))
+        self.n, self.d = int(self.L.as_nitems(self.sp)), int(self.L.as_nfeatures(self.sp))
+        return int(self.L.as_space_row_offset(self.sp)), int(self.L.as_nnodes(self.gr))
+
     # ---- batched staged search (32 slots per pass)
     def batch_open(self):
         torch = self.torch
@@ -508,6 +519,49 @@ class ShardedIndex:
             one_round(lambda h, b, rg, cg: e.knn_block_band(h, b, rg, cg))
             e.knn_merge(nmax)
         return e.lists()
+
+    def save(self, prefix):
+        """One file per rank: `<prefix>.rank<r>of<world>` holds the rank's items, its lambdas and the graph."""
+        self._sync()
+        self.engine.save("%s.rank%dof%d" % (prefix, self.rank, self.world))
+
+    @classmethod
+    def load(cls, prefix, graph_params, dist=None, group=None, device_is_cuda=True):
+        """The index `save` wrote, by the same number of ranks; no k-NN or graph work is redone."""
+        import contextlib
+
+        import torch
+
+        self = cls()
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.engine = HipEngine(graph_params)
+        self.stream = torch.cuda.Stream() if device_is_cuda else None
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        with ctx:
+            off, nn = self.engine.load("%s.rank%dof%d" % (prefix, self.rank, self.world))
+            rows = self.engine.n
+            if self.world > 1:
+                c = torch.tensor([rows], dtype=torch.int64, device=torch.device("cuda", self.engine.op.device) if device_is_cuda else "cpu")
+                cs = [torch.zeros_like(c) for _ in range(self.world)]
+                dist.all_gather(cs, c, group=group)
+                counts = [int(v.item()) for v in cs]
+            else:
+                counts = [rows]
+            # a replicated index saves every item in every file; a ring-built one saves the rank's rows
+            self.replicated = sum(counts) != nn if self.world > 1 else False
+            if self.replicated:
+                counts = [b - a for a, b in zip(shard_bounds(nn, self.world)[:-1], shard_bounds(nn, self.world)[1:])]
+            self.counts = counts
+            self.bounds = [0]
+            for v in counts:
+                self.bounds.append(self.bounds[-1] + v)
+            self.n = self.bounds[-1]
+            self.r0, self.r1 = self.bounds[self.rank], self.bounds[self.rank + 1]
+            self.scan_rows = (self.r0, self.r1) if self.replicated else (0, rows)
+            self.engine.query_open()
+        return self
 
     def _sync(self):
         if self.stream is not None:

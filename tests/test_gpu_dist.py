@@ -109,6 +109,17 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
         Qb = np.stack([X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d) for _ in range(45)])
         for tau in (0.62, 1.0):   # two passes of 32 slots, the second partly filled
             assert index.search_batch(Qb, tau) == [index.search(np.ascontiguousarray(q), tau) for q in Qb]
+        # sharded save / load: one file per rank, the loaded index answers like the one that was saved
+        prefix = os.path.join(os.environ.get("TMPDIR", "/tmp"), "as_shard_%d_%d" % (port, int(replicate)))
+        index.save(prefix)
+        dist.barrier()
+        loaded = CpuStaged.load(prefix, gp, dist)
+        assert (loaded.n, loaded.replicated) == (index.n, index.replicated)
+        assert replicate or (loaded.r0, loaded.r1) == (index.r0, index.r1)   # a replicated index is re-partitioned evenly
+        for q, tau in _queries(X, n, d)[:4]:
+            assert loaded.search(q, tau) == index.search(q, tau)
+        loaded.close()
+        os.remove("%s.rank%dof%d" % (prefix, rank, world))
         out[rank] = (index.lambdas().copy(), res)
         index.close()
     finally:
