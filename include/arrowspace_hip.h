@@ -155,6 +155,9 @@ as_status as_feat_energy(const as_space* sp, const as_graph* gr, int64_t row_beg
                          double* E_dev, double* G_dev);
 /* step 5f: tau0 = median of the positive E, lambdas of all n items into the space (E, G complete, device). */
 as_status as_feat_lambdas(as_space* sp, as_graph* gr, const double* E_dev, const double* G_dev);
+/* row-sharded form: E, G of ALL n_global items; this shard (rows [row_offset, row_offset + nitems)) gets its lambdas */
+as_status as_feat_lambdas_global(as_space* sp, as_graph* gr, const double* E_dev, const double* G_dev, int64_t n_global,
+                                 int64_t row_offset);
 
 /* ---- search: replaces prepare_query_item + search_lambda_aware, src/lib.rs:154,173 ---- */
 

@@ -40,7 +40,7 @@ class HitRec(C.Structure):
 # every symbol include/arrowspace_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "as_build", "as_build_dev", "as_space_create_dev", "as_knn_rows", "as_graph_from_knn", "as_feat_gram", "as_feat_graph",
-    "as_feat_energy", "as_feat_lambdas", "as_graph_lambda_mode", "as_knn_list_width", "as_space_nmax", "as_space_norms",
+    "as_feat_energy", "as_feat_lambdas", "as_feat_lambdas_global", "as_graph_lambda_mode", "as_knn_list_width", "as_space_nmax", "as_space_norms",
     "as_space_row_offset", "as_knn_block", "as_knn_merge", "as_knn_block_band", "as_graph_from_knn_global", "as_search",
     "as_search_batch", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
@@ -113,6 +113,7 @@ def load():
         "as_feat_graph": (i32, [vp, pgp, vp, pvp]),
         "as_feat_energy": (i32, [vp, vp, i64, i64, vp, vp]),
         "as_feat_lambdas": (i32, [vp, vp, vp, vp]),
+        "as_feat_lambdas_global": (i32, [vp, vp, vp, vp, i64, i64]),
         "as_graph_lambda_mode": (i32, [vp]),
         "as_search": (i32, [vp, vp, vp, i64, f64, vp, vp, C.POINTER(i64), C.POINTER(f64)]),
         "as_search_batch": (i32, [vp, vp, vp, i64, i64, f64, vp, vp, vp, vp, vp]),

@@ -441,7 +441,7 @@ static as_status search_single_locked(const as_space* sp, const as_graph* gr, co
 // the graph handle belongs to this space: item graphs have one node per item, feature graphs one per column
 static as_status graph_matches(const as_space* sp, const as_graph* gr, const char* who) {
     // a shard of a row-sharded index searches against the graph of all items
-    const bool ok = gr->lambda_mode == AS_LAMBDA_FEATURE ? (gr->n == sp->d && gr->nitems == sp->n) : gr->n >= sp->row_offset + sp->n;
+    const bool ok = gr->lambda_mode == AS_LAMBDA_FEATURE ? (gr->n == sp->d && gr->nitems >= sp->row_offset + sp->n) : gr->n >= sp->row_offset + sp->n;
     if (!ok) {
         set_err("%s: the graph (%lld nodes) was not built for this space (%lld items x %lld features)", who, (long long)gr->n,
                 (long long)sp->n, (long long)sp->d);
@@ -771,8 +771,9 @@ as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path
     if (s == AS_OK) s = dev_to_file(f, gr->lap, nnz);
     if (s == AS_OK) s = dev_to_file(f, gr->deg, nn);
     if (gr->lambda_mode == AS_LAMBDA_FEATURE) {
-        if (s == AS_OK) s = dev_to_file(f, gr->E, n);
-        if (s == AS_OK) s = dev_to_file(f, gr->G, n);
+        // a shard of a row-sharded index holds the energies of every item: this file keeps its own rows'
+        if (s == AS_OK) s = dev_to_file(f, gr->E + (gr->nitems > sp->n ? sp->row_offset : 0), n);
+        if (s == AS_OK) s = dev_to_file(f, gr->G + (gr->nitems > sp->n ? sp->row_offset : 0), n);
         if (s == AS_OK) s = dev_to_file(f, gr->colm, d);
     } else {
         if (s == AS_OK) s = dev_to_file(f, gr->ny, nn);
@@ -800,7 +801,7 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
     const bool modes_ok = (h.metric == AS_METRIC_L2 || h.metric == AS_METRIC_COSINE) &&
                           (h.kernel == AS_KERNEL_GAUSSIAN || h.kernel == AS_KERNEL_RATIONAL) &&
                           (h.lambda_mode == AS_LAMBDA_ITEM || h.lambda_mode == AS_LAMBDA_FEATURE) &&
-                          (h.lambda_mode == AS_LAMBDA_FEATURE ? (h.nnodes == h.d && h.row_offset == 0)
+                          (h.lambda_mode == AS_LAMBDA_FEATURE ? (h.nnodes == h.d && h.row_offset >= 0)
                                                               : (h.row_offset >= 0 && h.nnodes >= h.row_offset + h.n));
     as_graph_params gpr;
     if (need < 0 || !modes_ok || resolve_params(&h.gp, &gpr) != AS_OK || !(h.tau0 >= 0.0) || !(h.tau0 <= 1.0)) {
@@ -853,7 +854,7 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
         if (s != AS_OK) break;
         hipLaunchKernelGGL(lam32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sp->stream, h.n, sp->lam64, sp->lam32);
         gr = new as_graph();
-        gr->device = dev; gr->n = h.nnodes; gr->nitems = h.n; gr->nnz = h.nnz; gr->gp = gpr; gr->metric = h.metric; gr->kernel = h.kernel;
+        gr->device = dev; gr->n = h.nnodes; gr->nitems = h.row_offset + h.n; gr->nnz = h.nnz; gr->gp = gpr; gr->metric = h.metric; gr->kernel = h.kernel;
         gr->lambda_mode = h.lambda_mode; gr->tau0 = h.tau0;
         {   // the CSR is walked on trust afterwards: monotone row pointers ending at nnz, columns inside the graph
             std::vector<int64_t> ip;
@@ -881,6 +882,7 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
             if ((s = file_to_dev(f, &gr->G, n)) != AS_OK) break;
             if ((s = file_to_dev(f, &gr->colm, d)) != AS_OK) break;
             if ((s = feat_edges_from_csr(gr, sp->stream)) != AS_OK) break;
+            sp->row_offset = h.row_offset;
         } else {
             if ((s = file_to_dev(f, &gr->ny, nn)) != AS_OK) break;
             if ((s = file_to_dev(f, &gr->E, nn)) != AS_OK) break;

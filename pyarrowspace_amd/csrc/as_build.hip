@@ -2184,6 +2184,12 @@ __global__ void lam_slice_kernel(int64_t n, const double* __restrict__ src, doub
     lam32[i] = (float)src[i];
 }
 
+as_status lam_slice(hipStream_t st, int64_t n, const double* src, double* lam64, float* lam32) {
+    hipLaunchKernelGGL(lam_slice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, src, lam64, lam32);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
 // Graph stage over the lists of ALL n_global items (all-gathered by the host) for a space that holds only the rows
 // [row_offset, row_offset + sp->n): symmetrisation, Laplacian, energies and tau0 over the global graph, this
 // shard's slice of the lambdas into the space.

@@ -280,6 +280,8 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
 as_status csr_from_knn(hipStream_t st, int64_t n, int64_t k, const int32_t* idx, const double* dist, const double* gy,
                        const int32_t* cnt, double sigma, double p, int kernel, as_graph* gr);
 as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const double* G);
+as_status median_lambda_n(hipStream_t st, int64_t n, const double* E, const double* G, double* lam64, float* lam32, double* tau0_out);
+as_status lam_slice(hipStream_t st, int64_t n, const double* src, double* lam64, float* lam32);
 as_status graph_from_knn_global(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx,
                                 const double* dist, const double* gy, const int32_t* cnt, const double* n64_global, as_graph* gr);
 // k-NN over visiting column blocks (multi-GPU ring, as_build.hip)

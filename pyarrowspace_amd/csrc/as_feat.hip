@@ -533,6 +533,31 @@ as_status as_feat_energy(const as_space* sp, const as_graph* gr, int64_t row_beg
     return AS_OK;
 }
 
+// row-sharded form: E / G of ALL n_global items (all-gathered), tau0 over them, this shard's lambdas into the space
+as_status as_feat_lambdas_global(as_space* sp, as_graph* gr, const double* E_dev, const double* G_dev, int64_t n_global, int64_t row_offset) {
+    if (!sp || !gr || !E_dev || !G_dev || gr->lambda_mode != AS_LAMBDA_FEATURE || row_offset < 0 || row_offset + sp->n > n_global) {
+        set_err("as_feat_lambdas_global: null argument, not a feature-mode graph, or rows outside the items");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    hipStream_t st = sp->stream;
+    hipFree(gr->E);
+    hipFree(gr->G);
+    gr->E = gr->G = nullptr;
+    AS_HIP(hipMalloc(&gr->E, sizeof(double) * n_global));
+    AS_HIP(hipMalloc(&gr->G, sizeof(double) * n_global));
+    AS_HIP(hipMemcpyAsync(gr->E, E_dev, sizeof(double) * n_global, hipMemcpyDeviceToDevice, st));
+    AS_HIP(hipMemcpyAsync(gr->G, G_dev, sizeof(double) * n_global, hipMemcpyDeviceToDevice, st));
+    dev_tmp<double> lam;
+    AS_HIP(lam.alloc(n_global));
+    AS_TRY(median_lambda_n(st, n_global, gr->E, gr->G, lam, nullptr, &gr->tau0));
+    AS_TRY(lam_slice(st, sp->n, (const double*)lam + row_offset, sp->lam64, sp->lam32));
+    AS_HIP(hipStreamSynchronize(st));
+    sp->row_offset = row_offset;
+    gr->nitems = n_global;
+    return AS_OK;
+}
+
 as_status as_feat_lambdas(as_space* sp, as_graph* gr, const double* E_dev, const double* G_dev) {
     if (!sp || !gr || !E_dev || !G_dev || gr->lambda_mode != AS_LAMBDA_FEATURE) {
         set_err("as_feat_lambdas: null argument or not a feature-mode graph");

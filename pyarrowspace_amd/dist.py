@@ -242,6 +242,34 @@ class HipEngine:
         hits = [(int(self._idx[t]), float(self._sc[t])) for t in range(ln.value)]
         return hits, float(lq.value), st == self._lib.AS_EZEROLAMBDA, inexact, overflow
 
+    # ---- feature mode (lambda on the F x F feature-space Laplacian): Gram partials add up over the shards
+    def feature_mode(self):
+        return int(self.op.lambda_mode) == self._lib.LAMBDA_MODES["feature"]
+
+    def feat_gram(self):
+        torch = self.torch
+        g = torch.zeros((self.d, self.d), dtype=torch.float64, device=torch.device("cuda", self.op.device))
+        if self.n > 0:
+            self._check(self.L.as_feat_gram(self.sp, 0, self.n, C.c_void_p(g.data_ptr())))
+        return g
+
+    def feat_graph(self, gram):
+        self.torch.cuda.synchronize()
+        self._check(self.L.as_feat_graph(self.sp, C.byref(self.gp), C.c_void_p(gram.data_ptr()), C.byref(self.gr)))
+
+    def feat_energy(self):
+        torch = self.torch
+        dev = torch.device("cuda", self.op.device)
+        E = torch.zeros((max(self.n, 1),), dtype=torch.float64, device=dev)
+        G = torch.zeros_like(E)
+        if self.n > 0:
+            self._check(self.L.as_feat_energy(self.sp, self.gr, 0, self.n, C.c_void_p(E.data_ptr()), C.c_void_p(G.data_ptr())))
+        return E[: self.n], G[: self.n]
+
+    def feat_lambdas_global(self, E, G, n_global, row_offset):
+        self.torch.cuda.synchronize()
+        self._check(self.L.as_feat_lambdas_global(self.sp, self.gr, C.c_void_p(E.data_ptr()), C.c_void_p(G.data_ptr()), n_global, row_offset))
+
     # ---- persistence: this rank's shard + the graph, one file per rank
     def save(self, path):
         import os
@@ -434,6 +462,32 @@ class ShardedIndex:
             self.r0, self.r1 = self.bounds[self.rank], self.bounds[self.rank + 1]
             if min(counts) == 0 and isinstance(self.engine, HipEngine):
                 self.replicated = True      # a rank without rows has no space of its own to scan: keep the all-gather form
+            if getattr(self.engine, "feature_mode", lambda: False)():
+                # lambda on the F x F feature-space Laplacian: the D x D Gram partials of the shards add up (all-gather +
+                # fixed-order sum: the same bits on every rank), the feature graph is built redundantly (D nodes), the
+                # energies are local, tau0 needs all of them (all-gather of 16 B per item).  No item ever leaves its rank.
+                if min(counts) == 0:
+                    raise ValueError("feature mode needs at least one item on every rank")
+                self.replicated = False
+                X_shard = X_shard.contiguous()
+                self._sync()
+                self.engine.create_space(X_shard)
+                g = self.engine.feat_gram()
+                if self._collective():
+                    parts = self._gather_fixed(g).reshape(self.world, g.shape[0], g.shape[1])
+                    g = parts[0].clone()
+                    for r in range(1, self.world):
+                        g += parts[r]
+                self._sync()
+                self.engine.feat_graph(g)
+                E, G = self.engine.feat_energy()
+                E = self._gather_rows(E.contiguous(), counts).contiguous()
+                G = self._gather_rows(G.contiguous(), counts).contiguous()
+                self._sync()
+                self.engine.feat_lambdas_global(E, G, self.n, self.r0)
+                self.scan_rows = (0, rows)
+                self.engine.query_open()
+                return self
             if self.replicated:
                 X_full = self._gather_rows(X_shard.contiguous(), counts).contiguous()
                 self._sync()

@@ -151,6 +151,64 @@ def test_two_ranks_one_gpu_match_oracle(oracle_lib, replicate):
     assert out[0][1] == out[1][1]
 
 
+def _feature_worker(rank, world, port, n, d, split, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import calibrate_feature_eps
+        from pyarrowspace_amd.dist import ShardedIndex
+
+        class CpuStaged(ShardedIndex):
+            def _gather_rows(self, t, counts):
+                return super()._gather_rows(t.cpu(), counts).cuda()
+
+            def _gather_fixed(self, t):
+                torch.cuda.synchronize()
+                return super()._gather_fixed(t.cpu()).cuda()
+
+        X = clustered(n, d, nclust=8, seed=31)
+        gp = {"eps": calibrate_feature_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None, "metric": "cosine", "kernel": "rational",
+              "lambda_mode": "feature"}
+        bounds = [0, split, n]
+        index = CpuStaged.build(gp, torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy()).cuda(), dist)
+        res = [(index.search(q, tau), index.last_lambda_q) for q, tau in _queries(X, n, d)]
+        Qb = np.stack([q for q, _ in _queries(X, n, d)])
+        assert index.search_batch(Qb, 0.62) == [index.search(np.ascontiguousarray(q), 0.62) for q in Qb]
+        out[rank] = (index.lambdas().copy(), res)
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_feature_mode_match_oracle(oracle_lib):
+    """lambda_mode='feature' row-sharded: Gram partials all-gathered and summed, energies local, tau0 global."""
+    import torch.multiprocessing as mp
+    from conftest import calibrate_feature_eps
+    n, d, world, split = 1500, 96, 2, 400
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_feature_worker, args=(world, port, n, d, split, out), nprocs=world, join=True)
+    X = clustered(n, d, nclust=8, seed=31)
+    gp = {"eps": calibrate_feature_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None, "metric": "cosine", "kernel": "rational",
+          "lambda_mode": "feature"}
+    ref = oracle_lib.OracleIndex(X, gp)
+    want = [ref.search(q, tau) for q, tau in _queries(X, n, d)]
+    for rank in range(world):
+        lam, res = out[rank]
+        np.testing.assert_allclose(lam, ref.lambdas, rtol=1e-9)
+        for (hits, lq), (whits, wlq) in zip(res, want):
+            assert_hits_match(hits, whits, rtol=1e-9)
+            assert abs(lq - wlq) <= 1e-9 * abs(wlq)
+    assert out[0][1] == out[1][1]
+
+
 def test_one_rank_rccl_collectives_on_a_side_stream(oracle_lib):
     """The real N>1 code path (RCCL all_gather_into_tensor ordered against the query kernels on
     one dedicated stream) with a 1-rank nccl group: every collective is issued, nothing is skipped."""
