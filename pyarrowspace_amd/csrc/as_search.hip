@@ -91,6 +91,7 @@ __global__ void q_from_row_kernel(const float* __restrict__ x32, const double* _
 template <typename T>
 struct SelArgs {
     const T* dots;
+    const float* dots32;   // fp64 keys over the fp32 scan (SelArgs<double> only): the dot carries the fp32 error, nothing else does
     const float* n32;
     const float* inorm32;
     const double* n64;
@@ -120,7 +121,8 @@ __device__ __forceinline__ T dot_at(const SelArgs<T>& a, int64_t row) {
 template <typename T>
 __device__ __forceinline__ void sel_slot(SelArgs<T>& a) {
     const int z = blockIdx.z;
-    a.dots += (int64_t)z * a.sd;
+    if (a.dots) a.dots += (int64_t)z * a.sd;
+    if (a.dots32) a.dots32 += (int64_t)z * a.sd;
     a.info += z;
     a.info_w += z;
     a.gmin += (int64_t)z * CAND_CAP;
@@ -129,12 +131,13 @@ __device__ __forceinline__ void sel_slot(SelArgs<T>& a) {
 }
 
 struct ScoreCtx {
-    double nq, tau, lq;
+    double nq, tau, lq, rq;   // rq = 1/|q|
     float tau32, lq32, inq32;
 };
 __device__ __forceinline__ ScoreCtx load_ctx(const QInfo* info, double tau) {
     ScoreCtx c;
     c.nq = info->nq;
+    c.rq = info->nq > 0.0 ? rsqrt(info->nq) : 0.0;
     c.tau = tau;
     c.lq = info->lambda_q;
     c.tau32 = (float)c.tau;
@@ -152,6 +155,15 @@ __device__ __forceinline__ float score_key<float>(const SelArgs<float>& a, const
 }
 template <>
 __device__ __forceinline__ double score_key<double>(const SelArgs<double>& a, const ScoreCtx& c, int64_t row) {
+    if (a.dots32) {
+        // mixed form: the dot of the fp32 scan, everything else in fp64 -- |key - exact| <= tau * coef32 (the proof's
+        // bound), so rankings the lambda term decides (tau small) never depend on fp32.  No square root or division
+        // for the cosine (reciprocal square roots: a few ulp, inside the bound's slack).
+        const double nrow = a.n64[row];
+        const double dv = (double)a.dots32[(row >> 5) * a.ts + (row & 31)];
+        const double cs = nrow > 0.0 ? dv * rsqrt(nrow) * c.rq : 0.0;
+        return -(c.tau * cs + (1.0 - c.tau) / (1.0 + fabs(c.lq - a.lam64[row])));
+    }
     const double den = sqrt(a.n64[row] * c.nq);
     const double cs = den > 0.0 ? dot_at(a, row) / den : 0.0;
     return -(c.tau * cs + (1.0 - c.tau) / (1.0 + fabs(c.lq - a.lam64[row])));
@@ -407,6 +419,103 @@ __global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a) {
                 cidx[slot] = (int)row;
             } else {
                 full = true;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ batched selection: all query slots per read of a row
+// The per-slot kernels above read a row's norm and lambda once per slot: 32 slots x 20 B per row.  Here a thread owns
+// a row, reads its norm and lambda once and walks the NS slots' dots (tile-major: [32-row tile][slot][32 rows], 128
+// contiguous bytes per slot and half-wave) -- 4 NS + 16 bytes per row.  Mixed keys (fp32 dots, fp64 everything else).
+struct BatchSel {
+    const float* dots32;      // slot 0
+    const double* n64;
+    const double* lam64;
+    const QInfo* info;        // [NS]
+    QInfo* info_w;
+    int64_t r0, r1, sd, ts;
+    double tau;
+    double* gmin;             // [NS][CAND_CAP]
+    double* ckey;             // [NS][CAND_CAP]
+    int* cidx;
+    int ns;
+};
+
+// rn = 1/|x_row|, rq = 1/|q_s|: no square root or division for the cosine; one reciprocal for the lambda term
+__device__ __forceinline__ double batch_key(const BatchSel& a, int s, int64_t row, double rn, double lrow, double rq, double lq) {
+    const double dv = (double)a.dots32[(row >> 5) * a.ts + (int64_t)s * a.sd + (row & 31)];
+    return -(a.tau * (dv * rn * rq) + (1.0 - a.tau) / (1.0 + fabs(lq - lrow)));
+}
+
+// group minima: one wave per (group of G rows, NSW slots); blockIdx.y = slot octet
+template <int NSW>
+__global__ __launch_bounds__(256) void score_gmin_batch_kernel(BatchSel a, int64_t G, int ngroups) {
+    __shared__ double s_rq[NSW], s_lq[NSW];
+    const int s0 = blockIdx.y * NSW;
+    if (threadIdx.x < NSW) {
+        const double nq = a.info[s0 + threadIdx.x].nq;
+        s_rq[threadIdx.x] = nq > 0.0 ? rsqrt(nq) : 0.0;
+        s_lq[threadIdx.x] = a.info[s0 + threadIdx.x].lambda_q;
+    }
+    __syncthreads();
+    const int lane = lane_id();
+    const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const int64_t lo = a.r0 + g * G;
+    const int64_t hi = lo + G < a.r1 ? lo + G : a.r1;
+    double m[NSW];
+#pragma unroll
+    for (int s = 0; s < NSW; ++s) m[s] = key_traits<double>::inf();
+    for (int64_t row = lo + lane; row < hi; row += 64) {
+        const double nrow = a.n64[row], lrow = a.lam64[row];
+        const double rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) {
+            const double k = batch_key(a, s0 + s, row, rn, lrow, s_rq[s], s_lq[s]);
+            m[s] = k < m[s] ? k : m[s];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSW; ++s) {
+        double v = m[s];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(v, o, 64);
+            v = other < v ? other : v;
+        }
+        if (lane == s && s0 + s < a.ns) a.gmin[(int64_t)(s0 + s) * CAND_CAP + g] = v;
+    }
+}
+
+template <int NSW>
+__global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a) {
+    __shared__ double s_rq[NSW], s_lq[NSW], s_thr[NSW];
+    const int s0 = blockIdx.y * NSW;
+    if (threadIdx.x < NSW) {
+        const double nq = a.info[s0 + threadIdx.x].nq;
+        s_rq[threadIdx.x] = nq > 0.0 ? rsqrt(nq) : 0.0;
+        s_lq[threadIdx.x] = a.info[s0 + threadIdx.x].lambda_q;
+        // idle slots never pass
+        s_thr[threadIdx.x] = s0 + (int)threadIdx.x < a.ns ? a.info[s0 + threadIdx.x].thr64 : -key_traits<double>::inf();
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int full = 0;   // bit s: the slot has overflowed its candidate buffer (mass ties): stop adding to its counter
+    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
+        const double nrow = a.n64[row], lrow = a.lam64[row];
+        const double rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) {
+            const double k = batch_key(a, s0 + s, row, rn, lrow, s_rq[s], s_lq[s]);
+            if (k <= s_thr[s] && !((full >> s) & 1u)) {
+                const int slot = atomicAdd(&a.info_w[s0 + s].sc_cnt, 1);
+                if (slot < CAND_CAP) {
+                    a.ckey[(int64_t)(s0 + s) * CAND_CAP + slot] = k;
+                    a.cidx[(int64_t)(s0 + s) * CAND_CAP + slot] = (int)row;
+                } else {
+                    full |= 1u << s;
+                }
             }
         }
     }
@@ -1289,7 +1398,7 @@ template <typename T>
 static SelArgs<T> make_sel(as_query* q, const T* dots, int M, int64_t exclude) {
     const as_space* sp = q->sp;
     SelArgs<T> a;
-    a.dots = dots; a.n32 = sp->n32; a.inorm32 = sp->inorm32; a.n64 = sp->n64; a.lam32 = sp->lam32; a.lam64 = sp->lam64;
+    a.dots = dots; a.dots32 = nullptr; a.n32 = sp->n32; a.inorm32 = sp->inorm32; a.n64 = sp->n64; a.lam32 = sp->lam32; a.lam64 = sp->lam64;
     a.info = q->info; a.info_w = q->info; a.n = sp->n; a.r0 = q->r0; a.r1 = q->r1; a.exclude = exclude;
     a.M = M; a.metric = sp->opts.metric;
     a.epskey = 0; a.coef = 0; a.tau = 1.0;
@@ -1408,15 +1517,17 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lamb
 }
 
 template <typename T, typename U, int PASSES>
-static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_final) {
+static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_final, const float* dots32 = nullptr) {
     hipStream_t st = q->stream;
     f.M = q->Ms; f.hits = q->hits; f.fuse = fuse_final; f.hout = q->hout_dev; f.seq = q->seq;
-    const double coef_s = coef_query(q, sizeof(T) == 8);
+    // mixed (fp32 dots, fp64 keys): the only error of a key is the dot's, scaled by tau
+    const double coef_s = dots32 ? f.tau * (coef_query(q, false) + 1.0e-14) + 4.0 * 2.220446049250313e-16 : coef_query(q, sizeof(T) == 8);
     if (q->robust && q->Ms > MAX_LIST) {
         // wide lists: exact global selection, then the filter-path finish kernel on exactly M rows
         const int64_t rows = q->r1 - q->r0;
         const int KP = (int)sizeof(T);
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        a.dots32 = dots32;
         a.tau = f.tau;
         const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
         hipMemsetAsync(q->rsel, 0, sizeof(RSel), st);
@@ -1433,6 +1544,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         const int grid = sel_grid(q, &nw);
         f.nlists = nw;
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        a.dots32 = dots32;
         a.tau = f.tau;
         hipLaunchKernelGGL(score_partial_kernel<T>, dim3(grid), dim3(256), 0, st, a);
         f.ck = q->pkey; f.ci = q->pidx;
@@ -1443,12 +1555,27 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
         G = std::max<int64_t>(64, (G + 63) / 64 * 64);
         const int ng = (int)((rows + G - 1) / G);
         SelArgs<T> a = make_sel<T>(q, dots, q->Ms, -1);
+        a.dots32 = dots32;
         a.tau = f.tau;
         const unsigned nb = (unsigned)q->nb;
-        hipLaunchKernelGGL((score_gmin_kernel<T, 0>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
-        hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
         const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
-        hipLaunchKernelGGL((score_filter_kernel<T, 0>), dim3(fg, 1, nb), dim3(256), 0, st, a);
+        if (dots32 && q->cap == GQ && sizeof(T) == 8) {
+            // batched workspace: every slot's keys from one read of a row's norm and lambda (all GQ slots: idle ones hold
+            // zero queries and cost nothing but their share of the dots)
+            BatchSel b;
+            b.dots32 = dots32; b.n64 = q->sp->n64; b.lam64 = q->sp->lam64; b.info = q->info; b.info_w = q->info;
+            b.r0 = q->r0; b.r1 = q->r1; b.sd = q->ss.dots; b.ts = q->ss.dots_ts; b.tau = f.tau;
+            b.gmin = (double*)q->gmin; b.ckey = (double*)q->ckey_s; b.cidx = q->cidx_s; b.ns = q->nb;
+            constexpr int NSW = 8;   // slots per wave: a row's norm and lambda are read GQ / NSW times instead of GQ
+            const unsigned ny = (unsigned)((q->nb + NSW - 1) / NSW);
+            hipLaunchKernelGGL((score_gmin_batch_kernel<NSW>), dim3((unsigned)((ng + 3) / 4), ny), dim3(256), 0, st, b, G, ng);
+            hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
+            hipLaunchKernelGGL((score_filter_batch_kernel<NSW>), dim3(fg, ny), dim3(256), 0, st, b);
+        } else {
+            hipLaunchKernelGGL((score_gmin_kernel<T, 0>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
+            hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
+            hipLaunchKernelGGL((score_filter_kernel<T, 0>), dim3(fg, 1, nb), dim3(256), 0, st, a);
+        }
         f.ck = q->ckey_s; f.ci = q->cidx_s;
         hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1, 1, nb), dim3(1024), score_lds<T>(), st, f, coef_s);
     }
@@ -1463,8 +1590,9 @@ static as_status run_score(as_query* q, double tau, int fuse_final) {
     }
     FinishArgs f = make_finish(q);
     f.tau = tau;
+    // fp32 scan: the scorer's keys are evaluated in fp64 all the same (lambda term, norms), over the fp32 dots
     if (q->exact) launch_score<double, unsigned long long, 8>(q, q->dots64, f, fuse_final);
-    else launch_score<float, unsigned int, 4>(q, q->dots32, f, fuse_final);
+    else launch_score<double, unsigned long long, 8>(q, (const double*)nullptr, f, fuse_final, q->dots32);
     AS_HIP(hipGetLastError());
     return AS_OK;
 }
