@@ -304,6 +304,8 @@ as_status feat_build(as_space* sp, const as_graph_params* gp, as_graph* gr);
 as_status feat_edges_from_csr(as_graph* gr, hipStream_t st);   // rebuilds ea/eb/ew from the CSR (index load)
 struct QInfo;
 as_status feat_query_lambda(const as_graph* gr, const double* q64, int64_t dp, QInfo* info, int nslots, hipStream_t st);
+as_status feat_query_prepare(const as_graph* gr, const double* qin, int64_t d, int64_t dp, double* q64, float* q32, QInfo* info,
+                             int nslots, hipStream_t st);
 
 // query-as-row exact k-NN used by the build fallback (as_search.hip)
 as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, int32_t* out_idx,

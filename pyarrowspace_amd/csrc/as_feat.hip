@@ -234,8 +234,11 @@ __global__ void feat_edge_fill_kernel(int64_t d, const int64_t* __restrict__ ind
         }
 }
 
+static as_status feat_query_attr(int64_t d);   // per-device dynamic-LDS opt-in of the query kernel (defined below)
+
 as_status feat_edges_from_csr(as_graph* gr, hipStream_t st) {
     const int64_t d = gr->n;
+    AS_TRY(feat_query_attr(d));
     dev_tmp<int32_t> up;
     dev_tmp<int64_t> off;
     AS_HIP(up.alloc(d));
@@ -422,28 +425,50 @@ as_status feat_energy(const as_space* sp, const as_graph* gr, int64_t r0, int64_
     return AS_OK;
 }
 
-// FK4: lambda_q of the query slots (blockIdx.x = slot), one wave each; q64 is the zero-padded query the
-// prepare kernel wrote.  lambda_q == 0 is the reference's zero-lambda assert (src/lib.rs:156-159).
-__global__ __launch_bounds__(64) void feat_qlambda_kernel(const double* __restrict__ q64, int64_t d, int64_t dp, int64_t ne,
-                                                          const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
-                                                          const double* __restrict__ ew, double tau0, QInfo* info) {
+// FK4: lambda_q of the query slots (blockIdx.x = slot), one 1024-thread block each (a single wave walking ~19 000
+// edges took 55 us on the critical path of every search); q64 is the zero-padded query the prepare kernel wrote.
+// lambda_q == 0 is the reference's zero-lambda assert (src/lib.rs:156-159).
+__global__ __launch_bounds__(1024) void feat_qlambda_kernel(const double* __restrict__ q64, int64_t d, int64_t dp, int64_t ne,
+                                                            const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
+                                                            const double* __restrict__ ew, double tau0, QInfo* info) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* xs = (double*)smem;
-    const int lane = lane_id();
+    __shared__ double s_red[3][16];
+    const int lane = lane_id(), w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     q64 += (int64_t)blockIdx.x * dp;
     info += blockIdx.x;
-    double s = 0.0;
-    for (int64_t c = lane; c < d; c += 64) {
+    double nxl = 0.0;
+    for (int64_t c = threadIdx.x; c < d; c += blockDim.x) {
         const double v = q64[c];
         xs[c] = v;
-        s += v * v;
+        nxl += v * v;
     }
-    const double nx = wave_sum(s);
-    AS_LDS_FENCE();
-    double T[1], S2[1];
-    feat_accumulate<1>(xs, d, ne, ea, eb, ew, T, S2);
+    __syncthreads();
+    double T = 0.0, S2 = 0.0;
+    for (int64_t e = threadIdx.x; e < ne; e += blockDim.x) {
+        const double t = xs[ea[e]] - xs[eb[e]];
+        const double en = ew[e] * (t * t);
+        T += en;
+        S2 += en * en;
+    }
+    T = wave_sum(T);
+    S2 = wave_sum(S2);
+    nxl = wave_sum(nxl);
+    if (lane == 0) {
+        s_red[0][w] = T;
+        s_red[1][w] = S2;
+        s_red[2][w] = nxl;
+    }
+    __syncthreads();
+    if (w != 0) return;
+    T = S2 = nxl = 0.0;
+    for (int w2 = 0; w2 < nwv; ++w2) {   // fixed order: deterministic
+        T += s_red[0][w2];
+        S2 += s_red[1][w2];
+        nxl += s_red[2][w2];
+    }
     double e, g;
-    feat_finish(T[0], S2[0], nx, xs, ne, ea, eb, ew, e, g);
+    feat_finish(T, S2, nxl, xs, ne, ea, eb, ew, e, g);
     if (lane == 0) {
         const double lam = tau0 * (e / (e + tau0)) + (1.0 - tau0) * g;
         info->lambda_q = lam;
@@ -451,9 +476,85 @@ __global__ __launch_bounds__(64) void feat_qlambda_kernel(const double* __restri
     }
 }
 
+// q_prepare (query staging: fp64 + fp32 copies, norms, state reset) and FK4 in one launch: in feature mode lambda_q
+// needs nothing but the query, so the whole pre-scan work of a search is this one kernel.
+__global__ __launch_bounds__(1024) void q_prepare_feat_kernel(const double* __restrict__ qin, int64_t d, int64_t dp, double* __restrict__ q64,
+                                                              float* __restrict__ q32, QInfo* info, double tau, int64_t ne,
+                                                              const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
+                                                              const double* __restrict__ ew, double tau0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* xs = (double*)smem;
+    __shared__ double s_red[3][16];
+    const int lane = lane_id(), w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    qin += (int64_t)blockIdx.z * d;
+    q64 += (int64_t)blockIdx.z * dp;
+    q32 += (int64_t)blockIdx.z * dp;
+    info += blockIdx.z;
+    double nxl = 0.0;
+    for (int64_t c = threadIdx.x; c < dp; c += blockDim.x) {
+        const double v = c < d ? qin[c] : 0.0;
+        q64[c] = v;
+        q32[c] = (float)v;
+        if (c < d) xs[c] = v;
+        nxl += v * v;
+    }
+    __syncthreads();
+    double T = 0.0, S2 = 0.0;
+    for (int64_t e = threadIdx.x; e < ne; e += blockDim.x) {
+        const double t = xs[ea[e]] - xs[eb[e]];
+        const double en = ew[e] * (t * t);
+        T += en;
+        S2 += en * en;
+    }
+    T = wave_sum(T);
+    S2 = wave_sum(S2);
+    nxl = wave_sum(nxl);
+    if (lane == 0) {
+        s_red[0][w] = T;
+        s_red[1][w] = S2;
+        s_red[2][w] = nxl;
+    }
+    __syncthreads();
+    if (w != 0) return;
+    T = S2 = nxl = 0.0;
+    for (int w2 = 0; w2 < nwv; ++w2) {
+        T += s_red[0][w2];
+        S2 += s_red[1][w2];
+        nxl += s_red[2][w2];
+    }
+    double e, g;
+    feat_finish(T, S2, nxl, xs, ne, ea, eb, ew, e, g);
+    if (lane == 0) {
+        const double nq = nxl;
+        info->nq = nq;
+        info->inq = nq > 0.0 ? 1.0 / sqrt(nq) : 0.0;
+        info->nq32 = (float)nq;
+        info->inq32 = nq > 0.0 ? (float)(1.0 / sqrt(nq)) : 0.0f;
+        info->tau = tau;
+        reset_query_state(info);
+        const double lam = tau0 * (e / (e + tau0)) + (1.0 - tau0) * g;
+        info->lambda_q = lam;
+        info->status = lam == 0.0 ? AS_EZEROLAMBDA : AS_OK;
+    }
+}
+
+as_status feat_query_prepare(const as_graph* gr, const double* qin, int64_t d, int64_t dp, double* q64, float* q32, QInfo* info,
+                             int nslots, hipStream_t st) {
+    hipLaunchKernelGGL(q_prepare_feat_kernel, dim3(1, 1, (unsigned)nslots), dim3(1024), sizeof(double) * gr->n, st, qin, d, dp, q64, q32,
+                       info, 1.0, gr->ne, gr->ea, gr->eb, gr->ew, gr->tau0);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+static as_status feat_query_attr(int64_t d) {
+    AS_HIP(hipFuncSetAttribute((const void*)feat_qlambda_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * d)));
+    AS_HIP(hipFuncSetAttribute((const void*)q_prepare_feat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * d)));
+    return AS_OK;
+}
+
 as_status feat_query_lambda(const as_graph* gr, const double* q64, int64_t dp, QInfo* info, int nslots, hipStream_t st) {
     const size_t lds = sizeof(double) * gr->n;
-    hipLaunchKernelGGL(feat_qlambda_kernel, dim3((unsigned)nslots), dim3(64), lds, st, q64, gr->n, dp, gr->ne, gr->ea, gr->eb, gr->ew,
+    hipLaunchKernelGGL(feat_qlambda_kernel, dim3((unsigned)nslots), dim3(1024), lds, st, q64, gr->n, dp, gr->ne, gr->ea, gr->eb, gr->ew,
                        gr->tau0, info);
     AS_HIP(hipGetLastError());
     return AS_OK;

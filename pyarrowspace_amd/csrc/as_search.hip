@@ -1620,10 +1620,11 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->hq_dev);
     }
     const int nslots = q->cap > 1 ? q->cap : q->nb;
-    hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, nslots), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
     const bool feature = q->gr && q->gr->lambda_mode == AS_LAMBDA_FEATURE;
-    // feature mode: lambda_q is a functional of the query alone (SPEC F6/F7) -- no neighbour search, no prefilter
-    if (feature) AS_TRY(feat_query_lambda(q->gr, q->q64, sp->dp, q->info, nslots, st));
+    // feature mode: lambda_q is a functional of the query alone (SPEC F6/F7) -- no neighbour search, no prefilter, and
+    // it is computed by the staging kernel itself
+    if (feature) AS_TRY(feat_query_prepare(q->gr, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, nslots, st));
+    else hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, nslots), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
     if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
     const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !feature);
     AS_TRY(launch_scan(q, pre));
