@@ -128,8 +128,16 @@ as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t ro
                        const int32_t* p_cnt_dev, const float* p_t32_dev, const double* block_nmax_host, int32_t* out_idx_dev,
                        double* out_key_dev, double* out_dist_dev, double* out_gy_dev, int32_t* out_cnt_dev,
                        int32_t* out_flag_dev, double* out_band_dev, int64_t* out_nflagged);
+/* Running fold (what dist.py uses: two slices of list memory whatever the number of ranks): r_* <- the M smallest exact
+ * entries of r_* and b_* per row; r_t32 keeps min over blocks of (T32_b - e_b).  mode 0: every row; 1: rows with
+ * flag_dev != 0; 2: those rows, their running list discarded first (first block of the second round).  as_knn_merge
+ * with nblocks == 0 then finalises the one folded slice. */
+as_status as_knn_fold(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t mode,
+                      double block_nmax, const int32_t* flag_dev, double* r_key_dev, double* r_dist_dev, double* r_gy_dev,
+                      int32_t* r_idx_dev, int32_t* r_cnt_dev, float* r_t32_dev, const double* b_key_dev, const double* b_dist_dev,
+                      const double* b_gy_dev, const int32_t* b_idx_dev, const int32_t* b_cnt_dev, const float* b_t32_dev);
 as_status as_knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin,
-                            int64_t row_end, int64_t row_goff, int64_t col_goff, const int32_t* flag_dev,
+                            int64_t row_end, int64_t row_goff, int64_t col_goff, int32_t* flag_dev /* bit 1: band overflow */,
                             const double* band_dev, double* p_key_dev, double* p_dist_dev, double* p_gy_dev,
                             int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev, int64_t* out_overflowed);
 /* step 3 over the lists of ALL n_global items for a space that holds the rows [row_offset, row_offset + nitems):
@@ -238,6 +246,9 @@ as_status as_query_bind_records(as_query* q, as_knn_rec* knn_dev, as_hit_rec* hi
 void* as_query_stream(const as_query* q);
 
 /* ---- accessors: src/lib.rs:40-61 (GraphLaplacian), 78-124 (ArrowSpace) ---- */
+/* searches on this space whose answer was returned although it failed its a-posteriori check even on the strongest
+ * (fp64) path: more near-ties at the k-th distance / score than fp64 can order.  0 in normal operation. */
+int64_t as_unproven_searches(const as_space* sp);
 int64_t as_nitems(const as_space* sp);
 int64_t as_nfeatures(const as_space* sp);
 as_status as_get_item(const as_space* sp, int64_t idx, double* out_vec, double* out_lambda);

@@ -20,6 +20,10 @@ per-item spectral energy) and the documented variants of GRAPH_VARIABLES.md:7-10
 + dispersion synthesis, synthesis=Median per
 tests/output/1760705545_v0_16/suggested_eps.md:3).
 
+lambda_mode="feature" (SPEC F1-F7, below) restates the lambda those notes document -- TAUMODE.md:8,12-27 on the
+F x F feature-space Laplacian of GRAPH_VARIABLES.md:17 -- and is unpinned in the same way: the reference's only
+lambda-sensitive fixtures (tests/test_0.py:39-61) hold under no scale-invariant lambda.
+
 Brute force, O(N^2 D): intended for N up to a few thousand.  The C twin
 (oracle/arrowspace_oracle.c) is the same algorithm with OpenMP for larger N.
 """

@@ -287,6 +287,12 @@ class ArrowSpace:
             _raise(st)
         return {"scan_us": out[0], "rest_us": out[1]}
 
+    @property
+    def unproven_searches(self) -> int:
+        """Extension: searches whose answer failed its a-posteriori exactness check even on the fp64 path (ties inside
+        fp64 rounding); the library also says so on stderr the first time.  0 in normal operation."""
+        return int(_L.as_unproven_searches(self._h))
+
     def save(self, gl: GraphLaplacian, path: str) -> None:
         """Extension: write the built index (items, lambdas, graph) to one file."""
         st = _L.as_index_save(self._h, gl._h, os.fsencode(path))

@@ -239,6 +239,7 @@ as_status as_graph_from_knn_global(as_space* sp, const as_graph_params* gp, int6
 
 int32_t as_knn_list_width(int64_t k) { return knn_list_width(k); }
 double as_space_nmax(const as_space* sp) { return sp ? sp->nmax : 0.0; }
+int64_t as_unproven_searches(const as_space* sp) { return sp ? sp->unproven_searches : 0; }
 as_status as_space_norms(const as_space* sp, double* out_dev) {
     if (!sp || !out_dev) {
         set_err("as_space_norms: null argument");
@@ -277,8 +278,9 @@ as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t ro
                        const int32_t* p_cnt_dev, const float* p_t32_dev, const double* block_nmax_host, int32_t* out_idx_dev,
                        double* out_key_dev, double* out_dist_dev, double* out_gy_dev, int32_t* out_cnt_dev, int32_t* out_flag_dev,
                        double* out_band_dev, int64_t* out_nflagged) {
-    if (!sp || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev || !block_nmax_host || !out_idx_dev ||
-        !out_key_dev || !out_dist_dev || !out_gy_dev || !out_cnt_dev || !out_flag_dev || !out_band_dev || !out_nflagged || nblocks < 1) {
+    if (!sp || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev || !out_idx_dev ||
+        !out_key_dev || !out_dist_dev || !out_gy_dev || !out_cnt_dev || !out_flag_dev || !out_band_dev || !out_nflagged || nblocks < 0 ||
+        (nblocks > 0 && !block_nmax_host)) {
         set_err("as_knn_merge: null argument");
         return AS_EINVAL;
     }
@@ -293,8 +295,24 @@ as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t ro
     return s;
 }
 
+as_status as_knn_fold(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t mode, double block_nmax,
+                      const int32_t* flag_dev, double* r_key_dev, double* r_dist_dev, double* r_gy_dev, int32_t* r_idx_dev,
+                      int32_t* r_cnt_dev, float* r_t32_dev, const double* b_key_dev, const double* b_dist_dev, const double* b_gy_dev,
+                      const int32_t* b_idx_dev, const int32_t* b_cnt_dev, const float* b_t32_dev) {
+    if (!sp || !r_key_dev || !r_dist_dev || !r_gy_dev || !r_idx_dev || !r_cnt_dev || !r_t32_dev || !b_key_dev || !b_dist_dev ||
+        !b_gy_dev || !b_idx_dev || !b_cnt_dev || !b_t32_dev || (mode != 0 && !flag_dev) || mode < 0 || mode > 2) {
+        set_err("as_knn_fold: null argument or bad mode");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    return knn_fold(sp, row_begin, row_end, knn_list_width(r.k), mode, block_nmax, flag_dev, r_key_dev, r_dist_dev, r_gy_dev, r_idx_dev,
+                    r_cnt_dev, r_t32_dev, b_key_dev, b_dist_dev, b_gy_dev, b_idx_dev, b_cnt_dev, b_t32_dev);
+}
+
 as_status as_knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
-                            int64_t row_goff, int64_t col_goff, const int32_t* flag_dev, const double* band_dev, double* p_key_dev,
+                            int64_t row_goff, int64_t col_goff, int32_t* flag_dev, const double* band_dev, double* p_key_dev,
                             double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev,
                             int64_t* out_overflowed) {
     if (!sp || !cols || !flag_dev || !band_dev || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev ||
@@ -486,6 +504,16 @@ static as_status search_single_locked(const as_space* sp, const as_graph* gr, co
         mode = next;
     }
     if (s == AS_OK && out_lambda_q) dbg("search: qlen=%lld, lambda_q=%.6f", (long long)d, *out_lambda_q);  // src/lib.rs:161-165
+    {   // the strongest path has run and the answer still fails its a-posteriori check (more near-ties than fp64
+        // can order): it is returned, but never silently -- counted, and reported on stderr once per space
+        int ki = 0, si = 0;
+        query_flags(q, &ki, &si);
+        if (s == AS_OK && ((ki & 1) || (si & 1))) {
+            if (sp->unproven_searches++ == 0)
+                fprintf(stderr, "[pyarrowspace] warning: a search result could not be proven exact (ties at the k-th distance or score "
+                                "inside fp64 rounding); see as_unproven_searches()\n");
+        }
+    }
     return s;
 }
 

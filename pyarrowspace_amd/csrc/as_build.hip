@@ -1526,6 +1526,7 @@ struct MergeArgs {
     const int32_t* p_cnt;     // [nblocks][rows]
     const float* p_t32;
     const double* nmax;       // [nblocks]: largest squared norm of the block (error bound of what it dropped)
+    int folded;               // the one slice is a running fold of all blocks: p_t32 already holds min_b (T32_b - e_b)
     int32_t* out_idx;
     double *out_key, *out_dist, *out_gy;
     int32_t* out_cnt;
@@ -1590,7 +1591,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeArgs a) {
         for (int b = 0; b < a.nblocks; ++b) {
             const int cc = a.p_cnt[(size_t)b * a.rows + lr];
             if (!((cc >> 30) & 1) || (cc & 0xffff) == 0) continue;   // nothing was dropped from this block
-            const double e = a.metric == AS_METRIC_L2 ? a.coef * (ni + a.nmax[b]) : a.coef;
+            const double e = a.folded ? 0.0 : (a.metric == AS_METRIC_L2 ? a.coef * (ni + a.nmax[b]) : a.coef);
             if (!((double)a.p_t32[(size_t)b * a.rows + lr] - e > B)) bad = 1;
         }
         a.flag[lr] = bad;
@@ -1616,6 +1617,7 @@ struct BlockBandArgs {
     int32_t* p_cnt;
     float* p_t32;
     int* overflow;   // counts rows whose band did not fit
+    int* flag;       // bit 1 is set for such a row: its first-round list stands (unproven), the host restores it
 };
 
 __global__ __launch_bounds__(256) void knn_block_band_kernel(BlockBandArgs a) {
@@ -1641,7 +1643,12 @@ __global__ __launch_bounds__(256) void knn_block_band_kernel(BlockBandArgs a) {
     }
     __syncthreads();
     if (s_over) {
-        if (threadIdx.x == 0) atomicAdd(a.overflow, 1);   // the first pass's (unproven) list of this block stands
+        if (threadIdx.x == 0) {
+            atomicAdd(a.overflow, 1);
+            atomicOr(&a.flag[lr], 2);
+            a.p_cnt[lr] = 0;      // nothing from this block: the row's second-round list is void, the first-round one stands
+            a.p_t32[lr] = 0.0f;
+        }
         return;
     }
     const int C = s_C;
@@ -1692,6 +1699,99 @@ __global__ __launch_bounds__(256) void knn_block_band_kernel(BlockBandArgs a) {
         a.p_cnt[lr] = C < a.M ? C : a.M;   // complete inside the band: no "dropped" flag
         a.p_t32[lr] = 0.0f;
     }
+}
+
+// Running fold of the visiting blocks: run <- the M smallest (key64, id) of run U blk, per row; the running bound
+// min over blocks of (T32_b - e_b) is kept in run_t32 (rounded down: conservative).  Dropping EXACT entries beyond
+// the M-th needs no proof -- they cannot be among the k <= M - 8 nearest.  HBM for the lists: two slices, whatever the
+// number of ranks (all of them at once took 115 GB per rank at 64M x 768 / 8 GPUs).
+// mode 0: every row; 1: flagged rows only; 2: flagged rows only, their running list discarded first (first block of
+// the second round).
+struct FoldArgs {
+    int64_t rows, r0;
+    int M, metric, mode;
+    double coef, nmax_b;
+    const double* na64;
+    const int* flag;
+    double *r_key, *r_dist, *r_gy;
+    int32_t* r_idx;
+    int32_t* r_cnt;
+    float* r_t32;
+    const double *b_key, *b_dist, *b_gy;
+    const int32_t* b_idx;
+    const int32_t* b_cnt;
+    const float* b_t32;
+};
+
+__global__ __launch_bounds__(256) void knn_fold_kernel(FoldArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int cap = 2 * a.M;
+    char* base = smem + (size_t)w * ((sizeof(double) * 3 + sizeof(int)) * cap);
+    double* mk = (double*)base;
+    double* md = mk + cap;
+    double* mg = md + cap;
+    int* mi = (int*)(mg + cap);
+    const int64_t lr = (int64_t)blockIdx.x * 4 + w;
+    if (lr >= a.rows) return;
+    if (a.mode != 0 && !a.flag[lr]) return;
+    const size_t o = (size_t)lr * a.M;
+    const int rc = a.mode == 2 ? 0 : a.r_cnt[lr];
+    const int bc = a.b_cnt[lr];
+    const int cr = rc & 0xffff, cb = bc & 0xffff;
+    for (int t = lane; t < cr; t += 64) {
+        mk[t] = a.r_key[o + t];
+        md[t] = a.r_dist[o + t];
+        mg[t] = a.r_gy[o + t];
+        mi[t] = a.r_idx[o + t];
+    }
+    for (int t = lane; t < cb; t += 64) {
+        mk[cr + t] = a.b_key[o + t];
+        md[cr + t] = a.b_dist[o + t];
+        mg[cr + t] = a.b_gy[o + t];
+        mi[cr + t] = a.b_idx[o + t];
+    }
+    AS_LDS_FENCE();
+    const int C = cr + cb;
+    for (int t = lane; t < C; t += 64) {
+        int rank = 0;
+        for (int s2 = 0; s2 < C; ++s2) rank += lex_less<double>(mk[s2], mi[s2], mk[t], mi[t]) ? 1 : 0;
+        if (rank < a.M) {
+            a.r_key[o + rank] = mk[t];
+            a.r_dist[o + rank] = md[t];
+            a.r_gy[o + rank] = mg[t];
+            a.r_idx[o + rank] = mi[t];
+        }
+    }
+    if (lane == 0) {
+        const int anyb = (bc >> 30) & 1, anyr = (rc >> 30) & 1;
+        float tb = (a.mode == 2 || !anyr) ? __int_as_float(0x7f800000) : a.r_t32[lr];
+        if (anyb && cb > 0) {
+            const double e = a.metric == AS_METRIC_L2 ? a.coef * (a.na64[a.r0 + lr] + a.nmax_b) : a.coef;
+            const float nb = __double2float_rd((double)a.b_t32[lr] - e);
+            tb = nb < tb ? nb : tb;
+        }
+        a.r_cnt[lr] = (C < a.M ? C : a.M) | ((anyb | (a.mode == 2 ? 0 : anyr)) << 30);
+        a.r_t32[lr] = tb;
+    }
+}
+
+as_status knn_fold(const as_space* sp, int64_t r0, int64_t r1, int M, int mode, double block_nmax, const int32_t* flag, double* r_key,
+                   double* r_dist, double* r_gy, int32_t* r_idx, int32_t* r_cnt, float* r_t32, const double* b_key, const double* b_dist,
+                   const double* b_gy, const int32_t* b_idx, const int32_t* b_cnt, const float* b_t32) {
+    const int64_t rows = r1 - r0;
+    if (rows <= 0) return AS_OK;
+    FoldArgs fa;
+    fa.rows = rows; fa.r0 = r0; fa.M = M; fa.metric = sp->opts.metric; fa.mode = mode; fa.coef = err_coef(sp->dp); fa.nmax_b = block_nmax;
+    fa.na64 = sp->n64; fa.flag = flag;
+    fa.r_key = r_key; fa.r_dist = r_dist; fa.r_gy = r_gy; fa.r_idx = r_idx; fa.r_cnt = r_cnt; fa.r_t32 = r_t32;
+    fa.b_key = b_key; fa.b_dist = b_dist; fa.b_gy = b_gy; fa.b_idx = b_idx; fa.b_cnt = b_cnt; fa.b_t32 = b_t32;
+    const size_t lds = 4 * (sizeof(double) * 3 + sizeof(int)) * (size_t)(2 * M);
+    AS_HIP(hipFuncSetAttribute((const void*)knn_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(knn_fold_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), lds, sp->stream, fa);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(sp->stream));
+    return AS_OK;
 }
 
 // the fused MFMA kernel on (rows of sp) x (columns of cols), normal or collect mode
@@ -1789,11 +1889,13 @@ as_status knn_merge(const as_space* sp, const as_graph_params* gp, int64_t r0, i
     hipStream_t st = sp->stream;
     dev_tmp<double> nmax;
     dev_tmp<int> nflag;
-    AS_HIP(nmax.alloc(nblocks));
+    AS_HIP(nmax.alloc(std::max(nblocks, 1)));
     AS_HIP(nflag.alloc(1));
-    AS_HIP(hipMemcpyAsync(nmax, block_nmax_host, sizeof(double) * nblocks, hipMemcpyHostToDevice, st));
+    if (nblocks > 0) AS_HIP(hipMemcpyAsync(nmax, block_nmax_host, sizeof(double) * nblocks, hipMemcpyHostToDevice, st));
     AS_HIP(hipMemsetAsync(nflag, 0, sizeof(int), st));
     MergeArgs ma;
+    ma.folded = nblocks == 0 ? 1 : 0;
+    if (nblocks == 0) nblocks = 1;
     ma.rows = rows; ma.k = gp->k; ma.nblocks = nblocks; ma.M = M; ma.metric = sp->opts.metric;
     ma.epskey = ma.metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps; ma.coef = err_coef(sp->dp);
     ma.na64 = sp->n64; ma.r0 = r0;
@@ -1817,7 +1919,7 @@ as_status knn_merge(const as_space* sp, const as_graph_params* gp, int64_t r0, i
 
 // second pass of one visiting block, for the rows the merge flagged: collect mode + exact evaluation of the band
 as_status knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
-                         int64_t col_goff, int M, const int32_t* flag, const double* B, double* p_key, double* p_dist, double* p_gy,
+                         int64_t col_goff, int M, int32_t* flag, const double* B, double* p_key, double* p_dist, double* p_gy,
                          int32_t* p_idx, int32_t* p_cnt, float* p_t32, int64_t* overflowed) {
     AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block_band"));
     const int64_t rows = r1 - r0;
@@ -1866,6 +1968,7 @@ as_status knn_block_band(const as_space* sp, const as_space* cols, const as_grap
     ba.d = sp->d; ba.dp = sp->dp; ba.r0 = r0; ba.col_goff = col_goff; ba.S = S2; ba.CW = CAP; ba.M = M; ba.metric = metric; ba.nf = nf;
     ba.ids = d_ids; ba.c_idx = c2idx; ba.c_cnt = c2cnt;
     ba.p_key = p_key; ba.p_dist = p_dist; ba.p_gy = p_gy; ba.p_idx = p_idx; ba.p_cnt = p_cnt; ba.p_t32 = p_t32; ba.overflow = over;
+    ba.flag = flag;
     const size_t ldsb = (sizeof(double) * 3 + sizeof(int)) * (size_t)BAND_MAX;
     AS_HIP(hipFuncSetAttribute((const void*)knn_block_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     hipLaunchKernelGGL(knn_block_band_kernel, dim3((unsigned)nf), dim3(256), ldsb, st, ba);

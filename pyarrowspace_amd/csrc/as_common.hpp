@@ -65,6 +65,7 @@ struct as_space {
     mutable as_query* qcache_b = nullptr;     // batched workspace (QUERY_BATCH slots), lazily created
     mutable const as_graph* qcache_b_gr = nullptr;
     mutable std::mutex qmu;
+    mutable int64_t unproven_searches = 0;   // searches returned although their a-posteriori check failed on the strongest path
     mutable double kstats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // accumulated by as_knn_rows
 };
 
@@ -292,9 +293,12 @@ as_status knn_merge(const as_space* sp, const as_graph_params* gp, int64_t r0, i
                     const double* block_nmax_host, int32_t* out_idx, double* out_key, double* out_dist, double* out_gy,
                     int32_t* out_cnt, int32_t* flag, double* out_B, int64_t* nflagged);
 as_status knn_block_band(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
-                         int64_t col_goff, int M, const int32_t* flag, const double* B, double* p_key, double* p_dist, double* p_gy,
+                         int64_t col_goff, int M, int32_t* flag, const double* B, double* p_key, double* p_dist, double* p_gy,
                          int32_t* p_idx, int32_t* p_cnt, float* p_t32, int64_t* overflowed);
 int knn_list_width(int64_t k);
+as_status knn_fold(const as_space* sp, int64_t r0, int64_t r1, int M, int mode, double block_nmax, const int32_t* flag, double* r_key,
+                   double* r_dist, double* r_gy, int32_t* r_idx, int32_t* r_cnt, float* r_t32, const double* b_key, const double* b_dist,
+                   const double* b_gy, const int32_t* b_idx, const int32_t* b_cnt, const float* b_t32);
 
 // feature mode (as_feat.hip)
 as_status feat_gram(const as_space* sp, int64_t r0, int64_t r1, double* gram);

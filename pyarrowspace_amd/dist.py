@@ -110,19 +110,20 @@ class HipEngine:
 
     # ---- build without replication: visiting column blocks (ring)
     def ring_begin(self, nblocks):
+        """Two slices of list memory: [0] the running fold of the blocks seen so far, [1] the block at hand."""
         torch = self.torch
         self.M = int(self.L.as_knn_list_width(int(self.gp.k)))
         if self.M < 0:
             raise ValueError(f"graph_params['k']={int(self.gp.k)} exceeds the supported maximum of 56")
         dev = torch.device("cuda", self.op.device)
         rows, M = max(self.n, 1), self.M
-        self.p_key = torch.zeros((nblocks, rows, M), dtype=torch.float64, device=dev)
+        self.p_key = torch.zeros((2, rows, M), dtype=torch.float64, device=dev)
         self.p_dist = torch.zeros_like(self.p_key)
         self.p_gy = torch.zeros_like(self.p_key)
-        self.p_idx = torch.full((nblocks, rows, M), -1, dtype=torch.int32, device=dev)
-        self.p_cnt = torch.zeros((nblocks, rows), dtype=torch.int32, device=dev)
-        self.p_t32 = torch.zeros((nblocks, rows), dtype=torch.float32, device=dev)
-        self.nblocks = nblocks
+        self.p_idx = torch.full((2, rows, M), -1, dtype=torch.int32, device=dev)
+        self.p_cnt = torch.zeros((2, rows), dtype=torch.int32, device=dev)
+        self.p_t32 = torch.zeros((2, rows), dtype=torch.float32, device=dev)
+        self.nblocks, self._round2_first = nblocks, False
 
     def open_block(self, X):
         """A visiting shard as a temporary space (ingested into the HBM layout the kernels read)."""
@@ -145,30 +146,45 @@ class HipEngine:
     def _slice(self, b):
         return [C.c_void_p(t[b].data_ptr()) for t in (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
 
+    def _fold(self, mode, nmax_b):
+        flag = C.c_void_p(self.l_flag.data_ptr()) if mode else C.c_void_p()
+        self._check(self.L.as_knn_fold(self.sp, C.byref(self.gp), 0, self.n, mode, float(nmax_b), flag, *self._slice(0), *self._slice(1)))
+
     def knn_block(self, h, b, row_goff, col_goff):
         if self.n > 0:
-            self._check(self.L.as_knn_block(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff, *self._slice(b)))
+            self._check(self.L.as_knn_block(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff, *self._slice(1)))
+            self._fold(0, self.block_nmax(h))
 
-    def knn_merge(self, nmax):
+    def knn_merge(self, nmax=None):
+        """Final lists from the folded slice; returns the number of rows not provably exact."""
         torch = self.torch
         k, rows = int(self.gp.k), self.n
         dev = torch.device("cuda", self.op.device)
+        first = not hasattr(self, "l_idx")
+        if not first:
+            keep = (self.l_idx, self.l_key, self.l_dist, self.l_gy, self.l_cnt, self.l_flag)
         self.l_idx = torch.full((max(rows, 1), k), -1, dtype=torch.int32, device=dev)
         self.l_key = torch.zeros((max(rows, 1), k), dtype=torch.float64, device=dev)
         self.l_dist = torch.zeros_like(self.l_key)
         self.l_gy = torch.zeros_like(self.l_key)
         self.l_cnt = torch.zeros((max(rows, 1),), dtype=torch.int32, device=dev)
-        self.l_flag = torch.zeros((max(rows, 1),), dtype=torch.int32, device=dev)
-        self.l_band = torch.zeros((max(rows, 1),), dtype=torch.float64, device=dev)
-        nm = np.ascontiguousarray(nmax, dtype=np.float64)
+        flag2 = torch.zeros((max(rows, 1),), dtype=torch.int32, device=dev)
+        band = torch.zeros((max(rows, 1),), dtype=torch.float64, device=dev)
         nf = C.c_int64(0)
         torch.cuda.synchronize()
         if rows > 0:
-            self._check(self.L.as_knn_merge(self.sp, C.byref(self.gp), 0, rows, self.nblocks, *[C.c_void_p(t.data_ptr()) for t in
-                                            (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)],
-                                            nm.ctypes.data_as(C.c_void_p), *[C.c_void_p(t.data_ptr()) for t in
-                                            (self.l_idx, self.l_key, self.l_dist, self.l_gy, self.l_cnt, self.l_flag, self.l_band)],
+            self._check(self.L.as_knn_merge(self.sp, C.byref(self.gp), 0, rows, 0, *self._slice(0), C.c_void_p(),
+                                            *[C.c_void_p(t.data_ptr()) for t in (self.l_idx, self.l_key, self.l_dist, self.l_gy, self.l_cnt, flag2, band)],
                                             C.byref(nf)))
+        if first:
+            self.l_flag, self.l_band = flag2, band
+        else:
+            # second round: rows whose band overflowed somewhere (bit 1) keep their first-round list, unproven
+            ov = (keep[5] & 2) != 0
+            if bool(ov.any()):
+                for new, old in zip((self.l_idx, self.l_key, self.l_dist, self.l_gy, self.l_cnt), keep[:5]):
+                    new[ov] = old[ov]
+            self.l_flag = keep[5]
         return int(nf.value)
 
     def knn_block_band(self, h, b, row_goff, col_goff):
@@ -176,7 +192,9 @@ class HipEngine:
         if self.n > 0:
             self._check(self.L.as_knn_block_band(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff,
                                                  C.c_void_p(self.l_flag.data_ptr()), C.c_void_p(self.l_band.data_ptr()),
-                                                 *self._slice(b), C.byref(ov)))
+                                                 *self._slice(1), C.byref(ov)))
+            self._fold(1 if self._round2_first else 2, self.block_nmax(h))
+            self._round2_first = True
         return int(ov.value)
 
     def lists(self):
@@ -191,12 +209,18 @@ class HipEngine:
             self._check(self.L.as_space_norms(self.sp, C.c_void_p(out.data_ptr())))
         return out[: self.n]
 
+    def ring_end(self):
+        """Drop the ring's list memory (before the graph stage allocates its CSR)."""
+        for name in ("p_key", "p_dist", "p_gy", "p_idx", "p_cnt", "p_t32", "l_key", "l_band"):
+            if hasattr(self, name):
+                delattr(self, name)
+        self.torch.cuda.empty_cache()
+
     def graph_from_knn_global(self, n_global, row_offset, idx, dist, gy, cnt, n64):
         self.torch.cuda.synchronize()
         self._check(self.L.as_graph_from_knn_global(self.sp, C.byref(self.gp), n_global, row_offset, C.c_void_p(idx.data_ptr()),
                                                     C.c_void_p(dist.data_ptr()), C.c_void_p(gy.data_ptr()), C.c_void_p(cnt.data_ptr()),
                                                     C.c_void_p(n64.data_ptr()), C.byref(self.gr)))
-        del self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32
 
     # ---- search
     def query_open(self):
@@ -572,7 +596,12 @@ class ShardedIndex:
                 bufs[0][: X_shard.shape[0]] = X_shard
             one_round(lambda h, b, rg, cg: e.knn_block_band(h, b, rg, cg))
             e.knn_merge(nmax)
-        return e.lists()
+        out = e.lists()
+        if ring:
+            del bufs
+        if hasattr(e, "ring_end"):
+            e.ring_end()
+        return out
 
     def save(self, prefix):
         """One file per rank: `<prefix>.rank<r>of<world>` holds the rank's items, its lambdas and the graph."""
