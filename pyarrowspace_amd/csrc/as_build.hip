@@ -1193,7 +1193,11 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             int dev_cus = 256;
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
-            const int target_units = dev_cus * 2 * 8;
+            // an eps that admits (nearly) every pair -- `eps: 10` of tests/test_3_beir.py under the cosine distance -- makes
+            // every column segment converge its rows' bounds from scratch (all tiles pass until the lists have settled):
+            // fewer, longer segments then (61 -> TF/s at 200k x 768 with 8 segments)
+            const bool loose = metric == AS_METRIC_COSINE ? gp->eps >= 1.0 : gp->eps * gp->eps >= 4.0 * sp->nmax;
+            const int target_units = dev_cus * (loose ? 2 : 16);
             while (S < 8 && nrb * S < target_units && ntile / (S * 2) >= 8) S *= 2;
             if ((variant & 1) && !(variant & 32) && ntile >= 64) S = 8;  // XCD-grouped order: 4 row blocks x 8 column segments per XCD
         }

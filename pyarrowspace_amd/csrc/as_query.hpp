@@ -120,6 +120,8 @@ struct as_query {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int ev_valid = 0;
     double stats[4] = {0, 0, 0, 0};
+    int crowded = 0;         // > 0: recent queries overflowed the scan's candidate buffer (counts queries since)
+    int crowded_direct = 0;  // this query skips the prefilter and takes the threshold repair straight away
     int* unproven_dev = nullptr;   // build fallback: device counter (caller-owned) of rows that stay unproven
 };
 

@@ -1626,7 +1626,7 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     if (feature) AS_TRY(feat_query_prepare(q->gr, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, nslots, st));
     else hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, nslots), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
     if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
-    const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !feature);
+    const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !feature && !q->crowded_direct);
     AS_TRY(launch_scan(q, pre));
     if (stats) AS_HIP(hipEventRecord(q->ev[1], st));
     q->ev_valid = stats ? 1 : 0;
@@ -2025,13 +2025,27 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     q->exact = (mode & 1) || q->sp->opts.force_exact;
     q->robust = (mode & 2) ? 1 : 0;
     const bool feature = q->gr->lambda_mode == AS_LAMBDA_FEATURE;
-    AS_TRY(query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1));
-    if (!feature) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+    // Crowded neighbourhoods (an eps that admits thousands of rows, e.g. `eps: 10` of tests/test_3_beir.py under the
+    // cosine distance): once a query has overflowed the scan's candidate buffer, the following ones skip the prefilter
+    // and derive their neighbours from the dots by threshold straight away -- not a whole selection chain and a host
+    // wait later.  Every 64th query probes the plain path again.
+    const bool direct = !feature && !q->robust && q->crowded > 0 && (q->crowded++ & 63) != 0;
+    q->crowded_direct = direct ? 1 : 0;
+    const as_status qb = query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1);
+    q->crowded_direct = 0;
+    AS_TRY(qb);
+    if (direct) {
+        AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
+        AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1));
+    } else if (!feature) {
+        AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+    }
     q->seq += 1;
     AS_TRY(run_score(q, tau, 1));
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
     AS_TRY(wait_published(q));
-    if (!feature && !q->robust && q->hout->knn_inexact && !(q->hout->overflow & 1)) {
+    if (!direct && !feature && !q->robust) q->crowded = (q->hout->overflow & 1) ? 1 : 0;
+    if (!direct && !feature && !q->robust && q->hout->knn_inexact && !(q->hout->overflow & 1)) {
         // near-ties at the k-th distance the fp32 keys cannot order (duplicates, near-duplicates): every row inside
         // the eps bound is still in the candidate buffer -- evaluate them all exactly, no second scan
         AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1));
@@ -2040,7 +2054,7 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
         AS_TRY(run_score(q, tau, 1));
         AS_TRY(wait_published(q));
     }
-    if (!q->robust && (q->hout->overflow & 1)) {
+    if (!direct && !q->robust && (q->hout->overflow & 1)) {
         // more than CAND_CAP rows inside eps: re-derive the candidates from the kept dots, no second scan
         AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
         AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1));
