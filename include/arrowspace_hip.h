@@ -147,6 +147,26 @@ as_status as_graph_from_knn_global(as_space* sp, const as_graph_params* gp, int6
                                    const int32_t* idx_dev, const double* dist_dev, const double* gy_dev,
                                    const int32_t* cnt_dev, const double* n64_global_dev, as_graph** out_graph);
 
+/* step 3 without replication (SURVEY 8e "Symmetrise + Laplacian": one exchange step).  The space holds the rows
+ * [row_offset, row_offset + nitems); idx/dist/gy/cnt are ITS rows' lists (ids global).  in_*: the directed edges
+ * (in_col_dev[e] -> row_offset + in_row_dev[e]) of ALL ranks whose target row lives here, this rank's own included
+ * -- what the host's variable-count all-to-all delivers.  as_graph_shard_csr builds these rows of the symmetrised
+ * graph (column ids global) and their degrees (as_graph_deg_copy: nitems doubles, device to device);
+ * as_graph_shard_energy takes the degrees and squared norms of all items (all-gathered: 16 B per item) and leaves
+ * the rows' energies behind (as_graph_energy_copy); as_graph_shard_lambdas takes the energies of all items (8 B per
+ * item), selects tau0 over them and writes this shard's lambdas into the space.  O(N k) data never leaves its rank
+ * except as the edges themselves. */
+as_status as_graph_shard_csr(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset,
+                             const int32_t* idx_dev, const double* dist_dev, const double* gy_dev, const int32_t* cnt_dev,
+                             int64_t n_in, const int32_t* in_row_dev, const int32_t* in_col_dev, const double* in_dist_dev,
+                             const double* in_gy_dev, as_graph** out_graph);
+as_status as_graph_deg_copy(const as_graph* gr, double* out_dev);
+as_status as_graph_shard_energy(as_space* sp, as_graph* gr, const double* deg_global_dev, const double* n64_global_dev);
+as_status as_graph_energy_copy(const as_graph* gr, double* out_dev);
+as_status as_graph_shard_lambdas(as_space* sp, as_graph* gr, const double* E_global_dev, int64_t n_global);
+int64_t as_graph_row_offset(const as_graph* gr);      /* first row a sharded graph holds (0 for a whole graph) */
+int64_t as_graph_ncols(const as_graph* gr);           /* items the graph's columns range over */
+
 /* ---- staged build, feature mode (AS_LAMBDA_FEATURE): what as_build composes when opts->lambda_mode selects
  *      the F x F feature-space Laplacian; multi-GPU hosts call the steps with a row range per rank and exchange
  *      the D x D Gram partials and the N energies in between ---- */

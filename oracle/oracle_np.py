@@ -206,6 +206,70 @@ def graph_from_lists(X, prm, n, lists) -> dict:
                 knn=[l[0] for l in lists])
 
 
+def shard_csr(prm, row_offset, nrows, lists, incoming) -> dict:
+    """SPEC S4-S5 for the rows [row_offset, row_offset + nrows) alone (row-sharded build): lists[r] =
+    (idx, key, dist, gy) of local row r with GLOBAL ids; incoming = iterable of (local target row, source item id,
+    dist, gy) -- every directed edge of the whole graph whose target lives here.  Same entries, same order, same
+    sums as the corresponding rows of graph_from_lists."""
+    adj = [dict() for _ in range(nrows)]
+    for r, (idx, key, dist, gy) in enumerate(lists):
+        for j, dd, gg in zip(idx, dist, gy):
+            adj[r][int(j)] = (dd, gg)
+    for r, i, dd, gg in incoming:
+        if int(i) not in adj[int(r)]:
+            adj[int(r)][int(i)] = (dd, gg)
+    indptr = np.zeros(nrows + 1, dtype=np.int64)
+    cols, dists, gys = [], [], []
+    for r in range(nrows):
+        js = sorted(adj[r].keys())
+        indptr[r + 1] = indptr[r] + len(js)
+        cols.extend(js)
+        dists.extend(adj[r][j][0] for j in js)
+        gys.extend(adj[r][j][1] for j in js)
+    indices = np.asarray(cols, dtype=np.int64)
+    dist = np.asarray(dists, dtype=np.float64)
+    gy = np.asarray(gys, dtype=np.float64)
+    w = _edge_weight(dist, prm["sigma"], prm["p"], prm["kernel"]) if len(dist) else dist.copy()
+    deg = np.zeros(nrows)
+    for r in range(nrows):
+        s = 0.0
+        for e in range(indptr[r], indptr[r + 1]):
+            s += w[e]
+        deg[r] = s
+    return dict(prm=prm, row_offset=row_offset, indptr=indptr, indices=indices, dist=dist, gy=gy, w=w, deg=deg)
+
+
+def shard_energy(sh: dict, deg_global, n_global):
+    """SPEC S6/S7 for a shard's rows: the degrees and squared norms of ALL items give the neighbours' terms."""
+    prm, off = sh["prm"], sh["row_offset"]
+    indptr, indices, w, dist, gy = sh["indptr"], sh["indices"], sh["w"], sh["dist"], sh["gy"]
+    ny = n_global if prm["metric"] == METRIC_L2 else np.where(n_global > 0, 1.0, 0.0)
+    nrows = len(indptr) - 1
+    E, G, lap = np.zeros(nrows), np.zeros(nrows), np.zeros_like(w)
+    for r in range(nrows):
+        lo, hi = indptr[r], indptr[r + 1]
+        if hi == lo:
+            continue
+        i = r + off
+        eps_e = np.zeros(hi - lo)
+        for t, e in enumerate(range(lo, hi)):
+            j = indices[e]
+            lap[e] = -w[e] / np.sqrt(deg_global[i] * deg_global[j])
+            eps_e[t] = edge_energy(w[e], prm["metric"], dist[e], gy[e], deg_global[i], deg_global[j], ny[i], ny[j])
+        S = 0.0
+        for v in eps_e:
+            S += v
+        E[r] = (0.5 * S) / ny[i] if ny[i] > 0 else 0.0
+        if S > 0:
+            g = 0.0
+            for v in eps_e:
+                q = v / S
+                g += q * q
+            G[r] = min(1.0, max(0.0, g))
+    sh.update(E=E, G=G, lap=lap, ny=ny[off : off + nrows])
+    return E, G
+
+
 def median_tau(E):
     """SPEC S8: lower median of the strictly positive energies, clamped to [TAU_MIN, 1]."""
     pos = np.sort(E[E > 0])

@@ -237,6 +237,69 @@ as_status as_graph_from_knn_global(as_space* sp, const as_graph_params* gp, int6
     return AS_OK;
 }
 
+as_status as_graph_shard_csr(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx_dev,
+                             const double* dist_dev, const double* gy_dev, const int32_t* cnt_dev, int64_t n_in, const int32_t* in_row_dev,
+                             const int32_t* in_col_dev, const double* in_dist_dev, const double* in_gy_dev, as_graph** out_graph) {
+    if (!sp || !idx_dev || !dist_dev || !gy_dev || !cnt_dev || !out_graph || (n_in > 0 && (!in_row_dev || !in_col_dev || !in_dist_dev || !in_gy_dev))) {
+        set_err("as_graph_shard_csr: null argument");
+        return AS_EINVAL;
+    }
+    if (sp->opts.lambda_mode == AS_LAMBDA_FEATURE) {
+        set_err("as_graph_shard_csr: the space was created for the feature-mode lambda");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    as_graph* gr = new as_graph();
+    const double t0 = now_s();
+    as_status s = graph_shard_csr(sp, &r, n_global, row_offset, idx_dev, dist_dev, gy_dev, cnt_dev, n_in, in_row_dev, in_col_dev, in_dist_dev,
+                                  in_gy_dev, gr);
+    if (s != AS_OK) {
+        as_free_graph(gr);
+        return s;
+    }
+    for (int i = 0; i < 10; ++i) gr->stats[i] = sp->kstats[i];
+    gr->stats[4] = now_s() - t0;
+    *out_graph = gr;
+    return AS_OK;
+}
+static as_status graph_rows_copy(const as_graph* gr, const double* src, double* out_dev, const char* who) {
+    if (!gr || !src || !out_dev) {
+        set_err("%s: null argument or the stage that fills it has not run", who);
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(gr->device));
+    AS_HIP(hipMemcpy(out_dev, src, sizeof(double) * gr->n, hipMemcpyDeviceToDevice));
+    return AS_OK;
+}
+as_status as_graph_deg_copy(const as_graph* gr, double* out_dev) { return graph_rows_copy(gr, gr ? gr->deg : nullptr, out_dev, "as_graph_deg_copy"); }
+as_status as_graph_energy_copy(const as_graph* gr, double* out_dev) { return graph_rows_copy(gr, gr ? gr->E : nullptr, out_dev, "as_graph_energy_copy"); }
+int64_t as_graph_row_offset(const as_graph* gr) { return gr ? gr->row0 : 0; }
+int64_t as_graph_ncols(const as_graph* gr) { return gr ? (gr->ncols ? gr->ncols : gr->n) : 0; }
+as_status as_graph_shard_energy(as_space* sp, as_graph* gr, const double* deg_global_dev, const double* n64_global_dev) {
+    if (!sp || !gr || !deg_global_dev || !n64_global_dev || !gr->ncols || gr->n != sp->n) {
+        set_err("as_graph_shard_energy: null argument or not the sharded graph of this space");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    const double t0 = now_s();
+    AS_TRY(graph_shard_energy(sp, gr, deg_global_dev, n64_global_dev));
+    gr->stats[4] += now_s() - t0;
+    return AS_OK;
+}
+as_status as_graph_shard_lambdas(as_space* sp, as_graph* gr, const double* E_global_dev, int64_t n_global) {
+    if (!sp || !gr || !E_global_dev || !gr->ncols || gr->n != sp->n || !gr->E) {
+        set_err("as_graph_shard_lambdas: null argument, not the sharded graph of this space, or as_graph_shard_energy has not run");
+        return AS_EINVAL;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    const double t0 = now_s();
+    AS_TRY(graph_shard_lambdas(sp, gr, E_global_dev, n_global));
+    gr->stats[4] += now_s() - t0;
+    return AS_OK;
+}
+
 int32_t as_knn_list_width(int64_t k) { return knn_list_width(k); }
 double as_space_nmax(const as_space* sp) { return sp ? sp->nmax : 0.0; }
 int64_t as_unproven_searches(const as_space* sp) { return sp ? sp->unproven_searches : 0; }
@@ -459,7 +522,9 @@ static as_status search_single_locked(const as_space* sp, const as_graph* gr, co
 // the graph handle belongs to this space: item graphs have one node per item, feature graphs one per column
 static as_status graph_matches(const as_space* sp, const as_graph* gr, const char* who) {
     // a shard of a row-sharded index searches against the graph of all items
-    const bool ok = gr->lambda_mode == AS_LAMBDA_FEATURE ? (gr->n == sp->d && gr->nitems >= sp->row_offset + sp->n) : gr->n >= sp->row_offset + sp->n;
+    const bool ok = gr->lambda_mode == AS_LAMBDA_FEATURE ? (gr->n == sp->d && gr->nitems >= sp->row_offset + sp->n)
+                    : gr->ncols                          ? (gr->row0 == sp->row_offset && gr->n == sp->n && gr->ncols >= gr->row0 + gr->n)
+                                                         : gr->n >= sp->row_offset + sp->n;
     if (!ok) {
         set_err("%s: the graph (%lld nodes) was not built for this space (%lld items x %lld features)", who, (long long)gr->n,
                 (long long)sp->n, (long long)sp->d);
@@ -649,13 +714,14 @@ as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, do
     // ones; feature graph (L = D - W) the degree
     const bool comb = gr->lambda_mode == AS_LAMBDA_FEATURE;
     int64_t w = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        indptr[i] = w;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t i = r + gr->row0;   // a sharded graph holds the rows [row0, row0 + n): the diagonal sits at column row0 + r
+        indptr[r] = w;
         bool placed = false;
-        for (int64_t e = ip[i]; e < ip[i + 1]; ++e) {
+        for (int64_t e = ip[r]; e < ip[r + 1]; ++e) {
             if (!placed && col[e] > i) {
                 indices[w] = i;
-                values[w++] = comb ? deg[i] : (deg[i] > 0.0 ? 1.0 : 0.0);
+                values[w++] = comb ? deg[r] : (deg[r] > 0.0 ? 1.0 : 0.0);
                 placed = true;
             }
             indices[w] = col[e];
@@ -663,7 +729,7 @@ as_status as_graph_csr(const as_graph* gr, int64_t* indptr, int64_t* indices, do
         }
         if (!placed) {
             indices[w] = i;
-            values[w++] = comb ? deg[i] : (deg[i] > 0.0 ? 1.0 : 0.0);
+            values[w++] = comb ? deg[r] : (deg[r] > 0.0 ? 1.0 : 0.0);
         }
     }
     indptr[n] = w;
@@ -697,18 +763,20 @@ as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {
 // header-derived sizes before allocating anything and validates the CSR it is about to trust.
 namespace {
 struct IndexHeader {
-    char magic[8];           // "ASIDX03\0"
+    char magic[8];           // "ASIDX04\0"
     int32_t header_bytes;    // sizeof(IndexHeader) of the writer
-    int32_t version;         // 3
+    int32_t version;         // 4
     int64_t n, d, nnz;       // items held by this file, features, adjacency entries
-    int64_t nnodes;          // graph nodes: all items of the index (item mode; > n for one rank's shard of a
-                             // row-sharded index) or d (feature mode)
+    int64_t nnodes;          // graph rows in this file: the items of the whole index (item mode, replicated graph), this
+                             // shard's n rows (item mode, sharded graph: graph_ncols > 0) or d (feature mode)
+    int64_t graph_ncols;     // sharded item graph: the items its columns range over; 0 for a whole graph
+    int64_t graph_row0;      // sharded item graph: its first row (== row_offset)
     int64_t row_offset;      // global index of this file's first item (0 for a whole index)
     int32_t has_f64, metric, kernel, lambda_mode;
     as_graph_params gp;
     double tau0;
 };
-constexpr int32_t INDEX_VERSION = 3;
+constexpr int32_t INDEX_VERSION = 4;
 
 template <typename T>
 as_status dev_to_file(FILE* f, const T* dev, size_t count) {
@@ -772,10 +840,11 @@ as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path
     }
     IndexHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "ASIDX03", 8);
+    memcpy(h.magic, "ASIDX04", 8);
     h.header_bytes = (int32_t)sizeof(IndexHeader);
     h.version = INDEX_VERSION;
     h.n = sp->n; h.d = sp->d; h.nnz = gr->nnz; h.nnodes = gr->n; h.row_offset = sp->row_offset;
+    h.graph_ncols = gr->ncols; h.graph_row0 = gr->row0;
     h.has_f64 = sp->x64 ? 1 : 0; h.metric = gr->metric; h.kernel = gr->kernel; h.lambda_mode = gr->lambda_mode;
     h.gp = gr->gp; h.tau0 = gr->tau0;
     as_status s = fwrite(&h, sizeof(h), 1, f) == 1 ? AS_OK : AS_EINVAL;
@@ -820,7 +889,7 @@ __global__ void lam32_kernel(int64_t n, const double* __restrict__ lam64, float*
 
 static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts, as_space** out_space, as_graph** out_graph) {
     IndexHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ASIDX03", 8) != 0 || h.header_bytes != (int32_t)sizeof(IndexHeader) ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ASIDX04", 8) != 0 || h.header_bytes != (int32_t)sizeof(IndexHeader) ||
         h.version != INDEX_VERSION) {
         set_err("as_index_load: %s is not an arrowspace index file of format %d", path, INDEX_VERSION);
         return AS_EINVAL;
@@ -830,7 +899,9 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
                           (h.kernel == AS_KERNEL_GAUSSIAN || h.kernel == AS_KERNEL_RATIONAL) &&
                           (h.lambda_mode == AS_LAMBDA_ITEM || h.lambda_mode == AS_LAMBDA_FEATURE) &&
                           (h.lambda_mode == AS_LAMBDA_FEATURE ? (h.nnodes == h.d && h.row_offset >= 0)
-                                                              : (h.row_offset >= 0 && h.nnodes >= h.row_offset + h.n));
+                          : h.graph_ncols ? (h.row_offset >= 0 && h.graph_row0 == h.row_offset && h.nnodes == h.n &&
+                                             h.graph_ncols >= h.row_offset + h.n && h.graph_ncols < ((int64_t)1 << 31))
+                                          : (h.row_offset >= 0 && h.graph_row0 == 0 && h.nnodes >= h.row_offset + h.n));
     as_graph_params gpr;
     if (need < 0 || !modes_ok || resolve_params(&h.gp, &gpr) != AS_OK || !(h.tau0 >= 0.0) || !(h.tau0 <= 1.0)) {
         set_err("as_index_load: %s has an inconsistent header", path);
@@ -883,7 +954,7 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
         hipLaunchKernelGGL(lam32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sp->stream, h.n, sp->lam64, sp->lam32);
         gr = new as_graph();
         gr->device = dev; gr->n = h.nnodes; gr->nitems = h.row_offset + h.n; gr->nnz = h.nnz; gr->gp = gpr; gr->metric = h.metric; gr->kernel = h.kernel;
-        gr->lambda_mode = h.lambda_mode; gr->tau0 = h.tau0;
+        gr->lambda_mode = h.lambda_mode; gr->tau0 = h.tau0; gr->ncols = h.graph_ncols; gr->row0 = h.graph_row0;
         {   // the CSR is walked on trust afterwards: monotone row pointers ending at nnz, columns inside the graph
             std::vector<int64_t> ip;
             std::vector<int32_t> col;
@@ -891,7 +962,8 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
             if ((s = file_to_host(f, col, nnz)) != AS_OK) break;
             bool ok = ip[0] == 0 && ip[nn] == h.nnz;
             for (size_t i = 0; ok && i < nn; ++i) ok = ip[i] <= ip[i + 1];
-            for (size_t e = 0; ok && e < nnz; ++e) ok = col[e] >= 0 && (int64_t)col[e] < h.nnodes;
+            const int64_t colmax = h.graph_ncols ? h.graph_ncols : h.nnodes;
+            for (size_t e = 0; ok && e < nnz; ++e) ok = col[e] >= 0 && (int64_t)col[e] < colmax;
             if (!ok) {
                 set_err("as_index_load: %s holds an inconsistent graph (row pointers or column indices out of range)", path);
                 s = AS_EINVAL;

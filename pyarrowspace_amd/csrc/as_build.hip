@@ -33,7 +33,11 @@ __global__ void ingest_kernel(const T* __restrict__ src, int64_t ld, int64_t n, 
     const int lane = lane_id();
     double s = 0.0;
     bool ok = true;
-    for (int64_t c = lane; c < d; c += 64) {
+    for (int64_t c = lane; c < dp; c += 64) {
+        if (c >= d) {
+            x32[row * dp + c] = 0.0f;   // column padding: written here, so only the pad ROWS need a memset
+            continue;
+        }
         const double v = (double)src[row * ld + c];
         const float f = (float)v;
         x32[row * dp + c] = f;
@@ -70,7 +74,8 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
     AS_HIP(hipMalloc(&sp->inorm32, sizeof(float) * rows_alloc));
     AS_HIP(hipMalloc(&sp->lam64, sizeof(double) * n));
     AS_HIP(hipMalloc(&sp->lam32, sizeof(float) * rows_alloc));
-    AS_HIP(hipMemsetAsync(sp->x32, 0, sizeof(float) * rows_alloc * sp->dp, sp->stream));
+    // the ingest kernel writes every element of the n item rows (column padding included): zero the pad rows only
+    AS_HIP(hipMemsetAsync(sp->x32 + (size_t)n * sp->dp, 0, sizeof(float) * (size_t)(rows_alloc - n) * sp->dp, sp->stream));
     AS_HIP(hipMemsetAsync(sp->n32, 0, sizeof(float) * rows_alloc, sp->stream));
     AS_HIP(hipMemsetAsync(sp->inorm32, 0, sizeof(float) * rows_alloc, sp->stream));
     AS_HIP(hipMemsetAsync(sp->lam64, 0, sizeof(double) * n, sp->stream));
@@ -2120,15 +2125,16 @@ __global__ void energy_kernel(int64_t n, const int64_t* __restrict__ indptr, con
                               const double* __restrict__ wgt, const double* __restrict__ dist, const double* __restrict__ gy,
                               const double* __restrict__ deg,
                               const double* __restrict__ n64, int metric, double* __restrict__ ny, double* __restrict__ lap,
-                              double* __restrict__ E, double* __restrict__ G) {
+                              double* __restrict__ E, double* __restrict__ G, int64_t goff) {
+    // rows [goff, goff + n) of the graph: deg and n64 are indexed by item id (goff = 0: the whole graph), the outputs by row
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double nyi = metric == AS_METRIC_L2 ? n64[i] : (n64[i] > 0.0 ? 1.0 : 0.0);
+    const double nyi = metric == AS_METRIC_L2 ? n64[i + goff] : (n64[i + goff] > 0.0 ? 1.0 : 0.0);
     ny[i] = nyi;
     const int64_t lo = indptr[i], hi = indptr[i + 1];
     double Ei = 0.0, Gi = 0.0;
     if (hi > lo) {
-        const double di = deg[i];
+        const double di = deg[i + goff];
         double S = 0.0;
         for (int64_t e = lo; e < hi; ++e) {
             const int j = col[e];
@@ -2262,6 +2268,174 @@ as_status csr_from_knn(hipStream_t st, int64_t n, int64_t k, const int32_t* idx,
     return AS_OK;
 }
 
+// ------------------------------------------------------------------ K3, row-sharded (SURVEY 8e "Symmetrise + Laplacian")
+// This rank owns the graph rows [row0, row0 + n).  `in_*` are the directed edges (in_col -> row0 + in_row) whose TARGET
+// lives here, from every rank (this one included): the host's variable-count all-to-all delivers them.  An incoming
+// edge the row's own list already holds adds nothing (union symmetrisation); the others become reverse entries.
+__global__ void shard_count_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt, int64_t n, int64_t k, int64_t ncols,
+                                   int64_t n_in, const int32_t* __restrict__ in_row, const int32_t* __restrict__ in_col,
+                                   int* __restrict__ revcnt, int* __restrict__ bad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_in) return;
+    const int j = in_row[e], i = in_col[e];
+    if (j < 0 || j >= n || i < 0 || i >= ncols) {
+        *bad = 1;
+        return;
+    }
+    const int cj = cnt[j];
+    bool found = false;
+    for (int s = 0; s < cj; ++s) found = found || idx[(int64_t)j * k + s] == i;
+    if (!found) atomicAdd(&revcnt[j], 1);
+}
+
+__global__ void shard_fill_kernel(const int32_t* __restrict__ idx, const double* __restrict__ dist, const double* __restrict__ gy,
+                                  const int32_t* __restrict__ cnt, int64_t n, int64_t k, int64_t ncols, int64_t n_in,
+                                  const int32_t* __restrict__ in_row, const int32_t* __restrict__ in_col,
+                                  const double* __restrict__ in_dist, const double* __restrict__ in_gy,
+                                  const int64_t* __restrict__ indptr, int* __restrict__ cursor, int32_t* __restrict__ t_col,
+                                  double* __restrict__ t_dist, double* __restrict__ t_gy, int* __restrict__ bad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * k) {   // the rows' own lists
+        const int64_t i = e / k;
+        const int t = (int)(e % k);
+        if (t < cnt[i]) {
+            const int c = idx[e];
+            if (c < 0 || c >= ncols) *bad = 1;
+            const int64_t pos = indptr[i] + t;
+            t_col[pos] = c;
+            t_dist[pos] = dist[e];
+            t_gy[pos] = gy[e];
+        }
+    }
+    if (e < n_in) {    // reverse entries
+        const int j = in_row[e], i = in_col[e];
+        if (j < 0 || j >= n || i < 0 || i >= ncols) return;
+        const int cj = cnt[j];
+        bool found = false;
+        for (int s = 0; s < cj; ++s) found = found || idx[(int64_t)j * k + s] == i;
+        if (!found) {
+            const int64_t pos = indptr[j] + cj + atomicAdd(&cursor[j], 1);
+            t_col[pos] = i;
+            t_dist[pos] = in_dist[e];
+            t_gy[pos] = in_gy[e];
+        }
+    }
+}
+
+as_status graph_shard_csr(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx,
+                          const double* dist, const double* gy, const int32_t* cnt, int64_t n_in, const int32_t* in_row,
+                          const int32_t* in_col, const double* in_dist, const double* in_gy, as_graph* gr) {
+    const int64_t n = sp->n, k = gp->k;
+    hipStream_t st = sp->stream;
+    if (row_offset < 0 || row_offset + n > n_global || n_global >= ((int64_t)1 << 31) || n_in < 0) {
+        set_err("as_graph_shard_csr: rows [%lld, %lld) are outside the %lld items", (long long)row_offset, (long long)(row_offset + n),
+                (long long)n_global);
+        return AS_EINVAL;
+    }
+    gr->n = n;
+    gr->ncols = n_global;
+    gr->row0 = row_offset;
+    gr->device = sp->device;
+    gr->gp = *gp;
+    gr->metric = sp->opts.metric;
+    gr->kernel = sp->opts.kernel;
+    dev_tmp<int> revcnt;
+    dev_tmp<int64_t> len, bsum;
+    AS_HIP(revcnt.alloc(n * 2 + 1));
+    int* cursor = revcnt + n;
+    int* bad = revcnt + 2 * n;
+    AS_HIP(hipMemsetAsync(revcnt, 0, sizeof(int) * (n * 2 + 1), st));
+    AS_HIP(len.alloc(n));
+    const int64_t nb = (n + 1023) / 1024;
+    AS_HIP(bsum.alloc(nb + 1));
+    int64_t* total_d = bsum + nb;
+    AS_HIP(hipMalloc(&gr->indptr, sizeof(int64_t) * (n + 1)));
+    const unsigned gi = (unsigned)((std::max<int64_t>(n_in, 1) + 255) / 256), gn = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(shard_count_kernel, dim3(gi), dim3(256), 0, st, idx, cnt, n, k, n_global, n_in, in_row, in_col, revcnt, bad);
+    hipLaunchKernelGGL(rowlen_kernel, dim3(gn), dim3(256), 0, st, cnt, revcnt, n, len);
+    hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(256), 0, st, len, n, bsum);
+    hipLaunchKernelGGL(scan_top, dim3(1), dim3(64), 0, st, bsum, nb, total_d);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)nb), dim3(256), 0, st, len, n, bsum, gr->indptr);
+    AS_HIP(hipGetLastError());
+    int64_t nnz = 0;
+    AS_HIP(hipMemcpyAsync(&nnz, total_d, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    AS_HIP(hipStreamSynchronize(st));
+    AS_HIP(hipMemcpyAsync(gr->indptr + n, &nnz, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    gr->nnz = nnz;
+    const int64_t na = std::max<int64_t>(nnz, 1);
+    dev_tmp<int32_t> t_col;
+    dev_tmp<double> t_dist, t_gy;
+    AS_HIP(t_col.alloc(na));
+    AS_HIP(t_dist.alloc(na));
+    AS_HIP(t_gy.alloc(na));
+    AS_HIP(hipMalloc(&gr->indices, sizeof(int32_t) * na));
+    AS_HIP(hipMalloc(&gr->dist, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->gy, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->w, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->lap, sizeof(double) * na));
+    AS_HIP(hipMalloc(&gr->deg, sizeof(double) * n));
+    const unsigned gf = (unsigned)((std::max<int64_t>(std::max<int64_t>(n * k, n_in), 1) + 255) / 256);
+    hipLaunchKernelGGL(shard_fill_kernel, dim3(gf), dim3(256), 0, st, idx, dist, gy, cnt, n, k, n_global, n_in, in_row, in_col, in_dist, in_gy,
+                       gr->indptr, cursor, t_col, t_dist, t_gy, bad);
+    hipLaunchKernelGGL(sym_sort_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, gr->indptr, t_col, t_dist, t_gy,
+                       gr->indices, gr->dist, gr->gy, gr->w, gp->sigma, gp->p, gr->kernel);
+    hipLaunchKernelGGL(degree_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->w, gr->deg);
+    AS_HIP(hipGetLastError());
+    int hbad = 0;
+    AS_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    AS_HIP(hipStreamSynchronize(st));   // the temporaries die with this frame
+    if (hbad) {
+        set_err("as_graph_shard_csr: an edge names a row outside this shard or an item outside the %lld items", (long long)n_global);
+        return AS_EINVAL;
+    }
+    sp->row_offset = row_offset;
+    return AS_OK;
+}
+
+// Energies of this shard's rows: the degrees and squared norms of ALL items (all-gathered by the host, 16 B per item --
+// cheaper than per-edge replies, nnz > N) give the neighbours' terms.
+as_status graph_shard_energy(as_space* sp, as_graph* gr, const double* deg_global, const double* n64_global) {
+    const int64_t n = gr->n;
+    hipStream_t st = sp->stream;
+    if (!gr->ny) AS_HIP(hipMalloc(&gr->ny, sizeof(double) * n));
+    if (!gr->E) AS_HIP(hipMalloc(&gr->E, sizeof(double) * n));
+    if (!gr->G) AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
+    hipLaunchKernelGGL(energy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->dist, gr->gy,
+                       deg_global, n64_global, gr->metric, gr->ny, gr->lap, gr->E, gr->G, gr->row0);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(st));
+    return AS_OK;
+}
+
+__global__ void lambda_tau_kernel(int64_t n, const double* __restrict__ E, const double* __restrict__ G, double tau0,
+                                  double* __restrict__ lam64, float* __restrict__ lam32) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double l = tau0 * (E[i] / (E[i] + tau0)) + (1.0 - tau0) * G[i];   // the expression of lambda_kernel, bit for bit
+    lam64[i] = l;
+    lam32[i] = (float)l;
+}
+
+// tau0 over the energies of ALL items (all-gathered, 8 B per item), then this shard's lambdas from its own E / G
+as_status graph_shard_lambdas(as_space* sp, as_graph* gr, const double* E_global, int64_t n_global) {
+    hipStream_t st = sp->stream;
+    if (n_global != gr->ncols) {
+        set_err("as_graph_shard_lambdas: %lld energies for a graph over %lld items", (long long)n_global, (long long)gr->ncols);
+        return AS_EINVAL;
+    }
+    dev_tmp<double> lam;
+    AS_HIP(lam.alloc(n_global));
+    // G does not enter the median: the selection runs over E alone (lam is scratch here)
+    AS_TRY(median_lambda_n(st, n_global, E_global, E_global, lam, nullptr, &gr->tau0));
+    hipLaunchKernelGGL(lambda_tau_kernel, dim3((unsigned)((gr->n + 255) / 256)), dim3(256), 0, st, gr->n, gr->E, gr->G, gr->tau0, sp->lam64,
+                       sp->lam32);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(st));
+    dbg("graph (rows [%lld, %lld) of %lld): nnz=%lld tau0=%.6g", (long long)gr->row0, (long long)(gr->row0 + gr->n), (long long)gr->ncols,
+        (long long)gr->nnz, gr->tau0);
+    return AS_OK;
+}
+
 // S8 + S9: tau0 = lower median of the positive energies (8-pass radix select), lambdas of n nodes
 as_status median_lambda_n(hipStream_t st, int64_t n, const double* E, const double* G, double* lam64, float* lam32, double* tau0_out) {
     const unsigned gn = (unsigned)((n + 255) / 256);
@@ -2320,7 +2494,7 @@ as_status graph_from_knn_global(as_space* sp, const as_graph_params* gp, int64_t
     AS_HIP(hipMalloc(&gr->E, sizeof(double) * n));
     AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
     hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->dist, gr->gy, gr->deg, n64_global,
-                       gr->metric, gr->ny, gr->lap, gr->E, gr->G);
+                       gr->metric, gr->ny, gr->lap, gr->E, gr->G, (int64_t)0);
     AS_HIP(hipGetLastError());
     dev_tmp<double> lam;
     AS_HIP(lam.alloc(n));
@@ -2350,7 +2524,7 @@ as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t*
     AS_HIP(hipMalloc(&gr->E, sizeof(double) * n));
     AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
     hipLaunchKernelGGL(energy_kernel, dim3(gn), dim3(256), 0, st, n, gr->indptr, gr->indices, gr->w, gr->dist, gr->gy, gr->deg, sp->n64,
-                       gr->metric, gr->ny, gr->lap, gr->E, gr->G);
+                       gr->metric, gr->ny, gr->lap, gr->E, gr->G, (int64_t)0);
     AS_HIP(hipGetLastError());
     AS_TRY(median_lambda(sp, gr, gr->E, gr->G));
     dbg("graph: nnz=%lld tau0=%.6g", (long long)gr->nnz, gr->tau0);

@@ -96,7 +96,14 @@ struct as_graph {
     int32_t* eb = nullptr;
     double* ew = nullptr;
     double* colm = nullptr;     // [n] squared column norms (the Gram's diagonal)
+    // row-sharded item graph (as_graph_shard_*): the CSR holds the rows [row0, row0 + n) of the graph over ncols
+    // items, column ids global; deg / ny / E / G cover these rows only.  ncols == 0: a whole graph (ncols = n).
+    int64_t ncols = 0;
+    int64_t row0 = 0;
 };
+inline int64_t graph_items(const as_graph* gr) {   // items the index covers
+    return gr->lambda_mode == AS_LAMBDA_FEATURE ? gr->nitems : (gr->ncols ? gr->ncols : gr->n);
+}
 
 // ---------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)
@@ -283,6 +290,11 @@ as_status csr_from_knn(hipStream_t st, int64_t n, int64_t k, const int32_t* idx,
 as_status median_lambda(as_space* sp, as_graph* gr, const double* E, const double* G);
 as_status median_lambda_n(hipStream_t st, int64_t n, const double* E, const double* G, double* lam64, float* lam32, double* tau0_out);
 as_status lam_slice(hipStream_t st, int64_t n, const double* src, double* lam64, float* lam32);
+as_status graph_shard_csr(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx,
+                          const double* dist, const double* gy, const int32_t* cnt, int64_t n_in, const int32_t* in_row,
+                          const int32_t* in_col, const double* in_dist, const double* in_gy, as_graph* gr);
+as_status graph_shard_energy(as_space* sp, as_graph* gr, const double* deg_global, const double* n64_global);
+as_status graph_shard_lambdas(as_space* sp, as_graph* gr, const double* E_global, int64_t n_global);
 as_status graph_from_knn_global(as_space* sp, const as_graph_params* gp, int64_t n_global, int64_t row_offset, const int32_t* idx,
                                 const double* dist, const double* gy, const int32_t* cnt, const double* n64_global, as_graph* gr);
 // k-NN over visiting column blocks (multi-GPU ring, as_build.hip)

@@ -1421,7 +1421,8 @@ static FinishArgs make_finish(as_query* q) {
     FinishArgs f;
     memset(&f, 0, sizeof(f));
     f.x32 = sp->x32; f.x64 = sp->x64; f.n64 = sp->n64; f.q64 = q->q64; f.lam64 = sp->lam64;
-    f.deg = q->gr ? q->gr->deg : nullptr; f.ny = q->gr ? q->gr->ny : nullptr;
+    // deg / ny are read at item id (local row + goff): a sharded graph holds its own rows only, based at row0
+    f.deg = q->gr ? q->gr->deg - q->gr->row0 : nullptr; f.ny = q->gr ? q->gr->ny - q->gr->row0 : nullptr;
     f.info = q->info; f.n = sp->n; f.d = sp->d; f.dp = sp->dp; f.k = q->k; f.topk = q->topk; f.nrows = q->r1 - q->r0;
     f.metric = sp->opts.metric; f.kernel = sp->opts.kernel; f.nmax = sp->nmax; f.goff = sp->row_offset;
     if (q->gr) {
@@ -1962,7 +1963,7 @@ as_status as_query_finish_batch(as_query* q, const as_hit_rec* hits_dev, int32_t
         return AS_EUNSUPPORTED;
     }
     hipStream_t st = q->stream;
-    const int64_t topk = std::min<int64_t>(q->gr->gp.topk, q->gr->lambda_mode == AS_LAMBDA_FEATURE ? q->gr->nitems : q->gr->n);
+    const int64_t topk = std::min<int64_t>(q->gr->gp.topk, graph_items(q->gr));
     q->seq += 1;
     hipLaunchKernelGGL(hits_final_kernel, dim3((unsigned)q->nb), dim3(1024), (sizeof(double) + sizeof(int)) * HIT_CAP, st, hits_dev, m, per,
                        per * q->cap, topk, q->info, q->hout_dev, q->seq);

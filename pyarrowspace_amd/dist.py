@@ -222,6 +222,34 @@ class HipEngine:
                                                     C.c_void_p(dist.data_ptr()), C.c_void_p(gy.data_ptr()), C.c_void_p(cnt.data_ptr()),
                                                     C.c_void_p(n64.data_ptr()), C.byref(self.gr)))
 
+    # ---- graph stage without replication: this rank's rows of the symmetrised graph
+    def graph_shard_csr(self, n_global, row_offset, idx, dist, gy, cnt, in_row, in_col, in_dist, in_gy):
+        """-> the degrees of this rank's rows (device tensor, a copy)."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        keep = [t.contiguous() for t in (idx, dist, gy, cnt, in_row, in_col, in_dist, in_gy)]
+        assert keep[0].dtype == torch.int32 and keep[4].dtype == torch.int32 and keep[5].dtype == torch.int32
+        self._check(self.L.as_graph_shard_csr(self.sp, C.byref(self.gp), n_global, row_offset, *[C.c_void_p(t.data_ptr()) for t in keep[:4]],
+                                              int(keep[4].shape[0]), *[C.c_void_p(t.data_ptr()) for t in keep[4:]], C.byref(self.gr)))
+        return self._graph_vec(self.L.as_graph_deg_copy)
+
+    def _graph_vec(self, fn):
+        torch = self.torch
+        out = torch.empty((max(self.n, 1),), dtype=torch.float64, device=torch.device("cuda", self.op.device))
+        if self.n > 0:
+            self._check(fn(self.gr, C.c_void_p(out.data_ptr())))
+        return out[: self.n]
+
+    def graph_shard_energy(self, deg_global, n64_global):
+        """-> the energies E of this rank's rows (device tensor, a copy)."""
+        self.torch.cuda.synchronize()
+        self._check(self.L.as_graph_shard_energy(self.sp, self.gr, C.c_void_p(deg_global.data_ptr()), C.c_void_p(n64_global.data_ptr())))
+        return self._graph_vec(self.L.as_graph_energy_copy)
+
+    def graph_shard_lambdas(self, E_global):
+        self.torch.cuda.synchronize()
+        self._check(self.L.as_graph_shard_lambdas(self.sp, self.gr, C.c_void_p(E_global.data_ptr()), int(E_global.shape[0])))
+
     # ---- search
     def query_open(self):
         torch = self.torch
@@ -303,7 +331,7 @@ class HipEngine:
         import os
         self._check(self.L.as_index_load(os.fsencode(path), C.byref(self.op), C.byref(self.sp), C.byref(self.gr)))
         self.n, self.d = int(self.L.as_nitems(self.sp)), int(self.L.as_nfeatures(self.sp))
-        return int(self.L.as_space_row_offset(self.sp)), int(self.L.as_nnodes(self.gr))
+        return int(self.L.as_space_row_offset(self.sp)), int(self.L.as_graph_ncols(self.gr))
 
     # ---- batched staged search (32 slots per pass)
     def batch_open(self):
@@ -430,6 +458,14 @@ class ShardedIndex:
         for r in reqs:
             r.wait()
 
+    def _all_to_all(self, t, recv_counts, send_counts):
+        """Variable-count all-to-all over dim 0 (RCCL grouped send/recv): rows [sum(send_counts[:r]), ...) of t go to rank r;
+        counts None: one row each way."""
+        rows = t.shape[0] if recv_counts is None else sum(recv_counts)
+        out = self.torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_to_all_single(out, t.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
+        return out
+
     def _gather_fixed(self, t):
         torch = self.torch
         if not self._collective():
@@ -448,10 +484,12 @@ class ShardedIndex:
         return torch.cat(parts, dim=0)
 
     @classmethod
-    def build(cls, graph_params, X_shard, dist=None, group=None, engine=None, force_collectives=False, replicate=False):
+    def build(cls, graph_params, X_shard, dist=None, group=None, engine=None, force_collectives=False, replicate=False,
+              gather_lists=False):
         """X_shard: this rank's contiguous block of rows (torch tensor on this rank's device,
         fp32 or fp64).  Ranks hold consecutive blocks in rank order.  replicate=True: all-gather the
-        whole item matrix onto every rank first (round-1 form; twice the HBM)."""
+        whole item matrix onto every rank first (round-1 form; twice the HBM).  gather_lists=True: ring k-NN, but the
+        lists of all items on every rank and the graph stage replicated (O(N k) per rank)."""
         import contextlib
 
         import torch
@@ -525,19 +563,65 @@ class ShardedIndex:
                 self.engine.create_space(X_shard)
                 idx, dst, gy, cnt = self._ring_knn(X_shard)
                 self.scan_rows = (0, rows)               # the space holds this rank's rows only; ids come out global
-            idx = self._gather_rows(idx, counts).contiguous()
-            dst = self._gather_rows(dst, counts).contiguous()
-            gy = self._gather_rows(gy, counts).contiguous()
-            cnt = self._gather_rows(cnt, counts).contiguous()
             if self.replicated:
+                idx = self._gather_rows(idx, counts).contiguous()
+                dst = self._gather_rows(dst, counts).contiguous()
+                gy = self._gather_rows(gy, counts).contiguous()
+                cnt = self._gather_rows(cnt, counts).contiguous()
                 self._sync()
                 self.engine.graph_from_knn(idx, dst, gy, cnt)
-            else:
+            elif gather_lists or not hasattr(self.engine, "graph_shard_csr"):
+                # round-2a form: the lists of all items on every rank, the graph stage replicated
+                idx = self._gather_rows(idx, counts).contiguous()
+                dst = self._gather_rows(dst, counts).contiguous()
+                gy = self._gather_rows(gy, counts).contiguous()
+                cnt = self._gather_rows(cnt, counts).contiguous()
                 n64 = self._gather_rows(self.engine.norms(), counts).contiguous()
                 self._sync()
                 self.engine.graph_from_knn_global(self.n, self.r0, idx, dst, gy, cnt, n64)
+            else:
+                # one exchange step.  Every directed edge goes to the owner of its target row (variable-count
+                # all-to-all, 24 B per edge), each rank symmetrises and weighs ITS rows; what the energies need of the
+                # neighbours -- degree and squared norm -- and what tau0 needs -- every energy -- are O(N) vectors,
+                # all-gathered (8 B per item each).  Nothing of size N k is replicated.
+                inc = self._exchange_edges(idx, dst, gy, cnt)
+                self._sync()
+                deg = self.engine.graph_shard_csr(self.n, self.r0, idx, dst, gy, cnt, *inc)
+                del inc
+                deg_g = self._gather_rows(deg.contiguous(), counts).contiguous()
+                n64 = self._gather_rows(self.engine.norms().contiguous(), counts).contiguous()
+                self._sync()
+                E = self.engine.graph_shard_energy(deg_g, n64)
+                del deg_g, n64
+                E_g = self._gather_rows(E.contiguous(), counts).contiguous()
+                self._sync()
+                self.engine.graph_shard_lambdas(E_g)
             self.engine.query_open()
         return self
+
+    def _exchange_edges(self, idx, dst, gy, cnt):
+        """The directed edges i -> j of this rank's lists, delivered to the owner of row j: returns what arrived here
+        (from every rank, this one included) as (row local to this rank int32, source item id int32, dist, gy)."""
+        torch, dist = self.torch, self.dist
+        rows, k = int(idx.shape[0]), int(idx.shape[1])
+        dev = idx.device
+        valid = torch.arange(k, device=dev)[None, :] < cnt[:, None].long()
+        tgt = idx[valid].long()                                                        # global target item
+        src = (torch.arange(rows, device=dev) + self.r0)[:, None].expand(rows, k)[valid]
+        upper = torch.tensor(self.bounds[1:], dtype=torch.int64, device=dev)
+        lower = torch.tensor(self.bounds[:-1], dtype=torch.int64, device=dev)
+        owner = torch.bucketize(tgt, upper, right=True)                                # bounds[o] <= tgt < bounds[o + 1]
+        order = torch.argsort(owner, stable=True)
+        owner = owner[order]
+        ints = torch.stack([tgt[order] - lower[owner], src[order]], dim=1).to(torch.int32).contiguous()
+        reals = torch.stack([dst[valid][order], gy[valid][order]], dim=1).contiguous()
+        if self._collective():
+            send = torch.bincount(owner, minlength=self.world).to(torch.int64)
+            recv = self._all_to_all(send, None, None)
+            sc, rc = [int(v) for v in send.tolist()], [int(v) for v in recv.tolist()]
+            ints = self._all_to_all(ints, rc, sc)
+            reals = self._all_to_all(reals, rc, sc)
+        return (ints[:, 0].contiguous(), ints[:, 1].contiguous(), reals[:, 0].contiguous(), reals[:, 1].contiguous())
 
     def _ring_knn(self, X_shard):
         """Exact k-NN lists of this rank's rows against all items, the shards visiting one at a time.

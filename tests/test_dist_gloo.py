@@ -120,6 +120,30 @@ class OracleEngine:
         self.off, self.nlocal = row_offset, self.n
         self.n = n_global
 
+    # ---- graph stage without replication (oracle_np.shard_csr / shard_energy)
+    def graph_shard_csr(self, n_global, row_offset, idx, dist, gy, cnt, in_row, in_col, in_dist, in_gy):
+        idx, dist, gy, cnt = idx.numpy(), dist.numpy(), gy.numpy(), cnt.numpy()
+        lists = [(idx[i, : cnt[i]].astype(np.int64), dist[i, : cnt[i]], dist[i, : cnt[i]], gy[i, : cnt[i]]) for i in range(self.n)]
+        inc = zip(in_row.numpy(), in_col.numpy(), in_dist.numpy(), in_gy.numpy())
+        self.shard = self.o.shard_csr(self.prm, row_offset, self.n, lists, inc)
+        self.n_global, self.off, self.nlocal = n_global, row_offset, self.n
+        return __import__("torch").from_numpy(self.shard["deg"].copy())
+
+    def graph_shard_energy(self, deg_global, n64_global):
+        self.deg_g, self.n64_g = deg_global.numpy().copy(), n64_global.numpy().copy()
+        E, _ = self.o.shard_energy(self.shard, self.deg_g, self.n64_g)
+        return __import__("torch").from_numpy(E.copy())
+
+    def graph_shard_lambdas(self, E_global):
+        tau0 = self.o.median_tau(E_global.numpy())
+        lam = np.zeros(self.n_global)
+        lam[self.off : self.off + self.nlocal] = self.o.synth_lambda(self.shard["E"], self.shard["G"], tau0)
+        Xg = np.zeros((self.n_global, self.d))
+        Xg[self.off : self.off + self.nlocal] = self.X          # only this rank's rows are ever read (scans are local)
+        ny = self.n64_g if self.prm["metric"] == self.o.METRIC_L2 else np.where(self.n64_g > 0, 1.0, 0.0)
+        self.index = dict(prm=self.prm, X=Xg, n=self.n64_g, ny=ny, deg=self.deg_g, tau0=tau0, lambdas=lam)
+        self.n = self.n_global
+
     def graph_from_knn(self, idx, dist, gy, cnt):
         self.off = 0
         idx, dist, gy, cnt = idx.numpy(), dist.numpy(), gy.numpy(), cnt.numpy()
@@ -241,7 +265,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, d, split, out, replicate=False):
+def _worker(rank, world, port, n, d, split, out, mode="ring"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -253,8 +277,10 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
         gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
         bounds = [0, split, n] if world == 2 else [0, n]
         shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy())
-        index = ShardedIndex.build(gp, shard, dist, engine=OracleEngine(gp), replicate=replicate)
+        replicate = mode == "replicated"
+        index = ShardedIndex.build(gp, shard, dist, engine=OracleEngine(gp), replicate=replicate, gather_lists=mode == "ring_lists")
         assert (index.r0, index.r1) == (bounds[rank], bounds[rank + 1]) and index.n == n and index.replicated == replicate
+        assert hasattr(index.engine, "shard") == (mode == "ring")       # the sharded graph stage ran / did not run
         rng = np.random.default_rng(5)
         res = []
         for _ in range(4):
@@ -270,17 +296,18 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("replicate", [False, True], ids=["ring", "replicated"])
+@pytest.mark.parametrize("mode", ["ring", "ring_lists", "replicated"])
 @pytest.mark.parametrize("split", [97, 150, 0])
-def test_two_rank_sharded_index_matches_single_process(split, replicate):
-    """ring: every rank keeps only its rows, the shards visit over send/recv (uneven and EMPTY shards included);
-    replicated: the round-1 all-gather form."""
+def test_two_rank_sharded_index_matches_single_process(split, mode):
+    """ring: every rank keeps only its rows, the shards visit over send/recv (uneven and EMPTY shards included), the
+    edges reach their target's owner by one variable-count all-to-all and every rank builds its rows of the graph;
+    ring_lists: ring k-NN, lists all-gathered, graph stage replicated; replicated: the round-1 all-gather form."""
     import torch.multiprocessing as mp
     from oracle import oracle_np
     n, d, world = 300, 24, 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, d, split, out, replicate), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, d, split, out, mode), nprocs=world, join=True)
     X = clustered(n, d, nclust=6, seed=21)
     gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
     ref = oracle_np.build(X, gp)

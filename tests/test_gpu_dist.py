@@ -87,6 +87,10 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
                 torch.cuda.synchronize()
                 return super()._gather_fixed(t.cpu()).cuda()
 
+            def _all_to_all(self, t, recv_counts, send_counts):           # the edge exchange of the sharded graph stage
+                torch.cuda.synchronize()
+                return super()._all_to_all(t.cpu(), recv_counts, send_counts).cuda()
+
             def _exchange_start(self, send, recv, nxt_rank, prv_rank):   # the ring hop, staged through the CPU as well
                 torch.cuda.synchronize()
                 hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)

@@ -269,3 +269,35 @@ def test_numpy_and_c_restatements_agree_on_random_cases(oracle_lib):
                 assert abs(la - lb) <= 1e-6 * abs(lb), cfg
                 assert_hits_match(ha, hb, b.scores(q, tau, lb), rtol=1e-6, atol=1e-9)
     assert done >= 100
+
+
+@pytest.mark.parametrize("metric,kernel", [("l2", "gaussian"), ("cosine", "rational")])
+def test_sharded_graph_restatement_equals_the_whole_graph(metric, kernel):
+    """oracle_np.shard_csr / shard_energy (the row-sharded graph stage) over an uneven 4-way cut, one shard
+    empty: every shard's rows of the CSR, degrees, energies and lambdas equal graph_from_lists' bit for bit."""
+    from oracle import oracle_np as o
+    n, d, k = 240, 16, 5
+    X = clustered(n, d, nclust=5, seed=13)
+    prm = o.resolve_params({"eps": calibrate_eps(X, k, metric), "k": k, "topk": 4, "p": 2.0, "sigma": None, "metric": metric,
+                            "kernel": kernel})
+    ref = o.build(X, dict(prm))
+    nn, lists = o.knn_lists(X, prm)
+    cuts = [0, 50, 50, 170, n]
+    edges = [(i, int(j), dd, gg) for i, (idx, key, dist, gy) in enumerate(lists) for j, dd, gg in zip(idx, dist, gy)]
+    shards = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        inc = [(j - lo, i, dd, gg) for i, j, dd, gg in edges if lo <= j < hi]
+        shards.append(o.shard_csr(prm, lo, hi - lo, lists[lo:hi], inc))
+    deg = np.concatenate([s["deg"] for s in shards])
+    np.testing.assert_array_equal(deg, ref["deg"])
+    E = np.concatenate([o.shard_energy(s, deg, nn)[0] for s in shards])
+    np.testing.assert_array_equal(E, ref["E"])
+    tau0 = o.median_tau(E)
+    assert tau0 == ref["tau0"]
+    for s, lo, hi in zip(shards, cuts[:-1], cuts[1:]):
+        np.testing.assert_array_equal(o.synth_lambda(s["E"], s["G"], tau0), ref["lambdas"][lo:hi])
+        a, b = ref["indptr"][lo], ref["indptr"][hi]
+        np.testing.assert_array_equal(s["indptr"], ref["indptr"][lo : hi + 1] - a)
+        np.testing.assert_array_equal(s["indices"], ref["indices"][a:b])
+        np.testing.assert_array_equal(s["lap"], ref["lap"][a:b])
+        np.testing.assert_array_equal(s["w"], ref["w"][a:b])
