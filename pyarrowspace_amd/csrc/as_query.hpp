@@ -24,11 +24,17 @@ constexpr int GQ = 32;          // queries per MFMA (GEMM-shaped) batched scan p
 struct SlotStride {
     int64_t dots;   // elements between consecutive slots' dots inside one 32-row tile (32: tile-major, batched workspace)
     int64_t dots_ts; // elements between consecutive 32-row tiles (32 = plain row order, single slot; 32 * slots batched)
+    int dots_rs;     // elements between consecutive rows of one slot inside a tile: 1, or 4 in the batched workspace, whose
+                     // tiles are [slot quad][32 rows][4 slots] -- a lane of the MFMA scan holds 4 slots of one row and
+                     // stores them as one dwordx4, the selection kernels read a row's 8 slots as two dwordx4
     int64_t q;      // dp
     int64_t qin;    // d
     int64_t knn;    // k records
     int64_t hits;   // topk + 1 records
 };
+
+// element offset of slot s inside a 32-row tile of the dots (see SlotStride)
+__host__ __device__ inline int64_t dots_slot_off(int64_t s, int64_t sd, int rs) { return rs == 4 ? (s >> 2) * 128 + (s & 3) : s * sd; }
 
 struct QInfo {
     double nq;        // |q|^2

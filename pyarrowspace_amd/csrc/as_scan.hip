@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void scan_dots_f32_kernel(const float* __restr
 template <int NCH>
 __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __restrict__ x32, const float* __restrict__ q32,
                                                               int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
-                                                              int64_t sd, int64_t ts, PreArgs pre) {
+                                                              int64_t sd, int64_t ts, int rs, int slot0, PreArgs pre) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
     mine.infow = pre.infow + myq;
     mine.ckey = (void*)((float*)pre.ckey + (int64_t)myq * CAND_CAP);
     mine.cidx = pre.cidx + (int64_t)myq * CAND_CAP;
-    float* __restrict__ mydots = dots + (int64_t)myq * sd;   // tile-major: [32-row tile][slot][32]
+    float* __restrict__ mydots = dots + dots_slot_off(slot0 + myq, sd, rs);   // tile-major (SlotStride)
     for (int64_t row = r0 + gw; row < r1; row += nw) {
         const float* pa = x32 + row * dp + 4 * lane;
         f32x4 v[NCH];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
         k1 += __shfl_xor(k1, 2, 64);
         k1 += __shfl_xor(k1, 1, 64);
         if (owner) {
-            mydots[(row >> 5) * ts + (row & 31)] = k1;
+            mydots[(row >> 5) * ts + (row & 31) * rs] = k1;
             prefilter_f32(mine, row, k1, aux, nq32, inq32, full);
         }
     }
@@ -226,17 +226,21 @@ __device__ __forceinline__ float lds_read1(unsigned a) {
 // slab ring produces get an exact wait; anything else waits for everything (always correct).  A 14-way switch
 // at every slab of the unrolled K loop pushed the kernel into scratch spills.
 __device__ __forceinline__ void wait_vmcnt(int n) {
-    if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if (n == 4 || n == 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // always issued (an exec-masked store the compiler may not branch around): the wave's count of outstanding
 // operations must never be smaller than the ring's bookkeeping assumes
 __device__ __forceinline__ void store_dword_issued(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_x4_issued(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 // s_nop: the hazard recogniser does not look inside asm, and an MFMA result may be the operand
 __device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
@@ -248,11 +252,13 @@ __device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
 // Measured on that skeleton: fetching the same bytes as 2 rows x 512 B or 1 row x 1 KiB per instruction
 // instead of 8 rows x 128 B: no change; without the norm DMA: no change; without the 4 dot stores per row
 // block: 0.46 ms (7.0 TB/s); with nt stores: 0.52 ms -- but in the full kernel nt stores were slower (0.63 ms)
-// and cost the per-slot selection kernels their cache hits.
+// and cost the per-slot selection kernels their cache hits.  The cost is per byte, not per instruction or per
+// episode: 16 dword stores per row block, 4 dwordx4 stores, or the stores of 4 row blocks issued together all
+// measure the same (0.60 ms): 134 MB of write-backs among 3 GB of streamed reads cost what 0.9 GB of reads would.
 template <int NBUF, int DIAG = 0, int AUX = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
     const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
-    int64_t sd, int64_t ts, PreArgs pre, int nb) {
+    int64_t ts, PreArgs pre, int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     float* St = (float*)smem;   // per wave: NBUF slabs x [32 rows][32 floats]; Ex[owner wave][3 senders][64 lanes][4]; Ax[wave][64]
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ks < myns) {
                 // slab `cur` has landed once at most inflight-1 newer slabs (4 DMA ops each) are outstanding:
                 // loads retire in order, so the count is conservative whatever else is in flight
-                wait_vmcnt(4 * (inflight - 1) + (x0 >= 5 ? 5 : 0));
+                wait_vmcnt(4 * (inflight - 1) + (x0 >= 2 ? 2 : 0));
                 --inflight;
                 x0 = x1;
                 x1 = x2;
@@ -393,15 +399,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wait_vmcnt(myns >= NBUF - 1 ? 4 * inflight : 0);
         const float aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
         {
-            // all 4 stores are issued whatever the lane holds: rows past r1 land in the padding behind the last
-            // tile (np + ROW_TILE rows are allocated), idle slots have their places in every tile.  Tile-major
-            // dots: the wave's four stores fill 1 KiB of the row block's contiguous 4 KiB
-            float* const tile = dots + (row >> 5) * ts + (row & 31);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) store_dword_issued(tile + (int64_t)(e + 8 * wu + 4 * h) * sd, mine[e]);
-            x0 += 4;
-            x1 += 4;
-            x2 += 4;
+            // the store is issued whatever the lane holds: rows past r1 land in the padding behind the last tile
+            // (np + ROW_TILE rows are allocated), idle slots have their places in every tile.  Tile layout
+            // [slot quad][32 rows][4 slots]: the lane's four values (slots 8 wu + 4 h + {0..3} of row l31) are 16
+            // contiguous bytes, the wave's ONE dwordx4 store fills 1 KiB of the row block's contiguous 4 KiB
+            store_x4_issued(dots + (row >> 5) * ts + ((2 * wu + h) * 32 + (row & 31)) * 4, mine);
+            x0 += 1;
+            x1 += 1;
+            x2 += 1;
             const bool pf = pre.enabled && row < r1 && row < pre.n && row != pre.exclude;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -723,7 +728,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
         const int64_t nrb = (rows + 31) / 32;                                                                          \
         const unsigned grid = (unsigned)std::min<int64_t>(nrb, 2 * q->cus);                                            \
         hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
-                           q->dots32, q->ss.dots, q->ss.dots_ts, pre, q->nb);                                                         \
+                           q->dots32, q->ss.dots_ts, pre, q->nb);                                                                     \
     } while (0)
             if (q->gemm_variant == 1) AS_GSCAN(3, 0, 2);
             else if (q->gemm_variant == 2) AS_GSCAN(4, 0, 0);
@@ -750,7 +755,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             pj.ckey = (void*)((float*)pre.ckey + (int64_t)j0 * CAND_CAP);                                              \
             pj.cidx = pre.cidx + (int64_t)j0 * CAND_CAP;                                                               \
             hipLaunchKernelGGL(scan_dots_batch_kernel<N>, dim3(grid), dim3(256), 0, st, sp->x32, q->q32 + (int64_t)j0 * sp->dp, \
-                               sp->dp, q->r0, q->r1, q->dots32 + (int64_t)j0 * q->ss.dots, q->ss.dots, q->ss.dots_ts, pj);             \
+                               sp->dp, q->r0, q->r1, q->dots32, q->ss.dots, q->ss.dots_ts, q->ss.dots_rs, j0, pj);                     \
         }                                                                                                              \
     } while (0)
             switch (nch) {

@@ -109,20 +109,21 @@ struct SelArgs {
     int* cidx;
     int64_t sd;   // dots: elements between slots inside a 32-row tile
     int64_t ts;   // dots: elements between 32-row tiles (32 = plain row order)
+    int rs;       // dots: elements between rows of one slot inside a tile (SlotStride::dots_rs)
 };
 
 // The batched workspace keeps dots tile-major -- [32-row tile][slot][32 rows] -- so that the MFMA scan writes one
 // contiguous 4 KiB block per row block instead of 32 segments 4 MiB apart; with ts = 32 this is plain row order.
 template <typename T>
 __device__ __forceinline__ T dot_at(const SelArgs<T>& a, int64_t row) {
-    return a.dots[(row >> 5) * a.ts + (row & 31)];
+    return a.dots[(row >> 5) * a.ts + (row & 31) * a.rs];
 }
 
 template <typename T>
 __device__ __forceinline__ void sel_slot(SelArgs<T>& a) {
     const int z = blockIdx.z;
-    if (a.dots) a.dots += (int64_t)z * a.sd;
-    if (a.dots32) a.dots32 += (int64_t)z * a.sd;
+    if (a.dots) a.dots += dots_slot_off(z, a.sd, a.rs);
+    if (a.dots32) a.dots32 += dots_slot_off(z, a.sd, a.rs);
     a.info += z;
     a.info_w += z;
     a.gmin += (int64_t)z * CAND_CAP;
@@ -160,7 +161,7 @@ __device__ __forceinline__ double score_key<double>(const SelArgs<double>& a, co
         // bound), so rankings the lambda term decides (tau small) never depend on fp32.  No square root or division
         // for the cosine (reciprocal square roots: a few ulp, inside the bound's slack).
         const double nrow = a.n64[row];
-        const double dv = (double)a.dots32[(row >> 5) * a.ts + (row & 31)];
+        const double dv = (double)a.dots32[(row >> 5) * a.ts + (row & 31) * a.rs];
         const double cs = nrow > 0.0 ? dv * rsqrt(nrow) * c.rq : 0.0;
         return -(c.tau * cs + (1.0 - c.tau) / (1.0 + fabs(c.lq - a.lam64[row])));
     }
@@ -435,6 +436,7 @@ struct BatchSel {
     const QInfo* info;        // [NS]
     QInfo* info_w;
     int64_t r0, r1, sd, ts;
+    int rs;                   // SlotStride::dots_rs
     double tau;
     double* gmin;             // [NS][CAND_CAP]
     double* ckey;             // [NS][CAND_CAP]
@@ -443,9 +445,24 @@ struct BatchSel {
 };
 
 // rn = 1/|x_row|, rq = 1/|q_s|: no square root or division for the cosine; one reciprocal for the lambda term
-__device__ __forceinline__ double batch_key(const BatchSel& a, int s, int64_t row, double rn, double lrow, double rq, double lq) {
-    const double dv = (double)a.dots32[(row >> 5) * a.ts + (int64_t)s * a.sd + (row & 31)];
-    return -(a.tau * (dv * rn * rq) + (1.0 - a.tau) / (1.0 + fabs(lq - lrow)));
+__device__ __forceinline__ double batch_key(const BatchSel& a, float dot, double rn, double lrow, double rq, double lq) {
+    return -(a.tau * ((double)dot * rn * rq) + (1.0 - a.tau) / (1.0 + fabs(lq - lrow)));
+}
+// the dots of slots [s0, s0 + NSW) of one row: two dwordx4 in the batched workspace's [slot quad][32 rows][4] tiles
+template <int NSW>
+__device__ __forceinline__ void batch_dots(const BatchSel& a, int s0, int64_t row, float (&dv)[NSW]) {
+    const float* __restrict__ t = a.dots32 + (row >> 5) * a.ts;
+    if (a.rs == 4) {
+#pragma unroll
+        for (int g = 0; g < NSW / 4; ++g) {
+            const f32x4 v = *(const f32x4*)(t + ((s0 >> 2) + g) * 128 + (row & 31) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[4 * g + e] = v[e];
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) dv[s] = t[(int64_t)(s0 + s) * a.sd + (row & 31)];
+    }
 }
 
 // group minima: one wave per (group of G rows, NSW slots); blockIdx.y = slot octet
@@ -470,9 +487,11 @@ __global__ __launch_bounds__(256) void score_gmin_batch_kernel(BatchSel a, int64
     for (int64_t row = lo + lane; row < hi; row += 64) {
         const double nrow = a.n64[row], lrow = a.lam64[row];
         const double rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
+        float dv[NSW];
+        batch_dots<NSW>(a, s0, row, dv);
 #pragma unroll
         for (int s = 0; s < NSW; ++s) {
-            const double k = batch_key(a, s0 + s, row, rn, lrow, s_rq[s], s_lq[s]);
+            const double k = batch_key(a, dv[s], rn, lrow, s_rq[s], s_lq[s]);
             m[s] = k < m[s] ? k : m[s];
         }
     }
@@ -505,9 +524,11 @@ __global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a) {
     for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
         const double nrow = a.n64[row], lrow = a.lam64[row];
         const double rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
+        float dv[NSW];
+        batch_dots<NSW>(a, s0, row, dv);
 #pragma unroll
         for (int s = 0; s < NSW; ++s) {
-            const double k = batch_key(a, s0 + s, row, rn, lrow, s_rq[s], s_lq[s]);
+            const double k = batch_key(a, dv[s], rn, lrow, s_rq[s], s_lq[s]);
             if (k <= s_thr[s] && !((full >> s) & 1u)) {
                 const int slot = atomicAdd(&a.info_w[s0 + s].sc_cnt, 1);
                 if (slot < CAND_CAP) {
@@ -1403,7 +1424,7 @@ static SelArgs<T> make_sel(as_query* q, const T* dots, int M, int64_t exclude) {
     a.M = M; a.metric = sp->opts.metric;
     a.epskey = 0; a.coef = 0; a.tau = 1.0;
     a.pkey = (T*)q->pkey; a.pidx = q->pidx;
-    a.gmin = (T*)q->gmin; a.ckey = (T*)q->ckey_s; a.cidx = q->cidx_s; a.sd = q->ss.dots; a.ts = q->ss.dots_ts;
+    a.gmin = (T*)q->gmin; a.ckey = (T*)q->ckey_s; a.cidx = q->cidx_s; a.sd = q->ss.dots; a.ts = q->ss.dots_ts; a.rs = q->ss.dots_rs;
     return a;
 }
 
@@ -1565,7 +1586,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
             // zero queries and cost nothing but their share of the dots)
             BatchSel b;
             b.dots32 = dots32; b.n64 = q->sp->n64; b.lam64 = q->sp->lam64; b.info = q->info; b.info_w = q->info;
-            b.r0 = q->r0; b.r1 = q->r1; b.sd = q->ss.dots; b.ts = q->ss.dots_ts; b.tau = f.tau;
+            b.r0 = q->r0; b.r1 = q->r1; b.sd = q->ss.dots; b.ts = q->ss.dots_ts; b.rs = q->ss.dots_rs; b.tau = f.tau;
             b.gmin = (double*)q->gmin; b.ckey = (double*)q->ckey_s; b.cidx = q->cidx_s; b.ns = q->nb;
             constexpr int NSW = 8;   // slots per wave: a row's norm and lambda are read GQ / NSW times instead of GQ
             const unsigned ny = (unsigned)((q->nb + NSW - 1) / NSW);
@@ -1739,6 +1760,7 @@ static as_status query_alloc(as_query* q) {
     AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE) * C));
     q->ss.dots = C > 1 ? 32 : sp->np + ROW_TILE;
     q->ss.dots_ts = C > 1 ? 32 * (int64_t)C : 32;
+    q->ss.dots_rs = C > 1 && C % 4 == 0 ? 4 : 1;
     q->ss.q = sp->dp;
     q->ss.qin = sp->d;
     q->ss.knn = std::max<int64_t>(q->k, 1);
