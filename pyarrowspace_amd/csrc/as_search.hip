@@ -287,13 +287,15 @@ __device__ __forceinline__ U block_kth(const U (&v)[4], const bool (&have)[4], i
 // the rounding of the bin arithmetic, and within one bin width of the exact M-th minimum (the 4-pass radix select it
 // replaces took 7.7 us of every query).  Non-finite minima (NaN / inf keys of poisoned rows) are left out of the
 // range and counted last.
+// Threshold of a 1024-thread block over ng <= 4096 group minima: an upper bound of the M-th smallest, itself one of
+// the minima (so at least M rows have keys <= it).  One pass: range, 1024-bin linear histogram, the bin holding the
+// M-th, the largest minimum at or below that bin.  Every thread gets the result; +inf when fewer than M minima are
+// finite (no finite threshold is provable: everything passes).  Deterministic: any block computes the same value.
 template <typename T>
-__global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gmin, int ng, int M, QInfo* info) {
+__device__ __forceinline__ double pick_thr_block(const T* __restrict__ gmin, int ng, int M) {
     __shared__ unsigned int lhist[1024];
     __shared__ double s_lo[16], s_hi[16];
     __shared__ int s_bin, s_nfin[16];
-    gmin += (int64_t)blockIdx.z * CAND_CAP;
-    info += blockIdx.z;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const double big = 1.0e300;
     T v[4];
@@ -333,14 +335,7 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
         hi = s_hi[w2] > hi ? s_hi[w2] : hi;
         nfin += s_nfin[w2];
     }
-    if (nfin < M) {
-        // fewer finite minima than the list is wide: no finite threshold is provable -- everything passes
-        if (tid == 0) {
-            if (sizeof(T) == 4) info->thr32 = key_traits<float>::inf();
-            else info->thr64 = key_traits<double>::inf();
-        }
-        return;
-    }
+    if (nfin < M) return (double)key_traits<double>::inf();   // block-uniform
     const double scale = hi > lo ? 1024.0 / (hi - lo) : 0.0;
     int bin[4];
 #pragma unroll
@@ -393,22 +388,37 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
     __syncthreads();   // s_hi has been read by everybody
     if (lane == 0) s_hi[w] = mx;
     __syncthreads();
-    if (tid == 0) {
-        for (int w2 = 1; w2 < 16; ++w2) mx = s_hi[w2] > mx ? s_hi[w2] : mx;
-        if (sizeof(T) == 4) info->thr32 = (float)mx;   // mx is one of the (float) minima: exact
-        else info->thr64 = mx;
+    for (int w2 = 0; w2 < 16; ++w2) mx = s_hi[w2] > mx ? s_hi[w2] : mx;
+    return mx;   // one of the minima: exact in T
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gmin, int ng, int M, QInfo* info) {
+    gmin += (int64_t)blockIdx.z * CAND_CAP;
+    info += blockIdx.z;
+    const double thr = pick_thr_block<T>(gmin, ng, M);
+    if (threadIdx.x == 0) {
+        if (sizeof(T) == 4) info->thr32 = (float)thr;
+        else info->thr64 = thr;
     }
 }
 
-// (3) append every row whose key <= threshold
+// (2) + (3) threshold and filter in one launch (single-query chain: one dependent launch and one single-block kernel less).
+// Every block of 1024 threads derives the threshold from the group minima itself -- 32 KiB out of L2, the same value
+// in every block -- and filters its share of the rows.
 template <typename T, int KEY>
-__global__ __launch_bounds__(256) void score_filter_kernel(SelArgs<T> a) {
+__global__ __launch_bounds__(1024) void score_pickfilter_kernel(SelArgs<T> a, int ng, int M) {
     sel_slot(a);
+    const double thr_d = pick_thr_block<T>(a.gmin, ng, M);
+    const T thr = (T)thr_d;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (sizeof(T) == 4) a.info_w->thr32 = (float)thr_d;
+        else a.info_w->thr64 = thr_d;
+    }
     T* __restrict__ ckey = a.ckey;
     int* __restrict__ cidx = a.cidx;
     int* counter = KEY ? &a.info_w->knn_cnt : &a.info_w->sc_cnt;
     const ScoreCtx c = load_ctx(a.info, a.tau);
-    const T thr = sizeof(T) == 4 ? (T)a.info->thr32 : (T)a.info->thr64;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool full = false;   // mass ties at the threshold: the counter only has to exceed CAND_CAP
     for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1 && !full; row += stride) {
@@ -1483,9 +1493,9 @@ static void launch_knn_repair(as_query* q, const T* dots, double eps, int64_t ex
     a.cidx = q->cidx_k;
     const unsigned nb = (unsigned)q->nb;
     hipLaunchKernelGGL((score_gmin_kernel<T, 1>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
-    hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Mk, q->info);
-    const unsigned fg = (unsigned)std::min<int64_t>((rows + 255) / 256, 2048);
-    hipLaunchKernelGGL((score_filter_kernel<T, 1>), dim3(fg, 1, nb), dim3(256), 0, st, a);
+    // threshold + filter in one launch: every block derives the threshold itself (pick_thr_block)
+    const unsigned pg = (unsigned)std::min<int64_t>((rows + 1023) / 1024, std::max(q->cus, 1));
+    hipLaunchKernelGGL((score_pickfilter_kernel<T, 1>), dim3(pg, 1, nb), dim3(1024), 0, st, a, ng, q->Mk);
 }
 
 static as_status knn_repair(as_query* q, double eps, int64_t exclude) {
@@ -1595,8 +1605,8 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
             hipLaunchKernelGGL((score_filter_batch_kernel<NSW>), dim3(fg, ny), dim3(256), 0, st, b);
         } else {
             hipLaunchKernelGGL((score_gmin_kernel<T, 0>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
-            hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
-            hipLaunchKernelGGL((score_filter_kernel<T, 0>), dim3(fg, 1, nb), dim3(256), 0, st, a);
+            const unsigned pg = (unsigned)std::min<int64_t>((rows + 1023) / 1024, std::max(q->cus, 1));
+            hipLaunchKernelGGL((score_pickfilter_kernel<T, 0>), dim3(pg, 1, nb), dim3(1024), 0, st, a, ng, q->Ms);
         }
         f.ck = q->ckey_s; f.ci = q->cidx_s;
         hipLaunchKernelGGL((score_finish_kernel<T>), dim3(1, 1, nb), dim3(1024), score_lds<T>(), st, f, coef_s);
