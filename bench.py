@@ -232,18 +232,23 @@ def main():
     # extension, reported next to the headline, never as it: batched search, 32 query
     # slots per pass over the items (GEMM-shaped scan on fp32 MFMA)
     batched_qps = batch_pass_ms = None
-    if single and len(Q) >= 64:
+    if len(Q) >= 64:
         QB = np.ascontiguousarray(np.concatenate([Q[:64]] * 4))    # 256 queries = 8 passes of 32
-        aspace.search_batch(QB, gl, args.tau)
+        # N > 1: the staged batched path (ShardedIndex.search_batch: two collectives per pass of 32 queries)
+        run_batch = (lambda: aspace.search_batch(QB, gl, args.tau)) if single else (lambda: index.search_batch(QB, args.tau))
+        run_batch()
         tb = []
         for _ in range(7):
             barrier()
             t1 = time.perf_counter()
-            aspace.search_batch(QB, gl, args.tau)
+            run_batch()
             barrier()
             tb.append(time.perf_counter() - t1)
-        batched_qps = len(QB) / float(np.median(tb))
-        batch_pass_ms = float(np.median(tb)) / (len(QB) / 32) * 1e3
+        tbm = torch.tensor([float(np.median(tb))], device=device, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tbm, op=dist.ReduceOp.MAX)
+        batched_qps = len(QB) / float(tbm.item())
+        batch_pass_ms = float(tbm.item()) / (len(QB) / 32) * 1e3
 
     qps = args.steps / dt
     rows_per_gpu = (n + world - 1) // world
@@ -302,10 +307,10 @@ def main():
                            "note": "whole query, host-visible latency, per GPU"},
         "roofline_batch": None if batch_pass_ms is None else {
             "kernel": "scan_gemm_kernel + per-slot selection", "bound": "hbm", "queries_per_pass": 32,
-            "achieved": query_bytes / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": query_bytes / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
+            "achieved": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
             "traffic": traffic_batch,
-            "note": "whole 32-query pass, host-visible; N*(D+2)*4 bytes per pass; fp32 MFMA work 2*32*N*D flops"},
+            "note": "whole 32-query pass, host-visible, per GPU; N*(D+2)*4 bytes per pass; fp32 MFMA work 2*32*N*D flops"},
         "roofline_build": {"kernel": build_kernel, "bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak,
                            "unit": "TFLOP/s", "frac": mfma_tf / mfma_peak, "traffic": traffic_mfma,
                            "flops_issued": bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"],
