@@ -165,6 +165,26 @@ struct KnnArgs {
     // thresholds -- every column whose fp32 key is inside the threshold is kept, nothing is compacted away
     const int* a_ids;
     const float* a_thr;
+    // symmetric mode (whole-index builds with an eps that admits few pairs): only the column tiles at or above a row
+    // block's own rows are computed -- half the MFMA work.  A unit is (row block, tile range, segment) taken from a
+    // list sorted by length through an atomic cursor; a key d(i, j) computed above the diagonal also serves row j:
+    // when it is inside j's static eps bound it is appended to j's transposed buffer (t_cap entries per row, counter
+    // may exceed it: the row is then flagged), which the host compacts into one more segment of j's candidate lists.
+    const int4* units = nullptr;   // (row block, first tile, end tile, segment)
+    int nunits = 0;
+    int* unit_ctr = nullptr;
+    int* t_cnt = nullptr;          // [n]
+    float* t_key = nullptr;        // [n][t_cap]
+    int* t_idx = nullptr;
+    int t_cap = 0;
+    // Per-item thresholds: thr0[i] is an upper bound of the M-th smallest fp32 key of item i over ALL columns (the
+    // M-th smallest over a sample of the columns is one), or +inf.  A row starts from min(eps bound, thr0) instead of
+    // the eps bound alone (what that rejects is beyond the M-th smallest, like what a compaction drops), and the
+    // transposed appends of the symmetric mode use the column item's.  out_thr: the row bounds a pass ends with.
+    // Column tiles visited: tile index * tstride + tphase (a strided sample of the columns for the threshold pass).
+    const float* thr0 = nullptr;
+    float* out_thr = nullptr;
+    int tstride = 1, tphase = 0;
 };
 
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -649,7 +669,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // two waves share every SIMD's matrix pipe (wave w owns rows [32w, 32w+32) as 1x4 accumulators),
 // so one wave's DMA issue, fragment-read latency and epilogue run in the shadow of its
 // partner's MFMAs.  Waves 4-7 issue their DMA pieces mid-slab, waves 0-3 at the slab start.
-template <int METRIC, bool COLLECT = false>
+template <int METRIC, bool COLLECT = false, bool SYM = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_mfma_dma8_kernel(KnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Sl = (float*)smem;                  // 2 slab buffers
@@ -677,11 +697,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int s = 0; s < 4; ++s) foff[s] = (((2 * s + h) ^ ((l31 >> 1) & 7)) << 2);
     const bool late = wu >= 4;   // wave-uniform: second-dispatched half issues its DMA mid-slab
+    __shared__ int s_unit;
 
-    for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        const int rb = u / a.S, cs = u % a.S;
+    for (int u = blockIdx.x;; u += gridDim.x) {
+        int rb, cs, t0, t1;
+        if (SYM) {
+            // longest units first, handed out through an atomic cursor (the triangle's units differ in length)
+            if (tid == 0) s_unit = atomicAdd(a.unit_ctr, 1);
+            __syncthreads();   // the previous unit ended with a barrier: nobody still reads the old value
+            u = s_unit;
+            if (u >= a.nunits) break;
+            const int4 ud = a.units[u];
+            rb = ud.x; t0 = ud.y; t1 = ud.z; cs = ud.w;
+        } else {
+            if (u >= units) break;
+            rb = u / a.S;
+            cs = u % a.S;
+            t0 = (int)((int64_t)a.ntile * cs / a.S);
+            t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
+        }
         const int64_t rowbase = a.r0 + (int64_t)rb * BM;
-        const int t0 = (int)((int64_t)a.ntile * cs / a.S), t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
         if (tid < BM) {
             const int64_t rg = rowbase + tid;
             if (COLLECT) {
@@ -691,11 +726,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else {
                 const bool valid = rg < a.r1;
                 const float ni = valid ? a.a_n32[rg] : 0.0f;
-                const float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+                float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+                int dropped = 0;
+                if (a.thr0 && valid) {
+                    const float t0r = a.thr0[rg];
+                    if (t0r < bound) {   // what the tighter start rejects is beyond the row's M-th smallest key: a drop
+                        bound = t0r;
+                        dropped = 1;
+                    }
+                }
                 s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.a_inorm32[rg]) : 0.0f);
+                s_drop[tid] = dropped;
             }
             s_cur[tid] = 0;
-            s_drop[tid] = 0;
+            if (COLLECT) s_drop[tid] = 0;
         }
         const char* pa0 = (const char*)(a.xa + (size_t)(rowbase + wu * 32) * a.dp);
         // 6 pieces per wave and slab: j < 4 -> A rows [8j, 8j+8) of this wave's 32, j >= 4 -> B rows of its 16
@@ -711,7 +755,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                  (__attribute__((address_space(3))) void*)(dst + BM * DROW + (wu * 16 + 8 * jb) * DROW), 16, 0, 0);
             }
         };
-        auto colptr = [&](int ct) { return (const char*)(a.x32 + (size_t)((int64_t)ct * BN + wu * 16) * a.dp); };
+        auto colptr = [&](int ct) { return (const char*)(a.x32 + (size_t)(((int64_t)ct * a.tstride + a.tphase) * BN + wu * 16) * a.dp); };
         {
             const char* pb0 = colptr(t0);
 #pragma unroll
@@ -721,7 +765,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         int g = 0;
         for (int ct = t0; ct < t1; ++ct) {
-            const int64_t colbase = (int64_t)ct * BN;
+            const int64_t colbase = ((int64_t)ct * a.tstride + a.tphase) * BN;
             f32x16 acc[4];
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
@@ -796,6 +840,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             const int64_t colg = a.col_goff + colbase, rowg = a.row_goff + rowbase;   // global ids of the tile's corner
             const bool edge = COLLECT || colbase + BN > a.n || (colg < rowg + BM && colg + BN > rowg);
+            // symmetric mode: tiles strictly above the row block also serve the column items' rows (the diagonal tiles
+            // hold both (i, j) and (j, i) themselves)
+            const bool transp = SYM && colbase >= rowbase + BM;
+            float cb[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                cb[nn] = !transp || cj[nn] >= (int)a.n ? -finf : (METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (nj[nn] + a.nmax) : a.epskey + a.coef);
+                if (transp && a.thr0 && cj[nn] < (int)a.n) cb[nn] = fminf(cb[nn], a.thr0[cj[nn]]);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -806,7 +859,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
                     const float gg = acc[nn][r];
-                    key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * ai * nj[nn]);
+                    // both forms are symmetric in (i, j) bit for bit: a key computed once serves both rows
+                    key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * (ai * nj[nn]));
+                }
+                if (transp) {
+                    const bool rowok = rowbase + rl < a.r1;
+                    bool tp[4];
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) tp[nn] = rowok && key[nn] <= cb[nn];
+                    if (__ballot(tp[0] || tp[1] || tp[2] || tp[3])) {
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn)
+                            if (tp[nn]) {
+                                const int slot = atomicAdd(a.t_cnt + cj[nn], 1);
+                                if (slot < a.t_cap) {
+                                    a.t_key[(size_t)cj[nn] * a.t_cap + slot] = key[nn];
+                                    a.t_idx[(size_t)cj[nn] * a.t_cap + slot] = rg;
+                                }
+                            }
+                    }
                 }
                 if (edge) {  // wave-uniform: only tiles on the diagonal or at the padded tail pay for the exclusions
                     // collect mode: the band of a row may be unbounded (+inf: an item with an infinite norm makes
@@ -849,7 +920,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
                 a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
             }
-            if (lane == 0) a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = (int)((unsigned)cnt | ((unsigned)s_drop[rl] << 30));
+            if (lane == 0) {
+                a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = (int)((unsigned)cnt | ((unsigned)s_drop[rl] << 30));
+                if (!COLLECT && a.out_thr) a.out_thr[rg] = s_ta[rl].x;   // M-th smallest key seen (or the start bound): threshold pass, S = 1
+            }
         }
         __syncthreads();
     }
@@ -925,11 +999,12 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(RefineArgs a) {
     const int64_t row = a.r0 + (int64_t)blockIdx.x * 4 + w;
     if (row >= a.r1) return;
     const int64_t lr = row - a.r0;
-    int C = 0, anyfull = 0;
+    int C = 0, anyfull = 0, lost = 0;
     for (int cs = 0; cs < a.S; ++cs) {
         const int cc = a.c_cnt[lr * a.S + cs];
         const int c = cc & 0xffff;
         anyfull |= (cc >> 30) & 1;
+        lost |= (cc >> 31) & 1;   // a segment that lost candidates it cannot bound (transposed buffer overflow)
         const size_t ob = ((size_t)lr * a.S + cs) * a.M;
         for (int t = lane; t < c; t += 64) {
             ck[C + t] = a.c_key[ob + t];
@@ -999,6 +1074,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(RefineArgs a) {
             const double T32 = (double)lk[Mp - 1];
             bad = !(T32 - e > B);
         }
+        if (lost) bad = 1;
         a.flag[lr] = bad;
         if (bad) {
             atomicAdd(a.nflag, 1);
@@ -1141,6 +1217,43 @@ __global__ __launch_bounds__(256) void knn_band_refine_kernel(BandArgs a) {
     }
 }
 
+// ---- symmetric mode helpers
+// A row's transposed buffer -> the M smallest by (key32, id) as one more segment of its candidate lists; bit 30 of the
+// count: something was dropped (all of it beyond the M-th kept key); bit 31: the buffer overflowed (unbounded loss).
+__global__ __launch_bounds__(256) void transposed_compact_kernel(const int* __restrict__ t_cnt, const float* __restrict__ t_key,
+                                                                 const int* __restrict__ t_idx, int t_cap, int64_t rows, int S, int seg,
+                                                                 int M, float* __restrict__ c_key, int* __restrict__ c_idx,
+                                                                 int* __restrict__ c_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    float* ck = (float*)smem + (size_t)w * t_cap;
+    int* ci = (int*)((float*)smem + (size_t)4 * t_cap) + (size_t)w * t_cap;
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= rows) return;
+    const int raw = t_cnt[row];
+    const int cnt = raw < t_cap ? raw : t_cap;
+    for (int t = lane; t < cnt; t += 64) {
+        ck[t] = t_key[(size_t)row * t_cap + t];
+        ci[t] = t_idx[(size_t)row * t_cap + t];
+    }
+    AS_LDS_FENCE();
+    const size_t ob = ((size_t)row * S + seg) * M;
+    for (int t = lane; t < cnt; t += 64) {
+        const float k = ck[t];
+        const int i = ci[t];
+        int rank = 0;
+        for (int s2 = 0; s2 < cnt; ++s2) rank += lex_less<float>(ck[s2], ci[s2], k, i) ? 1 : 0;
+        if (rank < M) {
+            c_key[ob + rank] = k;
+            c_idx[ob + rank] = i;
+        }
+    }
+    if (lane == 0) {
+        const unsigned kept = (unsigned)(cnt < M ? cnt : M);
+        c_cnt[(size_t)row * S + seg] = (int)(kept | (cnt > M ? 1u << 30 : 0u) | (raw > t_cap ? 1u << 31 : 0u));
+    }
+}
+
 static int pick_list_width(int64_t k) {
     // M = k + margin rounded up to a power of two in [32, 64]; wider lists are not supported yet
     const int64_t need = k + 8;
@@ -1211,7 +1324,46 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
         }
-        const int units = nrb * S;
+        // ---- symmetric mode: a whole-index build whose eps admits few pairs computes only the tiles at or above each
+        // row block (half the MFMA work); the keys above the diagonal reach the column items' rows through
+        // transposed buffers.  Decided from a sample of the pair distribution: the buffers must hold what eps admits.
+        // (from 16 column tiles on: below that the threshold pass costs what the triangle saves)
+        bool sym = r0 == 0 && r1 == n && (variant & 48) == 48 && ntile >= 16 && !getenv("ARROWSPACE_NO_SYM");
+        const int T_CAP = 16 * M;   // a row's transposed buffer: ~8 M entries expected with thresholds from every 8th tile
+        {
+            size_t mfree = 0, mtotal = 0;
+            if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)n * T_CAP * 8.0 > 0.25 * (double)mfree) sym = false;
+        }
+        std::vector<int4> hunits;
+        dev_tmp<int4> d_units;
+        dev_tmp<int> tr_cnt, tr_idx;
+        dev_tmp<float> tr_key, thr0;
+        double sym_tiles = 0, thr_tiles = 0;
+        const int tstride = std::max(1, std::min(8, ntile / 8));   // the threshold pass visits every tstride-th column tile
+        if (sym) {
+            // units: every row block's tiles [rb * BM / BN, ntile) in pieces of at most L tiles, longest first
+            const int per = BM / BN;
+            double total = 0;
+            for (int rb = 0; rb < nrb; ++rb) total += std::max(0, ntile - rb * per);
+            int L = (int)std::max<double>(8.0, std::ceil(total / (dev_cus * 16.0)));
+            if ((ntile + L - 1) / L > 7) L = (ntile + 6) / 7;   // at most 7 own segments + the transposed one
+            S = (ntile + L - 1) / L + 1;
+            for (int rb = 0; rb < nrb; ++rb) {
+                const int tlo = rb * per;
+                int seg = 0;
+                for (int t = tlo; t < ntile; t += L, ++seg) hunits.push_back(make_int4(rb, t, std::min(ntile, t + L), seg));
+            }
+            std::stable_sort(hunits.begin(), hunits.end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
+            for (const int4& u : hunits) sym_tiles += u.z - u.y;
+            AS_HIP(d_units.alloc(hunits.size() + 1));
+            AS_HIP(hipMemcpyAsync(d_units, hunits.data(), sizeof(int4) * hunits.size(), hipMemcpyHostToDevice, st));
+            AS_HIP(tr_cnt.alloc(n + 1));
+            AS_HIP(tr_key.alloc((size_t)n * T_CAP));
+            AS_HIP(tr_idx.alloc((size_t)n * T_CAP));
+            AS_HIP(thr0.alloc(n));
+            AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (n + 1), st));
+        }
+        const int units = sym ? (int)hunits.size() : nrb * S;
         const int grid = std::min(units, dev_cus * 2);
         dev_tmp<float> bkey, ckey;
         dev_tmp<int> bidx, cidx, ccnt;
@@ -1229,6 +1381,10 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         ka.epskey = nextafterf(ka.epskey, INFINITY);
         ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
         ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = 0; ka.col_goff = 0; ka.a_ids = nullptr; ka.a_thr = nullptr;
+        ka.units = nullptr; ka.nunits = 0; ka.unit_ctr = nullptr; ka.t_cnt = nullptr; ka.t_key = nullptr; ka.t_idx = nullptr; ka.t_cap = 0;
+        if (sym) {
+            ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + n; ka.t_cnt = tr_cnt; ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
+        }
         dev_events<3> ev;
         AS_HIP(ev.create());
         hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
@@ -1237,7 +1393,33 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             AS_HIP(hipEventRecord(e0, st));
-            if (metric == AS_METRIC_L2)
+            if (sym) {
+                // threshold pass: every row against every tstride-th column tile (S = 1; the lists are not used): the
+                // bound a row ends with -- the M-th smallest key it saw there, or its eps bound -- is an upper bound of
+                // its M-th smallest key over all columns
+                KnnArgs k0 = ka;
+                k0.units = nullptr; k0.nunits = 0; k0.unit_ctr = nullptr; k0.t_cnt = nullptr; k0.t_key = nullptr; k0.t_idx = nullptr; k0.t_cap = 0;
+                k0.S = 1; k0.tstride = tstride; k0.tphase = 0; k0.ntile = (ntile + tstride - 1) / tstride; k0.thr0 = nullptr; k0.out_thr = thr0;
+                thr_tiles = (double)nrb * k0.ntile;
+                if (metric == AS_METRIC_L2)
+                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
+                else
+                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
+                AS_HIP(hipGetLastError());
+                AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));   // the pass above left its counts there
+                ka.thr0 = thr0;
+                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+                if (metric == AS_METRIC_L2)
+                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+                else
+                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+                AS_HIP(hipGetLastError());
+                // the transposed buffers become segment S - 1 of every row's candidate lists
+                const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
+                hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt,
+                                   (const float*)tr_key, (const int*)tr_idx, T_CAP, rows, S, S - 1, M, (float*)ckey, (int*)cidx, (int*)ccnt);
+            } else if (metric == AS_METRIC_L2)
                 hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
             else
                 hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
@@ -1298,9 +1480,10 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         AS_HIP(hipEventElapsedTime(&ms01, e0, e1));
         AS_HIP(hipEventElapsedTime(&ms12, e1, e2));
         t_mfma = ms01 * 1e-3; t_ref = ms12 * 1e-3;
-        flops = 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
-        dbg("knn_rows: rows=%lld S=%d M=%d grid=%d mfma=%.3fs (%.1f TF/s) refine=%.3fs flagged=%d", (long long)rows, S, M,
-            grid, t_mfma, flops / std::max(t_mfma, 1e-9) * 1e-12, t_ref, nflagged);
+        // flops actually issued: the triangle's tiles in symmetric mode
+        flops = sym ? 2.0 * (sym_tiles + thr_tiles) * BM * BN * (double)sp->dp : 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
+        dbg("knn_rows: rows=%lld %s S=%d M=%d units=%d mfma=%.3fs (%.1f TF/s issued) refine=%.3fs flagged=%d", (long long)rows,
+            sym ? "symmetric" : "full", S, M, units, t_mfma, flops / std::max(t_mfma, 1e-9) * 1e-12, t_ref, nflagged);
         if (nflagged > 0 && !getenv("ARROWSPACE_NO_BAND_PASS")) {
             // ---- second pass: complete band collection for the flagged rows (K2c)
             const double tb0 = now_s();
@@ -1332,6 +1515,8 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
                                (int*)a_ids, (float*)a_thr, (int64_t)0);
             AS_HIP(hipGetLastError());
             KnnArgs kb = ka;
+            kb.units = nullptr; kb.nunits = 0; kb.unit_ctr = nullptr; kb.t_cnt = nullptr; kb.t_key = nullptr; kb.t_idx = nullptr; kb.t_cap = 0;
+            kb.thr0 = nullptr; kb.out_thr = nullptr;
             kb.r0 = 0; kb.r1 = nf; kb.nrb = nrb2; kb.S = S2; kb.M = CAP;
             kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
             kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr;

@@ -1,0 +1,74 @@
+"""GPU: the symmetric k-NN build (whole-index builds compute only the column tiles at or above each row block; a key
+above the diagonal reaches the column item's row through its transposed buffer, gated by per-item thresholds from a
+pass over every 8th column tile) against the full pass (ARROWSPACE_NO_SYM=1): bit-identical graphs and lambdas, fewer
+MFMA flops issued; a transposed buffer that overflows sends its row to the band pass; an eps that admits every pair
+works the same way."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import calibrate_eps, clustered
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(X, gp, sym):
+    from pyarrowspace_amd import ArrowSpaceBuilder
+    old = os.environ.pop("ARROWSPACE_NO_SYM", None)
+    if not sym:
+        os.environ["ARROWSPACE_NO_SYM"] = "1"
+    try:
+        aspace, gl = ArrowSpaceBuilder.build(gp, X)
+    finally:
+        os.environ.pop("ARROWSPACE_NO_SYM", None)
+        if old is not None:
+            os.environ["ARROWSPACE_NO_SYM"] = old
+    return aspace, gl, gl.build_stats()
+
+
+def _same_index(a, b):
+    (sa, ga, _), (sb, gb, _) = a, b
+    np.testing.assert_array_equal(np.asarray(sa.lambdas()), np.asarray(sb.lambdas()))
+    for u, v in zip(ga.to_csr(), gb.to_csr()):
+        np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.parametrize("metric,kernel", [("l2", "gaussian"), ("cosine", "rational")])
+@pytest.mark.parametrize("n,d,k,ratio", [(5000, 96, 10, 0.85), (3000, 768, 25, 0.95), (20000, 64, 10, 0.7), (1100, 40, 6, None)])
+def test_symmetric_pass_equals_the_full_pass_bitwise(metric, kernel, n, d, k, ratio):
+    X = clustered(n, d, nclust=8, seed=4)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
+    sym, full = _build(X, gp, True), _build(X, gp, False)
+    _same_index(sym, full)
+    if ratio is None:   # fewer than 16 column tiles: the full pass either way
+        assert sym[2]["mfma_flops"] == full[2]["mfma_flops"]
+    else:               # the triangle plus the threshold pass, not the square
+        assert sym[2]["mfma_flops"] < ratio * full[2]["mfma_flops"]
+    assert sym[2]["fallback_rows"] == 0
+
+
+def test_overflowing_transposed_buffers_go_to_the_band_pass():
+    """900 exact copies of one item at the end of the index: every copy is at distance 0 from the 899 others, the
+    thresholds cannot separate them, and the copies in the last row blocks receive more transposed entries than a
+    buffer holds (16 M = 512): those rows are flagged and settled exactly by the band pass."""
+    n, d, k = 6000, 64, 12
+    X = clustered(n, d, nclust=12, seed=8, normalise=False)
+    X[5100:6000] = X[5100]
+    eps = calibrate_eps(X[:5000], k)
+    gp = {"eps": eps, "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    sym, full = _build(X, gp, True), _build(X, gp, False)
+    _same_index(sym, full)
+    assert sym[2]["mfma_flops"] < full[2]["mfma_flops"]
+    assert sym[2]["band_rows"] >= 100 and sym[2]["fallback_rows"] == 0
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_an_eps_that_admits_every_pair(metric):
+    """eps = 10 (tests/test_3_beir.py's literal): only the thresholds keep the transposed buffers small."""
+    n, d, k = 9000, 64, 8
+    X = clustered(n, d, nclust=6, seed=2)
+    gp = {"eps": 10.0, "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
+    sym, full = _build(X, gp, True), _build(X, gp, False)
+    _same_index(sym, full)
+    assert sym[2]["mfma_flops"] < 0.8 * full[2]["mfma_flops"]
