@@ -1329,17 +1329,24 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         // transposed buffers.  Decided from a sample of the pair distribution: the buffers must hold what eps admits.
         // (from 16 column tiles on: below that the threshold pass costs what the triangle saves)
         bool sym = r0 == 0 && r1 == n && (variant & 48) == 48 && ntile >= 16 && !getenv("ARROWSPACE_NO_SYM");
-        const int T_CAP = 16 * M;   // a row's transposed buffer: ~8 M entries expected with thresholds from every 8th tile
+        // The threshold pass visits every tstride-th column tile: a row's threshold is then about its (tstride * M)-th
+        // smallest key, and its transposed buffer has to hold that many entries (twice that is allocated).  Every 16th
+        // tile when the buffers fit in a sixth of the free memory, every 8th in a quarter, else the full pass.
+        int tstride = std::max(1, std::min(16, ntile / 8));
+        if (const char* ev = getenv("ARROWSPACE_SYM_STRIDE")) tstride = std::max(1, std::min(atoi(ev), ntile / 8));
         {
             size_t mfree = 0, mtotal = 0;
-            if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)n * T_CAP * 8.0 > 0.25 * (double)mfree) sym = false;
+            if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
+                if (tstride > 8 && (double)n * 2 * tstride * M * 8.0 > (double)mfree / 6) tstride = 8;
+                if ((double)n * 2 * tstride * M * 8.0 > 0.25 * (double)mfree) sym = false;
+            }
         }
+        const int T_CAP = 2 * tstride * M;
         std::vector<int4> hunits;
         dev_tmp<int4> d_units;
         dev_tmp<int> tr_cnt, tr_idx;
         dev_tmp<float> tr_key, thr0;
         double sym_tiles = 0, thr_tiles = 0;
-        const int tstride = std::max(1, std::min(8, ntile / 8));   // the threshold pass visits every tstride-th column tile
         if (sym) {
             // units: every row block's tiles [rb * BM / BN, ntile) in pieces of at most L tiles, longest first
             const int per = BM / BN;
