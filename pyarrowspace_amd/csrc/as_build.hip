@@ -28,31 +28,41 @@ template <typename T>
 __global__ void ingest_kernel(const T* __restrict__ src, int64_t ld, int64_t n, int64_t d, int64_t dp,
                               float* __restrict__ x32, double* __restrict__ n64, float* __restrict__ n32,
                               float* __restrict__ inorm32, int* lossless, unsigned long long* nmax_bits, unsigned long long* nmin_bits) {
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (row >= n) return;
+    // a wave per row, rows strided over a resident grid; the largest / smallest norm and the lossless flag are kept
+    // per wave and reach their global words ONCE per wave (a million same-address atomics cost 23 ms of a 25 ms ingest)
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x / 64);
     const int lane = lane_id();
-    double s = 0.0;
     bool ok = true;
-    for (int64_t c = lane; c < dp; c += 64) {
-        if (c >= d) {
-            x32[row * dp + c] = 0.0f;   // column padding: written here, so only the pad ROWS need a memset
-            continue;
+    unsigned long long wmax = 0ull, wmin = ~0ull;
+    for (int64_t row = gw; row < n; row += nw) {
+        double s = 0.0;
+        for (int64_t c = lane; c < dp; c += 64) {
+            if (c >= d) {
+                x32[row * dp + c] = 0.0f;   // column padding: written here, so only the pad ROWS need a memset
+                continue;
+            }
+            const double v = (double)src[row * ld + c];
+            const float f = (float)v;
+            x32[row * dp + c] = f;
+            s += v * v;
+            ok = ok && ((double)f == v || v != v);
         }
-        const double v = (double)src[row * ld + c];
-        const float f = (float)v;
-        x32[row * dp + c] = f;
-        s += v * v;
-        ok = ok && ((double)f == v || v != v);
+        s = wave_sum(s);
+        if (lane == 0) {
+            n64[row] = s;
+            n32[row] = (float)s;
+            inorm32[row] = s > 0.0 ? (float)(1.0 / sqrt(s)) : 0.0f;
+        }
+        // squared norms are >= 0: their bit patterns order like the values
+        const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+        if (s == s) wmax = b > wmax ? b : wmax;
+        if (s > 0.0 && s < 1.0e308) wmin = b < wmin ? b : wmin;
     }
-    s = wave_sum(s);
     if (!__all(ok) && lane == 0) atomicExch(lossless, 0);
     if (lane == 0) {
-        n64[row] = s;
-        n32[row] = (float)s;
-        inorm32[row] = s > 0.0 ? (float)(1.0 / sqrt(s)) : 0.0f;
-        // squared norms are >= 0: their bit patterns order like the values
-        if (s == s) atomicMax(nmax_bits, (unsigned long long)__double_as_longlong(s));
-        if (s > 0.0 && s < 1.0e308) atomicMin(nmin_bits, (unsigned long long)__double_as_longlong(s));
+        if (wmax != 0ull) atomicMax(nmax_bits, wmax);
+        if (wmin != ~0ull) atomicMin(nmin_bits, wmin);
     }
 }
 
@@ -87,7 +97,12 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
     unsigned long long* nmax_bits = (unsigned long long*)(flags + 2);
     unsigned long long* nmin_bits = (unsigned long long*)(flags + 4);
     const int wpb = 4;
-    const unsigned grid = (unsigned)((n + wpb - 1) / wpb);
+    int ing_cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) ing_cus = prop.multiProcessorCount;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>((n + wpb - 1) / wpb, (int64_t)ing_cus * 8);   // 32 waves per CU
     if (dtype == AS_DTYPE_F64)
         hipLaunchKernelGGL(ingest_kernel<double>, dim3(grid), dim3(64 * wpb), 0, sp->stream, (const double*)items_dev, ld,
                            n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits, nmin_bits);
@@ -1331,13 +1346,14 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         bool sym = r0 == 0 && r1 == n && (variant & 48) == 48 && ntile >= 16 && !getenv("ARROWSPACE_NO_SYM");
         // The threshold pass visits every tstride-th column tile: a row's threshold is then about its (tstride * M)-th
         // smallest key, and its transposed buffer has to hold that many entries (twice that is allocated).  Every 16th
-        // tile when the buffers fit in a sixth of the free memory, every 8th in a quarter, else the full pass.
+        // tile when the buffers fit in a sixth of the free memory, else every 8th or 4th, else the full pass.
         int tstride = std::max(1, std::min(16, ntile / 8));
         if (const char* ev = getenv("ARROWSPACE_SYM_STRIDE")) tstride = std::max(1, std::min(atoi(ev), ntile / 8));
         {
             size_t mfree = 0, mtotal = 0;
             if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-                if (tstride > 8 && (double)n * 2 * tstride * M * 8.0 > (double)mfree / 6) tstride = 8;
+                // a denser sample means tighter thresholds and smaller buffers (and a dearer threshold pass): 16, 8, 4
+                while (tstride > 4 && (double)n * 2 * tstride * M * 8.0 > (double)mfree / 6) tstride /= 2;
                 if ((double)n * 2 * tstride * M * 8.0 > 0.25 * (double)mfree) sym = false;
             }
         }
