@@ -198,6 +198,7 @@ struct KnnArgs {
     // transposed appends of the symmetric mode use the column item's.  out_thr: the row bounds a pass ends with.
     // Column tiles visited: tile index * tstride + tphase (a strided sample of the columns for the threshold pass).
     const float* thr0 = nullptr;
+    float* thr_pub = nullptr;   // == thr0 when the running bounds are published back during the symmetric main pass
     float* out_thr = nullptr;
     int tstride = 1, tphase = 0;
 };
@@ -211,7 +212,7 @@ __device__ __forceinline__ int ld_l2(const int* p) { return __hip_atomic_load(p,
 
 // keep the M smallest (key, idx) of the row's cnt buffered candidates; wave-cooperative
 __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, float* ck, int* ci, int* s_cur,
-                                            float* s_thr, int* s_drop, int tstride = 1) {
+                                            float* s_thr, int* s_drop, int tstride = 1, float* pub = nullptr) {
     const int lane = lane_id();
     AS_CBAR();
     const int cnt = s_cur[rl];
@@ -229,7 +230,13 @@ __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, f
         if (rank < M) {
             bk[rank] = k;
             bi[rank] = i;
-            if (rank == M - 1) s_thr[rl * tstride] = k;
+            if (rank == M - 1) {
+                s_thr[rl * tstride] = k;
+                // symmetric mode: the row's new bound -- the M-th smallest key of a subset of its columns, an upper bound
+                // of its M-th smallest over all of them -- is published for the blocks that hold this item as a column
+                // (non-negative floats order like their bit patterns; a stale read is only less tight)
+                if (pub) atomicMin((int*)pub, __float_as_int(fmaxf(k, 0.0f)));
+            }
         }
     }
     if (lane == 0) {
@@ -744,7 +751,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
                 int dropped = 0;
                 if (a.thr0 && valid) {
-                    const float t0r = a.thr0[rg];
+                    const float t0r = ld_l2(a.thr0 + rg);   // possibly tightened by other units of this row since the threshold pass
                     if (t0r < bound) {   // what the tighter start rejects is beyond the row's M-th smallest key: a drop
                         bound = t0r;
                         dropped = 1;
@@ -848,7 +855,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 while (need) {
                     const int r = __ffsll((long long)need) - 1;
                     const unsigned rr = w * 32 + r;
-                    compact_row(rr, a.M, bkey + rr * CAP, bidx + rr * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
+                    compact_row(rr, a.M, bkey + rr * CAP, bidx + rr * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2,
+                                SYM && a.thr_pub ? a.thr_pub + (rowbase + rr) : nullptr);
                     need &= need - 1;
                 }
                 AS_CBAR();
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn) {
                 cb[nn] = !transp || cj[nn] >= (int)a.n ? -finf : (METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (nj[nn] + a.nmax) : a.epskey + a.coef);
-                if (transp && a.thr0 && cj[nn] < (int)a.n) cb[nn] = fminf(cb[nn], a.thr0[cj[nn]]);
+                if (transp && a.thr0 && cj[nn] < (int)a.n) cb[nn] = fminf(cb[nn], ld_l2(a.thr0 + cj[nn]));   // live: past this XCD's L2
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -927,7 +935,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const unsigned rl = w * 32 + r;
             const int64_t rg = rowbase + rl;
             if (rg >= a.r1) break;
-            if (!COLLECT && s_cur[rl] > a.M) compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2);
+            if (!COLLECT && s_cur[rl] > a.M)
+                compact_row(rl, a.M, bkey + rl * CAP, bidx + rl * CAP, ck, ci, s_cur, (float*)s_ta, s_drop, 2,
+                            SYM && a.thr_pub ? a.thr_pub + rg : nullptr);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int cnt = s_cur[rl];
             const size_t ob = ((size_t)(rg - a.r0) * a.S + cs) * a.M;
@@ -1233,6 +1243,15 @@ __global__ __launch_bounds__(256) void knn_band_refine_kernel(BandArgs a) {
 }
 
 // ---- symmetric mode helpers
+// threshold pass, S = 1: rows whose candidate count in the sampled columns exceeds `limit` (or that compacted: >= M)
+__global__ void sym_risk_kernel(const int* __restrict__ c_cnt, int64_t rows, int limit, int* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cc = i < rows ? c_cnt[i] : 0;
+    const bool risky = (cc & 0xffff) > limit || ((cc >> 30) & 1);
+    const unsigned long long m = __ballot(risky);
+    if (lane_id() == 0 && m) atomicAdd(out, __popcll(m));
+}
+
 // A row's transposed buffer -> the M smallest by (key32, id) as one more segment of its candidate lists; bit 30 of the
 // count: something was dropped (all of it beyond the M-th kept key); bit 31: the buffer overflowed (unbounded loss).
 __global__ __launch_bounds__(256) void transposed_compact_kernel(const int* __restrict__ t_cnt, const float* __restrict__ t_key,
@@ -1344,20 +1363,20 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         // transposed buffers.  Decided from a sample of the pair distribution: the buffers must hold what eps admits.
         // (from 16 column tiles on: below that the threshold pass costs what the triangle saves)
         bool sym = r0 == 0 && r1 == n && (variant & 48) == 48 && ntile >= 16 && !getenv("ARROWSPACE_NO_SYM");
-        // The threshold pass visits every tstride-th column tile: a row's threshold is then about its (tstride * M)-th
-        // smallest key, and its transposed buffer has to hold that many entries (twice that is allocated).  Every 16th
-        // tile when the buffers fit in a sixth of the free memory, else every 8th or 4th, else the full pass.
-        int tstride = std::max(1, std::min(16, ntile / 8));
-        if (const char* ev = getenv("ARROWSPACE_SYM_STRIDE")) tstride = std::max(1, std::min(atoi(ev), ntile / 8));
-        {
-            size_t mfree = 0, mtotal = 0;
-            if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-                // a denser sample means tighter thresholds and smaller buffers (and a dearer threshold pass): 16, 8, 4
-                while (tstride > 4 && (double)n * 2 * tstride * M * 8.0 > (double)mfree / 6) tstride /= 2;
-                if ((double)n * 2 * tstride * M * 8.0 > 0.25 * (double)mfree) sym = false;
-            }
-        }
-        const int T_CAP = 2 * tstride * M;
+        // The threshold pass visits every tstride-th column tile; a row's threshold is then about its (tstride * M)-th
+        // smallest key, and its transposed buffer receives about tstride * (its sampled columns inside the threshold)
+        // entries.  Every 64th tile with 16 M entries per item first (an eps that prunes keeps most rows' counts small:
+        // no row flagged at 1M x 768, mean eps-degree 120); if the sample says more than 0.5 % of the rows would not
+        // fit -- an eps that admits every pair -- the pass is redone at every 16th tile with 32 M entries.  The buffers
+        // must fit in a quarter of the free memory, else the full pass.
+        int tstride = std::max(1, std::min(64, ntile / 8));
+        const char* ev_stride = getenv("ARROWSPACE_SYM_STRIDE");
+        if (ev_stride) tstride = std::max(1, std::min(atoi(ev_stride), ntile / 8));
+        const char* ev_tcap = getenv("ARROWSPACE_SYM_TCAP");
+        const bool publish = !getenv("ARROWSPACE_SYM_NO_PUBLISH");
+        int T_CAP = ev_tcap ? atoi(ev_tcap) : 16 * M;
+        size_t mfree = 0, mtotal = 0;
+        if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)n * T_CAP * 8.0 > 0.25 * (double)mfree) sym = false;
         std::vector<int4> hunits;
         dev_tmp<int4> d_units;
         dev_tmp<int> tr_cnt, tr_idx;
@@ -1380,11 +1399,9 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             for (const int4& u : hunits) sym_tiles += u.z - u.y;
             AS_HIP(d_units.alloc(hunits.size() + 1));
             AS_HIP(hipMemcpyAsync(d_units, hunits.data(), sizeof(int4) * hunits.size(), hipMemcpyHostToDevice, st));
-            AS_HIP(tr_cnt.alloc(n + 1));
-            AS_HIP(tr_key.alloc((size_t)n * T_CAP));
-            AS_HIP(tr_idx.alloc((size_t)n * T_CAP));
+            AS_HIP(tr_cnt.alloc(n + 2));   // per-item counters, the unit cursor, the count of rows at risk
             AS_HIP(thr0.alloc(n));
-            AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (n + 1), st));
+            AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (n + 2), st));
         }
         const int units = sym ? (int)hunits.size() : nrb * S;
         const int grid = std::min(units, dev_cus * 2);
@@ -1405,8 +1422,8 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
         ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = 0; ka.col_goff = 0; ka.a_ids = nullptr; ka.a_thr = nullptr;
         ka.units = nullptr; ka.nunits = 0; ka.unit_ctr = nullptr; ka.t_cnt = nullptr; ka.t_key = nullptr; ka.t_idx = nullptr; ka.t_cap = 0;
-        if (sym) {
-            ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + n; ka.t_cnt = tr_cnt; ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
+        if (sym) {   // (the transposed buffers are allocated once the threshold pass has settled their size)
+            ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + n; ka.t_cnt = tr_cnt;
         }
         dev_events<3> ev;
         AS_HIP(ev.create());
@@ -1420,17 +1437,38 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
                 // threshold pass: every row against every tstride-th column tile (S = 1; the lists are not used): the
                 // bound a row ends with -- the M-th smallest key it saw there, or its eps bound -- is an upper bound of
                 // its M-th smallest key over all columns
-                KnnArgs k0 = ka;
-                k0.units = nullptr; k0.nunits = 0; k0.unit_ctr = nullptr; k0.t_cnt = nullptr; k0.t_key = nullptr; k0.t_idx = nullptr; k0.t_cap = 0;
-                k0.S = 1; k0.tstride = tstride; k0.tphase = 0; k0.ntile = (ntile + tstride - 1) / tstride; k0.thr0 = nullptr; k0.out_thr = thr0;
-                thr_tiles = (double)nrb * k0.ntile;
-                if (metric == AS_METRIC_L2)
-                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
-                else
-                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
-                AS_HIP(hipGetLastError());
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    KnnArgs k0 = ka;
+                    k0.units = nullptr; k0.nunits = 0; k0.unit_ctr = nullptr; k0.t_cnt = nullptr; k0.t_key = nullptr; k0.t_idx = nullptr; k0.t_cap = 0;
+                    k0.S = 1; k0.tstride = tstride; k0.tphase = 0; k0.ntile = (ntile + tstride - 1) / tstride; k0.thr0 = nullptr; k0.out_thr = thr0;
+                    thr_tiles += (double)nrb * k0.ntile;
+                    if (metric == AS_METRIC_L2)
+                        hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
+                    else
+                        hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
+                    AS_HIP(hipGetLastError());
+                    if (attempt == 1 || ev_stride || ev_tcap || tstride <= 16) break;
+                    // rows whose sampled count says their transposed buffer would not hold what the main pass sends
+                    hipLaunchKernelGGL(sym_risk_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const int*)ccnt, rows,
+                                       T_CAP / tstride, (int*)tr_cnt + n + 1);
+                    AS_HIP(hipGetLastError());
+                    int risky = 0;
+                    AS_HIP(hipMemcpyAsync(&risky, tr_cnt + n + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                    AS_HIP(hipStreamSynchronize(st));
+                    dbg("knn_rows: threshold pass at every %dth tile: %d of %lld rows would overflow %d-entry buffers", tstride, risky,
+                        (long long)rows, T_CAP);
+                    if ((double)risky <= 0.005 * (double)rows) break;
+                    // (when the larger buffers do not fit, the rows that overflow go to the band pass instead)
+                    if (mfree && (double)n * 32 * M * 8.0 > 0.25 * (double)mfree) break;
+                    tstride = 16;
+                    T_CAP = 32 * M;
+                }
+                AS_HIP(tr_key.alloc((size_t)n * T_CAP));
+                AS_HIP(tr_idx.alloc((size_t)n * T_CAP));
+                ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
                 AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));   // the pass above left its counts there
                 ka.thr0 = thr0;
+                ka.thr_pub = publish ? (float*)thr0 : nullptr;
                 AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
                 AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
                 if (metric == AS_METRIC_L2)
@@ -1440,6 +1478,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
                 AS_HIP(hipGetLastError());
                 // the transposed buffers become segment S - 1 of every row's candidate lists
                 const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
+                AS_HIP(hipFuncSetAttribute((const void*)transposed_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
                 hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt,
                                    (const float*)tr_key, (const int*)tr_idx, T_CAP, rows, S, S - 1, M, (float*)ckey, (int*)cidx, (int*)ccnt);
             } else if (metric == AS_METRIC_L2)
