@@ -123,6 +123,23 @@ int64_t as_space_row_offset(const as_space* sp);      /* global index of row 0 (
 as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
                        int64_t row_goff, int64_t col_goff, double* p_key_dev, double* p_dist_dev, double* p_gy_dev,
                        int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev);
+/* Symmetric ring: an unordered pair of blocks is computed ONCE.  as_knn_block_pair runs the own rows
+ * [row_begin, row_end) against the visiting block's column tiles [col_tile_begin, col_tile_end) (128 items each; -1 /
+ * -1 = all) and lets every key serve both items: p_* is the own rows' slice exactly as as_knn_block's (indexed from
+ * row_begin), q_* the slice of ALL visiting items [cols nitems][M] with the own rows as their columns (ids global),
+ * refined here while both shards are resident, to be sent home and folded there (as_knn_fold with the sender's
+ * block_nmax).  A visiting item's candidates are admitted up to min(eps bound, col_thr_dev[item]); q_t32 carries the
+ * bound of what was turned away (-inf when its buffer overflowed: the item fails its proof and takes the second
+ * round).  as_knn_thresholds derives such thresholds from a rank's folded list (an upper bound of each row's M-th
+ * smallest fp32 key over all columns: its M-th exact key so far + the error bound; +inf while the list is not full);
+ * nmax_all = the largest squared norm of the whole index. */
+as_status as_knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                            int64_t col_tile_begin, int64_t col_tile_end, int64_t row_goff, int64_t col_goff,
+                            const float* col_thr_dev, double* p_key_dev, double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev,
+                            int32_t* p_cnt_dev, float* p_t32_dev, double* q_key_dev, double* q_dist_dev, double* q_gy_dev,
+                            int32_t* q_idx_dev, int32_t* q_cnt_dev, float* q_t32_dev);
+as_status as_knn_thresholds(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, double nmax_all,
+                            const double* r_key_dev, const int32_t* r_cnt_dev, float* out_thr_dev);
 as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t nblocks,
                        const double* p_key_dev, const double* p_dist_dev, const double* p_gy_dev, const int32_t* p_idx_dev,
                        const int32_t* p_cnt_dev, const float* p_t32_dev, const double* block_nmax_host, int32_t* out_idx_dev,

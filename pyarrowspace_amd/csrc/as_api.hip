@@ -336,6 +336,52 @@ as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_
     return s;
 }
 
+as_status as_knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                            int64_t col_tile_begin, int64_t col_tile_end, int64_t row_goff, int64_t col_goff, const float* col_thr_dev,
+                            double* p_key_dev, double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev,
+                            double* q_key_dev, double* q_dist_dev, double* q_gy_dev, int32_t* q_idx_dev, int32_t* q_cnt_dev, float* q_t32_dev) {
+    if (!sp || !cols || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev || !q_key_dev || !q_dist_dev ||
+        !q_gy_dev || !q_idx_dev || !q_cnt_dev || !q_t32_dev) {
+        set_err("as_knn_block_pair: null argument");
+        return AS_EINVAL;
+    }
+    if (sp == cols) {
+        set_err("as_knn_block_pair: a block is not paired with itself (as_knn_block)");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    const int M = knn_list_width(r.k);
+    if (M < 0) {
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 56", (long long)r.k);
+        return AS_EUNSUPPORTED;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    const double t0 = now_s();
+    const as_status s = knn_block_pair(sp, cols, &r, row_begin, row_end, col_tile_begin, col_tile_end, row_goff, col_goff, col_thr_dev, M,
+                                       p_key_dev, p_dist_dev, p_gy_dev, p_idx_dev, p_cnt_dev, p_t32_dev, q_key_dev, q_dist_dev, q_gy_dev,
+                                       q_idx_dev, q_cnt_dev, q_t32_dev);
+    sp->kstats[1] += now_s() - t0;
+    return s;
+}
+
+as_status as_knn_thresholds(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, double nmax_all,
+                            const double* r_key_dev, const int32_t* r_cnt_dev, float* out_thr_dev) {
+    if (!sp || !r_key_dev || !r_cnt_dev || !out_thr_dev || row_begin < 0 || row_end > sp->n || row_begin > row_end) {
+        set_err("as_knn_thresholds: null argument or bad row range");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    const int M = knn_list_width(r.k);
+    if (M < 0) {
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 56", (long long)r.k);
+        return AS_EUNSUPPORTED;
+    }
+    AS_HIP(hipSetDevice(sp->device));
+    return knn_thresholds(sp, row_begin, row_end, M, nmax_all, r_key_dev, r_cnt_dev, out_thr_dev);
+}
+
 as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t nblocks,
                        const double* p_key_dev, const double* p_dist_dev, const double* p_gy_dev, const int32_t* p_idx_dev,
                        const int32_t* p_cnt_dev, const float* p_t32_dev, const double* block_nmax_host, int32_t* out_idx_dev,

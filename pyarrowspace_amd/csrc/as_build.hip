@@ -198,6 +198,8 @@ struct KnnArgs {
     // transposed appends of the symmetric mode use the column item's.  out_thr: the row bounds a pass ends with.
     // Column tiles visited: tile index * tstride + tphase (a strided sample of the columns for the threshold pass).
     const float* thr0 = nullptr;
+    const float* thr_col = nullptr;   // the column items' thresholds (== thr0 in a self build; a visiting block's on the ring)
+    int t_all = 0;                    // block pairs: every tile is "above the diagonal" (rows and columns are different items)
     float* thr_pub = nullptr;   // == thr0 when the running bounds are published back during the symmetric main pass
     float* out_thr = nullptr;
     int tstride = 1, tphase = 0;
@@ -865,12 +867,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bool edge = COLLECT || colbase + BN > a.n || (colg < rowg + BM && colg + BN > rowg);
             // symmetric mode: tiles strictly above the row block also serve the column items' rows (the diagonal tiles
             // hold both (i, j) and (j, i) themselves)
-            const bool transp = SYM && colbase >= rowbase + BM;
+            const bool transp = SYM && a.t_cnt && (a.t_all || colbase >= rowbase + BM);
             float cb[4];
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn) {
                 cb[nn] = !transp || cj[nn] >= (int)a.n ? -finf : (METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (nj[nn] + a.nmax) : a.epskey + a.coef);
-                if (transp && a.thr0 && cj[nn] < (int)a.n) cb[nn] = fminf(cb[nn], ld_l2(a.thr0 + cj[nn]));   // live: past this XCD's L2
+                if (transp && a.thr_col && cj[nn] < (int)a.n) cb[nn] = fminf(cb[nn], ld_l2(a.thr_col + cj[nn]));   // live: past this XCD's L2
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1254,10 +1256,14 @@ __global__ void sym_risk_kernel(const int* __restrict__ c_cnt, int64_t rows, int
 
 // A row's transposed buffer -> the M smallest by (key32, id) as one more segment of its candidate lists; bit 30 of the
 // count: something was dropped (all of it beyond the M-th kept key); bit 31: the buffer overflowed (unbounded loss).
+// gate / out_bound (block pairs, ring): gate[row] is the threshold the appends were admitted with, +inf where it was the
+// eps bound alone; out_bound[row] is then a lower bound of every key the buffer did NOT keep -- the M-th kept key after
+// a compaction, else the gate -- and bit 30 says that such keys may exist; an overflowed buffer gets -inf.
 __global__ __launch_bounds__(256) void transposed_compact_kernel(const int* __restrict__ t_cnt, const float* __restrict__ t_key,
                                                                  const int* __restrict__ t_idx, int t_cap, int64_t rows, int S, int seg,
                                                                  int M, float* __restrict__ c_key, int* __restrict__ c_idx,
-                                                                 int* __restrict__ c_cnt) {
+                                                                 int* __restrict__ c_cnt, const float* __restrict__ gate = nullptr,
+                                                                 float* __restrict__ out_bound = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = threadIdx.x >> 6, lane = lane_id();
     float* ck = (float*)smem + (size_t)w * t_cap;
@@ -1282,9 +1288,21 @@ __global__ __launch_bounds__(256) void transposed_compact_kernel(const int* __re
             c_idx[ob + rank] = i;
         }
     }
+    float kth = 0.0f;   // the M-th kept key: the rank loop above wrote it
+    if (out_bound && cnt > M) {
+        for (int t = lane; t < cnt; t += 64) {
+            int rank = 0;
+            for (int s2 = 0; s2 < cnt; ++s2) rank += lex_less<float>(ck[s2], ci[s2], ck[t], ci[t]) ? 1 : 0;
+            if (rank == M - 1) kth = ck[t];
+        }
+        kth = wave_sum(kth);   // exactly one lane holds it
+    }
     if (lane == 0) {
         const unsigned kept = (unsigned)(cnt < M ? cnt : M);
-        c_cnt[(size_t)row * S + seg] = (int)(kept | (cnt > M ? 1u << 30 : 0u) | (raw > t_cap ? 1u << 31 : 0u));
+        const float g = gate ? gate[row] : __int_as_float(0x7f800000);
+        const bool gated = g < __int_as_float(0x7f800000);
+        c_cnt[(size_t)row * S + seg] = (int)(kept | ((cnt > M || (out_bound && gated)) ? 1u << 30 : 0u) | (raw > t_cap ? 1u << 31 : 0u));
+        if (out_bound) out_bound[row] = raw > t_cap ? -__int_as_float(0x7f800000) : (cnt > M ? kth : g);
     }
 }
 
@@ -1296,6 +1314,225 @@ static int pick_list_width(int64_t k) {
     return -1;
 }
 int knn_list_width(int64_t k) { return pick_list_width(k); }
+
+// First pass of the k-NN stage for the rows [r0, r1) of a space against all of its items: the candidate lists
+// c.ckey / c.cidx / c.ccnt ([rows][c.S][M], ids global: column + col_goff) that a refinement turns into exact lists.
+// A whole-space pass runs in symmetric mode (threshold pass, upper-triangle tiles, transposed buffers as one more
+// segment); row ranges run the full pass.  Shared by as_knn_rows and the ring's own-block step.
+struct KnnCand {
+    dev_tmp<float> bkey, ckey;
+    dev_tmp<int> bidx, cidx, ccnt;
+    KnnArgs ka;
+    int S = 1, grid = 0, dev_cus = 256, ntile = 0, nrb = 0, units = 0;
+    bool sym = false;
+    double flops = 0, t_mfma = 0;
+};
+
+static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int M, int64_t row_goff,
+                                int64_t col_goff, KnnCand& c) {
+    const int64_t n = sp->n, rows = r1 - r0;
+    hipStream_t st = sp->stream;
+    const int metric = sp->opts.metric;
+    const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
+    const double coef = err_coef(sp->dp);
+    const int nrb = (int)((rows + BM - 1) / BM);
+    const int ntile = (int)(sp->np / BN);
+    // default: 8-wave LDS-DMA kernel (48); 32 = 4-wave LDS-DMA; 0..31 = register-staged kernel and its A/B variants
+    int variant = 48;
+    if (const char* ev = getenv("ARROWSPACE_KNN_VARIANT")) variant = atoi(ev) & 63;
+    int S = 1;
+    {   // enough units to fill the chip several times over, but never thinner than 8 column tiles
+        int dev_cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
+        // an eps that admits (nearly) every pair -- `eps: 10` of tests/test_3_beir.py under the cosine distance -- makes
+        // every column segment converge its rows' bounds from scratch (all tiles pass until the lists have settled):
+        // fewer, longer segments then (61 -> TF/s at 200k x 768 with 8 segments)
+        const bool loose = metric == AS_METRIC_COSINE ? gp->eps >= 1.0 : gp->eps * gp->eps >= 4.0 * sp->nmax;
+        const int target_units = dev_cus * (loose ? 2 : 16);
+        while (S < 8 && nrb * S < target_units && ntile / (S * 2) >= 8) S *= 2;
+        if ((variant & 1) && !(variant & 32) && ntile >= 64) S = 8;  // XCD-grouped order: 4 row blocks x 8 column segments per XCD
+    }
+    int dev_cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
+    }
+    // ---- symmetric mode: a whole-index build whose eps admits few pairs computes only the tiles at or above each
+    // row block (half the MFMA work); the keys above the diagonal reach the column items' rows through
+    // transposed buffers.  Decided from a sample of the pair distribution: the buffers must hold what eps admits.
+    // (from 16 column tiles on: below that the threshold pass costs what the triangle saves)
+    bool sym = r0 == 0 && r1 == n && (variant & 48) == 48 && ntile >= 16 && !getenv("ARROWSPACE_NO_SYM");
+    // The threshold pass visits every tstride-th column tile; a row's threshold is then about its (tstride * M)-th
+    // smallest key, and its transposed buffer receives about tstride * (its sampled columns inside the threshold)
+    // entries.  Every 64th tile with 16 M entries per item first (an eps that prunes keeps most rows' counts small:
+    // no row flagged at 1M x 768, mean eps-degree 120); if the sample says more than 0.5 % of the rows would not
+    // fit -- an eps that admits every pair -- the pass is redone at every 16th tile with 32 M entries.  The buffers
+    // must fit in a quarter of the free memory, else the full pass.
+    int tstride = std::max(1, std::min(64, ntile / 8));
+    const char* ev_stride = getenv("ARROWSPACE_SYM_STRIDE");
+    if (ev_stride) tstride = std::max(1, std::min(atoi(ev_stride), ntile / 8));
+    const char* ev_tcap = getenv("ARROWSPACE_SYM_TCAP");
+    const bool publish = !getenv("ARROWSPACE_SYM_NO_PUBLISH");
+    int T_CAP = ev_tcap ? atoi(ev_tcap) : 16 * M;
+    size_t mfree = 0, mtotal = 0;
+    if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)n * T_CAP * 8.0 > 0.25 * (double)mfree) sym = false;
+    std::vector<int4> hunits;
+    dev_tmp<int4> d_units;
+    dev_tmp<int> tr_cnt, tr_idx;
+    dev_tmp<float> tr_key, thr0;
+    double sym_tiles = 0, thr_tiles = 0;
+    if (sym) {
+        // units: every row block's tiles [rb * BM / BN, ntile) in pieces of at most L tiles, longest first
+        const int per = BM / BN;
+        double total = 0;
+        for (int rb = 0; rb < nrb; ++rb) total += std::max(0, ntile - rb * per);
+        int L = (int)std::max<double>(8.0, std::ceil(total / (dev_cus * 16.0)));
+        if ((ntile + L - 1) / L > 7) L = (ntile + 6) / 7;   // at most 7 own segments + the transposed one
+        S = (ntile + L - 1) / L + 1;
+        for (int rb = 0; rb < nrb; ++rb) {
+            const int tlo = rb * per;
+            int seg = 0;
+            for (int t = tlo; t < ntile; t += L, ++seg) hunits.push_back(make_int4(rb, t, std::min(ntile, t + L), seg));
+        }
+        std::stable_sort(hunits.begin(), hunits.end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
+        for (const int4& u : hunits) sym_tiles += u.z - u.y;
+        AS_HIP(d_units.alloc(hunits.size() + 1));
+        AS_HIP(hipMemcpyAsync(d_units, hunits.data(), sizeof(int4) * hunits.size(), hipMemcpyHostToDevice, st));
+        AS_HIP(tr_cnt.alloc(n + 2));   // per-item counters, the unit cursor, the count of rows at risk
+        AS_HIP(thr0.alloc(n));
+        AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (n + 2), st));
+    }
+    const int units = sym ? (int)hunits.size() : nrb * S;
+    const int grid = std::min(units, dev_cus * 2);
+    dev_tmp<float>& bkey = c.bkey; dev_tmp<float>& ckey = c.ckey;
+    dev_tmp<int>& bidx = c.bidx; dev_tmp<int>& cidx = c.cidx; dev_tmp<int>& ccnt = c.ccnt;
+    AS_HIP(bkey.alloc((size_t)grid * BM * CAP));
+    AS_HIP(bidx.alloc((size_t)grid * BM * CAP));
+    AS_HIP(ckey.alloc((size_t)rows * S * M));
+    AS_HIP(cidx.alloc((size_t)rows * S * M));
+    AS_HIP(ccnt.alloc((size_t)rows * S));
+    KnnArgs& ka = c.ka;
+    ka.x32 = sp->x32; ka.n32 = sp->n32; ka.inorm32 = sp->inorm32;
+    ka.n = n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+    ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
+    ka.epskey = (float)epskey; ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(sp->nmax * 1.0000002);
+    // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
+    ka.epskey = nextafterf(ka.epskey, INFINITY);
+    ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
+    ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff; ka.a_ids = nullptr; ka.a_thr = nullptr;
+    ka.units = nullptr; ka.nunits = 0; ka.unit_ctr = nullptr; ka.t_cnt = nullptr; ka.t_key = nullptr; ka.t_idx = nullptr; ka.t_cap = 0;
+    if (sym) {   // (the transposed buffers are allocated once the threshold pass has settled their size)
+        ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + n; ka.t_cnt = tr_cnt;
+    }
+    dev_events<2> ev;
+    AS_HIP(ev.create());
+    hipEvent_t e0 = ev.e[0], e1 = ev.e[1];
+    if ((variant & 48) == 48) {
+        const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        AS_HIP(hipEventRecord(e0, st));
+        if (sym) {
+            // threshold pass: every row against every tstride-th column tile (S = 1; the lists are not used): the
+            // bound a row ends with -- the M-th smallest key it saw there, or its eps bound -- is an upper bound of
+            // its M-th smallest key over all columns
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                KnnArgs k0 = ka;
+                k0.units = nullptr; k0.nunits = 0; k0.unit_ctr = nullptr; k0.t_cnt = nullptr; k0.t_key = nullptr; k0.t_idx = nullptr; k0.t_cap = 0;
+                k0.S = 1; k0.tstride = tstride; k0.tphase = 0; k0.ntile = (ntile + tstride - 1) / tstride; k0.thr0 = nullptr; k0.out_thr = thr0;
+                thr_tiles += (double)nrb * k0.ntile;
+                if (metric == AS_METRIC_L2)
+                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
+                else
+                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
+                AS_HIP(hipGetLastError());
+                if (attempt == 1 || ev_stride || ev_tcap || tstride <= 16) break;
+                // rows whose sampled count says their transposed buffer would not hold what the main pass sends
+                hipLaunchKernelGGL(sym_risk_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const int*)ccnt, rows,
+                                   T_CAP / tstride, (int*)tr_cnt + n + 1);
+                AS_HIP(hipGetLastError());
+                int risky = 0;
+                AS_HIP(hipMemcpyAsync(&risky, tr_cnt + n + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                AS_HIP(hipStreamSynchronize(st));
+                dbg("knn_rows: threshold pass at every %dth tile: %d of %lld rows would overflow %d-entry buffers", tstride, risky,
+                    (long long)rows, T_CAP);
+                if ((double)risky <= 0.005 * (double)rows) break;
+                // (when the larger buffers do not fit, the rows that overflow go to the band pass instead)
+                if (mfree && (double)n * 32 * M * 8.0 > 0.25 * (double)mfree) break;
+                tstride = 16;
+                T_CAP = 32 * M;
+            }
+            AS_HIP(tr_key.alloc((size_t)n * T_CAP));
+            AS_HIP(tr_idx.alloc((size_t)n * T_CAP));
+            ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
+            AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));   // the pass above left its counts there
+            ka.thr0 = thr0;
+            ka.thr_col = thr0;
+            ka.thr_pub = publish ? (float*)thr0 : nullptr;
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            if (metric == AS_METRIC_L2)
+                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+            else
+                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+            AS_HIP(hipGetLastError());
+            // the transposed buffers become segment S - 1 of every row's candidate lists
+            const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
+            AS_HIP(hipFuncSetAttribute((const void*)transposed_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+            hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt,
+                               (const float*)tr_key, (const int*)tr_idx, T_CAP, rows, S, S - 1, M, (float*)ckey, (int*)cidx, (int*)ccnt);
+        } else if (metric == AS_METRIC_L2)
+            hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+        else
+            hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+    } else {
+#ifdef AS_ABLATION
+        const size_t lds = sizeof(float) * (BM + BN) * LROW * (((variant & 2) && !(variant & 16)) ? 2 : 1) + sizeof(float) * 4 * BM +
+                           (sizeof(float) + sizeof(int)) * 4 * CAP;
+        int lgrid = grid;
+        if ((variant & 1) && !(variant & 32)) lgrid = std::max(8, std::min(units, dev_cus) / 8 * 8);  // one resident block per CU, 8 XCD labels
+#define AS_KNN_LAUNCH(VV)                                                                                              \
+case VV:                                                                                                           \
+    AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_kernel<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    AS_HIP(hipEventRecord(e0, st));                                                                                \
+    hipLaunchKernelGGL(knn_mfma_kernel<VV>, dim3(lgrid), dim3(256), lds, st, ka);                                  \
+    break;
+        if (variant & 32) {
+            const size_t ldsd = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+            AS_HIP(hipEventRecord(e0, st));
+            if (variant & 1) hipLaunchKernelGGL(knn_mfma_dma_kernel<true>, dim3(grid), dim3(256), ldsd, st, ka);
+            else hipLaunchKernelGGL(knn_mfma_dma_kernel<false>, dim3(grid), dim3(256), ldsd, st, ka);
+        } else
+        switch (variant) {
+            AS_KNN_LAUNCH(0) AS_KNN_LAUNCH(1) AS_KNN_LAUNCH(2) AS_KNN_LAUNCH(3)
+            AS_KNN_LAUNCH(4) AS_KNN_LAUNCH(5) AS_KNN_LAUNCH(6) AS_KNN_LAUNCH(7)
+            AS_KNN_LAUNCH(8) AS_KNN_LAUNCH(16) AS_KNN_LAUNCH(24) AS_KNN_LAUNCH(10)
+            default:
+                set_err("unknown ARROWSPACE_KNN_VARIANT %d", variant);
+                return AS_EINVAL;
+        }
+#undef AS_KNN_LAUNCH
+#else
+        set_err("ARROWSPACE_KNN_VARIANT=%d selects an ablation kernel: rebuild with -DAS_ABLATION (make ABLATION=1)", variant);
+        return AS_EUNSUPPORTED;
+#endif
+    }
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipEventRecord(e1, st));
+    AS_HIP(hipEventSynchronize(e1));
+    float ms01 = 0;
+    AS_HIP(hipEventElapsedTime(&ms01, e0, e1));
+    c.t_mfma = ms01 * 1e-3;
+    // flops actually issued: the triangle's tiles in symmetric mode
+    c.flops = sym ? 2.0 * (sym_tiles + thr_tiles) * BM * BN * (double)sp->dp : 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
+    c.S = S; c.grid = grid; c.dev_cus = dev_cus; c.ntile = ntile; c.nrb = nrb; c.units = units; c.sym = sym;
+    return AS_OK;
+}
+
 
 as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int32_t* out_idx,
                    double* out_key, double* out_dist, double* out_gy, int32_t* out_cnt, double* stats) {
@@ -1335,191 +1572,20 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     int nflagged = 0, unproven = 0, band_rows = 0;
 
     if (!sp->opts.force_exact) {
-        const int nrb = (int)((rows + BM - 1) / BM);
-        const int ntile = (int)(sp->np / BN);
-        // default: 8-wave LDS-DMA kernel (48); 32 = 4-wave LDS-DMA; 0..31 = register-staged kernel and its A/B variants
-        int variant = 48;
-        if (const char* ev = getenv("ARROWSPACE_KNN_VARIANT")) variant = atoi(ev) & 63;
-        int S = 1;
-        {   // enough units to fill the chip several times over, but never thinner than 8 column tiles
-            int dev_cus = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
-            // an eps that admits (nearly) every pair -- `eps: 10` of tests/test_3_beir.py under the cosine distance -- makes
-            // every column segment converge its rows' bounds from scratch (all tiles pass until the lists have settled):
-            // fewer, longer segments then (61 -> TF/s at 200k x 768 with 8 segments)
-            const bool loose = metric == AS_METRIC_COSINE ? gp->eps >= 1.0 : gp->eps * gp->eps >= 4.0 * sp->nmax;
-            const int target_units = dev_cus * (loose ? 2 : 16);
-            while (S < 8 && nrb * S < target_units && ntile / (S * 2) >= 8) S *= 2;
-            if ((variant & 1) && !(variant & 32) && ntile >= 64) S = 8;  // XCD-grouped order: 4 row blocks x 8 column segments per XCD
-        }
-        int dev_cus = 256;
-        {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
-        }
-        // ---- symmetric mode: a whole-index build whose eps admits few pairs computes only the tiles at or above each
-        // row block (half the MFMA work); the keys above the diagonal reach the column items' rows through
-        // transposed buffers.  Decided from a sample of the pair distribution: the buffers must hold what eps admits.
-        // (from 16 column tiles on: below that the threshold pass costs what the triangle saves)
-        bool sym = r0 == 0 && r1 == n && (variant & 48) == 48 && ntile >= 16 && !getenv("ARROWSPACE_NO_SYM");
-        // The threshold pass visits every tstride-th column tile; a row's threshold is then about its (tstride * M)-th
-        // smallest key, and its transposed buffer receives about tstride * (its sampled columns inside the threshold)
-        // entries.  Every 64th tile with 16 M entries per item first (an eps that prunes keeps most rows' counts small:
-        // no row flagged at 1M x 768, mean eps-degree 120); if the sample says more than 0.5 % of the rows would not
-        // fit -- an eps that admits every pair -- the pass is redone at every 16th tile with 32 M entries.  The buffers
-        // must fit in a quarter of the free memory, else the full pass.
-        int tstride = std::max(1, std::min(64, ntile / 8));
-        const char* ev_stride = getenv("ARROWSPACE_SYM_STRIDE");
-        if (ev_stride) tstride = std::max(1, std::min(atoi(ev_stride), ntile / 8));
-        const char* ev_tcap = getenv("ARROWSPACE_SYM_TCAP");
-        const bool publish = !getenv("ARROWSPACE_SYM_NO_PUBLISH");
-        int T_CAP = ev_tcap ? atoi(ev_tcap) : 16 * M;
-        size_t mfree = 0, mtotal = 0;
-        if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)n * T_CAP * 8.0 > 0.25 * (double)mfree) sym = false;
-        std::vector<int4> hunits;
-        dev_tmp<int4> d_units;
-        dev_tmp<int> tr_cnt, tr_idx;
-        dev_tmp<float> tr_key, thr0;
-        double sym_tiles = 0, thr_tiles = 0;
-        if (sym) {
-            // units: every row block's tiles [rb * BM / BN, ntile) in pieces of at most L tiles, longest first
-            const int per = BM / BN;
-            double total = 0;
-            for (int rb = 0; rb < nrb; ++rb) total += std::max(0, ntile - rb * per);
-            int L = (int)std::max<double>(8.0, std::ceil(total / (dev_cus * 16.0)));
-            if ((ntile + L - 1) / L > 7) L = (ntile + 6) / 7;   // at most 7 own segments + the transposed one
-            S = (ntile + L - 1) / L + 1;
-            for (int rb = 0; rb < nrb; ++rb) {
-                const int tlo = rb * per;
-                int seg = 0;
-                for (int t = tlo; t < ntile; t += L, ++seg) hunits.push_back(make_int4(rb, t, std::min(ntile, t + L), seg));
-            }
-            std::stable_sort(hunits.begin(), hunits.end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
-            for (const int4& u : hunits) sym_tiles += u.z - u.y;
-            AS_HIP(d_units.alloc(hunits.size() + 1));
-            AS_HIP(hipMemcpyAsync(d_units, hunits.data(), sizeof(int4) * hunits.size(), hipMemcpyHostToDevice, st));
-            AS_HIP(tr_cnt.alloc(n + 2));   // per-item counters, the unit cursor, the count of rows at risk
-            AS_HIP(thr0.alloc(n));
-            AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (n + 2), st));
-        }
-        const int units = sym ? (int)hunits.size() : nrb * S;
-        const int grid = std::min(units, dev_cus * 2);
-        dev_tmp<float> bkey, ckey;
-        dev_tmp<int> bidx, cidx, ccnt;
-        AS_HIP(bkey.alloc((size_t)grid * BM * CAP));
-        AS_HIP(bidx.alloc((size_t)grid * BM * CAP));
-        AS_HIP(ckey.alloc((size_t)rows * S * M));
-        AS_HIP(cidx.alloc((size_t)rows * S * M));
-        AS_HIP(ccnt.alloc((size_t)rows * S));
-        KnnArgs ka;
-        ka.x32 = sp->x32; ka.n32 = sp->n32; ka.inorm32 = sp->inorm32;
-        ka.n = n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
-        ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
-        ka.epskey = (float)epskey; ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(sp->nmax * 1.0000002);
-        // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
-        ka.epskey = nextafterf(ka.epskey, INFINITY);
-        ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-        ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = 0; ka.col_goff = 0; ka.a_ids = nullptr; ka.a_thr = nullptr;
-        ka.units = nullptr; ka.nunits = 0; ka.unit_ctr = nullptr; ka.t_cnt = nullptr; ka.t_key = nullptr; ka.t_idx = nullptr; ka.t_cap = 0;
-        if (sym) {   // (the transposed buffers are allocated once the threshold pass has settled their size)
-            ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + n; ka.t_cnt = tr_cnt;
-        }
-        dev_events<3> ev;
+        KnnCand cand;
+        AS_TRY(knn_candidates(sp, gp, r0, r1, M, 0, 0, cand));
+        const int S = cand.S, grid = cand.grid, dev_cus = cand.dev_cus, ntile = cand.ntile, units = cand.units;
+        const bool sym = cand.sym;
+        dev_tmp<float>& ckey = cand.ckey;
+        dev_tmp<int>& cidx = cand.cidx;
+        dev_tmp<int>& ccnt = cand.ccnt;
+        dev_tmp<float>& bkey = cand.bkey;
+        dev_tmp<int>& bidx = cand.bidx;
+        KnnArgs& ka = cand.ka;
+        (void)bkey; (void)bidx;
+        dev_events<2> ev;
         AS_HIP(ev.create());
-        hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
-        if ((variant & 48) == 48) {
-            const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
-            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-            AS_HIP(hipEventRecord(e0, st));
-            if (sym) {
-                // threshold pass: every row against every tstride-th column tile (S = 1; the lists are not used): the
-                // bound a row ends with -- the M-th smallest key it saw there, or its eps bound -- is an upper bound of
-                // its M-th smallest key over all columns
-                for (int attempt = 0; attempt < 2; ++attempt) {
-                    KnnArgs k0 = ka;
-                    k0.units = nullptr; k0.nunits = 0; k0.unit_ctr = nullptr; k0.t_cnt = nullptr; k0.t_key = nullptr; k0.t_idx = nullptr; k0.t_cap = 0;
-                    k0.S = 1; k0.tstride = tstride; k0.tphase = 0; k0.ntile = (ntile + tstride - 1) / tstride; k0.thr0 = nullptr; k0.out_thr = thr0;
-                    thr_tiles += (double)nrb * k0.ntile;
-                    if (metric == AS_METRIC_L2)
-                        hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
-                    else
-                        hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
-                    AS_HIP(hipGetLastError());
-                    if (attempt == 1 || ev_stride || ev_tcap || tstride <= 16) break;
-                    // rows whose sampled count says their transposed buffer would not hold what the main pass sends
-                    hipLaunchKernelGGL(sym_risk_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const int*)ccnt, rows,
-                                       T_CAP / tstride, (int*)tr_cnt + n + 1);
-                    AS_HIP(hipGetLastError());
-                    int risky = 0;
-                    AS_HIP(hipMemcpyAsync(&risky, tr_cnt + n + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-                    AS_HIP(hipStreamSynchronize(st));
-                    dbg("knn_rows: threshold pass at every %dth tile: %d of %lld rows would overflow %d-entry buffers", tstride, risky,
-                        (long long)rows, T_CAP);
-                    if ((double)risky <= 0.005 * (double)rows) break;
-                    // (when the larger buffers do not fit, the rows that overflow go to the band pass instead)
-                    if (mfree && (double)n * 32 * M * 8.0 > 0.25 * (double)mfree) break;
-                    tstride = 16;
-                    T_CAP = 32 * M;
-                }
-                AS_HIP(tr_key.alloc((size_t)n * T_CAP));
-                AS_HIP(tr_idx.alloc((size_t)n * T_CAP));
-                ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
-                AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));   // the pass above left its counts there
-                ka.thr0 = thr0;
-                ka.thr_pub = publish ? (float*)thr0 : nullptr;
-                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-                if (metric == AS_METRIC_L2)
-                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-                else
-                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-                AS_HIP(hipGetLastError());
-                // the transposed buffers become segment S - 1 of every row's candidate lists
-                const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
-                AS_HIP(hipFuncSetAttribute((const void*)transposed_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
-                hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt,
-                                   (const float*)tr_key, (const int*)tr_idx, T_CAP, rows, S, S - 1, M, (float*)ckey, (int*)cidx, (int*)ccnt);
-            } else if (metric == AS_METRIC_L2)
-                hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-            else
-                hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-        } else {
-#ifdef AS_ABLATION
-            const size_t lds = sizeof(float) * (BM + BN) * LROW * (((variant & 2) && !(variant & 16)) ? 2 : 1) + sizeof(float) * 4 * BM +
-                               (sizeof(float) + sizeof(int)) * 4 * CAP;
-            int lgrid = grid;
-            if ((variant & 1) && !(variant & 32)) lgrid = std::max(8, std::min(units, dev_cus) / 8 * 8);  // one resident block per CU, 8 XCD labels
-#define AS_KNN_LAUNCH(VV)                                                                                              \
-    case VV:                                                                                                           \
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_kernel<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        AS_HIP(hipEventRecord(e0, st));                                                                                \
-        hipLaunchKernelGGL(knn_mfma_kernel<VV>, dim3(lgrid), dim3(256), lds, st, ka);                                  \
-        break;
-            if (variant & 32) {
-                const size_t ldsd = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 2 * BM + (sizeof(float) + sizeof(int)) * 4 * CAP;
-                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
-                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
-                AS_HIP(hipEventRecord(e0, st));
-                if (variant & 1) hipLaunchKernelGGL(knn_mfma_dma_kernel<true>, dim3(grid), dim3(256), ldsd, st, ka);
-                else hipLaunchKernelGGL(knn_mfma_dma_kernel<false>, dim3(grid), dim3(256), ldsd, st, ka);
-            } else
-            switch (variant) {
-                AS_KNN_LAUNCH(0) AS_KNN_LAUNCH(1) AS_KNN_LAUNCH(2) AS_KNN_LAUNCH(3)
-                AS_KNN_LAUNCH(4) AS_KNN_LAUNCH(5) AS_KNN_LAUNCH(6) AS_KNN_LAUNCH(7)
-                AS_KNN_LAUNCH(8) AS_KNN_LAUNCH(16) AS_KNN_LAUNCH(24) AS_KNN_LAUNCH(10)
-                default:
-                    set_err("unknown ARROWSPACE_KNN_VARIANT %d", variant);
-                    return AS_EINVAL;
-            }
-#undef AS_KNN_LAUNCH
-#else
-            set_err("ARROWSPACE_KNN_VARIANT=%d selects an ablation kernel: rebuild with -DAS_ABLATION (make ABLATION=1)", variant);
-            return AS_EUNSUPPORTED;
-#endif
-        }
-        AS_HIP(hipGetLastError());
+        hipEvent_t e1 = ev.e[0], e2 = ev.e[1];
         AS_HIP(hipEventRecord(e1, st));
         RefineArgs ra;
         ra.x32 = sp->x32; ra.x64 = sp->x64; ra.n64 = sp->n64; ra.n = n; ra.d = sp->d; ra.dp = sp->dp;
@@ -1538,12 +1604,10 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         AS_HIP(hipEventRecord(e2, st));
         AS_HIP(hipMemcpyAsync(&nflagged, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
         AS_HIP(hipStreamSynchronize(st));
-        float ms01 = 0, ms12 = 0;
-        AS_HIP(hipEventElapsedTime(&ms01, e0, e1));
+        float ms12 = 0;
         AS_HIP(hipEventElapsedTime(&ms12, e1, e2));
-        t_mfma = ms01 * 1e-3; t_ref = ms12 * 1e-3;
-        // flops actually issued: the triangle's tiles in symmetric mode
-        flops = sym ? 2.0 * (sym_tiles + thr_tiles) * BM * BN * (double)sp->dp : 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
+        t_mfma = cand.t_mfma; t_ref = ms12 * 1e-3;
+        flops = cand.flops;
         dbg("knn_rows: rows=%lld %s S=%d M=%d units=%d mfma=%.3fs (%.1f TF/s issued) refine=%.3fs flagged=%d", (long long)rows,
             sym ? "symmetric" : "full", S, M, units, t_mfma, flops / std::max(t_mfma, 1e-9) * 1e-12, t_ref, nflagged);
         if (nflagged > 0 && !getenv("ARROWSPACE_NO_BAND_PASS")) {
@@ -1578,7 +1642,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             AS_HIP(hipGetLastError());
             KnnArgs kb = ka;
             kb.units = nullptr; kb.nunits = 0; kb.unit_ctr = nullptr; kb.t_cnt = nullptr; kb.t_key = nullptr; kb.t_idx = nullptr; kb.t_cap = 0;
-            kb.thr0 = nullptr; kb.out_thr = nullptr;
+            kb.thr0 = nullptr; kb.thr_col = nullptr; kb.thr_pub = nullptr; kb.out_thr = nullptr;
             kb.r0 = 0; kb.r1 = nf; kb.nrb = nrb2; kb.S = S2; kb.M = CAP;
             kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
             kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr;
@@ -1689,6 +1753,7 @@ struct BlockRefineArgs {
     int32_t* p_idx;
     int32_t* p_cnt;
     float* p_t32;
+    const float* t32_given = nullptr;   // [r1]: the lower bound of everything these candidate lists did not keep (transposed slices)
 };
 
 __global__ __launch_bounds__(256) void knn_block_refine_kernel(BlockRefineArgs a) {
@@ -1707,11 +1772,12 @@ __global__ __launch_bounds__(256) void knn_block_refine_kernel(BlockRefineArgs a
     const int64_t row = a.r0 + (int64_t)blockIdx.x * 4 + w;
     if (row >= a.r1) return;
     const int64_t lr = row - a.r0;
-    int C = 0, anyfull = 0;
+    int C = 0, anyfull = 0, lost = 0;
     for (int cs = 0; cs < a.S; ++cs) {
         const int cc = a.c_cnt[lr * a.S + cs];
         const int c = cc & 0xffff;
         anyfull |= (cc >> 30) & 1;
+        lost |= (cc >> 31) & 1;   // a transposed buffer overflowed: candidates lost without a bound
         const size_t ob = ((size_t)lr * a.S + cs) * a.M;
         for (int t = lane; t < c; t += 64) {
             ck[C + t] = a.c_key[ob + t];
@@ -1766,8 +1832,8 @@ __global__ __launch_bounds__(256) void knn_block_refine_kernel(BlockRefineArgs a
         a.p_idx[o] = i;
     }
     if (lane == 0) {
-        a.p_cnt[lr] = Mp | (anyfull << 30);
-        a.p_t32[lr] = Mp > 0 ? lk[Mp - 1] : 0.0f;
+        a.p_cnt[lr] = Mp | ((anyfull | lost) << 30);
+        a.p_t32[lr] = lost ? -__int_as_float(0x7f800000) : (a.t32_given ? a.t32_given[row] : (Mp > 0 ? lk[Mp - 1] : 0.0f));
     }
 }
 
@@ -2022,7 +2088,7 @@ __global__ __launch_bounds__(256) void knn_fold_kernel(FoldArgs a) {
     if (lane == 0) {
         const int anyb = (bc >> 30) & 1, anyr = (rc >> 30) & 1;
         float tb = (a.mode == 2 || !anyr) ? __int_as_float(0x7f800000) : a.r_t32[lr];
-        if (anyb && cb > 0) {
+        if (anyb) {   // (a gated transposed slice may have kept nothing and still have turned candidates away: its bound counts)
             const double e = a.metric == AS_METRIC_L2 ? a.coef * (a.na64[a.r0 + lr] + a.nmax_b) : a.coef;
             const float nb = __double2float_rd((double)a.b_t32[lr] - e);
             tb = nb < tb ? nb : tb;
@@ -2095,6 +2161,23 @@ as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_par
     AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block"));
     const int64_t rows = r1 - r0;
     if (rows == 0) return AS_OK;
+    if (sp == cols && r0 == 0 && r1 == sp->n) {
+        // the own block: the same first pass as a single-space build (symmetric: half the tiles), ids global
+        KnnCand cand;
+        AS_TRY(knn_candidates(sp, gp, r0, r1, M, row_goff, col_goff, cand));
+        BlockRefineArgs ra;
+        ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = sp->x32; ra.xb64 = sp->x64; ra.na64 = sp->n64; ra.nb64 = sp->n64;
+        ra.d = sp->d; ra.dp = sp->dp; ra.r0 = r0; ra.r1 = r1; ra.col_goff = col_goff; ra.S = cand.S; ra.M = M; ra.metric = sp->opts.metric;
+        ra.c_key = cand.ckey; ra.c_idx = cand.cidx; ra.c_cnt = cand.ccnt;
+        ra.p_key = p_key; ra.p_dist = p_dist; ra.p_gy = p_gy; ra.p_idx = p_idx; ra.p_cnt = p_cnt; ra.p_t32 = p_t32;
+        const size_t pw = (sizeof(double) * 3 * M + sizeof(float) * ((size_t)cand.S * M + M) + sizeof(int) * ((size_t)cand.S * M + M) + 15) / 16 * 16;
+        AS_HIP(hipFuncSetAttribute((const void*)knn_block_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pw * 4)));
+        hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), pw * 4, sp->stream, ra);
+        AS_HIP(hipGetLastError());
+        AS_HIP(hipStreamSynchronize(sp->stream));
+        sp->kstats[7] += cand.flops;
+        return AS_OK;
+    }
     hipStream_t st = sp->stream;
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
@@ -2131,6 +2214,156 @@ as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_par
     hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), per_wave * 4, st, ra);
     AS_HIP(hipGetLastError());
     AS_HIP(hipStreamSynchronize(st));   // the scratch dies with this frame; the block may be freed by the caller
+    sp->kstats[7] += 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
+    return AS_OK;
+}
+
+// The threshold a visiting item's transposed appends were admitted with (min(eps bound, thr)), as +inf where the eps
+// bound decided: what the eps bound turns away is outside eps and bounds nothing.
+__global__ void pair_gate_kernel(const float* __restrict__ col_thr, const float* __restrict__ n32, int64_t nc, int64_t j0, int64_t j1,
+                                 int metric, float epskey, float coef, float nmax, float* __restrict__ gate) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nc) return;
+    const float eb = metric == AS_METRIC_L2 ? epskey + coef * (n32[j] + nmax) : epskey + coef;
+    const float t = col_thr && j >= j0 && j < j1 ? col_thr[j] : __int_as_float(0x7f800000);   // items outside the tile range took no part
+    gate[j] = t < eb ? t : __int_as_float(0x7f800000);
+}
+
+// Per-row thresholds from a folded partial list (ring): an upper bound of the row's M-th smallest fp32 key over all
+// columns -- its M-th exact key so far plus the fp32 error bound -- or +inf while the list is not full.
+__global__ void knn_thresholds_kernel(const double* __restrict__ r_key, const int32_t* __restrict__ r_cnt, const double* __restrict__ n64,
+                                      int64_t r0, int64_t rows, int M, int metric, double coef, double nmax, float* __restrict__ out) {
+    const int64_t lr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lr >= rows) return;
+    const int c = r_cnt[lr] & 0xffff;
+    float u = __int_as_float(0x7f800000);
+    if (c >= M) {
+        const double e = metric == AS_METRIC_L2 ? coef * (n64[r0 + lr] + nmax) : coef;
+        u = __double2float_ru((r_key[(size_t)lr * M + M - 1] + e) * 1.000001);
+    }
+    out[lr] = u;
+}
+
+as_status knn_thresholds(const as_space* sp, int64_t r0, int64_t r1, int M, double nmax_all, const double* r_key, const int32_t* r_cnt,
+                         float* out_thr) {
+    const int64_t rows = r1 - r0;
+    if (rows <= 0) return AS_OK;
+    hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, sp->stream, r_key, r_cnt, sp->n64, r0, rows,
+                       M, sp->opts.metric, err_coef(sp->dp), std::max(nmax_all, sp->nmax), out_thr);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(sp->stream));
+    return AS_OK;
+}
+
+// One unordered pair of blocks, computed once (symmetric ring): own rows [r0, r1) against the visiting block's column
+// tiles [ct0, ct1).  Every key serves both items: the own rows' candidate lists as in knn_block, and the visiting
+// items' transposed buffers, gated by their thresholds (col_thr, may be null: eps bound alone).  Both sides are refined
+// exactly here, while both shards are resident: p_* is the own rows' slice (as knn_block's, indexed from r0), q_* the
+// visiting items' slice [cols->n][M] w.r.t. the own rows as columns -- q_t32 the lower bound of what its buffers turned
+// away or dropped (-inf for a buffer that overflowed: the row fails its proof and goes round again).
+as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ct0,
+                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
+                         double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
+                         int32_t* q_idx, int32_t* q_cnt, float* q_t32) {
+    AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block_pair"));
+    hipStream_t st = sp->stream;
+    const int64_t rows = r1 - r0, nc = cols->n;
+    const int ntile_all = (int)(cols->np / BN);
+    if (ct0 < 0) ct0 = 0;
+    if (ct1 < 0 || ct1 > ntile_all) ct1 = ntile_all;
+    // the visiting items that take no part keep an empty slice
+    AS_HIP(hipMemsetAsync(q_cnt, 0, sizeof(int32_t) * nc, st));
+    AS_HIP(hipMemsetAsync(q_idx, 0xff, sizeof(int32_t) * nc * M, st));
+    if (rows <= 0 || ct1 <= ct0) {
+        AS_HIP(hipStreamSynchronize(st));
+        return AS_OK;
+    }
+    const int metric = sp->opts.metric;
+    const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
+    const double coef = err_coef(sp->dp);
+    const int dev_cus = device_cus(sp->device);
+    const int nrb = (int)((rows + BM - 1) / BM);
+    const int ntile = (int)(ct1 - ct0);
+    // units: every row block's tiles in pieces of at most L, one segment per piece
+    int L = (int)std::max<double>(8.0, std::ceil((double)nrb * ntile / (dev_cus * 16.0)));
+    if ((ntile + L - 1) / L > 8) L = (ntile + 7) / 8;
+    const int S = (ntile + L - 1) / L;
+    std::vector<int4> hunits;
+    for (int rb = 0; rb < nrb; ++rb) {
+        int seg = 0;
+        for (int t = (int)ct0; t < ct1; t += L, ++seg) hunits.push_back(make_int4(rb, t, (int)std::min<int64_t>(ct1, t + L), seg));
+    }
+    std::stable_sort(hunits.begin(), hunits.end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
+    const int units = (int)hunits.size(), grid = std::min(units, dev_cus);
+    const int T_CAP = 16 * M;
+    dev_tmp<int4> d_units;
+    dev_tmp<float> bkey, ckey, tr_key, c2key, gate, t_bound;
+    dev_tmp<int> bidx, cidx, ccnt, tr_cnt, tr_idx, c2idx, c2cnt;
+    AS_HIP(d_units.alloc(units));
+    AS_HIP(hipMemcpyAsync(d_units, hunits.data(), sizeof(int4) * units, hipMemcpyHostToDevice, st));
+    AS_HIP(bkey.alloc((size_t)grid * BM * CAP));
+    AS_HIP(bidx.alloc((size_t)grid * BM * CAP));
+    AS_HIP(ckey.alloc((size_t)rows * S * M));
+    AS_HIP(cidx.alloc((size_t)rows * S * M));
+    AS_HIP(ccnt.alloc((size_t)rows * S));
+    AS_HIP(tr_cnt.alloc(nc + 1));
+    AS_HIP(tr_key.alloc((size_t)nc * T_CAP));
+    AS_HIP(tr_idx.alloc((size_t)nc * T_CAP));
+    AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (nc + 1), st));
+    AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));
+    const double nmax = std::max(sp->nmax, cols->nmax);
+    KnnArgs ka;
+    ka.x32 = cols->x32; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+    ka.nrb = nrb; ka.S = S; ka.ntile = ntile_all; ka.M = M; ka.metric = metric;
+    ka.epskey = nextafterf((float)epskey, INFINITY); ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(nmax * 1.0000002);
+    ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
+    ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff;
+    ka.a_ids = nullptr; ka.a_thr = nullptr;
+    ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + nc; ka.t_cnt = tr_cnt; ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
+    ka.t_all = 1; ka.thr_col = col_thr;
+    const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
+    if (metric == AS_METRIC_L2) {
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(grid), dim3(512), lds8, st, ka);
+    } else {
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(grid), dim3(512), lds8, st, ka);
+    }
+    AS_HIP(hipGetLastError());
+    // own rows: as in knn_block
+    BlockRefineArgs ra;
+    ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = cols->x32; ra.xb64 = cols->x64; ra.na64 = sp->n64; ra.nb64 = cols->n64;
+    ra.d = sp->d; ra.dp = sp->dp; ra.r0 = r0; ra.r1 = r1; ra.col_goff = col_goff; ra.S = S; ra.M = M; ra.metric = metric;
+    ra.c_key = ckey; ra.c_idx = cidx; ra.c_cnt = ccnt;
+    ra.p_key = p_key; ra.p_dist = p_dist; ra.p_gy = p_gy; ra.p_idx = p_idx; ra.p_cnt = p_cnt; ra.p_t32 = p_t32;
+    const size_t per_wave = (sizeof(double) * 3 * M + sizeof(float) * ((size_t)S * M + M) + sizeof(int) * ((size_t)S * M + M) + 15) / 16 * 16;
+    AS_HIP(hipFuncSetAttribute((const void*)knn_block_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_wave * 4)));
+    hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), per_wave * 4, st, ra);
+    AS_HIP(hipGetLastError());
+    // visiting items: their transposed buffers -> one candidate list each (+ the bound of what was turned away) -> the same
+    // refinement with the roles swapped (rows = the visiting block, columns = the own rows, ids global)
+    AS_HIP(c2key.alloc((size_t)nc * M));
+    AS_HIP(c2idx.alloc((size_t)nc * M));
+    AS_HIP(c2cnt.alloc(nc));
+    AS_HIP(t_bound.alloc(nc));
+    AS_HIP(gate.alloc(nc));
+    hipLaunchKernelGGL(pair_gate_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, col_thr, cols->n32, nc, ct0 * BN, ct1 * BN, metric,
+                       ka.epskey, ka.coef, ka.nmax, (float*)gate);
+    const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
+    AS_HIP(hipFuncSetAttribute((const void*)transposed_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+    hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt, (const float*)tr_key,
+                       (const int*)tr_idx, T_CAP, nc, 1, 0, M, (float*)c2key, (int*)c2idx, (int*)c2cnt, (const float*)gate, (float*)t_bound);
+    AS_HIP(hipGetLastError());
+    BlockRefineArgs rb2;
+    rb2.xa32 = cols->x32; rb2.xa64 = cols->x64; rb2.xb32 = sp->x32; rb2.xb64 = sp->x64; rb2.na64 = cols->n64; rb2.nb64 = sp->n64;
+    rb2.d = sp->d; rb2.dp = sp->dp; rb2.r0 = 0; rb2.r1 = nc; rb2.col_goff = row_goff; rb2.S = 1; rb2.M = M; rb2.metric = metric;
+    rb2.c_key = c2key; rb2.c_idx = c2idx; rb2.c_cnt = c2cnt;
+    rb2.p_key = q_key; rb2.p_dist = q_dist; rb2.p_gy = q_gy; rb2.p_idx = q_idx; rb2.p_cnt = q_cnt; rb2.p_t32 = q_t32;
+    rb2.t32_given = t_bound;
+    const size_t per_wave2 = (sizeof(double) * 3 * M + sizeof(float) * ((size_t)M + M) + sizeof(int) * ((size_t)M + M) + 15) / 16 * 16;
+    hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), per_wave2 * 4, st, rb2);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(st));
     sp->kstats[7] += 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
     return AS_OK;
 }

@@ -308,6 +308,12 @@ as_status knn_block_band(const as_space* sp, const as_space* cols, const as_grap
                          int64_t col_goff, int M, int32_t* flag, const double* B, double* p_key, double* p_dist, double* p_gy,
                          int32_t* p_idx, int32_t* p_cnt, float* p_t32, int64_t* overflowed);
 int knn_list_width(int64_t k);
+as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ct0,
+                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
+                         double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
+                         int32_t* q_idx, int32_t* q_cnt, float* q_t32);
+as_status knn_thresholds(const as_space* sp, int64_t r0, int64_t r1, int M, double nmax_all, const double* r_key, const int32_t* r_cnt,
+                         float* out_thr);
 as_status knn_fold(const as_space* sp, int64_t r0, int64_t r1, int M, int mode, double block_nmax, const int32_t* flag, double* r_key,
                    double* r_dist, double* r_gy, int32_t* r_idx, int32_t* r_cnt, float* r_t32, const double* b_key, const double* b_dist,
                    const double* b_gy, const int32_t* b_idx, const int32_t* b_cnt, const float* b_t32);

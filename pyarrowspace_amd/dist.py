@@ -155,6 +155,68 @@ class HipEngine:
             self._check(self.L.as_knn_block(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff, *self._slice(1)))
             self._fold(0, self.block_nmax(h))
 
+    # ---- symmetric ring: an unordered pair of blocks is computed once (as_knn_block_pair)
+    def knn_thresholds(self, nmax_all):
+        """Per-row upper bounds of the M-th smallest fp32 key, from the list folded so far (fp32 device tensor)."""
+        torch = self.torch
+        out = torch.full((max(self.n, 1),), float("inf"), dtype=torch.float32, device=torch.device("cuda", self.op.device))
+        if self.n > 0:
+            torch.cuda.synchronize()
+            self._check(self.L.as_knn_thresholds(self.sp, C.byref(self.gp), 0, self.n, float(nmax_all), C.c_void_p(self.p_key[0].data_ptr()),
+                                                 C.c_void_p(self.p_cnt[0].data_ptr()), C.c_void_p(out.data_ptr())))
+        return out[: self.n]
+
+    def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols):
+        """Own rows [row0, row1) x the visiting block's column tiles [ct0, ct1): the own rows' slice is folded here; returns
+        the visiting items' slice, packed for the way home: (fp64 [ncols, 3, M] key/dist/gy, int32 [ncols, M + 2] ids,
+        count, the bits of the drop bound)."""
+        torch = self.torch
+        M = self.M
+        dev = torch.device("cuda", self.op.device)
+        F = torch.zeros((max(ncols, 1), 3, M), dtype=torch.float64, device=dev)
+        I = torch.full((max(ncols, 1), M + 2), -1, dtype=torch.int32, device=dev)
+        qk, qd, qg = (torch.zeros((max(ncols, 1), M), dtype=torch.float64, device=dev) for _ in range(3))
+        qi = torch.full((max(ncols, 1), M), -1, dtype=torch.int32, device=dev)
+        qc = torch.zeros((max(ncols, 1),), dtype=torch.int32, device=dev)
+        qt = torch.full((max(ncols, 1),), float("inf"), dtype=torch.float32, device=dev)
+        thr = col_thr.contiguous() if col_thr is not None else None
+        torch.cuda.synchronize()
+        if self.n > 0 and ncols > 0:
+            sl = [C.c_void_p(t[1].data_ptr() + row0 * t[1].stride(0) * t.element_size()) for t in
+                  (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
+            self._check(self.L.as_knn_block_pair(self.sp, h, C.byref(self.gp), row0, row1, ct0, ct1, row_goff, col_goff,
+                                                 C.c_void_p(thr.data_ptr()) if thr is not None else C.c_void_p(), *sl,
+                                                 *[C.c_void_p(t.data_ptr()) for t in (qk, qd, qg, qi, qc, qt)]))
+            if row1 > row0:
+                self._fold_rows(row0, row1, self.block_nmax(h), 1)
+        F[:, 0], F[:, 1], F[:, 2] = qk, qd, qg
+        I[:, :M], I[:, M], I[:, M + 1] = qi, qc, qt.view(torch.int32)
+        return F[:ncols], I[:ncols]
+
+    def _fold_rows(self, row0, row1, nmax_b, src_slice, ext=None):
+        """Fold rows [row0, row1) of a block slice (slice `src_slice` of the list memory, or the external tensors `ext`)
+        into the running list (slice 0)."""
+        def off(t, r):
+            return C.c_void_p(t.data_ptr() + r * t.stride(0) * t.element_size())
+        run = [off(t[0], row0) for t in (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
+        blk = [off(t, row0) for t in ext] if ext is not None else \
+              [off(t[src_slice], row0) for t in (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
+        self._check(self.L.as_knn_fold(self.sp, C.byref(self.gp), row0, row1, 0, float(nmax_b), C.c_void_p(), *run, *blk))
+
+    def fold_slice(self, F, I, nmax_src):
+        """A slice of MY rows that another rank computed (its items as my columns): into the running list."""
+        torch = self.torch
+        M = self.M
+        if self.n == 0:
+            return
+        ext = [F[:, 0].contiguous(), F[:, 1].contiguous(), F[:, 2].contiguous(), I[:, :M].contiguous(), I[:, M].contiguous(),
+               I[:, M + 1].contiguous().view(torch.float32)]
+        torch.cuda.synchronize()
+        self._fold_rows(0, self.n, nmax_src, None, ext)
+
+    def slice_shapes(self, nrows):
+        return (nrows, 3, self.M), (nrows, self.M + 2)
+
     def knn_merge(self, nmax=None):
         """Final lists from the folded slice; returns the number of rows not provably exact."""
         torch = self.torch
@@ -663,7 +725,12 @@ class ShardedIndex:
                     self._exchange_wait(pending)
                 cur ^= 1
 
-        one_round(lambda h, b, rg, cg: e.knn_block(h, b, rg, cg))
+        import os
+        self.ring_symmetric = ring and hasattr(e, "knn_block_pair") and not os.environ.get("ARROWSPACE_RING_FULL")
+        if self.ring_symmetric:
+            self._ring_round_symmetric(X_shard, bufs, nmax)
+        else:
+            one_round(lambda h, b, rg, cg: e.knn_block(h, b, rg, cg))
         nflag = e.knn_merge(nmax)
         if ring:
             t = torch.tensor([nflag], dtype=torch.int64, device=X_shard.device)
@@ -686,6 +753,63 @@ class ShardedIndex:
         if hasattr(e, "ring_end"):
             e.ring_end()
         return out
+
+    def _swap_slices(self, F, I, dst, src, nrows):
+        """Send a block's slice home to rank dst, receive the slice of MY rows from rank src (two tensors each way)."""
+        torch, dist = self.torch, self.dist
+        shF, shI = self.engine.slice_shapes(nrows)
+        rF = torch.empty(shF, dtype=F.dtype, device=F.device)
+        rI = torch.empty(shI, dtype=I.dtype, device=I.device)
+        ops = [dist.P2POp(dist.isend, F.contiguous(), dst, group=self.group), dist.P2POp(dist.irecv, rF, src, group=self.group),
+               dist.P2POp(dist.isend, I.contiguous(), dst, group=self.group), dist.P2POp(dist.irecv, rI, src, group=self.group)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        return rF, rI
+
+    def _ring_round_symmetric(self, X_shard, bufs, nmax):
+        """First round of the ring with every unordered pair of blocks computed ONCE: at step s a rank runs its rows against
+        the shard of rank - s (as_knn_block_pair: the keys serve both sides), keeps its own rows' slice and sends the
+        visiting rows' slice home to rank - s, receiving from rank + s the slice of its own rows against that rank's items.
+        Steps 1 .. (world - 1) // 2 are whole pairs; with an even world the pair at distance world / 2 is seen from both
+        ends and split: the lower rank takes the first half of the other block's column tiles, the higher rank its own rows
+        of the second half.  A rank computes world / 2 + 1 blocks' worth instead of world."""
+        torch, dist, e = self.torch, self.dist, self.engine
+        world, rank, counts, bounds = self.world, self.rank, self.counts, self.bounds
+        nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+        half = world // 2
+        mx = max(max(counts), 1)
+        # step 0: the own block, with the hop for step 1 in flight
+        pending = self._exchange_start(bufs[0], bufs[1], nxt_rank, prv_rank) if half >= 1 else None
+        e.knn_block(e.own_block(), rank, bounds[rank], bounds[rank])
+        # thresholds of every item from its own block's list: what a visiting item's candidates are admitted with
+        U = e.knn_thresholds(max(nmax))
+        Upad = torch.full((mx,), float("inf"), dtype=torch.float32, device=U.device)
+        Upad[: U.shape[0]] = U
+        U_all = self._gather_fixed(Upad).reshape(world, mx)
+        if pending is not None:
+            self._exchange_wait(pending)
+        cur = 1
+        for s in range(1, half + 1):
+            src = (rank - s) % world                 # whose shard is visiting, and where its slice goes home to
+            dst = (rank + s) % world                 # who holds MY shard at this step
+            self._sync()
+            h = e.open_block(bufs[cur][: counts[src]])
+            pending = self._exchange_start(bufs[cur], bufs[cur ^ 1], nxt_rank, prv_rank) if s + 1 <= half else None
+            row0, row1, ct0, ct1 = 0, counts[rank], -1, -1
+            if 2 * s == world:
+                q = max(rank, src)                   # the higher rank's block is the one cut in halves
+                tq = (counts[q] + 255) // 256 * 256 // 128
+                if rank == q:
+                    row0 = min(counts[q], (tq // 2) * 128)
+                else:
+                    ct0, ct1 = 0, tq // 2
+            F, I = e.knn_block_pair(h, row0, row1, ct0, ct1, bounds[rank], bounds[src], U_all[src][: counts[src]], counts[src])
+            e.close_block(h)
+            rF, rI = self._swap_slices(F, I, src, dst, counts[rank])
+            e.fold_slice(rF, rI, nmax[dst])
+            if pending is not None:
+                self._exchange_wait(pending)
+            cur ^= 1
 
     def save(self, prefix):
         """One file per rank: `<prefix>.rank<r>of<world>` holds the rank's items, its lambdas and the graph."""

@@ -90,6 +90,46 @@ class OracleEngine:
     def knn_block_band(self, h, b, row_goff, col_goff):
         return 0
 
+    # ---- symmetric ring: a pair of blocks computed once, both sides' slices from the same distances
+    def knn_thresholds(self, nmax_all):
+        import torch
+        return torch.full((self.n,), float("inf"), dtype=torch.float32)
+
+    def slice_shapes(self, nrows):
+        k = self.prm["k"]
+        return (nrows, 3, k), (nrows, k + 2)
+
+    def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols):
+        import torch
+        k, ek = self.prm["k"], self.o._eps_key(self.prm["eps"], self.prm["metric"])
+        j0, j1 = (0, ncols) if ct0 < 0 else (min(ncols, ct0 * 128), min(ncols, ct1 * 128))
+        nh = np.einsum("ij,ij->i", h, h)
+        own = [[] for _ in range(self.n)]
+        for i in range(row0, row1):
+            key, dd, gg = self.o.pair_quantities(self.X[i], h[j0:j1], self.nn[i], nh[j0:j1], self.prm["metric"])
+            c = np.nonzero(key <= ek)[0]
+            c = c[np.lexsort((c, key[c]))][:k]
+            own[i] = [(key[j], col_goff + j0 + j, dd[j], gg[j]) for j in c]
+        self.parts[("pair", col_goff, j0)] = own
+        F = np.zeros((ncols, 3, k))
+        I = np.full((ncols, k + 2), -1, dtype=np.int32)
+        I[:, k] = 0
+        I[:, k + 1] = np.array([np.inf], dtype=np.float32).view(np.int32)[0]
+        for j in range(j0, j1):
+            key, dd, gg = self.o.pair_quantities(h[j], self.X[row0:row1], nh[j], self.nn[row0:row1], self.prm["metric"])
+            c = np.nonzero(key <= ek)[0]
+            c = c[np.lexsort((c, key[c]))][:k]
+            F[j, 0, : len(c)], F[j, 1, : len(c)], F[j, 2, : len(c)] = key[c], dd[c], gg[c]
+            I[j, : len(c)] = row_goff + row0 + c
+            I[j, k] = len(c)
+        self.off = row_goff
+        return torch.from_numpy(F), torch.from_numpy(I)
+
+    def fold_slice(self, F, I, nmax_src):
+        F, I, k = F.numpy(), I.numpy(), self.prm["k"]
+        self.parts[("recv", len(self.parts))] = [[(F[i, 0, t], int(I[i, t]), F[i, 1, t], F[i, 2, t]) for t in range(I[i, k])]
+                                                  for i in range(self.n)]
+
     def knn_merge(self, nmax):
         import torch
         k = self.prm["k"]
@@ -275,12 +315,13 @@ def _worker(rank, world, port, n, d, split, out, mode="ring"):
         from pyarrowspace_amd.dist import ShardedIndex
         X = clustered(n, d, nclust=6, seed=21)
         gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
-        bounds = [0, split, n] if world == 2 else [0, n]
+        bounds = [0, split, n] if world == 2 else ([0, n] if world == 1 else sorted([0, n] + list(split)))
         shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy())
         replicate = mode == "replicated"
         index = ShardedIndex.build(gp, shard, dist, engine=OracleEngine(gp), replicate=replicate, gather_lists=mode == "ring_lists")
         assert (index.r0, index.r1) == (bounds[rank], bounds[rank + 1]) and index.n == n and index.replicated == replicate
         assert hasattr(index.engine, "shard") == (mode == "ring")       # the sharded graph stage ran / did not run
+        assert getattr(index, "ring_symmetric", False) == (mode != "replicated" and world > 1)   # every block pair computed once
         rng = np.random.default_rng(5)
         res = []
         for _ in range(4):
@@ -325,6 +366,25 @@ def test_two_rank_sharded_index_matches_single_process(split, mode):
             np.testing.assert_allclose([s for _, s in hits], [s for _, s in whits], rtol=1e-12)
             assert abs(lq - wlq) <= 1e-12 * abs(wlq)
     assert out[0][1] == out[1][1]          # every rank returns the same answer
+
+
+@pytest.mark.parametrize("world,cuts", [(3, (70, 190)), (4, (60, 61, 200))])
+def test_symmetric_ring_with_three_and_four_ranks(world, cuts):
+    """world 3: every pair is a whole pair (steps 1 .. 1); world 4: one whole-pair step and the split pair at distance 2
+    (the lower rank takes the first half of the other block's column tiles, the higher rank its rows of the second
+    half) -- uneven shards, one of a single row.  Lists, lambdas and searches equal the single-process oracle's."""
+    import torch.multiprocessing as mp
+    from oracle import oracle_np
+    n, d = 300, 24
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, d, cuts, out, "ring"), nprocs=world, join=True)
+    X = clustered(n, d, nclust=6, seed=21)
+    gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_np.build(X, gp)
+    for rank in range(world):
+        np.testing.assert_allclose(out[rank][0], ref["lambdas"], rtol=1e-12)
+    assert all(out[r][1] == out[0][1] for r in range(world))
 
 
 def test_shard_bounds():

@@ -87,6 +87,11 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
                 torch.cuda.synchronize()
                 return super()._gather_fixed(t.cpu()).cuda()
 
+            def _swap_slices(self, F, I, dst, src, nrows):               # the symmetric ring's slices, staged through the CPU
+                torch.cuda.synchronize()
+                rF, rI = super()._swap_slices(F.cpu(), I.cpu(), dst, src, nrows)
+                return rF.cuda(), rI.cuda()
+
             def _all_to_all(self, t, recv_counts, send_counts):           # the edge exchange of the sharded graph stage
                 torch.cuda.synchronize()
                 return super()._all_to_all(t.cpu(), recv_counts, send_counts).cuda()
@@ -107,7 +112,7 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
         bounds = [0, split, n]
         shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy()).cuda()
         index = CpuStaged.build(gp, shard, dist, replicate=replicate)
-        assert index.replicated == replicate
+        assert index.replicated == replicate and getattr(index, "ring_symmetric", False) == (not replicate)
         res = [(index.search(q, tau), index.last_lambda_q) for q, tau in _queries(X, n, d)]
         rng = np.random.default_rng(6)
         Qb = np.stack([X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d) for _ in range(45)])

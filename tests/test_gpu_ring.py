@@ -97,3 +97,111 @@ def test_blockwise_second_round_settles_duplicate_groups(oracle_lib):
         np.testing.assert_array_equal(cnt, ref.knn_cnt[lo:hi])
         np.testing.assert_array_equal(idx, ref.knn_idx[lo:hi])
     assert flagged > 0          # the second round did run
+
+
+def _symmetric_ring_lists(X, gp, cuts, dup_round=True):
+    """The symmetric ring's first round with every rank in this process: each unordered pair of blocks goes through
+    as_knn_block_pair ONCE (the even world's opposite pair split as ShardedIndex._ring_round_symmetric splits it), the
+    visiting rows' slice is handed to their engine and folded there; then merge, and the second round for flagged rows
+    exactly as the ranks would run it (every block visits, collect mode)."""
+    import torch
+
+    from pyarrowspace_amd.dist import HipEngine
+    G = len(cuts) - 1
+    counts = [cuts[b + 1] - cuts[b] for b in range(G)]
+    blocks = [torch.from_numpy(X[cuts[b]:cuts[b + 1]].copy()).cuda() for b in range(G)]
+    eng = []
+    for b in range(G):
+        e = HipEngine(gp)
+        e.create_space(blocks[b])
+        e.ring_begin(G)
+        eng.append(e)
+    nmax = [e.block_nmax(e.own_block()) for e in eng]
+    for r, e in enumerate(eng):
+        e.knn_block(e.own_block(), r, cuts[r], cuts[r])
+    U = [e.knn_thresholds(max(nmax)) for e in eng]
+    half = G // 2
+    for s in range(1, half + 1):
+        out = {}
+        for r, e in enumerate(eng):
+            src, dst = (r - s) % G, (r + s) % G
+            row0, row1, ct0, ct1 = 0, counts[r], -1, -1
+            if 2 * s == G:
+                q = max(r, src)
+                tq = (counts[q] + 255) // 256 * 256 // 128
+                if r == q:
+                    row0 = min(counts[q], (tq // 2) * 128)
+                else:
+                    ct0, ct1 = 0, tq // 2
+            h = e.open_block(blocks[src])
+            out[(r, src)] = e.knn_block_pair(h, row0, row1, ct0, ct1, cuts[r], cuts[src], U[src], counts[src])
+            e.close_block(h)
+        for (r, src), (F, I) in out.items():
+            eng[src].fold_slice(F, I, nmax[r])       # the slice of src's rows that rank r computed goes home
+    res, flagged = [], 0
+    for r, e in enumerate(eng):
+        nflag = e.knn_merge(nmax)
+        flagged += nflag
+        if nflag and dup_round:
+            for b in range(G):
+                h = e.own_block() if b == r else e.open_block(blocks[b])
+                e.knn_block_band(h, b, cuts[r], cuts[b])
+                if b != r:
+                    e.close_block(h)
+            e.knn_merge(nmax)
+        res.append([t.cpu().numpy() for t in e.lists()])
+    for e in eng:
+        e.close()
+    return res, flagged
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("n,d,k,cuts", [(3000, 96, 10, [0, 700, 1900, 3000]), (5000, 768, 25, [0, 2500, 5000]),
+                                        (2600, 40, 6, [0, 500, 501, 1700, 2600]), (4100, 64, 12, [0, 300, 1400, 2000, 3300, 4100])])
+def test_symmetric_ring_lists_equal_the_single_space_lists(metric, n, d, k, cuts):
+    """3, 2, 4 and 5 blocks (uneven, one of a single row): whole pairs, the split opposite pair of the even worlds."""
+    X = clustered(n, d, nclust=max(4, n // 200), seed=n + k)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
+    res, _ = _symmetric_ring_lists(X, gp, cuts)
+    for b in range(len(cuts) - 1):
+        lo, hi = cuts[b], cuts[b + 1]
+        idx, dist, gy, cnt = res[b]
+        sidx, sdist, sgy, scnt = _single_lists(X, gp, lo, hi)
+        np.testing.assert_array_equal(cnt, scnt)
+        np.testing.assert_array_equal(idx, sidx)
+        np.testing.assert_array_equal(dist, sdist)
+        np.testing.assert_array_equal(gy, sgy)
+
+
+def test_symmetric_ring_second_round_settles_duplicate_groups(oracle_lib):
+    rng = np.random.default_rng(3)
+    n, d, k = 2400, 64, 8
+    X = clustered(n, d, nclust=12, seed=17)
+    for g in range(6):
+        rows = rng.choice(n, 150, replace=False)
+        X[rows] = X[rows[0]]
+    gp = {"eps": calibrate_eps(clustered(n, d, nclust=12, seed=17), k), "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_lib.OracleIndex(X, gp)
+    cuts = [0, 800, 1700, 2400]
+    res, flagged = _symmetric_ring_lists(X, gp, cuts)
+    assert flagged > 0
+    for b in range(3):
+        lo, hi = cuts[b], cuts[b + 1]
+        np.testing.assert_array_equal(res[b][3], ref.knn_cnt[lo:hi])
+        np.testing.assert_array_equal(res[b][0], ref.knn_idx[lo:hi])
+
+
+def test_symmetric_ring_with_an_eps_that_admits_every_pair():
+    """Only the thresholds gate the visiting items' candidates: buffers that overflow fail their rows' proofs (bound
+    -inf) and the second round settles them."""
+    n, d, k = 3000, 48, 8
+    X = clustered(n, d, nclust=6, seed=5)
+    gp = {"eps": 10.0, "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    cuts = [0, 900, 2100, 3000]
+    res, _ = _symmetric_ring_lists(X, gp, cuts)
+    for b in range(3):
+        lo, hi = cuts[b], cuts[b + 1]
+        sidx, sdist, sgy, scnt = _single_lists(X, gp, lo, hi)
+        np.testing.assert_array_equal(res[b][3], scnt)
+        np.testing.assert_array_equal(res[b][0], sidx)
+        np.testing.assert_array_equal(res[b][1], sdist)
