@@ -1044,7 +1044,9 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         const int raw = a.info->knn_cnt;
         if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow |= 1;
         total = raw < CAND_CAP ? raw : CAND_CAP;
-        select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
+        // (the exhaustive evaluation below ranks every candidate by its exact key: no fp32 selection in front of it)
+        const bool exh = a.exhaustive && !a.thresholded && raw <= CAND_CAP && total > a.M;
+        if (!exh) select_candidates<T>(ckey, cidx, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
     }
     AS_STAMP(1);
     const double nq = a.info->nq;
