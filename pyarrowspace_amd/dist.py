@@ -430,12 +430,12 @@ class HipEngine:
                                                  self._bsc.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p),
                                                  lq.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)))
         out = []
+        il, sl, ll, ql, stl = self._bidx[:nb].tolist(), self._bsc[:nb].tolist(), ln.tolist(), lq.tolist(), st.tolist()
         for b in range(nb):
-            if st[b] == -1:
+            if stl[b] == -1:
                 out.append((None, 0.0, False))
             else:
-                out.append(([(int(self._bidx[b, t]), float(self._bsc[b, t])) for t in range(ln[b])], float(lq[b]),
-                            st[b] == self._lib.AS_EZEROLAMBDA))
+                out.append((list(zip(il[b][: ll[b]], sl[b][: ll[b]])), ql[b], stl[b] == self._lib.AS_EZEROLAMBDA))
         return out
 
     def lambdas(self):
