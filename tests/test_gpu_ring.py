@@ -205,3 +205,31 @@ def test_symmetric_ring_with_an_eps_that_admits_every_pair():
         np.testing.assert_array_equal(res[b][3], scnt)
         np.testing.assert_array_equal(res[b][0], sidx)
         np.testing.assert_array_equal(res[b][1], sdist)
+
+
+def test_symmetric_ring_seeded_fuzz():
+    """Random shapes, cuts (2 to 6 blocks, some tiny), k, metric and eps tightness: the symmetric ring's lists against
+    one space holding everything, bit for bit."""
+    rng = np.random.default_rng(20261004)
+    for case in range(14):
+        n = int(rng.integers(600, 5200))
+        d = int(rng.choice([16, 40, 96, 200]))
+        k = int(rng.integers(3, 31))
+        G = int(rng.integers(2, 7))
+        inner = np.sort(rng.choice(np.arange(1, n), size=G - 1, replace=False))
+        if rng.random() < 0.3:
+            inner[0] = max(1, min(int(inner[0]), int(rng.integers(1, 4))))      # a block of a few rows at the front
+            inner = np.unique(inner)
+        cuts = [0] + [int(v) for v in inner] + [n]
+        metric = str(rng.choice(["l2", "cosine"]))
+        X = clustered(n, d, nclust=int(rng.integers(2, 12)), noise=float(rng.uniform(0.1, 0.6)), seed=int(rng.integers(1 << 30)))
+        eps = calibrate_eps(X, k, metric) * float(rng.choice([0.6, 1.0, 1.0, 2.5]))
+        gp = {"eps": eps, "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
+        res, _ = _symmetric_ring_lists(X, gp, cuts)
+        for b in range(len(cuts) - 1):
+            lo, hi = cuts[b], cuts[b + 1]
+            sidx, sdist, sgy, scnt = _single_lists(X, gp, lo, hi)
+            ctx = "case %d: n=%d d=%d k=%d cuts=%s %s eps=%.4g block %d" % (case, n, d, k, cuts, metric, eps, b)
+            np.testing.assert_array_equal(res[b][3], scnt, err_msg=ctx)
+            np.testing.assert_array_equal(res[b][0], sidx, err_msg=ctx)
+            np.testing.assert_array_equal(res[b][1], sdist, err_msg=ctx)
