@@ -368,7 +368,7 @@ def test_two_rank_sharded_index_matches_single_process(split, mode):
     assert out[0][1] == out[1][1]          # every rank returns the same answer
 
 
-@pytest.mark.parametrize("world,cuts", [(3, (70, 190)), (4, (60, 61, 200))])
+@pytest.mark.parametrize("world,cuts", [(3, (70, 190)), (4, (60, 61, 200)), (6, (40, 95, 96, 180, 260))])
 def test_symmetric_ring_with_three_and_four_ranks(world, cuts):
     """world 3: every pair is a whole pair (steps 1 .. 1); world 4: one whole-pair step and the split pair at distance 2
     (the lower rank takes the first half of the other block's column tiles, the higher rank its rows of the second
