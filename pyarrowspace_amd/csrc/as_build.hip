@@ -2275,6 +2275,7 @@ as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_grap
     AS_HIP(hipMemsetAsync(q_cnt, 0, sizeof(int32_t) * nc, st));
     AS_HIP(hipMemsetAsync(q_idx, 0xff, sizeof(int32_t) * nc * M, st));
     if (rows <= 0 || ct1 <= ct0) {
+        if (rows > 0) AS_HIP(hipMemsetAsync(p_cnt, 0, sizeof(int32_t) * rows, st));   // an empty own slice too: folding it adds nothing
         AS_HIP(hipStreamSynchronize(st));
         return AS_OK;
     }
