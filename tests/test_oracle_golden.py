@@ -301,3 +301,35 @@ def test_sharded_graph_restatement_equals_the_whole_graph(metric, kernel):
         np.testing.assert_array_equal(s["indices"], ref["indices"][a:b])
         np.testing.assert_array_equal(s["lap"], ref["lap"][a:b])
         np.testing.assert_array_equal(s["w"], ref["w"][a:b])
+
+
+def test_recorded_reference_scores_follow_the_blend(oracle_lib):
+    """Reference-held numbers for SPEC S11 (TAUMODE.md:33).  tests/golden/cve_blend.json (make_cve_fixture.py) holds 37
+    (query, item) pairs of the reference's recorded CVE run with their scores at tau = 1.0, 0.8 and 0.62 from ONE index.
+    tau = 1.0 gives cos, tau = 0.8 then gives the lambda term T = 1/(1+|lq-li|); items with those cosines and lambdas
+    (2-D unit vectors at the recorded angle, lambda_i = lq + 1/T - 1) go through the oracle's scorers -- numpy and C --
+    at tau = 0.62 and must reproduce the recorded scores (6 decimals in, so 5e-6) and the recorded order."""
+    doc = json.load(open(os.path.join(G, "cve_blend.json")))
+    lq = 0.25
+    for qid, items in doc["queries"].items():
+        c = np.array([it["s_1.0"] for it in items])
+        T = (np.array([it["s_0.8"] for it in items]) - 0.8 * c) / 0.2
+        assert np.all(T > 0.0) and np.all(T <= 1.0 + 2e-5)            # a value 1/(1+|dl|) can take
+        T = np.minimum(T, 1.0)
+        want = np.array([it["s_0.62"] for it in items])
+        X = np.stack([c, np.sqrt(1.0 - c * c)], axis=1)
+        q = np.array([1.0, 0.0])
+        lam = lq + (1.0 / T - 1.0)
+        idx = dict(X=X, n=np.einsum("ij,ij->i", X, X), lambdas=lam)
+        got_np = oracle_np.scores(idx, q, 0.62, lq)
+        np.testing.assert_allclose(got_np, want, atol=5e-6, rtol=0)
+        gp = {"eps": 1.0, "k": 2, "topk": len(items), "p": 2.0, "sigma": None}
+        so = oracle_lib.OracleSearchOnly(X, gp, np.ones(len(items)), lam, 0.5)
+        got_c = so.scores(q, 0.62, lq)
+        np.testing.assert_allclose(got_c, want, atol=5e-6, rtol=0)
+        np.testing.assert_allclose(got_c, got_np, rtol=1e-14)
+        # the recorded tau = 0.62 ranks of these items are increasing in their recorded order: so are ours
+        by_rank = np.argsort([it["rank_0.62"] for it in items])
+        assert np.all(np.diff(got_c[by_rank]) <= 1e-6)
+        # and the blend is what moved them: at tau = 0.8 the same construction returns the recorded Hybrid scores
+        np.testing.assert_allclose(so.scores(q, 0.8, lq), [it["s_0.8"] for it in items], atol=5e-6, rtol=0)
