@@ -270,7 +270,10 @@ static as_status graph_rows_copy(const as_graph* gr, const double* src, double* 
         return AS_EINVAL;
     }
     AS_HIP(hipSetDevice(gr->device));
+    // a device-to-device hipMemcpy returns before the copy has run (legacy default stream), and the caller's streams
+    // are non-blocking: without the synchronisation its next kernel could read the destination too early
     AS_HIP(hipMemcpy(out_dev, src, sizeof(double) * gr->n, hipMemcpyDeviceToDevice));
+    AS_HIP(hipDeviceSynchronize());
     return AS_OK;
 }
 as_status as_graph_deg_copy(const as_graph* gr, double* out_dev) { return graph_rows_copy(gr, gr ? gr->deg : nullptr, out_dev, "as_graph_deg_copy"); }
@@ -310,6 +313,7 @@ as_status as_space_norms(const as_space* sp, double* out_dev) {
     }
     AS_HIP(hipSetDevice(sp->device));
     AS_HIP(hipMemcpy(out_dev, sp->n64, sizeof(double) * sp->n, hipMemcpyDeviceToDevice));
+    AS_HIP(hipDeviceSynchronize());   // device-to-device: asynchronous to the host, and the caller's streams are non-blocking
     return AS_OK;
 }
 int64_t as_space_row_offset(const as_space* sp) { return sp ? sp->row_offset : 0; }

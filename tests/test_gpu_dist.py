@@ -129,7 +129,10 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
             assert loaded.search(q, tau) == index.search(q, tau)
         loaded.close()
         os.remove("%s.rank%dof%d" % (prefix, rank, world))
-        out[rank] = (index.lambdas().copy(), res)
+        lists = None
+        if not replicate:   # the rank's k-NN lists (global ids), for a diagnosis by row when something is off
+            lists = tuple(t.cpu().numpy().copy() for t in index.engine.lists())
+        out[rank] = (index.lambdas().copy(), res, lists, (bounds[rank], bounds[rank + 1]))
         index.close()
     finally:
         dist.destroy_process_group()
@@ -152,12 +155,23 @@ def test_two_ranks_one_gpu_match_oracle(oracle_lib, replicate):
     ref = oracle_lib.OracleIndex(X, gp)
     want = [ref.search(q, tau) for q, tau in _queries(X, n, d)]
     for rank in range(world):
-        lam, res = out[rank]
+        lam, res, lists, (lo, hi) = out[rank]
+        if lists is not None:   # first the lists, row by row: a wrong lambda says nothing about where it came from
+            idx, dist_, gy, cnt = lists
+            bad = [r for r in range(hi - lo) if cnt[r] != ref.knn_cnt[lo + r] or list(idx[r, : cnt[r]]) != list(ref.knn_idx[lo + r, : cnt[r]])]
+            assert not bad, "rank %d: %d rows with wrong lists, first %s: got %s want %s (nan dists: %d)" % (
+                rank, len(bad), bad[:8], idx[bad[0]], ref.knn_idx[lo + bad[0]], int(np.isnan(dist_).sum()))
         np.testing.assert_allclose(lam, ref.lambdas, rtol=1e-9)
         for (hits, lq), (whits, wlq) in zip(res, want):
             assert_hits_match(hits, whits, rtol=1e-9)   # ties to rounding (tau = 0) may swap
             assert abs(lq - wlq) <= 1e-9 * abs(wlq)
     assert out[0][1] == out[1][1]
+
+
+@pytest.mark.parametrize("rep", range(4))
+def test_two_ranks_ring_repeats(oracle_lib, rep):
+    """The 2-rank ring build again and again (its kernels run concurrently with the other rank's on one GPU: timing varies)."""
+    test_two_ranks_one_gpu_match_oracle(oracle_lib, False)
 
 
 def _feature_worker(rank, world, port, n, d, split, out):
