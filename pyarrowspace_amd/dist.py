@@ -191,7 +191,8 @@ class HipEngine:
                 self._fold_rows(row0, row1, self.block_nmax(h), 1)
         F[:, 0], F[:, 1], F[:, 2] = qk, qd, qg
         I[:, :M], I[:, M], I[:, M + 1] = qi, qc, qt.view(torch.int32)
-        return F[:ncols], I[:ncols]
+        # one message per step and direction: the int32 columns ride along as (M + 2) / 2 float64 bit patterns
+        return torch.cat([F.reshape(F.shape[0], 3 * M), I.view(torch.float64)], dim=1)[:ncols].contiguous()
 
     def _fold_rows(self, row0, row1, nmax_b, src_slice, ext=None):
         """Fold rows [row0, row1) of a block slice (slice `src_slice` of the list memory, or the external tensors `ext`)
@@ -203,19 +204,21 @@ class HipEngine:
               [off(t[src_slice], row0) for t in (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
         self._check(self.L.as_knn_fold(self.sp, C.byref(self.gp), row0, row1, 0, float(nmax_b), C.c_void_p(), *run, *blk))
 
-    def fold_slice(self, F, I, nmax_src):
+    def fold_slice(self, P, nmax_src):
         """A slice of MY rows that another rank computed (its items as my columns): into the running list."""
         torch = self.torch
         M = self.M
         if self.n == 0:
             return
+        F = P[:, : 3 * M].reshape(P.shape[0], 3, M)
+        I = P[:, 3 * M :].contiguous().view(torch.int32)
         ext = [F[:, 0].contiguous(), F[:, 1].contiguous(), F[:, 2].contiguous(), I[:, :M].contiguous(), I[:, M].contiguous(),
                I[:, M + 1].contiguous().view(torch.float32)]
         torch.cuda.synchronize()
         self._fold_rows(0, self.n, nmax_src, None, ext)
 
-    def slice_shapes(self, nrows):
-        return (nrows, 3, self.M), (nrows, self.M + 2)
+    def slice_shape(self, nrows):
+        return (nrows, 3 * self.M + (self.M + 2) // 2)
 
     def knn_merge(self, nmax=None):
         """Final lists from the folded slice; returns the number of rows not provably exact."""
@@ -754,17 +757,14 @@ class ShardedIndex:
             e.ring_end()
         return out
 
-    def _swap_slices(self, F, I, dst, src, nrows):
-        """Send a block's slice home to rank dst, receive the slice of MY rows from rank src (two tensors each way)."""
+    def _swap_slices(self, P, dst, src, nrows):
+        """Send a block's slice home to rank dst, receive the slice of MY rows from rank src (one fp64 tensor each way)."""
         torch, dist = self.torch, self.dist
-        shF, shI = self.engine.slice_shapes(nrows)
-        rF = torch.empty(shF, dtype=F.dtype, device=F.device)
-        rI = torch.empty(shI, dtype=I.dtype, device=I.device)
-        ops = [dist.P2POp(dist.isend, F.contiguous(), dst, group=self.group), dist.P2POp(dist.irecv, rF, src, group=self.group),
-               dist.P2POp(dist.isend, I.contiguous(), dst, group=self.group), dist.P2POp(dist.irecv, rI, src, group=self.group)]
+        rP = torch.empty(self.engine.slice_shape(nrows), dtype=P.dtype, device=P.device)
+        ops = [dist.P2POp(dist.isend, P.contiguous(), dst, group=self.group), dist.P2POp(dist.irecv, rP, src, group=self.group)]
         for r in dist.batch_isend_irecv(ops):
             r.wait()
-        return rF, rI
+        return rP
 
     def _ring_round_symmetric(self, X_shard, bufs, nmax):
         """First round of the ring with every unordered pair of blocks computed ONCE: at step s a rank runs its rows against
@@ -803,10 +803,9 @@ class ShardedIndex:
                     row0 = min(counts[q], (tq // 2) * 128)
                 else:
                     ct0, ct1 = 0, tq // 2
-            F, I = e.knn_block_pair(h, row0, row1, ct0, ct1, bounds[rank], bounds[src], U_all[src][: counts[src]], counts[src])
+            P = e.knn_block_pair(h, row0, row1, ct0, ct1, bounds[rank], bounds[src], U_all[src][: counts[src]], counts[src])
             e.close_block(h)
-            rF, rI = self._swap_slices(F, I, src, dst, counts[rank])
-            e.fold_slice(rF, rI, nmax[dst])
+            e.fold_slice(self._swap_slices(P, src, dst, counts[rank]), nmax[dst])
             if pending is not None:
                 self._exchange_wait(pending)
             cur ^= 1

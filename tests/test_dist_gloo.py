@@ -95,9 +95,12 @@ class OracleEngine:
         import torch
         return torch.full((self.n,), float("inf"), dtype=torch.float32)
 
-    def slice_shapes(self, nrows):
+    def _wi(self):
         k = self.prm["k"]
-        return (nrows, 3, k), (nrows, k + 2)
+        return k + 2 + ((k + 2) & 1)            # int32 columns (ids, count, bound bits), padded to an even number
+
+    def slice_shape(self, nrows):
+        return (nrows, 3 * self.prm["k"] + self._wi() // 2)
 
     def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols):
         import torch
@@ -112,7 +115,7 @@ class OracleEngine:
             own[i] = [(key[j], col_goff + j0 + j, dd[j], gg[j]) for j in c]
         self.parts[("pair", col_goff, j0)] = own
         F = np.zeros((ncols, 3, k))
-        I = np.full((ncols, k + 2), -1, dtype=np.int32)
+        I = np.full((ncols, self._wi()), -1, dtype=np.int32)
         I[:, k] = 0
         I[:, k + 1] = np.array([np.inf], dtype=np.float32).view(np.int32)[0]
         for j in range(j0, j1):
@@ -123,10 +126,13 @@ class OracleEngine:
             I[j, : len(c)] = row_goff + row0 + c
             I[j, k] = len(c)
         self.off = row_goff
-        return torch.from_numpy(F), torch.from_numpy(I)
+        return torch.from_numpy(np.concatenate([F.reshape(ncols, 3 * k), np.ascontiguousarray(I).view(np.float64)], axis=1))
 
-    def fold_slice(self, F, I, nmax_src):
-        F, I, k = F.numpy(), I.numpy(), self.prm["k"]
+    def fold_slice(self, P, nmax_src):
+        k = self.prm["k"]
+        P = P.numpy()
+        F = P[:, : 3 * k].reshape(P.shape[0], 3, k)
+        I = np.ascontiguousarray(P[:, 3 * k :]).view(np.int32)
         self.parts[("recv", len(self.parts))] = [[(F[i, 0, t], int(I[i, t]), F[i, 1, t], F[i, 2, t]) for t in range(I[i, k])]
                                                   for i in range(self.n)]
 

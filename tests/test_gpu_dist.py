@@ -87,10 +87,9 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
                 torch.cuda.synchronize()
                 return super()._gather_fixed(t.cpu()).cuda()
 
-            def _swap_slices(self, F, I, dst, src, nrows):               # the symmetric ring's slices, staged through the CPU
+            def _swap_slices(self, P, dst, src, nrows):                  # the symmetric ring's slices, staged through the CPU
                 torch.cuda.synchronize()
-                rF, rI = super()._swap_slices(F.cpu(), I.cpu(), dst, src, nrows)
-                return rF.cuda(), rI.cuda()
+                return super()._swap_slices(P.cpu(), dst, src, nrows).cuda()
 
             def _all_to_all(self, t, recv_counts, send_counts):           # the edge exchange of the sharded graph stage
                 torch.cuda.synchronize()

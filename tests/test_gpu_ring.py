@@ -136,8 +136,8 @@ def _symmetric_ring_lists(X, gp, cuts, dup_round=True):
             h = e.open_block(blocks[src])
             out[(r, src)] = e.knn_block_pair(h, row0, row1, ct0, ct1, cuts[r], cuts[src], U[src], counts[src])
             e.close_block(h)
-        for (r, src), (F, I) in out.items():
-            eng[src].fold_slice(F, I, nmax[r])       # the slice of src's rows that rank r computed goes home
+        for (r, src), P in out.items():
+            eng[src].fold_slice(P, nmax[r])          # the slice of src's rows that rank r computed goes home
     res, flagged = [], 0
     for r, e in enumerate(eng):
         nflag = e.knn_merge(nmax)
