@@ -72,3 +72,21 @@ def test_an_eps_that_admits_every_pair(metric):
     sym, full = _build(X, gp, True), _build(X, gp, False)
     _same_index(sym, full)
     assert sym[2]["mfma_flops"] < 0.8 * full[2]["mfma_flops"]
+
+
+@pytest.mark.parametrize("scale", [0.7, 1.0, 2.0])
+def test_symmetric_pass_at_100k(scale):
+    """100 000 x 128, k = 25 (M = 64, every 64th tile sampled), eps tighter and looser than calibrated: bit-identical
+    graphs, well under the full pass's flops."""
+    import torch
+
+    from conftest import gpu_clustered
+    n, d, k = 100_000, 128, 25
+    X = gpu_clustered(n, d, 77, nclust=256).double().cpu().numpy()
+    eps = calibrate_eps(X[:20000], k) * scale
+    gp = {"eps": eps, "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    sym, full = _build(X, gp, True), _build(X, gp, False)
+    _same_index(sym, full)
+    assert sym[2]["mfma_flops"] < 0.62 * full[2]["mfma_flops"]
+    assert sym[2]["fallback_rows"] == 0
+    torch.cuda.empty_cache()
