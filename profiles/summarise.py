@@ -56,10 +56,13 @@ def timeline(d, out):
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), int(r.get("Grid_Size_Z", r.get("Grid_Size_z", 1)) or 1))
             for r in csv.DictReader(open(f)) if "as::" in r["Kernel_Name"]]
     rows.sort()
-    # a query = q_prepare (one slot) ... up to the next q_prepare
+    # a query = q_prepare (one slot) ... up to the next q_prepare; with a host-prepared query the chain opens with the
+    # scan itself (a single-slot scan that no staging kernel precedes)
     chains, cur = [], None
     for st, en, name, gz in rows:
-        if name.startswith("as::q_prepare_kernel"):
+        opens = name.startswith("as::q_prepare_kernel") or (
+            name.startswith("as::scan_dma_kernel") and not (cur and len(cur) == 1 and cur[0][2].startswith("as::q_prepare_kernel")))
+        if opens:
             if cur:
                 chains.append(cur)
             cur = [(st, en, name, gz)]

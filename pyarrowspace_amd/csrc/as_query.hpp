@@ -74,6 +74,7 @@ struct HostOut {
     int64_t len;
     double lambda_q;
     int status, knn_inexact, score_inexact, overflow;
+    int state_reset, pad_;   // the publishing kernel has cleared QInfo's per-search state (clean search, single-query path)
     int64_t idx[MAX_TOPK];
     double score[MAX_TOPK];
 };
@@ -104,8 +105,15 @@ struct as_query {
     int exact = 0;
     int robust = 0;          // 1: wavefront-list path instead of the filter path
     int64_t seq = 0;
-    double* hq = nullptr;    // pinned host staging of the query (device-readable)
+    double* hq = nullptr;    // pinned host staging of the query (device-readable; dp doubles per slot region, zero padded)
     double* hq_dev = nullptr;
+    float* hq32 = nullptr;   // pinned fp32 query of the host-prepared fast path (dp floats, zero padded)
+    float* hq32_dev = nullptr;
+    const double* q64_src = nullptr;   // where the kernels behind the scan read the fp64 query this time (q64 or hq_dev)
+    const float* q32_src = nullptr;
+    int host_q = 0;          // this query was prepared by the host (PreArgs::host_q)
+    double h_nq = 0.0, h_inq = 0.0;
+    int info_clean = 0;      // a reset of QInfo's per-search state is queued behind everything that used it
     double* q64 = nullptr;   // [dp] zero padded
     float* q32 = nullptr;    // [dp]
     as::QInfo* info = nullptr;
@@ -145,6 +153,12 @@ struct PreArgs {
     double epskey, coef;
     int64_t n, exclude;
     int metric, enabled;
+    // host-prepared query (single-query fast path): the host has written the fp32 query and its norms; the scan reads the
+    // query from pinned host memory (as cheap as HBM at kernel start: measured, tools/probe/hostq_probe.hip) and block 0
+    // files the norms in QInfo for the kernels behind it -- no staging kernel in front of the scan
+    int host_q = 0;
+    float nq32 = 0.0f, inq32 = 0.0f;
+    double nq = 0.0, inq = 0.0;
 };
 
 constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats

@@ -483,7 +483,14 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         on[u] = 4 * (lane + 64 * u) < dp;
         qv[u] = on[u] ? *(const f32x4*)(q32 + 4 * (lane + 64 * u)) : f32x4{0, 0, 0, 0};
     }
-    float nq32 = pre.info->nq32, inq32 = pre.info->inq32;
+    float nq32 = pre.host_q ? pre.nq32 : pre.info->nq32, inq32 = pre.host_q ? pre.inq32 : pre.info->inq32;
+    if (pre.host_q && blockIdx.x == 0 && tid == 0) {   // what q_prepare would have filed: read by the kernels behind the scan
+        pre.infow->nq = pre.nq;
+        pre.infow->inq = pre.inq;
+        pre.infow->nq32 = pre.nq32;
+        pre.infow->inq32 = pre.inq32;
+        pre.infow->tau = 1.0;
+    }
 #pragma unroll
     for (int u = 0; u < NCH; ++u) asm volatile("" : "+v"(qv[u]));   // loads complete here, once (see scan_gemm_kernel)
     asm volatile("" : "+v"(nq32), "+v"(inq32));
@@ -686,6 +693,11 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     p.epskey = p.metric == AS_METRIC_L2 ? eps * eps : eps;
     p.coef = coef_query(q, q->exact != 0);
     p.n = sp->n; p.exclude = exclude; p.enabled = enabled ? 1 : 0;
+    p.host_q = q->host_q;
+    if (q->host_q) {
+        p.nq = q->h_nq; p.inq = q->h_inq;
+        p.nq32 = (float)q->h_nq; p.inq32 = q->h_nq > 0.0 ? (float)(1.0 / sqrt(q->h_nq)) : 0.0f;
+    }
     return p;
 }
 
@@ -798,7 +810,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
 #define AS_DSCAN(N, S)                                                                                                 \
     do {                                                                                                               \
         const size_t lds = dma_lds(N, S);                                                                              \
-        hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
+        hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), lds, st, sp->x32, q->q32_src, sp->dp, q->r0, \
                            q->r1, q->dots32, pre, rounds, tail_rows);                                                  \
     } while (0)
             switch (nch) {

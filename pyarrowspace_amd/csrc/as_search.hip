@@ -60,10 +60,12 @@ __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int6
     info += blockIdx.z;
     double s = 0.0;
     for (int64_t c = threadIdx.x; c < dp; c += blockDim.x) {
+#pragma clang fp contract(off)   // product and sum rounded separately: host_query_norm reproduces this sum bit for bit
         const double v = c < d ? qin[c] : 0.0;
         q64[c] = v;
         q32[c] = (float)v;
-        s += v * v;
+        const double sq = v * v;
+        s = s + sq;
     }
     sh[threadIdx.x] = s;
     __syncthreads();
@@ -80,6 +82,26 @@ __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int6
         info->tau = tau;
         reset_query_state(info);
     }
+}
+
+// |q|^2 exactly as q_prepare_kernel forms it (256 strided partial sums, rounded products and sums, then the halving
+// tree): the host-prepared fast path and the staged / batched paths must give a query the same norm, bit for bit.
+// (No fma on either side: std::fma without -mfma is a library call, 6 us for 768 elements.)
+static double host_query_norm(const double* q, int64_t d) {
+    double p[256];
+    for (int t = 0; t < 256; ++t) p[t] = 0.0;
+    for (int64_t c = 0; c < d; ++c) {     // element c belongs to partial c % 256, visited in increasing c: the kernel's order
+        volatile double sq = q[c] * q[c];   // rounded product, kept apart from the sum (no contraction whatever the flags)
+        p[c & 255] = p[c & 255] + sq;
+    }
+    for (int o = 128; o > 0; o >>= 1)
+        for (int t = 0; t < o; ++t) p[t] += p[t + o];
+    return p[0];
+}
+
+// the per-search state of QInfo, cleared behind a finished search so that the next one starts without a launch for it
+__global__ void reset_info_kernel(QInfo* info) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) reset_query_state(info);
 }
 
 __global__ void q_from_row_kernel(const float* __restrict__ x32, const double* __restrict__ x64, int64_t d, int64_t dp,
@@ -970,6 +992,7 @@ struct FinishArgs {
     double* o_gy;
     int32_t* o_cnt;
     int* unproven;      // build fallback: counts the rows whose list failed the a-posteriori check even in fp64
+    int auto_reset;     // score_finish (fused publish, single query): clear QInfo's per-search state behind a clean search
 };
 
 // SPEC S10 given the selected neighbours in LDS in (key, index) rank order; one wave, lane t
@@ -1351,6 +1374,11 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
             a.hout->knn_inexact = a.info->knn_inexact;
             a.hout->score_inexact = bad;
             a.hout->overflow = a.info->overflow;
+            // a clean search leaves nothing for a rerun to read: clear the per-search state here, so that the next query's
+            // scan (whose prefilter counts into it from its first wave on) needs no kernel in front of it
+            const int clean = a.auto_reset && !a.info->knn_inexact && !bad && !a.info->overflow;
+            a.hout->state_reset = clean;
+            if (clean) reset_query_state(a.info);
             publish(a.hout, a.seq);
         }
     }
@@ -1453,7 +1481,7 @@ static FinishArgs make_finish(as_query* q) {
     const as_space* sp = q->sp;
     FinishArgs f;
     memset(&f, 0, sizeof(f));
-    f.x32 = sp->x32; f.x64 = sp->x64; f.n64 = sp->n64; f.q64 = q->q64; f.lam64 = sp->lam64;
+    f.x32 = sp->x32; f.x64 = sp->x64; f.n64 = sp->n64; f.q64 = q->q64_src ? q->q64_src : q->q64; f.lam64 = sp->lam64;
     // deg / ny are read at item id (local row + goff): a sharded graph holds its own rows only, based at row0
     f.deg = q->gr ? q->gr->deg - q->gr->row0 : nullptr; f.ny = q->gr ? q->gr->ny - q->gr->row0 : nullptr;
     f.info = q->info; f.n = sp->n; f.d = sp->d; f.dp = sp->dp; f.k = q->k; f.topk = q->topk; f.nrows = q->r1 - q->r0;
@@ -1554,6 +1582,7 @@ template <typename T, typename U, int PASSES>
 static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_final, const float* dots32 = nullptr) {
     hipStream_t st = q->stream;
     f.M = q->Ms; f.hits = q->hits; f.fuse = fuse_final; f.hout = q->hout_dev; f.seq = q->seq;
+    f.auto_reset = fuse_final && q->cap == 1 ? 1 : 0;
     // mixed (fp32 dots, fp64 keys): the only error of a key is the dot's, scaled by tau
     const double coef_s = dots32 ? f.tau * (coef_query(q, false) + 1.0e-14) + 4.0 * 2.220446049250313e-16 : coef_query(q, sizeof(T) == 8);
     if (q->robust && q->Ms > MAX_LIST) {
@@ -1647,6 +1676,36 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     q->r1 = r1;
     hipStream_t st = q->stream;
     const bool stats = g_search_stats.load(std::memory_order_relaxed) != 0;
+    const bool feature = q->gr && q->gr->lambda_mode == AS_LAMBDA_FEATURE;
+    q->host_q = 0;
+    q->q64_src = q->q64;
+    q->q32_src = q->q32;
+    // Host-prepared query: one query, fp32 LDS-DMA scan (rows up to 1024 floats), item mode.  The host converts the query
+    // and forms its norm (768 elements: a fraction of a microsecond), the scan reads the fp32 query from pinned host
+    // memory and files the norms, the kernels behind it read the fp64 query from the pinned buffer: the staging kernel
+    // and the idle gap behind it (6 + 5 us in front of every scan) are gone.
+    static const bool no_hostq = getenv("ARROWSPACE_NO_HOSTQ") != nullptr;
+    if (query_host && q->cap == 1 && !q->exact && !feature && sp->dp <= 1024 && !(q->scan_variant & 4) && q->hq32 && !no_hostq) {
+        for (int64_t c = 0; c < d; ++c) {
+            const double v = query_host[c];
+            q->hq[c] = v;
+            q->hq32[c] = (float)v;
+        }
+        q->h_nq = host_query_norm(query_host, d);
+        q->h_inq = q->h_nq > 0.0 ? 1.0 / sqrt(q->h_nq) : 0.0;
+        q->host_q = 1;
+        q->q64_src = q->hq_dev;
+        q->q32_src = q->hq32_dev;
+        if (!q->info_clean) hipLaunchKernelGGL(reset_info_kernel, dim3(1), dim3(64), 0, st, q->info);
+        q->info_clean = 0;
+        if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
+        const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !q->crowded_direct);
+        AS_TRY(launch_scan(q, pre));
+        if (stats) AS_HIP(hipEventRecord(q->ev[1], st));
+        q->ev_valid = stats ? 1 : 0;
+        return AS_OK;
+    }
+    q->info_clean = 0;
     if (query_host) {
         memcpy(q->hq, query_host, sizeof(double) * d * q->nb);  // pinned + device-mapped: read in place by the kernel
         if (q->cap > q->nb) memset(q->hq + d * q->nb, 0, sizeof(double) * d * (q->cap - q->nb));  // idle slots: zero query
@@ -1654,7 +1713,6 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->hq_dev);
     }
     const int nslots = q->cap > 1 ? q->cap : q->nb;
-    const bool feature = q->gr && q->gr->lambda_mode == AS_LAMBDA_FEATURE;
     // feature mode: lambda_q is a functional of the query alone (SPEC F6/F7) -- no neighbour search, no prefilter, and
     // it is computed by the staging kernel itself
     if (feature) AS_TRY(feat_query_prepare(q->gr, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, nslots, st));
@@ -1764,8 +1822,17 @@ static as_status query_alloc(as_query* q) {
     }
     AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));
     q->stream = q->own_stream;
-    AS_HIP(hipHostMalloc(&q->hq, sizeof(double) * sp->d * C, hipHostMallocMapped | hipHostMallocCoherent));
+    {   // (dp doubles at least: the host-prepared fast path reads the zero padding behind the d elements)
+        const size_t hq_n = std::max<size_t>((size_t)sp->d * C, (size_t)sp->dp);
+        AS_HIP(hipHostMalloc(&q->hq, sizeof(double) * hq_n, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(q->hq, 0, sizeof(double) * hq_n);
+    }
     AS_HIP(hipHostGetDevicePointer((void**)&q->hq_dev, q->hq, 0));
+    if (C == 1) {
+        AS_HIP(hipHostMalloc(&q->hq32, sizeof(float) * sp->dp, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(q->hq32, 0, sizeof(float) * sp->dp);
+        AS_HIP(hipHostGetDevicePointer((void**)&q->hq32_dev, q->hq32, 0));
+    }
     AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp * C));
     AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp * C));
     AS_HIP(hipMalloc(&q->info, sizeof(QInfo) * C));
@@ -1813,6 +1880,7 @@ void as_query_free(as_query* q) {
     hipSetDevice(q->sp->device);
     if (q->stream) hipStreamSynchronize(q->stream);
     if (q->hq) hipHostFree(q->hq);
+    if (q->hq32) hipHostFree(q->hq32);
     hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32);
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
@@ -2097,6 +2165,7 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
         AS_TRY(run_score(q, tau, 1));
         AS_TRY(wait_published(q));
     }
+    q->info_clean = q->hout->state_reset ? 1 : 0;   // the publishing kernel cleared the per-search state behind itself
     return collect(q, out_idx, out_score, out_len, out_lambda_q);
 }
 
