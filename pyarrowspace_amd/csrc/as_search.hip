@@ -443,6 +443,8 @@ __global__ __launch_bounds__(1024) void score_pickfilter_kernel(SelArgs<T> a, in
     const ScoreCtx c = load_ctx(a.info, a.tau);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool full = false;   // mass ties at the threshold: the counter only has to exceed CAND_CAP
+    // (reading only the groups whose minimum is under the threshold was tried here: no gain -- this kernel is its
+    // threshold prologue; the batched filter, which streams 134 MB of dots, does skip them)
     for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1 && !full; row += stride) {
         const T k = sel_key<T, KEY>(a, c, row);
         if (k <= thr && (KEY == 0 || k < key_traits<T>::inf())) {
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256) void score_gmin_batch_kernel(BatchSel a, int64
 }
 
 template <int NSW>
-__global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a) {
+__global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a, int64_t G) {
     __shared__ double s_rq[NSW], s_lq[NSW], s_thr[NSW];
     const int s0 = blockIdx.y * NSW;
     if (threadIdx.x < NSW) {
@@ -554,12 +556,24 @@ __global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned int full = 0;   // bit s: the slot has overflowed its candidate buffer (mass ties): stop adding to its counter
     for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
+        // a group whose minimum key is above a slot's threshold holds nothing for that slot: a wave (64 consecutive rows,
+        // one group: G is a multiple of 64) reads its rows only for the slots that can still take some -- a few per cent
+        // of the (group, slot) pairs
+        const int64_t g = (row - a.r0) / G;
+        bool act[NSW], any = false;
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) {
+            act[s] = a.gmin[(int64_t)(s0 + s) * CAND_CAP + g] <= s_thr[s];
+            any = any || act[s];
+        }
+        if (!any) continue;
         const double nrow = a.n64[row], lrow = a.lam64[row];
         const double rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
         float dv[NSW];
         batch_dots<NSW>(a, s0, row, dv);
 #pragma unroll
         for (int s = 0; s < NSW; ++s) {
+            if (!act[s]) continue;
             const double k = batch_key(a, dv[s], rn, lrow, s_rq[s], s_lq[s]);
             if (k <= s_thr[s] && !((full >> s) & 1u)) {
                 const int slot = atomicAdd(&a.info_w[s0 + s].sc_cnt, 1);
@@ -1633,7 +1647,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
             const unsigned ny = (unsigned)((q->nb + NSW - 1) / NSW);
             hipLaunchKernelGGL((score_gmin_batch_kernel<NSW>), dim3((unsigned)((ng + 3) / 4), ny), dim3(256), 0, st, b, G, ng);
             hipLaunchKernelGGL((pick_thr_kernel<T>), dim3(1, 1, nb), dim3(1024), 0, st, (const T*)q->gmin, ng, q->Ms, q->info);
-            hipLaunchKernelGGL((score_filter_batch_kernel<NSW>), dim3(fg, ny), dim3(256), 0, st, b);
+            hipLaunchKernelGGL((score_filter_batch_kernel<NSW>), dim3(fg, ny), dim3(256), 0, st, b, G);
         } else {
             hipLaunchKernelGGL((score_gmin_kernel<T, 0>), dim3((unsigned)((ng + 3) / 4), 1, nb), dim3(256), 0, st, a, G, ng);
             const unsigned pg = (unsigned)std::min<int64_t>((rows + 1023) / 1024, std::max(q->cus, 1));
