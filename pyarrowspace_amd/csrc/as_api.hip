@@ -104,6 +104,7 @@ void as_free_space(as_space* sp) {
     hipSetDevice(sp->device);
     if (sp->qcache) as_query_free(sp->qcache);
     if (sp->qcache_b) as_query_free(sp->qcache_b);
+    if (sp->qcache_b2) as_query_free(sp->qcache_b2);
     if (sp->stream) hipStreamSynchronize(sp->stream);
     hipFree(sp->x32); hipFree(sp->x64); hipFree(sp->n64); hipFree(sp->n32); hipFree(sp->inorm32);
     hipFree(sp->lam64); hipFree(sp->lam32);
@@ -653,18 +654,49 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
         if (sp->qcache_b && sp->qcache_b_gr != gr) {
             as_query_free(sp->qcache_b);
             sp->qcache_b = nullptr;
+            if (sp->qcache_b2) as_query_free(sp->qcache_b2);
+            sp->qcache_b2 = nullptr;
         }
         if (!sp->qcache_b) {
             AS_TRY(query_create(sp, gr, QUERY_BATCH, &sp->qcache_b));
             sp->qcache_b_gr = gr;
         }
+        // more than one pass: a second workspace, and the passes alternate -- pass p + 1 is queued (on its own stream)
+        // before pass p is waited for, so its scan runs under pass p's selection and finish kernels
+        if (b > QUERY_BATCH && !sp->qcache_b2 && !getenv("ARROWSPACE_NO_BATCH_PIPELINE")) {
+            if (query_create(sp, gr, QUERY_BATCH, &sp->qcache_b2) != AS_OK) sp->qcache_b2 = nullptr;   // (memory: stay sequential)
+        }
     }
+    as_query* ws[2] = {sp->qcache_b, sp->qcache_b2 && b > QUERY_BATCH ? sp->qcache_b2 : sp->qcache_b};
+    const bool piped = batched && ws[1] != ws[0];
+    // an error leaves no pass in flight behind it (the other workspace's kernels would otherwise still be running when the
+    // caller comes back)
+    auto drain = [&](as_status s) {
+        if (piped)
+            for (int w = 0; w < 2; ++w) (void)hipStreamSynchronize((hipStream_t)as_query_stream(ws[w]));
+        return s;
+    };
     int32_t st_chunk[QUERY_BATCH];
-    for (int64_t i0 = 0; i0 < b; i0 += QUERY_BATCH) {
+    if (piped) {
+        const as_status s0 = search_batch_launch(ws[0], queries, (int)std::min<int64_t>(QUERY_BATCH, b), d, tau);
+        if (s0 != AS_OK) return drain(s0);
+    }
+    int64_t pass = 0;
+    for (int64_t i0 = 0; i0 < b; i0 += QUERY_BATCH, ++pass) {
         const int nb = (int)std::min<int64_t>(QUERY_BATCH, b - i0);
         if (batched) {
-            AS_TRY(search_batch_once(sp->qcache_b, queries + i0 * d, nb, d, tau, topk, out_idx + i0 * topk, out_score + i0 * topk,
-                                     out_len + i0, out_lambda_q ? out_lambda_q + i0 : nullptr, st_chunk));
+            as_query* cur = ws[pass & 1];
+            as_status s = AS_OK;
+            if (piped) {
+                const int64_t i1 = i0 + QUERY_BATCH;
+                if (i1 < b) s = search_batch_launch(ws[(pass + 1) & 1], queries + i1 * d, (int)std::min<int64_t>(QUERY_BATCH, b - i1), d, tau);
+            } else {
+                s = search_batch_launch(cur, queries + i0 * d, nb, d, tau);
+            }
+            if (s == AS_OK)
+                s = search_batch_collect(cur, nb, tau, topk, out_idx + i0 * topk, out_score + i0 * topk, out_len + i0,
+                                         out_lambda_q ? out_lambda_q + i0 : nullptr, st_chunk);
+            if (s != AS_OK) return drain(s);
         } else {
             for (int t = 0; t < nb; ++t) st_chunk[t] = -1;
         }
@@ -676,7 +708,7 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
                                                           out_len + i, &lq);
                 if (out_lambda_q) out_lambda_q[i] = lq;
                 st_chunk[t] = (int32_t)s1;
-                if (s1 != AS_OK && s1 != AS_EZEROLAMBDA) return s1;
+                if (s1 != AS_OK && s1 != AS_EZEROLAMBDA) return drain(s1);
             }
             if (st_chunk[t] == AS_EZEROLAMBDA) out_len[i] = 0;
             if (out_status) out_status[i] = st_chunk[t];

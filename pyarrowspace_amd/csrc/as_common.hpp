@@ -63,6 +63,7 @@ struct as_space {
     mutable as_query* qcache = nullptr;       // lazily created by as_search
     mutable const as_graph* qcache_gr = nullptr;
     mutable as_query* qcache_b = nullptr;     // batched workspace (QUERY_BATCH slots), lazily created
+    mutable as_query* qcache_b2 = nullptr;    // its twin: passes alternate, one scans while the other finishes
     mutable const as_graph* qcache_b_gr = nullptr;
     mutable std::mutex qmu;
     mutable int64_t unproven_searches = 0;   // searches returned although their a-posteriori check failed on the strongest path
@@ -336,8 +337,9 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
                       double* out_score, int64_t* out_len, double* out_lambda_q);
 void query_flags(const as_query* q, int* knn_inexact, int* score_inexact);
 as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out);
-as_status search_batch_once(as_query* q, const double* queries, int nb, int64_t d, double tau, int64_t topk, int64_t* out_idx,
-                            double* out_score, int64_t* out_len, double* out_lambda_q, int32_t* out_status);
+as_status search_batch_launch(as_query* q, const double* queries, int nb, int64_t d, double tau);
+as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, int64_t* out_idx, double* out_score, int64_t* out_len,
+                               double* out_lambda_q, int32_t* out_status);
 constexpr int QUERY_BATCH = 32;  // == GQ in as_search.hip: query slots of the batched workspace
 
 }  // namespace as

@@ -2186,15 +2186,21 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
 // up to QB queries in one pass over the items (filter path, fp32 prefilters); out_status[b] is
 // AS_OK / AS_EZEROLAMBDA, or -1 when slot b must be rerun on the single-query path (a candidate
 // buffer overflowed or an a-posteriori check failed)
-as_status search_batch_once(as_query* q, const double* queries, int nb, int64_t d, double tau, int64_t topk, int64_t* out_idx,
-                            double* out_score, int64_t* out_len, double* out_lambda_q, int32_t* out_status) {
+// The pass in two halves, so that two workspaces can alternate: every kernel of a pass is queued by _launch (nothing
+// waits), _collect waits for its slots and reads them.  While one workspace's selection and finish kernels run, the
+// other's scan -- on its own stream -- already streams the items.
+as_status search_batch_launch(as_query* q, const double* queries, int nb, int64_t d, double tau) {
     q->exact = 0;
     q->robust = 0;
     q->nb = nb;
     AS_TRY(query_begin(q, queries, -1, d, 0, q->sp->n, q->gr->gp.eps, -1));
     if (q->gr->lambda_mode != AS_LAMBDA_FEATURE) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
     q->seq += 1;
-    AS_TRY(run_score(q, tau, 1));
+    return run_score(q, tau, 1);
+}
+
+as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, int64_t* out_idx, double* out_score, int64_t* out_len,
+                               double* out_lambda_q, int32_t* out_status) {
     bool crowded = false;
     for (int b = 0; b < nb; ++b) {
         AS_TRY(wait_published(q, b));
