@@ -90,3 +90,22 @@ def test_symmetric_pass_at_100k(scale):
     assert sym[2]["mfma_flops"] < 0.62 * full[2]["mfma_flops"]
     assert sym[2]["fallback_rows"] == 0
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_symmetric_pass_with_zero_rows_duplicates_and_unrepresentable_items(metric):
+    """All-zero rows (under cosine they tie with everything at distance 1), groups of exact duplicates and fp64 items that
+    do not round-trip through fp32 (the exact re-evaluation then reads the fp64 copy): still bit-identical to the full
+    pass."""
+    n, d, k = 5200, 48, 9
+    X = clustered(n, d, nclust=10, seed=12) * (1.0 + 1e-9 * np.arange(n)[:, None])     # not fp32-representable
+    rng = np.random.default_rng(4)
+    X[rng.choice(n, 40, replace=False)] = 0.0
+    for g in range(5):
+        rows = rng.choice(n, 30, replace=False)
+        X[rows] = X[rows[0]]
+    gp = {"eps": calibrate_eps(clustered(n, d, nclust=10, seed=12), k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None,
+          "metric": metric}
+    sym, full = _build(X, gp, True), _build(X, gp, False)
+    _same_index(sym, full)
+    assert sym[2]["mfma_flops"] < full[2]["mfma_flops"] and sym[2]["fallback_rows"] == full[2]["fallback_rows"]
