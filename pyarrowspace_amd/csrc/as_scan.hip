@@ -714,6 +714,8 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_gemm_kernel<4, 0, 2>), gemm_lds(4));
     AS_ATTR((scan_dma_kernel<1, 8>), dma_lds(1, 8));
     AS_ATTR((scan_dma_kernel<2, 8>), dma_lds(2, 8));
+    AS_ATTR((scan_dma_kernel<2, 5>), dma_lds(2, 5));
+    AS_ATTR((scan_dma_kernel<2, 4>), dma_lds(2, 4));
     AS_ATTR((scan_dma_kernel<3, 5>), dma_lds(3, 5));
     AS_ATTR((scan_dma_kernel<4, 4>), dma_lds(4, 4));
 #undef AS_ATTR
@@ -801,8 +803,13 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
         // default for rows up to 1024 floats: the LDS-DMA ring scan (ARROWSPACE_SCAN_VARIANT bit2 = register-staged scan)
         if (nch <= 4 && !(q->scan_variant & 4)) {
             const int64_t want = std::max<int64_t>(1, (rows + 63) / 64);                 // blocks that still get >= 16 rows per wave
-            // 2 blocks per CU, ring of 5 rows at 768 columns; rings of 4 or 6 rows and 3 blocks per CU measured the same or slower
-            const int64_t nblk = std::min<int64_t>(want, 2 * (int64_t)q->cus);
+            // 2 blocks per CU, ring of 5 rows at 768 columns; rings of 4 or 6 rows and 3 blocks per CU measured the same or slower.
+            // Short rows (up to 512 floats) pay the same per-row bookkeeping for half the bytes: 4 blocks per CU there
+            // (ring of 4 two-KiB slots, or of 8 one-KiB slots) -- 400k x 384: 105 -> 99 us, x 256: 78.5 -> 75.7, x 512: 141 -> 137.
+            // (measurement: ARROWSPACE_SCAN_GEOM=<blocks per CU><ring slots> for rows up to 512 floats, e.g. 28 = the old form)
+            static const int geom = getenv("ARROWSPACE_SCAN_GEOM") ? atoi(getenv("ARROWSPACE_SCAN_GEOM")) : 0;
+            const int bpc = nch <= 2 ? (geom ? geom / 10 : 4) : 2;
+            const int64_t nblk = std::min<int64_t>(want, bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
             const int rounds = (int)(rows / (NW * 64));
             const int64_t rem = rows - (int64_t)rounds * NW * 64;
@@ -815,7 +822,11 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
     } while (0)
             switch (nch) {
                 case 1: AS_DSCAN(1, 8); break;
-                case 2: AS_DSCAN(2, 8); break;
+                case 2:
+                    if (geom % 10 == 5) AS_DSCAN(2, 5);
+                    else if (geom % 10 == 8) AS_DSCAN(2, 8);
+                    else AS_DSCAN(2, 4);
+                    break;
                 case 3: AS_DSCAN(3, 5); break;
                 default: AS_DSCAN(4, 4); break;
             }
