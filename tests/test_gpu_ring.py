@@ -233,3 +233,35 @@ def test_symmetric_ring_seeded_fuzz():
             np.testing.assert_array_equal(res[b][3], scnt, err_msg=ctx)
             np.testing.assert_array_equal(res[b][0], sidx, err_msg=ctx)
             np.testing.assert_array_equal(res[b][1], sdist, err_msg=ctx)
+
+
+def test_block_pair_refuses_bad_arguments():
+    """as_knn_block_pair: a block is not paired with itself, the row range must lie inside the space, the visiting block
+    must match the space (features); as_knn_thresholds: row range inside the space."""
+    import ctypes as C
+
+    import torch
+
+    from pyarrowspace_amd.dist import HipEngine
+    X = clustered(700, 32, nclust=4, seed=1)
+    gp = {"eps": calibrate_eps(X, 5), "k": 5, "topk": 5, "p": 2.0, "sigma": None}
+    e = HipEngine(gp)
+    e.create_space(torch.from_numpy(X[:400].copy()).cuda())
+    e.ring_begin(2)
+    with pytest.raises(ValueError, match="not paired with itself"):
+        e.knn_block_pair(e.own_block(), 0, 400, -1, -1, 0, 0, None, 400)
+    h = e.open_block(torch.from_numpy(X[400:].copy()).cuda())
+    with pytest.raises(ValueError, match="bad row range"):
+        e.knn_block_pair(h, 0, 401, -1, -1, 0, 400, None, 300)
+    other = e.open_block(torch.from_numpy(np.ascontiguousarray(X[400:, :16])).cuda())
+    with pytest.raises(ValueError, match="does not match"):
+        e.knn_block_pair(other, 0, 400, -1, -1, 0, 400, None, 300)
+    out = torch.zeros(400, dtype=torch.float32, device="cuda")
+    st = e.L.as_knn_thresholds(e.sp, C.byref(e.gp), 0, 401, 1.0, C.c_void_p(e.p_key[0].data_ptr()), C.c_void_p(e.p_cnt[0].data_ptr()),
+                               C.c_void_p(out.data_ptr()))
+    assert st != 0
+    # and a proper call still works afterwards: the empty own list gives +inf thresholds
+    assert bool(torch.isinf(e.knn_thresholds(1.0)).all())
+    e.close_block(other)
+    e.close_block(h)
+    e.close()
