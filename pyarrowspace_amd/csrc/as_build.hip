@@ -2032,6 +2032,7 @@ __global__ __launch_bounds__(256) void knn_block_band_kernel(BlockBandArgs a) {
 struct FoldArgs {
     int64_t rows, r0;
     int M, metric, mode;
+    int raw = 0;   // the block's bound is taken as it is (chunks of one block: the error term is subtracted later, once)
     double coef, nmax_b;
     const double* na64;
     const int* flag;
@@ -2090,7 +2091,7 @@ __global__ __launch_bounds__(256) void knn_fold_kernel(FoldArgs a) {
         float tb = (a.mode == 2 || !anyr) ? __int_as_float(0x7f800000) : a.r_t32[lr];
         if (anyb) {   // (a gated transposed slice may have kept nothing and still have turned candidates away: its bound counts)
             const double e = a.metric == AS_METRIC_L2 ? a.coef * (a.na64[a.r0 + lr] + a.nmax_b) : a.coef;
-            const float nb = __double2float_rd((double)a.b_t32[lr] - e);
+            const float nb = a.raw ? a.b_t32[lr] : __double2float_rd((double)a.b_t32[lr] - e);
             tb = nb < tb ? nb : tb;
         }
         a.r_cnt[lr] = (C < a.M ? C : a.M) | ((anyb | (a.mode == 2 ? 0 : anyr)) << 30);
@@ -2098,12 +2099,13 @@ __global__ __launch_bounds__(256) void knn_fold_kernel(FoldArgs a) {
     }
 }
 
-as_status knn_fold(const as_space* sp, int64_t r0, int64_t r1, int M, int mode, double block_nmax, const int32_t* flag, double* r_key,
-                   double* r_dist, double* r_gy, int32_t* r_idx, int32_t* r_cnt, float* r_t32, const double* b_key, const double* b_dist,
-                   const double* b_gy, const int32_t* b_idx, const int32_t* b_cnt, const float* b_t32) {
+static as_status fold_launch(const as_space* sp, int64_t r0, int64_t r1, int M, int mode, int raw, double block_nmax, const int32_t* flag,
+                             double* r_key, double* r_dist, double* r_gy, int32_t* r_idx, int32_t* r_cnt, float* r_t32, const double* b_key,
+                             const double* b_dist, const double* b_gy, const int32_t* b_idx, const int32_t* b_cnt, const float* b_t32) {
     const int64_t rows = r1 - r0;
     if (rows <= 0) return AS_OK;
     FoldArgs fa;
+    fa.raw = raw;
     fa.rows = rows; fa.r0 = r0; fa.M = M; fa.metric = sp->opts.metric; fa.mode = mode; fa.coef = err_coef(sp->dp); fa.nmax_b = block_nmax;
     fa.na64 = sp->n64; fa.flag = flag;
     fa.r_key = r_key; fa.r_dist = r_dist; fa.r_gy = r_gy; fa.r_idx = r_idx; fa.r_cnt = r_cnt; fa.r_t32 = r_t32;
@@ -2114,6 +2116,19 @@ as_status knn_fold(const as_space* sp, int64_t r0, int64_t r1, int M, int mode, 
     AS_HIP(hipGetLastError());
     AS_HIP(hipStreamSynchronize(sp->stream));
     return AS_OK;
+}
+
+as_status knn_fold(const as_space* sp, int64_t r0, int64_t r1, int M, int mode, double block_nmax, const int32_t* flag, double* r_key,
+                   double* r_dist, double* r_gy, int32_t* r_idx, int32_t* r_cnt, float* r_t32, const double* b_key, const double* b_dist,
+                   const double* b_gy, const int32_t* b_idx, const int32_t* b_cnt, const float* b_t32) {
+    return fold_launch(sp, r0, r1, M, mode, 0, block_nmax, flag, r_key, r_dist, r_gy, r_idx, r_cnt, r_t32, b_key, b_dist, b_gy, b_idx, b_cnt, b_t32);
+}
+
+// chunks of ONE block's slice: lists merged, the smaller raw bound kept (pointers indexed from the first row)
+static as_status knn_fold_raw(const as_space* sp, int64_t rows, int M, double* r_key, double* r_dist, double* r_gy, int32_t* r_idx,
+                              int32_t* r_cnt, float* r_t32, const double* b_key, const double* b_dist, const double* b_gy, const int32_t* b_idx,
+                              const int32_t* b_cnt, const float* b_t32) {
+    return fold_launch(sp, 0, rows, M, 0, 1, 0.0, nullptr, r_key, r_dist, r_gy, r_idx, r_cnt, r_t32, b_key, b_dist, b_gy, b_idx, b_cnt, b_t32);
 }
 
 // the fused MFMA kernel on (rows of sp) x (columns of cols), normal or collect mode
@@ -2261,30 +2276,23 @@ as_status knn_thresholds(const as_space* sp, int64_t r0, int64_t r1, int M, doub
 // exactly here, while both shards are resident: p_* is the own rows' slice (as knn_block's, indexed from r0), q_* the
 // visiting items' slice [cols->n][M] w.r.t. the own rows as columns -- q_t32 the lower bound of what its buffers turned
 // away or dropped (-inf for a buffer that overflowed: the row fails its proof and goes round again).
-as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ct0,
-                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
-                         double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
-                         int32_t* q_idx, int32_t* q_cnt, float* q_t32) {
-    AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block_pair"));
+//
+// pair_chunk: the column tiles [ca, cb) of the visiting block -- its scratch (transposed buffers of 16 M entries per
+// visiting item, 8 KiB each at M = 64) covers the chunk's items only.
+static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ca,
+                            int64_t cb, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
+                            double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
+                            int32_t* q_idx, int32_t* q_cnt, float* q_t32) {
     hipStream_t st = sp->stream;
-    const int64_t rows = r1 - r0, nc = cols->n;
+    const int64_t rows = r1 - r0;
+    const int64_t j0 = ca * BN, j1 = std::min<int64_t>(cols->n, cb * BN), ncc = j1 - j0;   // the chunk's items
     const int ntile_all = (int)(cols->np / BN);
-    if (ct0 < 0) ct0 = 0;
-    if (ct1 < 0 || ct1 > ntile_all) ct1 = ntile_all;
-    // the visiting items that take no part keep an empty slice
-    AS_HIP(hipMemsetAsync(q_cnt, 0, sizeof(int32_t) * nc, st));
-    AS_HIP(hipMemsetAsync(q_idx, 0xff, sizeof(int32_t) * nc * M, st));
-    if (rows <= 0 || ct1 <= ct0) {
-        if (rows > 0) AS_HIP(hipMemsetAsync(p_cnt, 0, sizeof(int32_t) * rows, st));   // an empty own slice too: folding it adds nothing
-        AS_HIP(hipStreamSynchronize(st));
-        return AS_OK;
-    }
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
     const double coef = err_coef(sp->dp);
     const int dev_cus = device_cus(sp->device);
     const int nrb = (int)((rows + BM - 1) / BM);
-    const int ntile = (int)(ct1 - ct0);
+    const int ntile = (int)(cb - ca);
     // units: every row block's tiles in pieces of at most L, one segment per piece
     int L = (int)std::max<double>(8.0, std::ceil((double)nrb * ntile / (dev_cus * 16.0)));
     if ((ntile + L - 1) / L > 8) L = (ntile + 7) / 8;
@@ -2292,7 +2300,7 @@ as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_grap
     std::vector<int4> hunits;
     for (int rb = 0; rb < nrb; ++rb) {
         int seg = 0;
-        for (int t = (int)ct0; t < ct1; t += L, ++seg) hunits.push_back(make_int4(rb, t, (int)std::min<int64_t>(ct1, t + L), seg));
+        for (int t = (int)ca; t < cb; t += L, ++seg) hunits.push_back(make_int4(rb, t, (int)std::min<int64_t>(cb, t + L), seg));
     }
     std::stable_sort(hunits.begin(), hunits.end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
     const int units = (int)hunits.size(), grid = std::min(units, dev_cus);
@@ -2307,10 +2315,10 @@ as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_grap
     AS_HIP(ckey.alloc((size_t)rows * S * M));
     AS_HIP(cidx.alloc((size_t)rows * S * M));
     AS_HIP(ccnt.alloc((size_t)rows * S));
-    AS_HIP(tr_cnt.alloc(nc + 1));
-    AS_HIP(tr_key.alloc((size_t)nc * T_CAP));
-    AS_HIP(tr_idx.alloc((size_t)nc * T_CAP));
-    AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (nc + 1), st));
+    AS_HIP(tr_cnt.alloc(ncc + 1));
+    AS_HIP(tr_key.alloc((size_t)ncc * T_CAP));
+    AS_HIP(tr_idx.alloc((size_t)ncc * T_CAP));
+    AS_HIP(hipMemsetAsync(tr_cnt, 0, sizeof(int) * (ncc + 1), st));
     AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));
     const double nmax = std::max(sp->nmax, cols->nmax);
     KnnArgs ka;
@@ -2320,7 +2328,10 @@ as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_grap
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
     ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff;
     ka.a_ids = nullptr; ka.a_thr = nullptr;
-    ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + nc; ka.t_cnt = tr_cnt; ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
+    // the kernel addresses the transposed buffers by the item's number inside the block: bases moved back by the chunk's
+    // first item (only items of the chunk's tiles are ever addressed)
+    ka.units = d_units; ka.nunits = units; ka.unit_ctr = (int*)tr_cnt + ncc; ka.t_cnt = (int*)tr_cnt - j0;
+    ka.t_key = (float*)tr_key - (size_t)j0 * T_CAP; ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP; ka.t_cap = T_CAP;
     ka.t_all = 1; ka.thr_col = col_thr;
     const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
     if (metric == AS_METRIC_L2) {
@@ -2342,30 +2353,89 @@ as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_grap
     hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), per_wave * 4, st, ra);
     AS_HIP(hipGetLastError());
     // visiting items: their transposed buffers -> one candidate list each (+ the bound of what was turned away) -> the same
-    // refinement with the roles swapped (rows = the visiting block, columns = the own rows, ids global)
-    AS_HIP(c2key.alloc((size_t)nc * M));
-    AS_HIP(c2idx.alloc((size_t)nc * M));
-    AS_HIP(c2cnt.alloc(nc));
-    AS_HIP(t_bound.alloc(nc));
-    AS_HIP(gate.alloc(nc));
-    hipLaunchKernelGGL(pair_gate_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, col_thr, cols->n32, nc, ct0 * BN, ct1 * BN, metric,
-                       ka.epskey, ka.coef, ka.nmax, (float*)gate);
+    // refinement with the roles swapped (rows = the chunk's items, columns = the own rows, ids global)
+    AS_HIP(c2key.alloc((size_t)ncc * M));
+    AS_HIP(c2idx.alloc((size_t)ncc * M));
+    AS_HIP(c2cnt.alloc(ncc));
+    AS_HIP(t_bound.alloc(ncc));
+    AS_HIP(gate.alloc(ncc));
+    hipLaunchKernelGGL(pair_gate_kernel, dim3((unsigned)((ncc + 255) / 256)), dim3(256), 0, st, col_thr ? col_thr + j0 : nullptr, cols->n32 + j0, ncc,
+                       (int64_t)0, ncc, metric, ka.epskey, ka.coef, ka.nmax, (float*)gate);
     const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
     AS_HIP(hipFuncSetAttribute((const void*)transposed_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
-    hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt, (const float*)tr_key,
-                       (const int*)tr_idx, T_CAP, nc, 1, 0, M, (float*)c2key, (int*)c2idx, (int*)c2cnt, (const float*)gate, (float*)t_bound);
+    hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((ncc + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt, (const float*)tr_key,
+                       (const int*)tr_idx, T_CAP, ncc, 1, 0, M, (float*)c2key, (int*)c2idx, (int*)c2cnt, (const float*)gate, (float*)t_bound);
     AS_HIP(hipGetLastError());
     BlockRefineArgs rb2;
     rb2.xa32 = cols->x32; rb2.xa64 = cols->x64; rb2.xb32 = sp->x32; rb2.xb64 = sp->x64; rb2.na64 = cols->n64; rb2.nb64 = sp->n64;
-    rb2.d = sp->d; rb2.dp = sp->dp; rb2.r0 = 0; rb2.r1 = nc; rb2.col_goff = row_goff; rb2.S = 1; rb2.M = M; rb2.metric = metric;
+    rb2.d = sp->d; rb2.dp = sp->dp; rb2.r0 = j0; rb2.r1 = j1; rb2.col_goff = row_goff; rb2.S = 1; rb2.M = M; rb2.metric = metric;
     rb2.c_key = c2key; rb2.c_idx = c2idx; rb2.c_cnt = c2cnt;
-    rb2.p_key = q_key; rb2.p_dist = q_dist; rb2.p_gy = q_gy; rb2.p_idx = q_idx; rb2.p_cnt = q_cnt; rb2.p_t32 = q_t32;
-    rb2.t32_given = t_bound;
+    rb2.p_key = q_key + (size_t)j0 * M; rb2.p_dist = q_dist + (size_t)j0 * M; rb2.p_gy = q_gy + (size_t)j0 * M; rb2.p_idx = q_idx + (size_t)j0 * M;
+    rb2.p_cnt = q_cnt + j0; rb2.p_t32 = q_t32 + j0;
+    rb2.t32_given = (const float*)t_bound - j0;   // read by the item's number inside the block
     const size_t per_wave2 = (sizeof(double) * 3 * M + sizeof(float) * ((size_t)M + M) + sizeof(int) * ((size_t)M + M) + 15) / 16 * 16;
-    hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), per_wave2 * 4, st, rb2);
+    hipLaunchKernelGGL(knn_block_refine_kernel, dim3((unsigned)((ncc + 3) / 4)), dim3(256), per_wave2 * 4, st, rb2);
     AS_HIP(hipGetLastError());
     AS_HIP(hipStreamSynchronize(st));
     sp->kstats[7] += 2.0 * (double)nrb * BM * (double)ntile * BN * (double)sp->dp;
+    return AS_OK;
+}
+
+as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ct0,
+                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
+                         double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
+                         int32_t* q_idx, int32_t* q_cnt, float* q_t32) {
+    AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block_pair"));
+    hipStream_t st = sp->stream;
+    const int64_t rows = r1 - r0, nc = cols->n;
+    const int64_t ntile_all = (nc + BN - 1) / BN;   // tiles that hold items (the padded layout may end in a tile of padding)
+    if (ct0 < 0) ct0 = 0;
+    if (ct1 < 0 || ct1 > ntile_all) ct1 = ntile_all;
+    // the visiting items that take no part keep an empty slice
+    AS_HIP(hipMemsetAsync(q_cnt, 0, sizeof(int32_t) * nc, st));
+    AS_HIP(hipMemsetAsync(q_idx, 0xff, sizeof(int32_t) * nc * M, st));
+    if (rows <= 0 || ct1 <= ct0) {
+        if (rows > 0) AS_HIP(hipMemsetAsync(p_cnt, 0, sizeof(int32_t) * rows, st));   // an empty own slice too: folding it adds nothing
+        AS_HIP(hipStreamSynchronize(st));
+        return AS_OK;
+    }
+    // The transposed buffers take 16 M x 8 B per visiting item (65 GB for a shard of 8M items at M = 64): the visiting
+    // block is taken in chunks of column tiles whose buffers fit in an eighth of the free memory (at most 16 GB).  A
+    // visiting item belongs to one chunk -- its slice is complete after it; the own rows' slices of the chunks are folded
+    // (the M smallest exact keys of their union, the smallest drop bound).
+    int64_t chunk = ct1 - ct0;
+    {
+        size_t mfree = 0, mtotal = 0;
+        double budget = 16e9;
+        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) budget = std::min(budget, 0.125 * (double)mfree);
+        const double per_tile = (double)BN * 16.0 * M * 8.0;
+        chunk = std::max<int64_t>(8, std::min<int64_t>(chunk, (int64_t)(budget / per_tile)));
+        const char* ev = getenv("ARROWSPACE_PAIR_CHUNK_TILES");   // tests: force the chunked path at small sizes
+        if (ev && atoll(ev) > 0) chunk = atoll(ev);
+    }
+    const int64_t nchunk = (ct1 - ct0 + chunk - 1) / chunk;
+    if (nchunk <= 1)
+        return pair_chunk(sp, cols, gp, r0, r1, ct0, ct1, row_goff, col_goff, col_thr, M, p_key, p_dist, p_gy, p_idx, p_cnt, p_t32, q_key, q_dist,
+                          q_gy, q_idx, q_cnt, q_t32);
+    chunk = (ct1 - ct0 + nchunk - 1) / nchunk;   // even pieces
+    dev_tmp<double> c_key, c_dist, c_gy;
+    dev_tmp<int32_t> c_idx, c_cnt;
+    dev_tmp<float> c_t32;
+    AS_HIP(c_key.alloc((size_t)rows * M));
+    AS_HIP(c_dist.alloc((size_t)rows * M));
+    AS_HIP(c_gy.alloc((size_t)rows * M));
+    AS_HIP(c_idx.alloc((size_t)rows * M));
+    AS_HIP(c_cnt.alloc(rows));
+    AS_HIP(c_t32.alloc(rows));
+    AS_HIP(hipMemsetAsync(p_cnt, 0, sizeof(int32_t) * rows, st));   // an empty running slice: no entries, nothing dropped
+    for (int64_t ca = ct0; ca < ct1; ca += chunk) {
+        const int64_t cb = std::min(ct1, ca + chunk);
+        AS_TRY(pair_chunk(sp, cols, gp, r0, r1, ca, cb, row_goff, col_goff, col_thr, M, c_key, c_dist, c_gy, c_idx, c_cnt, c_t32, q_key, q_dist,
+                          q_gy, q_idx, q_cnt, q_t32));
+        // NOT the fold's error term: the chunk's bound is a raw fp32 key, as a block slice's is -- the caller's fold
+        // subtracts the error once.  Here only the lists are merged and the smaller raw bound is kept.
+        AS_TRY(knn_fold_raw(sp, rows, M, p_key, p_dist, p_gy, p_idx, p_cnt, p_t32, c_key, c_dist, c_gy, c_idx, c_cnt, c_t32));
+    }
     return AS_OK;
 }
 

@@ -166,19 +166,34 @@ class HipEngine:
                                                  C.c_void_p(self.p_cnt[0].data_ptr()), C.c_void_p(out.data_ptr())))
         return out[: self.n]
 
+    def _slice_sections(self, P, nrows):
+        """The sections of a packed slice: key / dist / gy fp64 [nrows, M], ids int32 [nrows, M], count int32 [nrows],
+        drop bound fp32 [nrows] -- contiguous views of ONE flat fp64 buffer (the int32 / fp32 sections as bit patterns,
+        each padded to a whole number of 8-byte words), so that the library writes the message in place and the receiver
+        folds it in place."""
+        torch = self.torch
+        M, n = self.M, max(nrows, 1)
+        w = n * M
+        h = (n + 1) // 2
+        o = [0, w, 2 * w, 3 * w, 3 * w + (w + 1) // 2, 3 * w + (w + 1) // 2 + h, 3 * w + (w + 1) // 2 + 2 * h]
+        assert P.shape == (o[6],)
+        return [P[o[0]:o[1]].view(n, M), P[o[1]:o[2]].view(n, M), P[o[2]:o[3]].view(n, M),
+                P[o[3]:o[4]].view(torch.int32)[:w].view(n, M), P[o[4]:o[5]].view(torch.int32)[:n], P[o[5]:o[6]].view(torch.float32)[:n]]
+
+    def slice_shape(self, nrows):
+        n = max(nrows, 1)
+        w = n * self.M
+        return (3 * w + (w + 1) // 2 + 2 * ((n + 1) // 2),)
+
     def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols):
         """Own rows [row0, row1) x the visiting block's column tiles [ct0, ct1): the own rows' slice is folded here; returns
-        the visiting items' slice, packed for the way home: (fp64 [ncols, 3, M] key/dist/gy, int32 [ncols, M + 2] ids,
-        count, the bits of the drop bound)."""
+        the visiting items' slice, packed for the way home (one flat fp64 tensor: _slice_sections)."""
         torch = self.torch
-        M = self.M
         dev = torch.device("cuda", self.op.device)
-        F = torch.zeros((max(ncols, 1), 3, M), dtype=torch.float64, device=dev)
-        I = torch.full((max(ncols, 1), M + 2), -1, dtype=torch.int32, device=dev)
-        qk, qd, qg = (torch.zeros((max(ncols, 1), M), dtype=torch.float64, device=dev) for _ in range(3))
-        qi = torch.full((max(ncols, 1), M), -1, dtype=torch.int32, device=dev)
-        qc = torch.zeros((max(ncols, 1),), dtype=torch.int32, device=dev)
-        qt = torch.full((max(ncols, 1),), float("inf"), dtype=torch.float32, device=dev)
+        P = torch.zeros(self.slice_shape(ncols), dtype=torch.float64, device=dev)
+        qk, qd, qg, qi, qc, qt = self._slice_sections(P, ncols)
+        qi.fill_(-1)
+        qt.fill_(float("inf"))
         thr = col_thr.contiguous() if col_thr is not None else None
         torch.cuda.synchronize()
         if self.n > 0 and ncols > 0:
@@ -189,10 +204,7 @@ class HipEngine:
                                                  *[C.c_void_p(t.data_ptr()) for t in (qk, qd, qg, qi, qc, qt)]))
             if row1 > row0:
                 self._fold_rows(row0, row1, self.block_nmax(h), 1)
-        F[:, 0], F[:, 1], F[:, 2] = qk, qd, qg
-        I[:, :M], I[:, M], I[:, M + 1] = qi, qc, qt.view(torch.int32)
-        # one message per step and direction: the int32 columns ride along as (M + 2) / 2 float64 bit patterns
-        return torch.cat([F.reshape(F.shape[0], 3 * M), I.view(torch.float64)], dim=1)[:ncols].contiguous()
+        return P
 
     def _fold_rows(self, row0, row1, nmax_b, src_slice, ext=None):
         """Fold rows [row0, row1) of a block slice (slice `src_slice` of the list memory, or the external tensors `ext`)
@@ -206,19 +218,11 @@ class HipEngine:
 
     def fold_slice(self, P, nmax_src):
         """A slice of MY rows that another rank computed (its items as my columns): into the running list."""
-        torch = self.torch
-        M = self.M
         if self.n == 0:
             return
-        F = P[:, : 3 * M].reshape(P.shape[0], 3, M)
-        I = P[:, 3 * M :].contiguous().view(torch.int32)
-        ext = [F[:, 0].contiguous(), F[:, 1].contiguous(), F[:, 2].contiguous(), I[:, :M].contiguous(), I[:, M].contiguous(),
-               I[:, M + 1].contiguous().view(torch.float32)]
-        torch.cuda.synchronize()
+        ext = self._slice_sections(P, self.n)
+        self.torch.cuda.synchronize()
         self._fold_rows(0, self.n, nmax_src, None, ext)
-
-    def slice_shape(self, nrows):
-        return (nrows, 3 * self.M + (self.M + 2) // 2)
 
     def knn_merge(self, nmax=None):
         """Final lists from the folded slice; returns the number of rows not provably exact."""

@@ -135,3 +135,65 @@ def test_config4_one_rank_slice_of_8_8M():
         for v, j in zip(key_h[lr, :c], got):               # the exact keys, against the brute force
             assert abs(v - float(keys[t, j])) <= 1e-9
     L.as_free_space(sp)
+
+
+def test_config5_block_pair_beyond_2G_elements():
+    """config 5's per-rank shape is 8M x 768 per GPU: blocks of more than 2^31 floats, transposed buffers of more than
+    2^32 entries.  as_knn_block_pair on an own block of 2.9M x 768 (2.2e9 floats) and a visiting block of 4.3M x 768
+    (3.3e9 floats; 4.3M x 1024 transposed entries = 4.4e9), the own rows restricted to the last ~100k (the highest
+    addresses of the own block) against ALL column tiles of the visiting block, once in one piece (35 GB of transposed buffers) and once in
+    chunks of 6 719 tiles: the own rows' lists and the visiting items' lists against torch fp64 brute force."""
+    import os
+
+    import torch
+
+    import bench
+    from pyarrowspace_amd.dist import HipEngine
+    na, nb, d, k = 2_900_000, 4_300_000, 768, 25
+    X = gpu_clustered(na + nb, d, 17, nclust=8192)
+    eps = bench.calibrate_eps(X, k, "l2", sample=256)
+    gp = {"eps": eps, "k": k, "topk": 15, "p": 2.0, "sigma": None}
+    A, B = X[:na], X[na:]
+    row0 = (na - 100_000) // 128 * 128
+    sample_a = (row0 + np.random.default_rng(1).choice(na - row0, 48, replace=False)).tolist()
+    keys_a = brute_keys(X, sample_a, "l2")[:, na:].cpu().numpy()                  # own rows against the visiting block
+    # visiting items with neighbours among the own rows: the nearest items of a few own rows
+    near = torch.topk(torch.from_numpy(keys_a[:24]), 2, dim=1, largest=False)[1].reshape(-1).unique().tolist()
+    sample_b = sorted(set(near) | set(np.random.default_rng(2).choice(nb, 24, replace=False).tolist()))
+    keys_b = brute_keys(X, [na + j for j in sample_b], "l2")[:, row0:na].cpu().numpy()   # visiting items against the own rows
+    for tiles in (1_000_000, 7_000):
+        os.environ["ARROWSPACE_PAIR_CHUNK_TILES"] = str(tiles)
+        try:
+            ea, eb = HipEngine(gp), HipEngine(gp)
+            ea.create_space(A)
+            ea.ring_begin(2)
+            eb.create_space(B)
+            eb.ring_begin(2)
+            nmax = [ea.block_nmax(ea.own_block()), eb.block_nmax(eb.own_block())]
+            h = ea.open_block(B)
+            P = ea.knn_block_pair(h, row0, na, -1, -1, 0, na, None, nb)
+            ea.close_block(h)
+            eb.fold_slice(P, nmax[0])
+            del P
+            fa, fb = ea.knn_merge(nmax), eb.knn_merge(nmax)
+        finally:
+            os.environ.pop("ARROWSPACE_PAIR_CHUNK_TILES", None)
+        assert fa == 0 and fb == 0
+        for e, rows, keys, goff, lo in ((ea, sample_a, keys_a, na, 0), (eb, sample_b, keys_b, row0, 0)):
+            idx_h, key_h, cnt_h = (t[torch.as_tensor(rows, device="cuda")].cpu().numpy() for t in (e.l_idx, e.l_key, e.l_cnt))
+            for t in range(len(rows)):
+                c = int(cnt_h[t])
+                got = idx_h[t, :c] - goff
+                assert (idx_h[t, c:] == -1).all() and len(set(got.tolist())) == c and (got >= 0).all() and (got < keys.shape[1]).all()
+                assert (np.diff(key_h[t, :c]) >= 0).all() and (key_h[t, :c] <= eps * eps).all()
+                order = np.argsort(keys[t], kind="stable")[: k + 8]
+                vals = keys[t][order]
+                inside = [int(j) for v, j in zip(vals[:k], order[:k]) if v <= eps * eps - 1e-9 and (vals[k] - v) > 1e-9]
+                assert set(inside) <= set(got.tolist()), (rows[t], set(inside) - set(got.tolist()))
+                assert c >= min(k, int((keys[t] <= eps * eps - 1e-9).sum()))
+                for v, j in zip(key_h[t, :c], got):
+                    assert abs(v - float(keys[t, j])) <= 1e-9
+        assert int(ea.l_cnt[:row0].sum()) == 0 and int(ea.l_cnt[row0:].sum()) > 0 and int(eb.l_cnt.sum()) > 0
+        ea.close()
+        eb.close()
+        torch.cuda.empty_cache()

@@ -235,6 +235,75 @@ def test_symmetric_ring_seeded_fuzz():
             np.testing.assert_array_equal(res[b][1], sdist, err_msg=ctx)
 
 
+class _pair_chunks:
+    """as_knn_block_pair takes the visiting block in chunks of `tiles` column tiles (128 items each): what a shard of
+    millions of items gets by itself (the transposed buffers of a chunk must fit in an eighth of the free memory)."""
+
+    def __init__(self, tiles):
+        self.tiles = tiles
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("ARROWSPACE_PAIR_CHUNK_TILES")
+        os.environ["ARROWSPACE_PAIR_CHUNK_TILES"] = str(self.tiles)
+
+    def __exit__(self, *exc):
+        import os
+        os.environ.pop("ARROWSPACE_PAIR_CHUNK_TILES", None)
+        if self.old is not None:
+            os.environ["ARROWSPACE_PAIR_CHUNK_TILES"] = self.old
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("n,d,k,cuts,tiles", [(5000, 768, 25, [0, 2500, 5000], 8), (4100, 64, 12, [0, 300, 1400, 2000, 3300, 4100], 3),
+                                              (6000, 96, 10, [0, 1700, 4100, 6000], 1)])
+def test_symmetric_ring_in_column_chunks(metric, n, d, k, cuts, tiles):
+    """The visiting block in chunks of 8, 3 and 1 column tiles: the same lists as one space holding everything, and the
+    same as the unchunked ring, bit for bit (a visiting item's slice comes from its one chunk; the own rows' slices of
+    the chunks are folded: the M smallest exact keys of their union, the smallest drop bound)."""
+    X = clustered(n, d, nclust=max(4, n // 200), seed=n + k + 1)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
+    with _pair_chunks(tiles):
+        res, _ = _symmetric_ring_lists(X, gp, cuts)
+    plain, _ = _symmetric_ring_lists(X, gp, cuts)
+    for b in range(len(cuts) - 1):
+        lo, hi = cuts[b], cuts[b + 1]
+        single = _single_lists(X, gp, lo, hi)
+        for t in range(4):
+            np.testing.assert_array_equal(res[b][t], single[t])
+            np.testing.assert_array_equal(res[b][t], plain[b][t])
+
+
+def test_symmetric_ring_in_column_chunks_with_duplicates_and_wide_eps(oracle_lib):
+    """Chunks of 2 tiles with duplicate groups (second round) and with an eps that admits every pair."""
+    rng = np.random.default_rng(5)
+    n, d, k = 2400, 64, 8
+    X = clustered(n, d, nclust=12, seed=19)
+    for g in range(6):
+        rows = rng.choice(n, 150, replace=False)
+        X[rows] = X[rows[0]]
+    gp = {"eps": calibrate_eps(clustered(n, d, nclust=12, seed=19), k), "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_lib.OracleIndex(X, gp)
+    cuts = [0, 800, 1700, 2400]
+    with _pair_chunks(2):
+        res, flagged = _symmetric_ring_lists(X, gp, cuts)
+    assert flagged > 0
+    for b in range(3):
+        lo, hi = cuts[b], cuts[b + 1]
+        np.testing.assert_array_equal(res[b][3], ref.knn_cnt[lo:hi])
+        np.testing.assert_array_equal(res[b][0], ref.knn_idx[lo:hi])
+    X = clustered(3000, 48, nclust=6, seed=6)
+    gp = {"eps": 10.0, "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    cuts = [0, 900, 2100, 3000]
+    with _pair_chunks(2):
+        res, _ = _symmetric_ring_lists(X, gp, cuts)
+    for b in range(3):
+        sidx, sdist, sgy, scnt = _single_lists(X, gp, cuts[b], cuts[b + 1])
+        np.testing.assert_array_equal(res[b][3], scnt)
+        np.testing.assert_array_equal(res[b][0], sidx)
+        np.testing.assert_array_equal(res[b][1], sdist)
+
+
 def test_block_pair_refuses_bad_arguments():
     """as_knn_block_pair: a block is not paired with itself, the row range must lie inside the space, the visiting block
     must match the space (features); as_knn_thresholds: row range inside the space."""
