@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=24)
     ap.add_argument("--cpu-build-n", type=int, nargs="*", default=[20000, 100000],
                     help="item counts the CPU all-pairs build is timed at (SURVEY section 8d: 20k and 100k)")
-    ap.add_argument("--cpu-build-budget", type=float, default=45.0, help="skip a CPU build size predicted to take longer (s)")
+    ap.add_argument("--cpu-build-budget", type=float, default=90.0, help="skip a CPU build size predicted to take longer (s)")
     args = ap.parse_args()
 
     import torch
@@ -350,7 +350,7 @@ def main():
                 oracle_c.OracleIndex(Xh[:nb], gp)
                 tb_ = time.perf_counter() - t0
                 per_pair = tb_ / (nb * nb)
-                cpu_build.append({"value": tb_, "unit": "s", "n": nb, "sample": "all-pairs fp64 build on the first %d rows" % nb})
+                cpu_build.append({"value": tb_, "unit": "s", "n": nb, "sample": "all-pairs fp64 build on the first %d rows (cache-blocked tiles of 8 rows, AVX2 / AVX-512)" % nb})
         out["cpu_baseline"] = {
             "value": nq / cpu_dt, "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": "%d single queries over the full N=%d x D=%d fp64 items; one fused pass per query (neighbour search and "

@@ -57,8 +57,10 @@ static double edge_weight(double d, double sigma, double p, int kernel) {
     return kernel == ASO_GAUSSIAN ? exp(-0.5 * u) : 1.0 / (1.0 + u);
 }
 
-/* sequential-order dot products (no -ffast-math): sum_c a_c*b_c and sum_c (a_c-b_c)^2 */
-static inline void pair_l2(const double *a, const double *b, int64_t d, double *sq, double *dot) {
+/* sequential-order dot products (no -ffast-math): sum_c a_c*b_c and sum_c (a_c-b_c)^2; every product is rounded
+ * before it is added (no FMA contraction), so that the tile kernel of the build below gives the same bits */
+#define ASO_NOFMA __attribute__((optimize("fp-contract=off")))
+ASO_NOFMA static inline void pair_l2(const double *a, const double *b, int64_t d, double *sq, double *dot) {
     double s = 0.0, g = 0.0;
     for (int64_t c = 0; c < d; ++c) {
         double t = a[c] - b[c];
@@ -68,7 +70,7 @@ static inline void pair_l2(const double *a, const double *b, int64_t d, double *
     *sq = s;
     *dot = g;
 }
-static inline double dotp(const double *a, const double *b, int64_t d) {
+ASO_NOFMA static inline double dotp(const double *a, const double *b, int64_t d) {
     double g = 0.0;
     for (int64_t c = 0; c < d; ++c) g += a[c] * b[c];
     return g;
@@ -91,23 +93,99 @@ static double edge_energy(double w, int metric, double dist, double g, double di
     return v > floor_ ? v : 0.0;
 }
 
-/* SPEC S2: key (eps test + ordering), dist, gy for the pair (a,b) */
-static inline void pair_q(const double *a, const double *b, int64_t d, double na, double nb, int metric,
-                          double *key, double *dist, double *gy) {
+/* SPEC S2: key (eps test + ordering), dist, gy for a pair, from its sums sum (a_c-b_c)^2 (L2 only) and sum a_c b_c */
+static inline void pair_from_sums(double sq, double g, double na, double nb, int metric, double *key, double *dist, double *gy) {
     if (metric == ASO_L2) {
-        double sq, g;
-        pair_l2(a, b, d, &sq, &g);
         *key = sq;
         *dist = sqrt(sq);
         *gy = g;
     } else {
-        double g = dotp(a, b, d);
         double den = sqrt(na * nb);
         double c = den > 0.0 ? g / den : 0.0;
         double dd = 1.0 - (c > 0.0 ? (c < 1.0 ? c : 1.0) : 0.0);   /* rounding can push a cosine past 1: no negative distances */
         *key = dd;
         *dist = dd;
         *gy = c;
+    }
+}
+static inline void pair_q(const double *a, const double *b, int64_t d, double na, double nb, int metric,
+                          double *key, double *dist, double *gy) {
+    double sq = 0.0, g;
+    if (metric == ASO_L2) pair_l2(a, b, d, &sq, &g);
+    else g = dotp(a, b, d);
+    pair_from_sums(sq, g, na, nb, metric, key, dist, gy);
+}
+
+/* ASO_NR rows a[0..] against a tile of ASO_TJ rows stored column-major (xt[c * ASO_TJ + u] = column c of the tile's
+ * row u): the pair sums of pair_l2 (L2: the squared distance only -- the dot product of the few pairs inside eps is
+ * taken by dotp afterwards) / dotp (cosine), lane u <-> the tile's row u, columns in order, products rounded.  Two
+ * builds of the same arithmetic: 2 rows on 4-lane vectors (AVX2, the library's baseline ISA) and 4 rows on 8-lane
+ * vectors where the CPU has AVX-512 (chosen at run time; the same bits lane by lane). */
+#define ASO_TJ 8
+#define ASO_IB 64
+#define ASO_NR 4
+typedef double aso_v4 __attribute__((vector_size(32)));
+typedef double aso_v8 __attribute__((vector_size(64)));
+ASO_NOFMA static void tile_pairs_v4(const double *const *a, int nr, const double *xt, int64_t d, int l2, double sq[ASO_NR][ASO_TJ],
+                                    double g[ASO_NR][ASO_TJ]) {
+    const aso_v4 z = {0.0, 0.0, 0.0, 0.0};
+    for (int r0 = 0; r0 < nr; r0 += 2) {
+        const double *a0 = a[r0], *a1 = a[r0 + 1 < nr ? r0 + 1 : r0];
+        aso_v4 s00 = z, s01 = z, s10 = z, s11 = z, g00 = z, g01 = z, g10 = z, g11 = z;
+        if (l2) {
+            for (int64_t c = 0; c < d; ++c) {
+                const aso_v4 b0 = *(const aso_v4 *)(xt + c * ASO_TJ), b1 = *(const aso_v4 *)(xt + c * ASO_TJ + 4);
+                const aso_v4 x0 = {a0[c], a0[c], a0[c], a0[c]}, x1 = {a1[c], a1[c], a1[c], a1[c]};
+                aso_v4 t;
+                t = x0 - b0; s00 += t * t;
+                t = x0 - b1; s01 += t * t;
+                t = x1 - b0; s10 += t * t;
+                t = x1 - b1; s11 += t * t;
+            }
+        } else {
+            for (int64_t c = 0; c < d; ++c) {
+                const aso_v4 b0 = *(const aso_v4 *)(xt + c * ASO_TJ), b1 = *(const aso_v4 *)(xt + c * ASO_TJ + 4);
+                const aso_v4 x0 = {a0[c], a0[c], a0[c], a0[c]}, x1 = {a1[c], a1[c], a1[c], a1[c]};
+                g00 += x0 * b0; g01 += x0 * b1; g10 += x1 * b0; g11 += x1 * b1;
+            }
+        }
+        for (int u = 0; u < 4; ++u) {
+            sq[r0][u] = s00[u]; sq[r0][u + 4] = s01[u];
+            g[r0][u] = g00[u]; g[r0][u + 4] = g01[u];
+            if (r0 + 1 < nr) {
+                sq[r0 + 1][u] = s10[u]; sq[r0 + 1][u + 4] = s11[u];
+                g[r0 + 1][u] = g10[u]; g[r0 + 1][u + 4] = g11[u];
+            }
+        }
+    }
+}
+__attribute__((target("avx512f"), optimize("fp-contract=off")))
+static void tile_pairs_v8(const double *const *a, int nr, const double *xt, int64_t d, int l2, double sq[ASO_NR][ASO_TJ],
+                          double g[ASO_NR][ASO_TJ]) {
+    const aso_v8 z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const double *a0 = a[0], *a1 = a[nr > 1 ? 1 : 0], *a2 = a[nr > 2 ? 2 : 0], *a3 = a[nr > 3 ? 3 : 0];
+    aso_v8 s0 = z, s1 = z, s2 = z, s3 = z, g0 = z, g1 = z, g2 = z, g3 = z;
+    if (l2) {
+        for (int64_t c = 0; c < d; ++c) {
+            const aso_v8 b = *(const aso_v8 *)(xt + c * ASO_TJ);
+            const aso_v8 x0 = z + a0[c], x1 = z + a1[c], x2 = z + a2[c], x3 = z + a3[c];
+            aso_v8 t;
+            t = x0 - b; s0 += t * t;
+            t = x1 - b; s1 += t * t;
+            t = x2 - b; s2 += t * t;
+            t = x3 - b; s3 += t * t;
+        }
+    } else {
+        for (int64_t c = 0; c < d; ++c) {
+            const aso_v8 b = *(const aso_v8 *)(xt + c * ASO_TJ);
+            g0 += (z + a0[c]) * b; g1 += (z + a1[c]) * b; g2 += (z + a2[c]) * b; g3 += (z + a3[c]) * b;
+        }
+    }
+    for (int u = 0; u < ASO_TJ; ++u) {
+        sq[0][u] = s0[u]; g[0][u] = g0[u];
+        if (nr > 1) { sq[1][u] = s1[u]; g[1][u] = g1[u]; }
+        if (nr > 2) { sq[2][u] = s2[u]; g[2][u] = g2[u]; }
+        if (nr > 3) { sq[3][u] = s3[u]; g[3][u] = g3[u]; }
     }
 }
 
@@ -170,19 +248,52 @@ aso_index *aso_build(const double *X, int64_t n, int64_t d, double eps, int64_t 
     /* S3 directed kNN lists */
     cand_t *lists = (cand_t *)malloc(sizeof(cand_t) * n * k);
     int64_t *cnt = (int64_t *)calloc(n, sizeof(int64_t));
-#pragma omp parallel for schedule(dynamic, 16)
-    for (int64_t i = 0; i < n; ++i) {
-        cand_t *lst = lists + i * k;
-        int64_t m = 0;
-        for (int64_t j = 0; j < n; ++j) {
-            if (j == i) continue;
-            cand_t c;
-            c.j = j;
-            pair_q(X + i * d, X + j * d, d, ix->nrm[i], ix->nrm[j], metric, &c.key, &c.dist, &c.gy);
-            if (c.key <= epskey) cand_insert(lst, &m, k, c);
+    /* All pairs, cache-blocked: the items once more in tiles of 8 rows, column-major inside a tile, so that one row i
+     * meets 8 rows j per step with the sums of every pair still running over the columns in order (the bits of
+     * pair_l2 / dotp); a task owns ASO_IB rows i and streams the tiles past them (a tile stays in L1/L2 for all of
+     * them).  Same candidates in the same order (j ascending) as the plain double loop. */
+    const int64_t ntile = (n + ASO_TJ - 1) / ASO_TJ;
+    const int wide = __builtin_cpu_supports("avx512f") && !getenv("ASO_NO_AVX512");
+    double *Xt = (double *)aligned_alloc(64, sizeof(double) * (size_t)ntile * d * ASO_TJ);
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < ntile; ++t)
+        for (int64_t c = 0; c < d; ++c)
+            for (int u = 0; u < ASO_TJ; ++u) {
+                int64_t j = t * ASO_TJ + u;
+                Xt[((size_t)t * d + c) * ASO_TJ + u] = j < n ? X[j * d + c] : 0.0;
+            }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t ib = 0; ib < n; ib += ASO_IB) {
+        const int64_t ie = ib + ASO_IB < n ? ib + ASO_IB : n;
+        for (int64_t i = ib; i < ie; ++i) cnt[i] = 0;
+        for (int64_t t = 0; t < ntile; ++t) {
+            const double *xt = Xt + (size_t)t * d * ASO_TJ;
+            for (int64_t i = ib; i < ie; i += ASO_NR) {
+                const int nr = (int)(ie - i < ASO_NR ? ie - i : ASO_NR);
+                double sq[ASO_NR][ASO_TJ], g[ASO_NR][ASO_TJ];
+                const double *rows[ASO_NR];
+                for (int r = 0; r < nr; ++r) rows[r] = X + (i + r) * d;
+                if (wide) tile_pairs_v8(rows, nr, xt, d, metric == ASO_L2, sq, g);
+                else tile_pairs_v4(rows, nr, xt, d, metric == ASO_L2, sq, g);
+                for (int r = 0; r < nr; ++r) {
+                    const int64_t ii = i + r;
+                    for (int u = 0; u < ASO_TJ; ++u) {
+                        const int64_t j = t * ASO_TJ + u;
+                        if (j >= n || j == ii) continue;
+                        cand_t c;
+                        c.j = j;
+                        if (metric == ASO_L2) {
+                            if (!(sq[r][u] <= epskey)) continue;
+                            g[r][u] = dotp(X + ii * d, X + j * d, d);
+                        }
+                        pair_from_sums(sq[r][u], g[r][u], ix->nrm[ii], ix->nrm[j], metric, &c.key, &c.dist, &c.gy);
+                        if (c.key <= epskey) cand_insert(lists + ii * k, &cnt[ii], k, c);
+                    }
+                }
+            }
         }
-        cnt[i] = m;
     }
+    free(Xt);
     ix->knn_idx = (int64_t *)malloc(sizeof(int64_t) * n * k);
     ix->knn_cnt = cnt;
     for (int64_t i = 0; i < n; ++i)
@@ -730,6 +841,14 @@ int aso_threads(void) {
     return omp_get_max_threads();
 #else
     return 1;
+#endif
+}
+
+void aso_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
 #endif
 }
 

@@ -58,11 +58,40 @@ def lib():
             getattr(L, name).restype = pi64
             getattr(L, name).argtypes = [C.c_void_p]
         L.aso_threads.restype = C.c_int
+        L.aso_set_threads.argtypes = [C.c_int]
+        # a container's CPU quota, not the host's core count: 128 OpenMP threads on a quota of 16 CPUs spend their time
+        # throttled, and "cores" in the bench line would overstate what ran (OMP_NUM_THREADS set by the caller wins)
+        quota = _cpu_quota()
+        if quota and "OMP_NUM_THREADS" not in os.environ and quota < int(L.aso_threads()):
+            L.aso_set_threads(quota)
         L.aso_from_parts.restype = C.c_void_p
         L.aso_from_parts.argtypes = [p64, C.c_int64, C.c_int64, C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, p64, p64, C.c_double]
         L.aso_free_parts.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+def _cpu_quota():
+    """CPUs this process may use: the cgroup quota (v2 cpu.max, v1 cfs_quota / cfs_period) and the affinity mask."""
+    q = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            q = max(1, int(int(a) / int(b)))
+    except (OSError, ValueError):
+        try:
+            a = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            b = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if a > 0 and b > 0:
+                q = max(1, a // b)
+        except (OSError, ValueError):
+            pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+        q = aff if q is None else min(q, aff)
+    except (AttributeError, OSError):
+        pass
+    return q
 
 
 def _p64(a):
