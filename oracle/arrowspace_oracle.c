@@ -12,7 +12,8 @@
  * tests/test_0.py:4-18,24,29-32 (tau=1 order), TAUMODE.md:33 + src/lib.rs:169-173
  * (scorer form, topk results sorted descending over a full scan).
  *
- * Build: gcc -O3 -march=native -fopenmp -shared -fPIC (oracle/Makefile).
+ * Build: gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC (oracle/Makefile); the all-pairs tile kernel also has an
+ * AVX-512 build chosen at run time.  No -ffast-math, and no FMA contraction in the pair sums.
  */
 #include <math.h>
 #include <stdint.h>
