@@ -60,6 +60,24 @@ def gen_case(rng, case):
         eps = float(dv.max()) * 1.5 + 1e-12          # every pair inside eps
     sigma = None if rng.random() < 0.5 else eps * float(rng.uniform(0.2, 3.0))
     gp = {"eps": eps, "k": k, "topk": topk, "p": p, "sigma": sigma, "metric": metric, "kernel": kernel}
+    if os.environ.get("FUZZ_FEATURE") and d >= 2 and rng.random() < 0.7:
+        # lambda on the feature-space Laplacian (TAUMODE.md:8,12-27): the graph is over the d columns -- eps from a
+        # quantile of the column pair distances, k capped by the number of columns
+        gp["lambda_mode"] = "feature"
+        F = X.T
+        if metric == "l2":
+            Df = np.sqrt(np.maximum(((F[:, None, :200] - F[None, :, :200]) ** 2).sum(-1), 0)) if d <= 64 else None
+        else:
+            Df = None
+        if Df is None:
+            nf = np.linalg.norm(F, axis=1); nf[nf == 0] = 1
+            Df = 1 - np.maximum(0, (F @ F.T) / np.outer(nf, nf)) if metric == "cosine" else \
+                np.sqrt(np.maximum((F * F).sum(1)[:, None] + (F * F).sum(1)[None, :] - 2 * F @ F.T, 0))
+        dvf = Df[np.triu_indices(d, 1)]
+        gp["eps"] = float(np.quantile(dvf, rng.uniform(0.0, 1.0))) * float(rng.uniform(0.9, 1.1)) + 1e-12
+        gp["k"] = int(min(gp["k"], 56))
+        if sigma is not None:
+            gp["sigma"] = gp["eps"] * float(rng.uniform(0.2, 3.0))
     cfg = dict(case=case, n=n, d=d, kind=str(kind), gp=gp)
     return X, gp, cfg
 
@@ -78,7 +96,7 @@ def one_case(rng, case, sharded=False):
     if not np.allclose(aspace.lambdas(), ref.lambdas, rtol=1e-9, atol=1e-300):
         LOOSE.append(case)
     indptr, indices, values = gl.to_csr()
-    rows = np.repeat(np.arange(n), np.diff(indptr))
+    rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))      # n nodes, or d in feature mode
     assert np.array_equal(indices[indices != rows], ref.indices), cfg
     if rng.random() < 0.3:
         batch_case(rng, aspace, gl, X, cfg)
