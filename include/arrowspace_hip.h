@@ -158,6 +158,13 @@ as_status as_knn_block_band(const as_space* sp, const as_space* cols, const as_g
                             int64_t row_end, int64_t row_goff, int64_t col_goff, int32_t* flag_dev /* bit 1: band overflow */,
                             const double* band_dev, double* p_key_dev, double* p_dist_dev, double* p_gy_dev,
                             int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev, int64_t* out_overflowed);
+/* Last resort of the ring (third round): rows whose band overflowed the collection buffers somewhere (flag_dev != 0 --
+ * thousands of exact duplicates, or of items at one distance) take the block's k nearest inside eps by exact evaluation
+ * of every pair, ordered by (key, global id); the slice carries no drop bound.  Row-serial cost, as the last resort of
+ * as_knn_rows (the reference's own loop is this for every row: the crate's all-pairs build, src/lib.rs:278-289). */
+as_status as_knn_block_exact(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                             int64_t row_goff, int64_t col_goff, const int32_t* flag_dev, double* p_key_dev, double* p_dist_dev,
+                             double* p_gy_dev, int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev);
 /* step 3 over the lists of ALL n_global items for a space that holds the rows [row_offset, row_offset + nitems):
  * global graph, Laplacian, energies, tau0; this shard's lambdas into the space.  n64_global_dev: fp64 squared norms
  * of all items (device).  Searches on the space then report global item ids. */

@@ -445,6 +445,23 @@ as_status as_knn_block_band(const as_space* sp, const as_space* cols, const as_g
     return s;
 }
 
+as_status as_knn_block_exact(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
+                             int64_t row_goff, int64_t col_goff, const int32_t* flag_dev, double* p_key_dev, double* p_dist_dev,
+                             double* p_gy_dev, int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev) {
+    if (!sp || !cols || !flag_dev || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev) {
+        set_err("as_knn_block_exact: null argument");
+        return AS_EINVAL;
+    }
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    AS_HIP(hipSetDevice(sp->device));
+    const double t0 = now_s();
+    const as_status s = knn_block_exact(sp, cols, &r, row_begin, row_end, row_goff, col_goff, knn_list_width(r.k), flag_dev, p_key_dev,
+                                        p_dist_dev, p_gy_dev, p_idx_dev, p_cnt_dev, p_t32_dev);
+    sp->kstats[3] += now_s() - t0;
+    return s;
+}
+
 as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_graph_params* gp,
                        const as_opts* opts, as_space** out_space, as_graph** out_graph) {
     if (!out_space || !out_graph) {

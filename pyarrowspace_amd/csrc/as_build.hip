@@ -2540,6 +2540,137 @@ as_status knn_block_band(const as_space* sp, const as_space* cols, const as_grap
     return AS_OK;
 }
 
+// Third pass of one visiting block (last resort): rows whose band did not fit the collection buffers somewhere -- more
+// rows inside the band than BAND_MAX, e.g. thousands of exact duplicates or of items at one and the same distance --
+// take the block's k nearest inside eps by EXACT evaluation of every pair, ordered by (key64, global id): nothing is
+// dropped that could matter, so the slice carries no bound.  One workgroup per flagged row, a wave per column, the
+// waves' sorted k-lists merged at the end; row-serial cost (block rows x D per flagged row), as the single-space path's
+// last resort is.
+struct BlockExactArgs {
+    const float *xa32, *xb32;
+    const double *xa64, *xb64, *na64, *nb64;
+    int64_t d, dp, r0, nb, row_goff, col_goff;
+    int M, k, metric;
+    double epskey;
+    const int* ids;
+    double *p_key, *p_dist, *p_gy;
+    int32_t* p_idx;
+    int32_t* p_cnt;
+    float* p_t32;
+};
+
+constexpr int EXACT_K = 64;   // >= the widest k (56)
+
+__global__ __launch_bounds__(256) void knn_block_exact_kernel(BlockExactArgs a) {
+    __shared__ double sk[4][EXACT_K], sd[4][EXACT_K], sg[4][EXACT_K];
+    __shared__ int si[4][EXACT_K];
+    __shared__ int sc[4];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int lr = a.ids[blockIdx.x];
+    const int64_t row = a.r0 + lr;
+    const int64_t self = a.row_goff + row - a.col_goff;   // the row's own number inside this block, if it lives there
+    const double ni = a.na64[row];
+    const int k = a.k;
+    int cnt = 0;
+    for (int64_t j = w; j < a.nb; j += 4) {
+        if (j == self) continue;
+        double sq, dot;
+        exact_pair2(a.xa32, a.xa64, a.xb32, a.xb64, a.d, a.dp, row, j, sq, dot);
+        sq = bcast_lane(sq, 0);
+        dot = bcast_lane(dot, 0);
+        double key, dist, gy;
+        if (a.metric == AS_METRIC_L2) {
+            key = sq;
+            dist = sqrt(sq);
+            gy = dot;
+        } else {
+            const double den = sqrt(ni * a.nb64[j]);
+            const double c = den > 0.0 ? dot / den : 0.0;
+            key = cosine_distance(c);
+            dist = key;
+            gy = c;
+        }
+        if (!(key <= a.epskey)) continue;
+        const int gid = (int)(a.col_goff + j);
+        if (cnt == k && !lex_less<double>(key, gid, sk[w][k - 1], si[w][k - 1])) continue;
+        if (lane == 0) {
+            int pos = cnt < k ? cnt : k - 1;
+            while (pos > 0 && lex_less<double>(key, gid, sk[w][pos - 1], si[w][pos - 1])) {
+                sk[w][pos] = sk[w][pos - 1];
+                sd[w][pos] = sd[w][pos - 1];
+                sg[w][pos] = sg[w][pos - 1];
+                si[w][pos] = si[w][pos - 1];
+                --pos;
+            }
+            sk[w][pos] = key;
+            sd[w][pos] = dist;
+            sg[w][pos] = gy;
+            si[w][pos] = gid;
+        }
+        if (cnt < k) ++cnt;
+        AS_LDS_FENCE();
+    }
+    if (lane == 0) sc[w] = cnt;
+    __syncthreads();
+    const int c0 = sc[0], c1 = sc[1], c2 = sc[2], c3 = sc[3];
+    const int C = c0 + c1 + c2 + c3;
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+        const int ww = t < c0 ? 0 : (t < c0 + c1 ? 1 : (t < c0 + c1 + c2 ? 2 : 3));
+        const int e = t - (ww == 0 ? 0 : (ww == 1 ? c0 : (ww == 2 ? c0 + c1 : c0 + c1 + c2)));
+        const double kk = sk[ww][e];
+        const int id = si[ww][e];
+        int rank = 0;
+        for (int v = 0; v < 4; ++v)
+            for (int s2 = 0; s2 < sc[v]; ++s2) rank += lex_less<double>(sk[v][s2], si[v][s2], kk, id) ? 1 : 0;
+        if (rank < k) {
+            const size_t o = (size_t)lr * a.M + rank;
+            a.p_key[o] = kk;
+            a.p_dist[o] = sd[ww][e];
+            a.p_gy[o] = sg[ww][e];
+            a.p_idx[o] = id;
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.p_cnt[lr] = C < k ? C : k;   // the block's k nearest inside eps, exact: no "dropped" flag
+        a.p_t32[lr] = 0.0f;
+    }
+}
+
+as_status knn_block_exact(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
+                          int64_t col_goff, int M, const int32_t* flag, double* p_key, double* p_dist, double* p_gy, int32_t* p_idx,
+                          int32_t* p_cnt, float* p_t32) {
+    AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block_exact"));
+    const int64_t rows = r1 - r0;
+    if (rows == 0) return AS_OK;
+    if (gp->k > EXACT_K || gp->k > M) {
+        set_err("as_knn_block_exact: k=%lld exceeds the list width", (long long)gp->k);
+        return AS_EUNSUPPORTED;
+    }
+    hipStream_t st = sp->stream;
+    std::vector<int> hflag(rows);
+    AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
+    std::vector<int> ids;
+    for (int64_t lr = 0; lr < rows; ++lr)
+        if (hflag[lr]) ids.push_back((int)lr);
+    const int nf = (int)ids.size();
+    if (nf == 0) return AS_OK;
+    dev_tmp<int> d_ids;
+    AS_HIP(d_ids.alloc(nf));
+    AS_HIP(hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
+    BlockExactArgs ea;
+    ea.xa32 = sp->x32; ea.xa64 = sp->x64; ea.xb32 = cols->x32; ea.xb64 = cols->x64; ea.na64 = sp->n64; ea.nb64 = cols->n64;
+    ea.d = sp->d; ea.dp = sp->dp; ea.r0 = r0; ea.nb = cols->n; ea.row_goff = row_goff; ea.col_goff = col_goff;
+    ea.M = M; ea.k = (int)gp->k; ea.metric = sp->opts.metric;
+    ea.epskey = ea.metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
+    ea.ids = d_ids;
+    ea.p_key = p_key; ea.p_dist = p_dist; ea.p_gy = p_gy; ea.p_idx = p_idx; ea.p_cnt = p_cnt; ea.p_t32 = p_t32;
+    hipLaunchKernelGGL(knn_block_exact_kernel, dim3((unsigned)nf), dim3(256), 0, st, ea);
+    AS_HIP(hipGetLastError());
+    AS_HIP(hipStreamSynchronize(st));
+    if (sp == cols) sp->kstats[6] += nf;   // rows settled by the last resort (every rank sees its own block once per round)
+    return AS_OK;
+}
+
 // ------------------------------------------------------------------ K3 symmetrise -> CSR
 __global__ void sym_count_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt, int64_t n, int64_t k,
                                  int* __restrict__ revcnt) {

@@ -146,8 +146,8 @@ class HipEngine:
     def _slice(self, b):
         return [C.c_void_p(t[b].data_ptr()) for t in (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
 
-    def _fold(self, mode, nmax_b):
-        flag = C.c_void_p(self.l_flag.data_ptr()) if mode else C.c_void_p()
+    def _fold(self, mode, nmax_b, flags=None):
+        flag = C.c_void_p((self.l_flag if flags is None else flags).data_ptr()) if mode else C.c_void_p()
         self._check(self.L.as_knn_fold(self.sp, C.byref(self.gp), 0, self.n, mode, float(nmax_b), flag, *self._slice(0), *self._slice(1)))
 
     def knn_block(self, h, b, row_goff, col_goff):
@@ -224,8 +224,9 @@ class HipEngine:
         self.torch.cuda.synchronize()
         self._fold_rows(0, self.n, nmax_src, None, ext)
 
-    def knn_merge(self, nmax=None):
-        """Final lists from the folded slice; returns the number of rows not provably exact."""
+    def knn_merge(self, nmax=None, final=False):
+        """Final lists from the folded slice; returns the number of rows not provably exact.  final: after the third round
+        (every formerly overflowed row now holds exact per-block lists -- nothing is restored)."""
         torch = self.torch
         k, rows = int(self.gp.k), self.n
         dev = torch.device("cuda", self.op.device)
@@ -250,10 +251,10 @@ class HipEngine:
         else:
             # second round: rows whose band overflowed somewhere (bit 1) keep their first-round list, unproven
             ov = (keep[5] & 2) != 0
-            if bool(ov.any()):
+            if bool(ov.any()) and not final:
                 for new, old in zip((self.l_idx, self.l_key, self.l_dist, self.l_gy, self.l_cnt), keep[:5]):
                     new[ov] = old[ov]
-            self.l_flag = keep[5]
+            self.l_flag = flag2 if final else keep[5]
         return int(nf.value)
 
     def knn_block_band(self, h, b, row_goff, col_goff):
@@ -265,6 +266,23 @@ class HipEngine:
             self._fold(1 if self._round2_first else 2, self.block_nmax(h))
             self._round2_first = True
         return int(ov.value)
+
+    # ---- third round (last resort): rows whose band overflowed somewhere, by exact evaluation of every pair
+    def overflowed_rows(self):
+        """Rows left unproven by the second round (their band did not fit the collection buffers in some block)."""
+        if self.n == 0 or not hasattr(self, "l_flag"):
+            return 0
+        self.l_over = ((self.l_flag[: self.n] & 2) != 0).to(self.torch.int32).contiguous()
+        self._round3_first = False
+        return int(self.l_over.sum().item())
+
+    def knn_block_exact(self, h, b, row_goff, col_goff):
+        if self.n > 0:
+            self.torch.cuda.synchronize()
+            self._check(self.L.as_knn_block_exact(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff, C.c_void_p(self.l_over.data_ptr()),
+                                                  *self._slice(1)))
+            self._fold(1 if self._round3_first else 2, self.block_nmax(h), self.l_over)
+            self._round3_first = True
 
     def lists(self):
         rows = self.n
@@ -754,6 +772,23 @@ class ShardedIndex:
                 bufs[0][: X_shard.shape[0]] = X_shard
             one_round(lambda h, b, rg, cg: e.knn_block_band(h, b, rg, cg))
             e.knn_merge(nmax)
+            # rows whose band did not fit the collection buffers in some block (thousands of duplicates, or of items at one
+            # distance): a third round settles them by exact evaluation of every pair -- collective as well
+            nover = e.overflowed_rows() if hasattr(e, "overflowed_rows") else 0
+            if ring:
+                t = torch.tensor([nover], dtype=torch.int64, device=X_shard.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                anyover = int(t.item())
+            else:
+                anyover = nover
+            self.ring_overflowed = nover
+            if anyover:
+                if ring:
+                    bufs[0].zero_()
+                    bufs[0][: X_shard.shape[0]] = X_shard
+                one_round(lambda h, b, rg, cg: e.knn_block_exact(h, b, rg, cg))
+                if nover:
+                    e.knn_merge(nmax, final=True)
         out = e.lists()
         if ring:
             del bufs

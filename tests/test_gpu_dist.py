@@ -70,6 +70,42 @@ def test_staged_path_repairs_a_crowded_neighbourhood(oracle_lib):
     index.close()
 
 
+def _cpu_staged():
+    """ShardedIndex with every collective staged through the CPU (gloo): two ranks can then share ONE GPU."""
+    import torch
+
+    from pyarrowspace_amd.dist import ShardedIndex
+
+    class CpuStaged(ShardedIndex):
+        def _gather_rows(self, t, counts):
+            return super()._gather_rows(t.cpu(), counts).cuda()
+
+        def _gather_fixed(self, t):
+            torch.cuda.synchronize()
+            return super()._gather_fixed(t.cpu()).cuda()
+
+        def _swap_slices(self, P, dst, src, nrows):                  # the symmetric ring's slices, staged through the CPU
+            torch.cuda.synchronize()
+            return super()._swap_slices(P.cpu(), dst, src, nrows).cuda()
+
+        def _all_to_all(self, t, recv_counts, send_counts):           # the edge exchange of the sharded graph stage
+            torch.cuda.synchronize()
+            return super()._all_to_all(t.cpu(), recv_counts, send_counts).cuda()
+
+        def _exchange_start(self, send, recv, nxt_rank, prv_rank):   # the ring hop, staged through the CPU as well
+            torch.cuda.synchronize()
+            hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            return (super()._exchange_start(hs, hr, nxt_rank, prv_rank), hr, recv, hs)
+
+        def _exchange_wait(self, pending):
+            reqs, hr, recv, _ = pending
+            super()._exchange_wait(reqs)
+            recv.copy_(hr)
+            torch.cuda.synchronize()
+
+    return CpuStaged
+
+
 def _worker(rank, world, port, n, d, split, out, replicate=False):
     import torch
     import torch.distributed as dist
@@ -77,34 +113,7 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from pyarrowspace_amd.dist import ShardedIndex
-
-        class CpuStaged(ShardedIndex):
-            def _gather_rows(self, t, counts):
-                return super()._gather_rows(t.cpu(), counts).cuda()
-
-            def _gather_fixed(self, t):
-                torch.cuda.synchronize()
-                return super()._gather_fixed(t.cpu()).cuda()
-
-            def _swap_slices(self, P, dst, src, nrows):                  # the symmetric ring's slices, staged through the CPU
-                torch.cuda.synchronize()
-                return super()._swap_slices(P.cpu(), dst, src, nrows).cuda()
-
-            def _all_to_all(self, t, recv_counts, send_counts):           # the edge exchange of the sharded graph stage
-                torch.cuda.synchronize()
-                return super()._all_to_all(t.cpu(), recv_counts, send_counts).cuda()
-
-            def _exchange_start(self, send, recv, nxt_rank, prv_rank):   # the ring hop, staged through the CPU as well
-                torch.cuda.synchronize()
-                hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-                return (super()._exchange_start(hs, hr, nxt_rank, prv_rank), hr, recv, hs)
-
-            def _exchange_wait(self, pending):
-                reqs, hr, recv, _ = pending
-                super()._exchange_wait(reqs)
-                recv.copy_(hr)
-                torch.cuda.synchronize()
+        CpuStaged = _cpu_staged()
 
         X = clustered(n, d, nclust=8, seed=31)
         gp = {"eps": calibrate_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
@@ -165,6 +174,59 @@ def test_two_ranks_one_gpu_match_oracle(oracle_lib, replicate):
             assert_hits_match(hits, whits, rtol=1e-9)   # ties to rounding (tau = 0) may swap
             assert abs(lq - wlq) <= 1e-9 * abs(wlq)
     assert out[0][1] == out[1][1]
+
+
+def _dup_worker(rank, world, port, n, d, split, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, gp = _dup_data(n, d)
+        bounds = [0, split, n]
+        index = _cpu_staged().build(gp, torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy()).cuda(), dist)
+        lists = tuple(t.cpu().numpy().copy() for t in index.engine.lists())
+        out[rank] = (index.lambdas().copy(), lists, index.ring_flagged, index.ring_overflowed, index.search(X[5000].copy(), 0.62))
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _dup_data(n, d):
+    """6 000 exact copies of one item in rows 3000..8999 and 60 more among the first 2 000 rows."""
+    X = clustered(n, d, nclust=8, seed=37, normalise=False)
+    item = X[11].copy()
+    X[3000:9000] = item
+    X[np.random.default_rng(3).choice(2000, 60, replace=False)] = item
+    gp = {"eps": calibrate_eps(clustered(n, d, nclust=8, seed=37, normalise=False), 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None}
+    return X, gp
+
+
+def test_two_ranks_third_round_is_collective(oracle_lib):
+    """Rank 1's block holds 6 000 copies of one item: the band of every copy (and of rank 0's 60 copies) overflows the
+    collection buffers there, so both ranks go round a third time (exact evaluation); lists and lambdas as the oracle's."""
+    import torch.multiprocessing as mp
+    n, d, world, split = 12000, 16, 2, 2000
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dup_worker, args=(world, port, n, d, split, out), nprocs=world, join=True)
+    X, gp = _dup_data(n, d)
+    ref = oracle_lib.OracleIndex(X, gp)
+    bounds = [0, split, n]
+    for rank in range(world):
+        lam, (idx, dist_, gy, cnt), flagged, over, hits = out[rank]
+        lo, hi = bounds[rank], bounds[rank + 1]
+        assert flagged > 0 and over > 0, (rank, flagged, over)
+        np.testing.assert_array_equal(cnt, ref.knn_cnt[lo:hi])
+        np.testing.assert_array_equal(idx, ref.knn_idx[lo:hi])
+        np.testing.assert_allclose(lam, ref.lambdas, rtol=1e-9)
+    assert out[0][4] == out[1][4]
+    assert_hits_match(out[0][4], ref.search(X[5000].copy(), 0.62)[0], rtol=1e-9)
 
 
 @pytest.mark.parametrize("rep", range(4))

@@ -39,6 +39,9 @@ def _ring_lists(X, gp, cuts, own):
         round_(lambda h, b, rg, cg: res.append(e.knn_block_band(h, b, rg, cg)))
         over = sum(res)
         e.knn_merge(nmax)
+        if e.overflowed_rows():          # third round: exact evaluation of every pair for the rows whose band overflowed
+            round_(e.knn_block_exact)
+            e.knn_merge(nmax, final=True)
     idx, dist, gy, cnt = [t.cpu().numpy() for t in e.lists()]
     key = e.l_key[: hi - lo].cpu().numpy()
     e.close()
@@ -149,6 +152,13 @@ def _symmetric_ring_lists(X, gp, cuts, dup_round=True):
                 if b != r:
                     e.close_block(h)
             e.knn_merge(nmax)
+            if e.overflowed_rows():
+                for b in range(G):
+                    h = e.own_block() if b == r else e.open_block(blocks[b])
+                    e.knn_block_exact(h, b, cuts[r], cuts[b])
+                    if b != r:
+                        e.close_block(h)
+                e.knn_merge(nmax, final=True)
         res.append([t.cpu().numpy() for t in e.lists()])
     for e in eng:
         e.close()
@@ -233,6 +243,60 @@ def test_symmetric_ring_seeded_fuzz():
             np.testing.assert_array_equal(res[b][3], scnt, err_msg=ctx)
             np.testing.assert_array_equal(res[b][0], sidx, err_msg=ctx)
             np.testing.assert_array_equal(res[b][1], sdist, err_msg=ctx)
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_third_round_settles_thousands_of_duplicates(oracle_lib, metric):
+    """5 000 exact copies of one item inside one block, 500 more spread over all blocks, 700 copies of a second item: the
+    band of such a row holds more entries than the collection buffers take (4096) in the middle block, the second round
+    cannot settle it (overflow), and the third round evaluates every pair exactly -- lists equal to the oracle's (lowest
+    ids first among equals) and to the single-space build's."""
+    rng = np.random.default_rng(11)
+    n, d, k = 9000, 24, 9
+    X = clustered(n, d, nclust=10, seed=23, normalise=False)
+    item = X[7].copy()
+    X[2100:7100] = item
+    X[rng.choice(n, 500, replace=False)] = item
+    X[rng.choice(n, 700, replace=False)] = X[11].copy()
+    gp = {"eps": calibrate_eps(clustered(n, d, nclust=10, seed=23, normalise=False), k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None,
+          "metric": metric}
+    ref = oracle_lib.OracleIndex(X, gp)
+    cuts = [0, 2000, 7500, 9000]
+    for b in range(3):
+        lo, hi = cuts[b], cuts[b + 1]
+        idx, key, dist, gy, cnt, nflag, over = _ring_lists(X, gp, cuts, b)
+        assert nflag > 0 and over > 0
+        np.testing.assert_array_equal(cnt, ref.knn_cnt[lo:hi])
+        np.testing.assert_array_equal(idx, ref.knn_idx[lo:hi])
+        sidx, sdist, sgy, scnt = _single_lists(X, gp, lo, hi)
+        np.testing.assert_array_equal(idx, sidx)
+        # (the single-space last resort sums a pair's columns in another order than the ring's: last-bit differences)
+        np.testing.assert_allclose(dist, sdist, rtol=1e-14, atol=0)
+    res, flagged = _symmetric_ring_lists(X, gp, cuts)
+    assert flagged > 0
+    for b in range(3):
+        lo, hi = cuts[b], cuts[b + 1]
+        np.testing.assert_array_equal(res[b][3], ref.knn_cnt[lo:hi])
+        np.testing.assert_array_equal(res[b][0], ref.knn_idx[lo:hi])
+
+
+def test_third_round_on_one_dimensional_items():
+    """d = 1 (the fuzz case that found the gap): normalised 1-D items are +1 or -1 -- two groups of thousands of
+    duplicates; under cosine every pair of a group is at distance 0."""
+    import torch
+
+    from pyarrowspace_amd import ArrowSpaceBuilder
+    from pyarrowspace_amd.dist import ShardedIndex
+    for metric, kernel in (("l2", "gaussian"), ("cosine", "rational")):
+        X = clustered(6000, 1, nclust=3, seed=5)
+        gp = {"eps": 1e-12, "k": 21, "topk": 10, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
+        aspace, gl = ArrowSpaceBuilder.build(gp, X)
+        index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())
+        assert index.ring_overflowed > 0
+        np.testing.assert_allclose(index.lambdas(), np.asarray(aspace.lambdas()), rtol=1e-12)
+        q = X[3].copy()
+        assert index.search(q, 0.62) == aspace.search(q, gl, 0.62)
+        index.close()
 
 
 class _pair_chunks:
