@@ -191,6 +191,7 @@ as_status as_graph_energy_copy(const as_graph* gr, double* out_dev);
 as_status as_graph_shard_lambdas(as_space* sp, as_graph* gr, const double* E_global_dev, int64_t n_global);
 int64_t as_graph_row_offset(const as_graph* gr);      /* first row a sharded graph holds (0 for a whole graph) */
 int64_t as_graph_ncols(const as_graph* gr);           /* items the graph's columns range over */
+int64_t as_graph_nitems(const as_graph* gr);         /* items the whole index covers (all ranks' rows), item or feature mode */
 
 /* ---- staged build, feature mode (AS_LAMBDA_FEATURE): what as_build composes when opts->lambda_mode selects
  *      the F x F feature-space Laplacian; multi-GPU hosts call the steps with a row range per rank and exchange

@@ -281,6 +281,7 @@ as_status as_graph_deg_copy(const as_graph* gr, double* out_dev) { return graph_
 as_status as_graph_energy_copy(const as_graph* gr, double* out_dev) { return graph_rows_copy(gr, gr ? gr->E : nullptr, out_dev, "as_graph_energy_copy"); }
 int64_t as_graph_row_offset(const as_graph* gr) { return gr ? gr->row0 : 0; }
 int64_t as_graph_ncols(const as_graph* gr) { return gr ? (gr->ncols ? gr->ncols : gr->n) : 0; }
+int64_t as_graph_nitems(const as_graph* gr) { return gr ? graph_items(gr) : 0; }
 as_status as_graph_shard_energy(as_space* sp, as_graph* gr, const double* deg_global_dev, const double* n64_global_dev) {
     if (!sp || !gr || !deg_global_dev || !n64_global_dev || !gr->ncols || gr->n != sp->n) {
         set_err("as_graph_shard_energy: null argument or not the sharded graph of this space");
@@ -943,7 +944,8 @@ as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path
     h.header_bytes = (int32_t)sizeof(IndexHeader);
     h.version = INDEX_VERSION;
     h.n = sp->n; h.d = sp->d; h.nnz = gr->nnz; h.nnodes = gr->n; h.row_offset = sp->row_offset;
-    h.graph_ncols = gr->ncols; h.graph_row0 = gr->row0;
+    h.graph_ncols = gr->lambda_mode == AS_LAMBDA_FEATURE ? gr->nitems : gr->ncols;   // feature mode: the items the lambdas were ranked over
+    h.graph_row0 = gr->row0;
     h.has_f64 = sp->x64 ? 1 : 0; h.metric = gr->metric; h.kernel = gr->kernel; h.lambda_mode = gr->lambda_mode;
     h.gp = gr->gp; h.tau0 = gr->tau0;
     as_status s = fwrite(&h, sizeof(h), 1, f) == 1 ? AS_OK : AS_EINVAL;
@@ -1053,7 +1055,9 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
         hipLaunchKernelGGL(lam32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sp->stream, h.n, sp->lam64, sp->lam32);
         gr = new as_graph();
         gr->device = dev; gr->n = h.nnodes; gr->nitems = h.row_offset + h.n; gr->nnz = h.nnz; gr->gp = gpr; gr->metric = h.metric; gr->kernel = h.kernel;
-        gr->lambda_mode = h.lambda_mode; gr->tau0 = h.tau0; gr->ncols = h.graph_ncols; gr->row0 = h.graph_row0;
+        gr->lambda_mode = h.lambda_mode; gr->tau0 = h.tau0; gr->row0 = h.graph_row0;
+        if (h.lambda_mode == AS_LAMBDA_FEATURE) gr->nitems = std::max<int64_t>(gr->nitems, h.graph_ncols);
+        else gr->ncols = h.graph_ncols;
         {   // the CSR is walked on trust afterwards: monotone row pointers ending at nnz, columns inside the graph
             std::vector<int64_t> ip;
             std::vector<int32_t> col;

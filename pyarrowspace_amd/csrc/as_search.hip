@@ -1807,7 +1807,9 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     q->gr = gr;
     const bool feature = gr && gr->lambda_mode == AS_LAMBDA_FEATURE;
     q->k = gr && !feature ? gr->gp.k : 1;   // feature mode: the query has no k-NN step
-    q->topk = gr ? std::min<int64_t>(gr->gp.topk, sp->n) : 1;
+    // the record layout ([topk hits][flags]) must be the same on every rank of a row-sharded index: topk is capped by the
+    // items the whole index covers, not by this shard's rows (the kernels take min(topk, rows scanned) themselves)
+    q->topk = gr ? std::min<int64_t>(gr->gp.topk, std::max<int64_t>(sp->n, graph_items(gr))) : 1;
     q->Mk = list_width(std::min<int64_t>(q->k, sp->n));
     q->Ms = score_width(q->topk);
     if (q->Mk < 0 || q->Ms < 0) {
@@ -1993,7 +1995,7 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
         return AS_EUNSUPPORTED;
     }
     hipStream_t st = q->stream;
-    const int64_t topk = std::min<int64_t>(q->gr->gp.topk, q->sp->n);
+    const int64_t topk = q->topk;   // capped by the items of the whole index, not by this shard's rows
     q->seq += 1;
     hipLaunchKernelGGL(hits_final_kernel, dim3(1), dim3(1024), (sizeof(double) + sizeof(int)) * HIT_CAP, st, hits_dev, m, m, m, topk,
                        q->info, q->hout_dev, q->seq);
@@ -2079,7 +2081,7 @@ as_status as_query_finish_batch(as_query* q, const as_hit_rec* hits_dev, int32_t
         return AS_EUNSUPPORTED;
     }
     hipStream_t st = q->stream;
-    const int64_t topk = std::min<int64_t>(q->gr->gp.topk, graph_items(q->gr));
+    const int64_t topk = q->topk;
     q->seq += 1;
     hipLaunchKernelGGL(hits_final_kernel, dim3((unsigned)q->nb), dim3(1024), (sizeof(double) + sizeof(int)) * HIT_CAP, st, hits_dev, m, per,
                        per * q->cap, topk, q->info, q->hout_dev, q->seq);

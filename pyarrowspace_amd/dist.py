@@ -418,7 +418,7 @@ class HipEngine:
         import os
         self._check(self.L.as_index_load(os.fsencode(path), C.byref(self.op), C.byref(self.sp), C.byref(self.gr)))
         self.n, self.d = int(self.L.as_nitems(self.sp)), int(self.L.as_nfeatures(self.sp))
-        return int(self.L.as_space_row_offset(self.sp)), int(self.L.as_graph_ncols(self.gr))
+        return int(self.L.as_space_row_offset(self.sp)), int(self.L.as_graph_nitems(self.gr))
 
     # ---- batched staged search (32 slots per pass)
     def batch_open(self):

@@ -229,6 +229,66 @@ def test_two_ranks_third_round_is_collective(oracle_lib):
     assert_hits_match(out[0][4], ref.search(X[5000].copy(), 0.62)[0], rtol=1e-9)
 
 
+_TINY = [   # (n, d, split, graph_params): shards of a few rows, topk beyond a shard's (or the index's) rows
+    (5, 2, 2, {"eps": 0.9, "k": 2, "topk": 19, "p": 0.5, "sigma": None, "metric": "cosine", "kernel": "gaussian"}),
+    (9, 3, 8, {"eps": 6.0, "k": 3, "topk": 7, "p": 2.0, "sigma": None}),
+    (40, 8, 1, {"eps": 8.0, "k": 5, "topk": 30, "p": 2.0, "sigma": None}),
+]
+
+
+def _tiny_data(n, d, seed):
+    return np.abs(np.random.default_rng(seed).standard_normal((n, d))) + 0.05
+
+
+def _tiny_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = []
+        for c, (n, d, split, gp) in enumerate(_TINY):
+            X = _tiny_data(n, d, c)
+            bounds = [0, split, n]
+            index = _cpu_staged().build(gp, torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy()).cuda(), dist)
+            qs = [X[0].copy(), X[n - 1] * 1.01, X[n // 2] + 0.01]
+            hits = [index.search(np.ascontiguousarray(q), tau) for q in qs for tau in (1.0, 0.62)]
+            assert index.search_batch(np.stack(qs), 0.62) == hits[1::2]
+            res.append((index.lambdas().copy(), hits))
+            index.close()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_shards_of_a_few_rows(oracle_lib):
+    """topk larger than a rank's row count (19 of 2 + 3 rows), a one-row shard: the hit records every rank contributes
+    have one layout -- capped by the items of the whole index, not by the shard (found by tools/fuzz_2rank.py)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tiny_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0][0][1] == out[1][0][1]
+    for c, (n, d, split, gp) in enumerate(_TINY):
+        X = _tiny_data(n, d, c)
+        ref = oracle_lib.OracleIndex(X, gp)
+        lam, hits = out[0][c]
+        np.testing.assert_allclose(lam, ref.lambdas, rtol=1e-9)
+        qs = [X[0].copy(), X[n - 1] * 1.01, X[n // 2] + 0.01]
+        t = 0
+        for q in qs:
+            for tau in (1.0, 0.62):
+                want, lq = ref.search(np.ascontiguousarray(q), tau)
+                assert len(hits[t]) == min(gp["topk"], n)
+                assert_hits_match(hits[t], want, ref.scores(np.ascontiguousarray(q), tau, lq), rtol=1e-9)
+                t += 1
+
+
 @pytest.mark.parametrize("rep", range(4))
 def test_two_ranks_ring_repeats(oracle_lib, rep):
     """The 2-rank ring build again and again (its kernels run concurrently with the other rank's on one GPU: timing varies)."""
@@ -261,6 +321,17 @@ def _feature_worker(rank, world, port, n, d, split, out):
         res = [(index.search(q, tau), index.last_lambda_q) for q, tau in _queries(X, n, d)]
         Qb = np.stack([q for q, _ in _queries(X, n, d)])
         assert index.search_batch(Qb, 0.62) == [index.search(np.ascontiguousarray(q), 0.62) for q in Qb]
+        # sharded save / load in feature mode: the rank's rows + the feature graph; the loaded index knows how many items
+        # the lambdas were ranked over (all ranks' rows) and answers like the one that was saved
+        prefix = os.path.join(os.environ.get("TMPDIR", "/tmp"), "as_fshard_%d" % port)
+        index.save(prefix)
+        dist.barrier()
+        loaded = CpuStaged.load(prefix, gp, dist)
+        assert (loaded.n, loaded.replicated, loaded.r0, loaded.r1) == (index.n, False, index.r0, index.r1)
+        for q, tau in _queries(X, n, d)[:4]:
+            assert loaded.search(q, tau) == index.search(q, tau)
+        loaded.close()
+        os.remove("%s.rank%dof%d" % (prefix, rank, world))
         out[rank] = (index.lambdas().copy(), res)
         index.close()
     finally:

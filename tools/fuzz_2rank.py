@@ -1,0 +1,106 @@
+"""Randomised check of the 2-rank sharded index on ONE GPU (collectives staged through the CPU, gloo):
+python tools/fuzz_2rank.py [cases] [seed].  The configurations of tools/fuzz_parity.py, a random split of the items
+over the two ranks (sometimes a handful of rows on one side); lambdas, k-NN lists of both ranks and a few searches
+(single and batched) against the oracle.  One pair of processes runs all the cases."""
+import os, socket, sys, time
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+
+
+def worker(rank, world, port, cases, seed, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pyarrowspace_amd as asp
+    from conftest import assert_hits_match
+    from fuzz_parity import gen_case
+    from oracle import oracle_c
+    from test_gpu_dist import _cpu_staged
+    Staged = _cpu_staged()
+    rng = np.random.default_rng(seed)
+    bad, t0 = [], time.time()
+    for c in range(cases):
+        sub = np.random.default_rng(rng.integers(1 << 62))
+        X, gp, cfg = gen_case(sub, c)
+        n, d = X.shape
+        if n < 4 or d > 1024:
+            continue
+        split = int(sub.integers(1, n)) if sub.random() < 0.8 else int(sub.choice([1, 2, n - 2, n - 1]))
+        cfg = dict(cfg, split=split)
+        bounds = [0, split, n]
+        qs = [np.ascontiguousarray(X[int(sub.integers(n))] * 1.01), np.ascontiguousarray(X[int(sub.integers(n))]),
+              np.ascontiguousarray(sub.standard_normal(d) * (np.abs(X).mean() + 1e-9))]
+        taus = [float(sub.choice([1.0, 0.62, 0.0])) for _ in qs]
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("rank %d case %d: %s" % (rank, c, cfg), flush=True)
+        index = Staged.build(gp, torch.from_numpy(X[bounds[rank]:bounds[rank + 1]].copy()).cuda(), dist)
+        lam = index.lambdas()
+        lists = [t.cpu().numpy().copy() for t in index.engine.lists()]
+        got = []
+        for q, tau in zip(qs, taus):
+            try:
+                got.append(index.search(q, tau))
+            except asp.PanicException:
+                got.append("panic")
+        try:
+            gotb = index.search_batch(np.stack(qs), taus[0])
+        except asp.PanicException:
+            gotb = "panic"
+        index.close()
+        # ---- checks (no collective below this line: a failure must not leave the other rank waiting)
+        try:
+            ref = oracle_c.OracleIndex(X, gp)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            np.testing.assert_array_equal(lists[3], ref.knn_cnt[lo:hi])
+            np.testing.assert_allclose(lam, ref.lambdas, rtol=1e-6, atol=1e-300)
+            wants = []
+            for q, tau, g in zip(qs, taus, got):
+                try:
+                    want, lq = ref.search(q, tau)
+                except oracle_c.ZeroLambda:
+                    assert g == "panic", "answered where the oracle panics"
+                    wants.append("panic")
+                    continue
+                assert g != "panic", "panicked where the oracle answers"
+                assert_hits_match(g, want, ref.scores(q, tau, lq), rtol=1e-6, atol=1e-9)
+                wants.append(g)
+            if "panic" in [wants[i] for i in range(len(qs))]:
+                pass   # (a batch with a zero-lambda query panics as a whole)
+            elif gotb != "panic":
+                for i, tau in enumerate(taus):
+                    if tau == taus[0]:
+                        assert gotb[i] == got[i], "batch != single"
+        except BaseException as e:   # noqa: BLE001
+            bad.append(c)
+            import traceback
+            tb = traceback.extract_tb(e.__traceback__)[-1]
+            print("FAIL rank %d case %d: %s at %s:%d (%s): %s\n   %s" % (rank, c, type(e).__name__, os.path.basename(tb.filename), tb.lineno,
+                                                                      tb.line, str(e)[:500], cfg), flush=True)
+        if rank == 0 and c % 20 == 19:
+            print("  ... %d cases, %d failures on rank 0, %.0fs" % (c + 1, len(bad), time.time() - t0), flush=True)
+    out[rank] = bad
+    dist.destroy_process_group()
+
+
+def main():
+    import torch.multiprocessing as mp
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(worker, args=(2, port, cases, seed, out), nprocs=2, join=True)
+    bad = sorted(set(out[0]) | set(out[1]))
+    print("fuzz_2rank: %d cases, failures in %s, seed %d" % (cases, bad, seed))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
