@@ -124,6 +124,8 @@ class HipEngine:
         self.p_cnt = torch.zeros((2, rows), dtype=torch.int32, device=dev)
         self.p_t32 = torch.zeros((2, rows), dtype=torch.float32, device=dev)
         self.nblocks, self._round2_first = nblocks, False
+        # torch fills these on ITS stream, the library reads and writes them on its own: the fills must have run
+        torch.cuda.synchronize()
 
     def open_block(self, X):
         """A visiting shard as a temporary space (ingested into the HBM layout the kernels read)."""
@@ -388,6 +390,7 @@ class HipEngine:
     def feat_gram(self):
         torch = self.torch
         g = torch.zeros((self.d, self.d), dtype=torch.float64, device=torch.device("cuda", self.op.device))
+        torch.cuda.synchronize()   # (the zero fill runs on torch's stream, the library writes on its own: a late fill would wipe the result)
         if self.n > 0:
             self._check(self.L.as_feat_gram(self.sp, 0, self.n, C.c_void_p(g.data_ptr())))
         return g
@@ -401,6 +404,7 @@ class HipEngine:
         dev = torch.device("cuda", self.op.device)
         E = torch.zeros((max(self.n, 1),), dtype=torch.float64, device=dev)
         G = torch.zeros_like(E)
+        torch.cuda.synchronize()   # as in feat_gram
         if self.n > 0:
             self._check(self.L.as_feat_energy(self.sp, self.gr, 0, self.n, C.c_void_p(E.data_ptr()), C.c_void_p(G.data_ptr())))
         return E[: self.n], G[: self.n]
