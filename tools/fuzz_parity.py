@@ -161,7 +161,18 @@ def sharded_case(rng, X, gp, cfg):
     from pyarrowspace_amd.dist import ShardedIndex
     n, d = X.shape
     ref = oracle_c.OracleIndex(X, gp)
-    index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())
+    if os.environ.get("FUZZ_RCCL"):
+        # one rank, but every collective really issued (RCCL, on the index's side stream): all-gathers, the edge
+        # all-to-all, the record exchanges of every search
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        index = ShardedIndex.build(gp, torch.from_numpy(X).cuda(), dist, force_collectives=True)
+    else:
+        index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())
     try:
         np.testing.assert_allclose(index.lambdas(), ref.lambdas, rtol=1e-6, atol=1e-300, err_msg=str(cfg))
         for qi in range(4):
@@ -178,6 +189,12 @@ def sharded_case(rng, X, gp, cfg):
                     continue
             got = index.search(q, tau)
             assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-6, atol=1e-9)
+            if qi == 1 and d <= 1024:
+                try:
+                    gb = index.search_batch(np.stack([q, q]), tau)
+                except asp.PanicException:
+                    gb = None
+                assert gb is not None and gb[0] == got and gb[1] == got, ("staged batch != single", cfg)
     finally:
         index.close()
 
