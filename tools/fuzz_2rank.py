@@ -1,7 +1,7 @@
-"""Randomised check of the 2-rank sharded index on ONE GPU (collectives staged through the CPU, gloo):
-python tools/fuzz_2rank.py [cases] [seed].  The configurations of tools/fuzz_parity.py, a random split of the items
-over the two ranks (sometimes a handful of rows on one side); lambdas, k-NN lists of both ranks and a few searches
-(single and batched) against the oracle.  One pair of processes runs all the cases."""
+"""Randomised check of the row-sharded index with 2 (or 3, 4 ... 6) ranks on ONE GPU (collectives staged through the
+CPU, gloo): python tools/fuzz_2rank.py [cases] [seed] [world].  The configurations of tools/fuzz_parity.py, random cuts
+of the items over the ranks (sometimes a handful of rows on one side); lambdas, k-NN lists of every rank and a few
+searches (single and batched) against the oracle.  One set of processes runs all the cases."""
 import os, socket, sys, time
 os.environ.setdefault("OMP_NUM_THREADS", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,9 +29,17 @@ def worker(rank, world, port, cases, seed, out):
         n, d = X.shape
         if n < 4 or d > 1024:
             continue
-        split = int(sub.integers(1, n)) if sub.random() < 0.8 else int(sub.choice([1, 2, n - 2, n - 1]))
-        cfg = dict(cfg, split=split)
-        bounds = [0, split, n]
+        if n < world + 2:
+            continue
+        if world == 2:
+            split = int(sub.integers(1, n)) if sub.random() < 0.8 else int(sub.choice([1, 2, n - 2, n - 1]))
+            bounds = [0, split, n]
+        else:
+            inner = np.sort(sub.choice(np.arange(1, n), size=world - 1, replace=False))
+            if sub.random() < 0.25:
+                inner[0] = int(sub.integers(1, min(4, int(inner[1]))))     # a rank with a few rows
+            bounds = [0] + [int(v) for v in inner] + [n]
+        cfg = dict(cfg, split=bounds[1:-1])
         qs = [np.ascontiguousarray(X[int(sub.integers(n))] * 1.01), np.ascontiguousarray(X[int(sub.integers(n))]),
               np.ascontiguousarray(sub.standard_normal(d) * (np.abs(X).mean() + 1e-9))]
         taus = [float(sub.choice([1.0, 0.62, 0.0])) for _ in qs]
@@ -92,15 +100,17 @@ def main():
     import torch.multiprocessing as mp
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    world = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    assert 2 <= world <= 6   # a GPU box takes at most 6 processes on its card
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(worker, args=(2, port, cases, seed, out), nprocs=2, join=True)
-    bad = sorted(set(out[0]) | set(out[1]))
-    print("fuzz_2rank: %d cases, failures in %s, seed %d" % (cases, bad, seed))
+    mp.spawn(worker, args=(world, port, cases, seed, out), nprocs=world, join=True)
+    bad = sorted(set().union(*[set(out[r]) for r in range(world)]))
+    print("fuzz_2rank: %d cases on %d ranks, failures in %s, seed %d" % (cases, world, bad, seed))
     sys.exit(1 if bad else 0)
 
 
