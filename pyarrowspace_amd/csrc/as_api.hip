@@ -869,7 +869,8 @@ struct IndexHeader {
     int64_t n, d, nnz;       // items held by this file, features, adjacency entries
     int64_t nnodes;          // graph rows in this file: the items of the whole index (item mode, replicated graph), this
                              // shard's n rows (item mode, sharded graph: graph_ncols > 0) or d (feature mode)
-    int64_t graph_ncols;     // sharded item graph: the items its columns range over; 0 for a whole graph
+    int64_t graph_ncols;     // sharded item graph: the items its columns range over; 0 for a whole graph.  Feature mode: the
+                             // items the lambdas were ranked over (all ranks' rows)
     int64_t graph_row0;      // sharded item graph: its first row (== row_offset)
     int64_t row_offset;      // global index of this file's first item (0 for a whole index)
     int32_t has_f64, metric, kernel, lambda_mode;
@@ -1065,7 +1066,7 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
             if ((s = file_to_host(f, col, nnz)) != AS_OK) break;
             bool ok = ip[0] == 0 && ip[nn] == h.nnz;
             for (size_t i = 0; ok && i < nn; ++i) ok = ip[i] <= ip[i + 1];
-            const int64_t colmax = h.graph_ncols ? h.graph_ncols : h.nnodes;
+            const int64_t colmax = h.lambda_mode != AS_LAMBDA_FEATURE && h.graph_ncols ? h.graph_ncols : h.nnodes;   // (feature mode: the field counts items)
             for (size_t e = 0; ok && e < nnz; ++e) ok = col[e] >= 0 && (int64_t)col[e] < colmax;
             if (!ok) {
                 set_err("as_index_load: %s holds an inconsistent graph (row pointers or column indices out of range)", path);

@@ -100,6 +100,8 @@ def one_case(rng, case, sharded=False):
     assert np.array_equal(indices[indices != rows], ref.indices), cfg
     if rng.random() < 0.3:
         batch_case(rng, aspace, gl, X, cfg)
+    if os.environ.get("FUZZ_EXTRAS"):
+        extras_case(rng, aspace, gl, X, gp, cfg)
     for qi in range(4):
         r = int(rng.integers(n))
         qk = rng.choice(["near", "item", "random", "far"])
@@ -129,6 +131,59 @@ def one_case(rng, case, sharded=False):
             if g2 is not None:
                 gb = aspace.search_batch(np.stack([q, q2, q]), gl, tau)
                 assert gb[0] == got and gb[1] == g2 and gb[2] == got, ("batch", cfg)
+
+
+def extras_case(rng, aspace, gl, X, gp, cfg):
+    """The entry points around the build: a strided device matrix (fp32 or fp64) through build_from_device, a save /
+    load round trip, strided host items, four threads searching one space -- all against the index just built."""
+    import tempfile, threading
+    import torch
+    n, d = X.shape
+    qs = [np.ascontiguousarray(X[int(rng.integers(n))] * 1.01) for _ in range(3)]
+    tau = float(rng.choice([1.0, 0.62, 0.0]))
+
+    def answers(sp, g):
+        out = []
+        for q in qs:
+            try:
+                out.append(sp.search(q, g, tau))
+            except asp.PanicException:
+                out.append("panic")
+        return out
+
+    base = answers(aspace, gl)
+    which = int(rng.integers(0, 4))
+    if which == 0:      # device matrix with a row stride beyond d
+        ld = d + int(rng.integers(0, 9))
+        f32 = bool(np.array_equal(X.astype(np.float32).astype(np.float64), X))
+        T = torch.zeros((n, ld), dtype=torch.float32 if f32 else torch.float64, device="cuda")
+        T[:, :d] = torch.from_numpy(X).to(T.dtype)
+        torch.cuda.synchronize()
+        a2, g2 = asp.ArrowSpaceBuilder.build_from_device(gp, T.data_ptr(), T.dtype, n, d, ld)
+        assert np.array_equal(a2.lambdas(), aspace.lambdas()), ("build_from_device lambdas", cfg)
+        assert answers(a2, g2) == base, ("build_from_device answers", cfg)
+    elif which == 1:    # save / load
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "idx.bin")
+            aspace.save(gl, path)
+            a2, g2 = asp.ArrowSpaceBuilder.load(path)
+        assert np.array_equal(a2.lambdas(), aspace.lambdas()), ("load lambdas", cfg)
+        assert answers(a2, g2) == base, ("load answers", cfg)
+    elif which == 2:    # strided host items (column-major, and every other row of a taller matrix)
+        a2, g2 = asp.ArrowSpaceBuilder.build(gp, np.asfortranarray(X))
+        assert np.array_equal(a2.lambdas(), aspace.lambdas()), ("fortran-order lambdas", cfg)
+        tall = np.zeros((2 * n, d))
+        tall[::2] = X
+        a3, g3 = asp.ArrowSpaceBuilder.build(gp, tall[::2])
+        assert np.array_equal(a3.lambdas(), aspace.lambdas()) and answers(a3, g3) == base, ("strided rows", cfg)
+    else:               # threads
+        got = [None] * 4
+        def work(t):
+            got[t] = [answers(aspace, gl) for _ in range(3)]
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert all(g == [base] * 3 for g in got), ("threads", cfg)
 
 
 def batch_case(rng, aspace, gl, X, cfg):
