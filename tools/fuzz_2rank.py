@@ -59,9 +59,25 @@ def worker(rank, world, port, cases, seed, out):
             gotb = index.search_batch(np.stack(qs), taus[0])
         except asp.PanicException:
             gotb = "panic"
+        reload_ok = True
+        if sub.random() < 0.25:    # one file per rank, loaded again: same shard bounds, same answers
+            prefix = os.path.join(os.environ.get("TMPDIR", "/tmp"), "as_fuzz_%d_%d" % (port, c))
+            index.save(prefix)
+            dist.barrier()
+            loaded = Staged.load(prefix, gp, dist)
+            again = []
+            for q, tau in zip(qs, taus):
+                try:
+                    again.append(loaded.search(q, tau))
+                except asp.PanicException:
+                    again.append("panic")
+            reload_ok = again == got and (loaded.n, loaded.r0, loaded.r1) == (index.n, index.r0, index.r1)
+            loaded.close()
+            os.remove("%s.rank%dof%d" % (prefix, rank, world))
         index.close()
         # ---- checks (no collective below this line: a failure must not leave the other rank waiting)
         try:
+            assert reload_ok, "the loaded index answers differently"
             ref = oracle_c.OracleIndex(X, gp)
             lo, hi = bounds[rank], bounds[rank + 1]
             if lists is not None:
