@@ -117,6 +117,7 @@ as_status as_graph_from_knn(as_space* sp, const as_graph_params* gp, const int32
  *      device memory, caller-allocated: key / dist / gy fp64 and idx int32 [nblocks][rows][M], cnt int32 and t32 fp32
  *      [nblocks][rows]; the pointers passed to as_knn_block / _band are those of ONE block's slice. ---- */
 int32_t as_knn_list_width(int64_t k);                 /* M; < 0 when k is not supported */
+int32_t as_record_capacity(int32_t which);            /* 0: k-NN records a query merges (ranks x k); 1: hit records (ranks x (topk + 1)) */
 double as_space_nmax(const as_space* sp);             /* largest squared norm (error bound of a block's dropped candidates) */
 as_status as_space_norms(const as_space* sp, double* out_dev); /* fp64 squared norms of the space's rows, device to device */
 int64_t as_space_row_offset(const as_space* sp);      /* global index of row 0 (set by as_graph_from_knn_global) */

@@ -41,7 +41,7 @@ class HitRec(C.Structure):
 SYMBOLS = [
     "as_build", "as_build_dev", "as_space_create_dev", "as_knn_rows", "as_graph_from_knn", "as_feat_gram", "as_feat_graph",
     "as_feat_energy", "as_feat_lambdas", "as_feat_lambdas_global", "as_graph_lambda_mode", "as_knn_list_width", "as_space_nmax", "as_space_norms",
-    "as_space_row_offset", "as_knn_block", "as_knn_block_pair", "as_knn_thresholds", "as_knn_merge", "as_knn_fold", "as_knn_block_band", "as_knn_block_exact", "as_graph_from_knn_global", "as_graph_shard_csr", "as_graph_deg_copy", "as_graph_shard_energy",
+    "as_space_row_offset", "as_knn_block", "as_knn_block_pair", "as_knn_thresholds", "as_knn_merge", "as_knn_fold", "as_knn_block_band", "as_knn_block_exact", "as_record_capacity", "as_graph_from_knn_global", "as_graph_shard_csr", "as_graph_deg_copy", "as_graph_shard_energy",
     "as_graph_energy_copy", "as_graph_shard_lambdas", "as_graph_row_offset", "as_graph_ncols", "as_graph_nitems", "as_search",
     "as_search_batch", "as_unproven_searches", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
@@ -107,6 +107,7 @@ def load():
         "as_space_norms": (i32, [vp, vp]),
         "as_space_row_offset": (i64, [vp]),
         "as_knn_block": (i32, [vp, vp, pgp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
+        "as_record_capacity": (i32, [i32]),
         "as_knn_block_exact": (i32, [vp, vp, pgp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]),
         "as_knn_block_pair": (i32, [vp, vp, pgp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "as_knn_thresholds": (i32, [vp, pgp, i64, i64, f64, vp, vp, vp]),

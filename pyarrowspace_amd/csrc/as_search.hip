@@ -1939,6 +1939,7 @@ const as_knn_rec* as_query_knn_records(const as_query* q) { return q->knn; }
 int64_t as_query_knn_capacity(const as_query* q) { return q->k; }
 const as_hit_rec* as_query_hit_records(const as_query* q) { return q->hits; }
 int64_t as_query_hit_capacity(const as_query* q) { return q->topk + 1; }
+int32_t as_record_capacity(int32_t which) { return which == 0 ? REC_CAP : HIT_CAP; }
 
 as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end) {
     if (!q || !query_host || !q->gr) {

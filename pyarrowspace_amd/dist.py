@@ -34,6 +34,21 @@ def shard_bounds(n: int, world: int) -> list[int]:
     return b
 
 
+def check_world_limits(graph_params, world: int):
+    """A query merges world * k neighbour records and world * (topk + 1) hit records in one workgroup: refuse a
+    combination beyond the library's capacities (512 and 8 208: e.g. k = 56 on 10 ranks) before anything is built."""
+    from . import _lib
+    L = _lib.load()
+    gp = graph_params or {}
+    k, topk = int(gp.get("k", 0)), int(gp.get("topk", 0))
+    rec, hit = int(L.as_record_capacity(0)), int(L.as_record_capacity(1))
+    if gp.get("lambda_mode", "item") != "feature" and world * k > rec:
+        raise ValueError(f"graph_params['k']={k} on {world} ranks: a query merges world * k = {world * k} neighbour records, the maximum is {rec}")
+    if world * (topk + 1) > hit:
+        raise ValueError(f"graph_params['topk']={topk} on {world} ranks: a query merges world * (topk + 1) = {world * (topk + 1)} hit records, "
+                         f"the maximum is {hit}")
+
+
 def next_mode(mode: int, inexact: bool, overflow: int):
     """Escalation of one sharded search (every rank sees the same merged flags, so every rank takes the
     same step).  mode bits as in as_query_set_exact: 1 = fp64 scans, 2 = wavefront-list selection,
@@ -589,6 +604,7 @@ class ShardedIndex:
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
+        check_world_limits(graph_params, self.world)      # before any upload or GPU work
         self.force_collectives = bool(force_collectives) and dist is not None
         self.engine = engine if engine is not None else HipEngine(graph_params)
         self.replicated = bool(replicate) or not hasattr(self.engine, "knn_block")
