@@ -45,7 +45,10 @@ def worker(rank, world, port, cases, seed, out):
         taus = [float(sub.choice([1.0, 0.62, 0.0])) for _ in qs]
         if os.environ.get("FUZZ_VERBOSE"):
             print("rank %d case %d: %s" % (rank, c, cfg), flush=True)
-        index = Staged.build(gp, torch.from_numpy(X[bounds[rank]:bounds[rank + 1]].copy()).cuda(), dist)
+        shard = X[bounds[rank]:bounds[rank + 1]].copy()
+        if sub.random() < 0.5 and np.array_equal(X.astype(np.float32).astype(np.float64), X):
+            shard = shard.astype(np.float32)      # fp32 device shards (what bench.py hands over): same index
+        index = Staged.build(gp, torch.from_numpy(shard).cuda(), dist)
         lam = index.lambdas()
         feature = gp.get("lambda_mode") == "feature"     # (no item k-NN lists in feature mode)
         lists = None if feature else [t.cpu().numpy().copy() for t in index.engine.lists()]
