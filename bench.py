@@ -208,6 +208,14 @@ def main():
     build_s = float(bt.item())
 
     # ---------------- search: W warmup + K timed steps
+    primed = 0
+    if not single:
+        # N > 1 (and its 1-GPU rehearsal): the first few hundred sharded searches after a build see one-off stalls of the
+        # collective layer (tools/staged_overhead.py: one of ~37 ms some 140 ms after the first search, torch's NCCL
+        # watchdog waking up) -- run them here, outside both the build time and the W + K steps
+        primed = 300
+        for i in range(primed):
+            searcher(Q[i % len(Q)])
     for i in range(args.warmup):
         searcher(Q[i % len(Q)])
     scan_us = []
@@ -295,6 +303,7 @@ def main():
                    "n": n, "d": d, "metric": args.metric, "kernel": args.kernel, "lambda_mode": args.lambda_mode,
                    "parallelism": "row-shard x%d" % world},
         "index_build_sec": build_s,
+        "priming_queries": primed,
         "batched_queries_per_sec": batched_qps,
         "build_stages_sec": {k: bstats[k] for k in ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s")},
         "build_fallback_rows": bstats["fallback_rows"],
