@@ -104,3 +104,28 @@ def test_sharded_index_refuses_record_counts_beyond_the_merge_capacity(asp):
     check_world_limits(dict(gp, k=25, topk=1024), 8)           # 8 200 hit records
     with pytest.raises(ValueError, match="hit records"):
         check_world_limits(dict(gp, k=25, topk=1024), 9)
+
+
+def test_slice_message_sections_tile_the_flat_buffer():
+    """The symmetric ring's slice message is ONE flat fp64 buffer whose sections (keys, distances, y.y, ids, counts,
+    bounds) the library writes in place: contiguous views that do not overlap, cover the buffer, and are 8-byte aligned,
+    for odd row counts and both list widths."""
+    import torch
+
+    from pyarrowspace_amd.dist import HipEngine
+    for M in (32, 64):
+        for n in (1, 2, 3, 7, 128, 1001):
+            e = HipEngine.__new__(HipEngine)
+            e.torch, e.M = torch, M
+            shape = e.slice_shape(n)
+            P = torch.zeros(shape, dtype=torch.float64)
+            sec = e._slice_sections(P, n)
+            assert [tuple(s.shape) for s in sec] == [(n, M), (n, M), (n, M), (n, M), (n,), (n,)]
+            assert [s.dtype for s in sec] == [torch.float64] * 3 + [torch.int32, torch.int32, torch.float32]
+            assert all(s.is_contiguous() and s.data_ptr() % 8 == 0 for s in sec)
+            spans = sorted((s.data_ptr() - P.data_ptr(), s.data_ptr() - P.data_ptr() + s.numel() * s.element_size()) for s in sec)
+            assert spans[0][0] == 0 and all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= P.numel() * 8
+            for v, s in enumerate(sec):      # writing one section touches no other
+                s.fill_(v + 1)
+            assert all(bool((s == v + 1).all()) for v, s in enumerate(sec))
+            assert e.slice_shape(0) == e.slice_shape(1)
