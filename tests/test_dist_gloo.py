@@ -393,6 +393,91 @@ def test_symmetric_ring_with_three_and_four_ranks(world, cuts):
     assert all(out[r][1] == out[0][1] for r in range(world))
 
 
+class RoundsEngine(OracleEngine):
+    """The ring's second and third rounds on the CPU: one rank reports unproven rows after the first merge, another one
+    overflowed bands after the second round -- every rank must then go round again (the rounds are collective), and the
+    lists recomputed from the visiting blocks are the same exact lists."""
+
+    def __init__(self, gp, rank, flag_rank, over_rank):
+        super().__init__(gp)
+        self.rank, self.flag_rank, self.over_rank = rank, flag_rank, over_rank
+        self.merges, self.band_blocks, self.exact_blocks = 0, [], []
+
+    def knn_merge(self, nmax, final=False):
+        import torch
+        k = self.prm["k"]
+        idx = np.full((self.n, k), -1, dtype=np.int32)
+        dist = np.zeros((self.n, k))
+        gy = np.zeros((self.n, k))
+        cnt = np.zeros(self.n, dtype=np.int32)
+        for i in range(self.n):      # (a block seen in several rounds contributes the same entries again: a set)
+            allc = sorted(set(c for b in self.parts for c in self.parts[b][i]))[:k]
+            for t, (kk, j, dd, gg) in enumerate(allc):
+                idx[i, t], dist[i, t], gy[i, t] = j, dd, gg
+            cnt[i] = len(allc)
+        self._lists = tuple(torch.from_numpy(a) for a in (idx, dist, gy, cnt))
+        self.merges += 1
+        self.final = final
+        return 3 if self.merges == 1 and self.rank == self.flag_rank else 0
+
+    def knn_block_band(self, h, b, row_goff, col_goff):
+        self.band_blocks.append(b)
+        self.knn_block(h, b, row_goff, col_goff)
+        return 0
+
+    def overflowed_rows(self):
+        return 2 if self.rank == self.over_rank else 0
+
+    def knn_block_exact(self, h, b, row_goff, col_goff):
+        self.exact_blocks.append(b)
+        self.knn_block(h, b, row_goff, col_goff)
+
+
+def _rounds_worker(rank, world, port, n, d, cuts, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyarrowspace_amd.dist import ShardedIndex
+        X = clustered(n, d, nclust=6, seed=21)
+        gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+        bounds = sorted([0, n] + list(cuts))
+        shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy())
+        e = RoundsEngine(gp, rank, flag_rank=0, over_rank=world - 1)
+        index = ShardedIndex.build(gp, shard, dist, engine=e)
+        # every rank saw every block in the second and in the third round; only the overflowed rank merged once more
+        assert sorted(e.band_blocks) == list(range(world)) and sorted(e.exact_blocks) == list(range(world))
+        assert e.merges == (3 if rank == world - 1 else 2) and e.final == (rank == world - 1)
+        assert index.ring_flagged == (3 if rank == 0 else 0) and index.ring_overflowed == (2 if rank == world - 1 else 0)
+        q = X[17] + 0.01
+        out[rank] = (index.lambdas().copy(), [index.search(q, tau) for tau in (1.0, 0.62)])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cuts", [(2, (120,)), (3, (70, 190)), (4, (60, 61, 200))])
+def test_second_and_third_ring_rounds_are_collective(world, cuts):
+    """Unproven rows on one rank, overflowed bands on another: all ranks send their shards round a second and a third
+    time (ShardedIndex._ring_knn), the rank without flags just passes blocks on; same index as the single process."""
+    import torch.multiprocessing as mp
+    from oracle import oracle_np
+    n, d = 300, 24
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rounds_worker, args=(world, _free_port(), n, d, cuts, out), nprocs=world, join=True)
+    X = clustered(n, d, nclust=6, seed=21)
+    gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_np.build(X, gp)
+    for rank in range(world):
+        np.testing.assert_allclose(out[rank][0], ref["lambdas"], rtol=1e-12)
+    assert all(out[r][1] == out[0][1] for r in range(world))
+    want = [oracle_np.search(ref, X[17] + 0.01, tau) for tau in (1.0, 0.62)]
+    for hits, (whits, _) in zip(out[0][1], want):
+        assert [i for i, _ in hits] == [i for i, _ in whits]
+
+
 def test_shard_bounds():
     from pyarrowspace_amd.dist import shard_bounds
     assert shard_bounds(10, 4) == [0, 3, 6, 8, 10]
