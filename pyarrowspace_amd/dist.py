@@ -2,12 +2,16 @@
 (backend "nccl" = RCCL over xGMI) for the exchange steps, the C ABI for every kernel.
 
 Build   (DESIGN.md section 6): a rank keeps only ITS rows.  The raw shards travel round a ring (send to
-        rank+1, receive from rank-1, double-buffered against the compute): per visiting shard the fused
-        X.X^T k-NN kernel runs own rows x visiting columns and leaves M exact candidates per row; after the
-        last shard they are merged into the exact k-NN lists (rows not provably exact go round once more in
-        collect mode) -> all-gather of the lists and of the squared norms -> the O(N k) graph / Laplacian /
-        lambda stage is computed redundantly on every rank.  `replicate=True` keeps the round-1 form
-        (all-gather of the whole item matrix, every rank holds all of it).
+        rank+1, receive from rank-1, double-buffered against the compute).  Every unordered pair of shards is computed
+        ONCE (as_knn_block_pair: the keys of own rows x visiting columns serve both sides, the visiting rows' slice is
+        sent home as one flat fp64 buffer), so the shards travel world // 2 hops; per block M exact candidates per row
+        are folded into a running list, and after the last block as_knn_merge proves the k-NN lists exact.  Rows it
+        cannot prove go round once more in collect mode (band pass), rows whose band overflows a third time (exact
+        evaluation of every pair) -- both rounds collective.  Graph stage: every directed edge goes to the owner of
+        its target row by one variable-count all-to-all, each rank builds ITS rows of the CSR; degrees, squared norms
+        and energies (8 B per item each) are all-gathered, nothing of size N k is replicated.  `gather_lists=True`
+        keeps the form with all-gathered lists and a replicated graph stage, `replicate=True` the round-1 form
+        (all-gather of the whole item matrix).  Feature mode: the D x D Gram partials are all-gathered and summed.
 Search: every rank scans its own rows, the k nearest-neighbour records and the top-k hit
         records (fixed-size structs of include/arrowspace_hip.h) are all-gathered and merged
         identically on every rank; two collectives of a few KB per query.
