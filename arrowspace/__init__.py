@@ -1,6 +1,21 @@
 """Drop-in module name of the reference (`Cargo.toml:7`, `src/lib.rs:380`):
-`from arrowspace import ArrowSpaceBuilder` resolves to the MI355X-native implementation."""
-from pyarrowspace_amd import (ArrowSpace, ArrowSpaceBuilder, GraphLaplacian, PanicException,  # noqa: F401
-                              set_debug)
+`from arrowspace import ArrowSpaceBuilder` resolves to the MI355X-native implementation.
+
+Mode defaults.  The reference's scripts pass parameter sets written for the graph its notes document -- rectified-cosine
+distance `d = 1 - max(0, cos)`, weights `1 / (1 + (d / sigma)^p)` (`GRAPH_VARIABLES.md:7-10`): `eps: 0.05` of
+`tests/test_0.py:13`, `eps: 0.5` of `tests/test_1_quora_questions.py:78`, `eps: 10` on x100-scaled embeddings of
+`tests/test_3_beir.py:194-200`.  Under this module name those are the defaults (`metric="cosine"`,
+`kernel="rational"`), so the scripts run with their dicts unmodified and no environment variables.  `pyarrowspace_amd`
+and `bench.py` keep BASELINE.json's north_star default (L2 distance, Gaussian weights).  Either way a `metric` /
+`kernel` / `lambda_mode` key in the dict, or ARROWSPACE_METRIC / _KERNEL / _LAMBDA_MODE, overrides."""
+import pyarrowspace_amd as _amd
+from pyarrowspace_amd import ArrowSpace, GraphLaplacian, PanicException, set_debug  # noqa: F401
+
+
+class ArrowSpaceBuilder(_amd.ArrowSpaceBuilder):
+    """`ArrowSpaceBuilder` of `src/lib.rs:265-377` with the documented graph as the default mode."""
+
+    _mode = _amd.REFERENCE_MODE
+
 
 __all__ = ["ArrowSpaceBuilder", "ArrowSpace", "GraphLaplacian", "set_debug", "PanicException"]

@@ -4,7 +4,8 @@
 # Usage: bash profiles/collect.sh <round-tag> [bench args...]
 set -o pipefail
 TAG=${1:-r01}; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"   # the repo this script lives in (never an unset variable: `cd ""` stays put)
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline "$@" > $OUT/stats.log 2>&1 || exit 1

@@ -53,16 +53,24 @@ def enable_search_stats(enabled: bool) -> None:
     _L.as_enable_search_stats(1 if enabled else 0)
 
 
-def _parse_graph_params(graph_params) -> tuple[GraphParams, Opts]:
+NORTH_STAR_MODE = {"metric": "l2", "kernel": "gaussian", "lambda_mode": "item"}        # BASELINE.json north_star
+REFERENCE_MODE = {"metric": "cosine", "kernel": "rational", "lambda_mode": "item"}      # GRAPH_VARIABLES.md:7-10
+
+
+def _parse_graph_params(graph_params, mode=None) -> tuple[GraphParams, Opts]:
     """src/helpers.rs:48-76.  eps,k,topk,p required; sigma missing/None -> eps*0.5.
     Keys the reference ignores select the documented variants: 'metric' in
     {'l2','cosine'}, 'kernel' in {'gaussian','rational'}, 'lambda_mode' in {'item','feature'}
-    (env ARROWSPACE_METRIC / _KERNEL / _LAMBDA_MODE set the defaults)."""
+    (DESIGN.md section 2).  Precedence: the dict's keys, then env ARROWSPACE_METRIC / _KERNEL / _LAMBDA_MODE, then
+    `mode` -- the defaults of the module the caller imported (NORTH_STAR_MODE for pyarrowspace_amd and bench.py,
+    REFERENCE_MODE for the reference-named module `arrowspace`, whose scripts' parameter sets are rectified-cosine
+    distances)."""
+    mode = NORTH_STAR_MODE if mode is None else mode
     gp, op = GraphParams(), Opts()
     op.device = int(os.environ.get("ARROWSPACE_DEVICE", "-1"))
-    metric = os.environ.get("ARROWSPACE_METRIC", "l2")
-    kernel = os.environ.get("ARROWSPACE_KERNEL", "gaussian")
-    lmode = os.environ.get("ARROWSPACE_LAMBDA_MODE", "item")
+    metric = os.environ.get("ARROWSPACE_METRIC", mode["metric"])
+    kernel = os.environ.get("ARROWSPACE_KERNEL", mode["kernel"])
+    lmode = os.environ.get("ARROWSPACE_LAMBDA_MODE", mode["lambda_mode"])
     if graph_params is None:
         # builder defaults (GRAPH_VARIABLES.md:15: eps~1e-3, k~6, p=2, sigma:=eps)
         gp.eps, gp.k, gp.topk, gp.p, gp.sigma, gp.has_sigma = 1e-3, 6, 3, 2.0, 1e-3, 1
@@ -323,17 +331,20 @@ class ArrowSpace:
 
 
 class ArrowSpaceBuilder:
-    """src/lib.rs:265-377."""
+    """src/lib.rs:265-377.  The methods are class methods only so that the reference-named module can carry other
+    mode defaults (`_mode`); they are called exactly like the reference's static methods."""
 
-    @staticmethod
-    def build(graph_params, items):
+    _mode = NORTH_STAR_MODE
+
+    @classmethod
+    def build(cls, graph_params, items):
         """(graph_params: dict|None, items: ndarray[float64, 2-D]) -> (ArrowSpace, GraphLaplacian).
         Argument order as the reference (src/lib.rs:271-275)."""
         if not isinstance(items, np.ndarray) or items.dtype != np.float64 or items.ndim != 2:
             raise TypeError("argument 'items': expected a 2-D numpy.ndarray of dtype float64")
         if items.shape[0] == 0 or items.shape[1] == 0:
             raise ValueError("items must be non-empty 2D array")
-        gp, op = _parse_graph_params(graph_params)
+        gp, op = _parse_graph_params(graph_params, cls._mode)
         esz = items.itemsize
         rs, cs = items.strides[0] // esz, items.strides[1] // esz
         if items.strides[0] % esz or items.strides[1] % esz or rs < 0 or cs < 0:
@@ -346,11 +357,11 @@ class ArrowSpaceBuilder:
             _raise(st)
         return ArrowSpace._wrap(sp), GraphLaplacian._wrap(gr)
 
-    @staticmethod
-    def build_from_device(graph_params, data_ptr: int, dtype, n: int, d: int, ld: int | None = None):
+    @classmethod
+    def build_from_device(cls, graph_params, data_ptr: int, dtype, n: int, d: int, ld: int | None = None):
         """Extension: items already resident in HBM (row-major fp32 or fp64 at `data_ptr`,
         e.g. `torch_tensor.data_ptr()`); same result as build() on the same values."""
-        gp, op = _parse_graph_params(graph_params)
+        gp, op = _parse_graph_params(graph_params, cls._mode)
         dt = {"float32": _lib.DTYPE_F32, "float64": _lib.DTYPE_F64}[str(dtype).replace("torch.", "")]
         sp, gr = C.c_void_p(), C.c_void_p()
         st = _L.as_build_dev(C.c_void_p(int(data_ptr)), dt, int(n), int(d), int(ld if ld is not None else d),

@@ -970,9 +970,15 @@ as_status as_index_save(const as_space* sp, const as_graph* gr, const char* path
     if (s == AS_OK) s = dev_to_file(f, gr->lap, nnz);
     if (s == AS_OK) s = dev_to_file(f, gr->deg, nn);
     if (gr->lambda_mode == AS_LAMBDA_FEATURE) {
-        // a shard of a row-sharded index holds the energies of every item: this file keeps its own rows'
-        if (s == AS_OK) s = dev_to_file(f, gr->E + (gr->nitems > sp->n ? sp->row_offset : 0), n);
-        if (s == AS_OK) s = dev_to_file(f, gr->G + (gr->nitems > sp->n ? sp->row_offset : 0), n);
+        // a shard of a row-sharded index holds the energies of every item right after its build (e_rows == nitems) and
+        // its own rows' after a load (e_rows == n): this file keeps its own rows' either way
+        const int64_t eoff = gr->e_rows > sp->n ? sp->row_offset : 0;
+        if (s == AS_OK && gr->e_rows < eoff + sp->n) {
+            set_err("as_index_save: the graph holds %lld energies, the space rows [%lld, %lld)", (long long)gr->e_rows, (long long)eoff, (long long)(eoff + sp->n));
+            s = AS_EINVAL;
+        }
+        if (s == AS_OK) s = dev_to_file(f, gr->E + eoff, n);
+        if (s == AS_OK) s = dev_to_file(f, gr->G + eoff, n);
         if (s == AS_OK) s = dev_to_file(f, gr->colm, d);
     } else {
         if (s == AS_OK) s = dev_to_file(f, gr->ny, nn);
@@ -1084,6 +1090,7 @@ static as_status index_load_impl(FILE* f, const char* path, const as_opts* opts,
         if (h.lambda_mode == AS_LAMBDA_FEATURE) {
             if ((s = file_to_dev(f, &gr->E, n)) != AS_OK) break;
             if ((s = file_to_dev(f, &gr->G, n)) != AS_OK) break;
+            gr->e_rows = h.n;
             if ((s = file_to_dev(f, &gr->colm, d)) != AS_OK) break;
             if ((s = feat_edges_from_csr(gr, sp->stream)) != AS_OK) break;
             sp->row_offset = h.row_offset;

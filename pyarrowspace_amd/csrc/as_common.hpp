@@ -92,6 +92,8 @@ struct as_graph {
     // off-diagonal of L = D - W), nitems the number of items E / G / the lambdas cover
     int lambda_mode = 0;
     int64_t nitems = 0;
+    int64_t e_rows = 0;         // feature mode: entries E / G hold -- nitems after as_feat_lambdas_global (every item's, all-gathered),
+                                // the space's own rows after a single-space build or a load
     int64_t ne = 0;             // edges a < b
     int32_t* ea = nullptr;      // [ne]
     int32_t* eb = nullptr;

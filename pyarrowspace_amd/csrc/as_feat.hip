@@ -576,6 +576,7 @@ as_status feat_build(as_space* sp, const as_graph_params* gp, as_graph* gr) {
     AS_TRY(feat_energy(sp, gr, 0, n, gr->E, gr->G));
     AS_HIP(hipStreamSynchronize(sp->stream));
     const double t3 = now();
+    gr->e_rows = n;
     AS_TRY(median_lambda(sp, gr, gr->E, gr->G));
     const double t4 = now();
     // stats slots shared with the item build: [1] = the MFMA block (here: the Gram), [2] = refine (feature
@@ -656,6 +657,7 @@ as_status as_feat_lambdas_global(as_space* sp, as_graph* gr, const double* E_dev
     AS_HIP(hipStreamSynchronize(st));
     sp->row_offset = row_offset;
     gr->nitems = n_global;
+    gr->e_rows = n_global;
     return AS_OK;
 }
 
@@ -670,6 +672,7 @@ as_status as_feat_lambdas(as_space* sp, as_graph* gr, const double* E_dev, const
     if (!gr->G) AS_HIP(hipMalloc(&gr->G, sizeof(double) * n));
     if (gr->E != E_dev) AS_HIP(hipMemcpyAsync(gr->E, E_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, sp->stream));
     if (gr->G != G_dev) AS_HIP(hipMemcpyAsync(gr->G, G_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, sp->stream));
+    gr->e_rows = n;
     return median_lambda(sp, gr, gr->E, gr->G);
 }
 

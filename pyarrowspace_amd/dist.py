@@ -95,6 +95,12 @@ class HipEngine:
             from . import _raise
             _raise(st)
 
+    def _fills_done(self):
+        """torch fills its tensors on ITS current stream (ShardedIndex.stream), the library reads and writes them on the
+        space's own: wait for that ONE stream.  Not torch.cuda.synchronize(): a device-wide wait would also sit out the
+        ring hop that is in flight on RCCL's stream, and the hop is there to be hidden behind the kernels launched next."""
+        self.torch.cuda.current_stream().synchronize()
+
     # ---- build
     def create_space(self, X):
         torch = self.torch
@@ -182,7 +188,7 @@ class HipEngine:
         torch = self.torch
         out = torch.full((max(self.n, 1),), float("inf"), dtype=torch.float32, device=torch.device("cuda", self.op.device))
         if self.n > 0:
-            torch.cuda.synchronize()
+            self._fills_done()
             self._check(self.L.as_knn_thresholds(self.sp, C.byref(self.gp), 0, self.n, float(nmax_all), C.c_void_p(self.p_key[0].data_ptr()),
                                                  C.c_void_p(self.p_cnt[0].data_ptr()), C.c_void_p(out.data_ptr())))
         return out[: self.n]
@@ -216,7 +222,7 @@ class HipEngine:
         qi.fill_(-1)
         qt.fill_(float("inf"))
         thr = col_thr.contiguous() if col_thr is not None else None
-        torch.cuda.synchronize()
+        self._fills_done()
         if self.n > 0 and ncols > 0:
             sl = [C.c_void_p(t[1].data_ptr() + row0 * t[1].stride(0) * t.element_size()) for t in
                   (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
@@ -242,7 +248,7 @@ class HipEngine:
         if self.n == 0:
             return
         ext = self._slice_sections(P, self.n)
-        self.torch.cuda.synchronize()
+        self._fills_done()
         self._fold_rows(0, self.n, nmax_src, None, ext)
 
     def knn_merge(self, nmax=None, final=False):
@@ -299,7 +305,7 @@ class HipEngine:
 
     def knn_block_exact(self, h, b, row_goff, col_goff):
         if self.n > 0:
-            self.torch.cuda.synchronize()
+            self._fills_done()
             self._check(self.L.as_knn_block_exact(self.sp, h, C.byref(self.gp), 0, self.n, row_goff, col_goff, C.c_void_p(self.l_over.data_ptr()),
                                                   *self._slice(1)))
             self._fold(1 if self._round3_first else 2, self.block_nmax(h), self.l_over)
@@ -576,17 +582,20 @@ class ShardedIndex:
         self.dist.all_to_all_single(out, t.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
         return out
 
-    def _gather_fixed(self, t):
+    def _gather_fixed(self, t, persistent=False):
+        """All-gather of equally shaped tensors.  persistent: t is one of the engine's record tensors, alive as long as
+        the index -- its [world * rows, ...] output buffer is allocated once and reused by every query; build-time
+        temporaries (Gram partials, thresholds) take a fresh buffer that dies with them."""
         torch = self.torch
         if not self._collective():
             return t
         if t.is_cuda:
-            # one collective into a preallocated [world * rows, ...] buffer, no per-call allocation
-            key = (t.data_ptr(), tuple(t.shape))
-            out = self._gbuf.get(key)
+            key = (t.data_ptr(), tuple(t.shape), t.dtype)
+            out = self._gbuf.get(key) if persistent else None
             if out is None:
                 out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                self._gbuf[key] = out
+                if persistent:
+                    self._gbuf[key] = out
             self.dist.all_gather_into_tensor(out, t, group=self.group)
             return out
         parts = [torch.empty_like(t) for _ in range(self.world)]
@@ -933,10 +942,10 @@ class ShardedIndex:
             for _ in range(8):
                 e.set_mode(mode)
                 e.query_scan(q, *self.scan_rows)
-                knn_all = self._gather_fixed(e.knn_local)
+                knn_all = self._gather_fixed(e.knn_local, persistent=True)
                 e.query_lambda(knn_all)
                 e.query_score(tau)
-                hits_all = self._gather_fixed(e.hits_local)
+                hits_all = self._gather_fixed(e.hits_local, persistent=True)
                 hits, lq, zero, inexact, overflow = e.query_finish(hits_all)
                 mode = next_mode(mode, inexact, overflow)
                 if mode is None:
@@ -972,10 +981,10 @@ class ShardedIndex:
             for i0 in range(0, Q.shape[0], cap):
                 chunk = Q[i0 : i0 + cap]
                 e.query_scan_batch(chunk, *self.scan_rows)
-                knn_all = self._gather_fixed(e.knn_local_b)
+                knn_all = self._gather_fixed(e.knn_local_b, persistent=True)
                 e.query_lambda_batch(knn_all, nranks)
                 e.query_score_batch(tau)
-                hits_all = self._gather_fixed(e.hits_local_b)
+                hits_all = self._gather_fixed(e.hits_local_b, persistent=True)
                 for b, (hits, lq, zero) in enumerate(e.query_finish_batch(hits_all, nranks, chunk.shape[0])):
                     if hits is None:
                         try:
@@ -1008,3 +1017,38 @@ class ShardedIndex:
         if self.engine is not None:
             self.engine.close()
             self.engine = None
+
+
+class HostStagedIndex(ShardedIndex):
+    """ShardedIndex whose every exchange step is staged through host memory (torch.distributed backend "gloo"): the
+    form for ranks that SHARE one GPU -- RCCL wants one device per rank -- i.e. the one-GPU rehearsal of an N-rank job
+    (bench.py --gpus N on a box with fewer devices, the multi-rank tests of tests/test_gpu_*.py).  Same host logic,
+    same kernels, same results; only the transport differs."""
+
+    def _gather_rows(self, t, counts):
+        self.torch.cuda.synchronize()
+        return super()._gather_rows(t.cpu(), counts).cuda()
+
+    def _gather_fixed(self, t, persistent=False):
+        self.torch.cuda.synchronize()
+        return super()._gather_fixed(t.cpu()).cuda()
+
+    def _swap_slices(self, P, dst, src, nrows):                  # the symmetric ring's slices
+        self.torch.cuda.synchronize()
+        return super()._swap_slices(P.cpu(), dst, src, nrows).cuda()
+
+    def _all_to_all(self, t, recv_counts, send_counts):           # the edge exchange of the sharded graph stage
+        self.torch.cuda.synchronize()
+        return super()._all_to_all(t.cpu(), recv_counts, send_counts).cuda()
+
+    def _exchange_start(self, send, recv, nxt_rank, prv_rank):   # the ring hop
+        torch = self.torch
+        torch.cuda.synchronize()
+        hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        return (super()._exchange_start(hs, hr, nxt_rank, prv_rank), hr, recv, hs)
+
+    def _exchange_wait(self, pending):
+        reqs, hr, recv, _ = pending
+        super()._exchange_wait(reqs)
+        recv.copy_(hr)
+        self.torch.cuda.synchronize()

@@ -72,38 +72,8 @@ def test_staged_path_repairs_a_crowded_neighbourhood(oracle_lib):
 
 def _cpu_staged():
     """ShardedIndex with every collective staged through the CPU (gloo): two ranks can then share ONE GPU."""
-    import torch
-
-    from pyarrowspace_amd.dist import ShardedIndex
-
-    class CpuStaged(ShardedIndex):
-        def _gather_rows(self, t, counts):
-            return super()._gather_rows(t.cpu(), counts).cuda()
-
-        def _gather_fixed(self, t):
-            torch.cuda.synchronize()
-            return super()._gather_fixed(t.cpu()).cuda()
-
-        def _swap_slices(self, P, dst, src, nrows):                  # the symmetric ring's slices, staged through the CPU
-            torch.cuda.synchronize()
-            return super()._swap_slices(P.cpu(), dst, src, nrows).cuda()
-
-        def _all_to_all(self, t, recv_counts, send_counts):           # the edge exchange of the sharded graph stage
-            torch.cuda.synchronize()
-            return super()._all_to_all(t.cpu(), recv_counts, send_counts).cuda()
-
-        def _exchange_start(self, send, recv, nxt_rank, prv_rank):   # the ring hop, staged through the CPU as well
-            torch.cuda.synchronize()
-            hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-            return (super()._exchange_start(hs, hr, nxt_rank, prv_rank), hr, recv, hs)
-
-        def _exchange_wait(self, pending):
-            reqs, hr, recv, _ = pending
-            super()._exchange_wait(reqs)
-            recv.copy_(hr)
-            torch.cuda.synchronize()
-
-    return CpuStaged
+    from pyarrowspace_amd.dist import HostStagedIndex
+    return HostStagedIndex
 
 
 def _worker(rank, world, port, n, d, split, out, replicate=False):
@@ -303,15 +273,7 @@ def _feature_worker(rank, world, port, n, d, split, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from conftest import calibrate_feature_eps
-        from pyarrowspace_amd.dist import ShardedIndex
-
-        class CpuStaged(ShardedIndex):
-            def _gather_rows(self, t, counts):
-                return super()._gather_rows(t.cpu(), counts).cuda()
-
-            def _gather_fixed(self, t):
-                torch.cuda.synchronize()
-                return super()._gather_fixed(t.cpu()).cuda()
+        from pyarrowspace_amd.dist import HostStagedIndex as CpuStaged
 
         X = clustered(n, d, nclust=8, seed=31)
         gp = {"eps": calibrate_feature_eps(X, 8), "k": 8, "topk": 6, "p": 2.0, "sigma": None, "metric": "cosine", "kernel": "rational",
@@ -330,8 +292,20 @@ def _feature_worker(rank, world, port, n, d, split, out):
         assert (loaded.n, loaded.replicated, loaded.r0, loaded.r1) == (index.n, False, index.r0, index.r1)
         for q, tau in _queries(X, n, d)[:4]:
             assert loaded.search(q, tau) == index.search(q, tau)
+        # load -> save -> load: a loaded shard holds its own rows' energies only (a built one every item's) and must
+        # write them from the right offset on every rank
+        loaded.save(prefix + "_again")
+        dist.barrier()
+        again = CpuStaged.load(prefix + "_again", gp, dist)
+        np.testing.assert_array_equal(again.lambdas(), index.lambdas())
+        for q, tau in _queries(X, n, d)[:4]:
+            assert again.search(q, tau) == index.search(q, tau)
+        a, b = ("%s.rank%dof%d" % (prefix, rank, world)), ("%s_again.rank%dof%d" % (prefix, rank, world))
+        assert open(a, "rb").read() == open(b, "rb").read()
+        again.close()
         loaded.close()
-        os.remove("%s.rank%dof%d" % (prefix, rank, world))
+        os.remove(a)
+        os.remove(b)
         out[rank] = (index.lambdas().copy(), res)
         index.close()
     finally:

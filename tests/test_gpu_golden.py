@@ -13,8 +13,10 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_readme_example_runs_verbatim():
-    """README.md:33-70, literally (module name `arrowspace`, positional call, tau=1.0)."""
+    """README.md:33-70, literally (module name `arrowspace`, positional call, tau=1.0; no environment variables)."""
+    import arrowspace
     from arrowspace import ArrowSpaceBuilder
+    assert arrowspace.ArrowSpaceBuilder._mode == {"metric": "cosine", "kernel": "rational", "lambda_mode": "item"}
     t = json.load(open(os.path.join(G, "readme_toy.json")))
     items = np.array(t["items"], dtype=np.float64)
     aspace, gl = ArrowSpaceBuilder.build(t["graph_params"], items)
@@ -26,18 +28,43 @@ def test_readme_example_runs_verbatim():
     assert aspace.lambdas().shape == (3,)
 
 
-def test_test0_toy():
-    """tests/test_0.py: tau=1.0 order [2,1,4] under the cosine variant; under the L2 default
-    eps=0.05 leaves no edges and the zero-lambda assert fires (src/lib.rs:156-159)."""
-    import arrowspace
+def test_test0_script_replayed_through_the_reference_named_module(monkeypatch):
+    """tests/test_0.py:4-32 replayed through `import arrowspace` with the reference's dict UNMODIFIED and no environment
+    variables: the module's default mode is the documented rectified-cosine / rational graph, under which eps = 0.05
+    means what the script means.  tau = 1.0: three hits, order [2, 1, 4] (tests/test_0.py:28-32).  The tau < 1 asserts
+    (:34-61) are lambda-sensitive and unreachable (profiles/r03_test0_families.md): the search
+    runs and returns three hits with item 2 -- lambda_q == lambda_2 -- first."""
+    for v in ("ARROWSPACE_METRIC", "ARROWSPACE_KERNEL", "ARROWSPACE_LAMBDA_MODE"):
+        monkeypatch.delenv(v, raising=False)
+    from arrowspace import ArrowSpaceBuilder, GraphLaplacian  # noqa: F401  (the script's import line)
+    t = json.load(open(os.path.join(G, "test0_toy.json")))
+    items = np.array(t["items"], dtype=np.float64)
+    graph_params = {"eps": 0.05, "k": len(items), "topk": 3, "p": 2.0, "sigma": 0.05}
+    assert graph_params == t["graph_params"]
+    aspace, gl = ArrowSpaceBuilder.build(graph_params, items)
+    query1 = np.array(items[2] * 1.05, dtype=np.float64)
+    hits = aspace.search(query1, gl, 1.0)
+    assert len(hits) == 3
+    assert hits[0][0] == 2
+    assert hits[1][0] == 1
+    assert hits[2][0] == 4
+    for tau in (0.9, 0.6, 0.55):
+        hits = aspace.search(query1, gl, tau)
+        assert len(hits) == 3 and hits[0][0] == 2
+
+
+def test_test0_toy_under_the_north_star_default():
+    """The same toy through `pyarrowspace_amd` (north_star default: L2 distance): eps = 0.05 leaves no edge and the
+    zero-lambda assert fires (src/lib.rs:156-159); with the mode keys in the dict it answers like `arrowspace`."""
+    import pyarrowspace_amd as asp
     t = json.load(open(os.path.join(G, "test0_toy.json")))
     items = np.array(t["items"], dtype=np.float64)
     q = np.array(items[2] * 1.05, dtype=np.float64)
-    aspace, gl = arrowspace.ArrowSpaceBuilder.build(dict(t["graph_params"], metric="cosine", kernel="rational"), items)
+    aspace, gl = asp.ArrowSpaceBuilder.build(dict(t["graph_params"], metric="cosine", kernel="rational"), items)
     hits = aspace.search(q, gl, 1.0)
     assert len(hits) == 3 and [i for i, _ in hits] == t["expected_order"]["1.0"]
-    aspace2, gl2 = arrowspace.ArrowSpaceBuilder.build(t["graph_params"], items)
-    with pytest.raises(arrowspace.PanicException, match="lambdas are zero"):
+    aspace2, gl2 = asp.ArrowSpaceBuilder.build(t["graph_params"], items)
+    with pytest.raises(asp.PanicException, match="lambdas are zero"):
         aspace2.search(q, gl2, 0.9)
 
 

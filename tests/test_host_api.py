@@ -35,7 +35,11 @@ def test_module_surface_matches_reference(asp):
     import arrowspace
     for name in ("ArrowSpaceBuilder", "ArrowSpace", "GraphLaplacian", "set_debug"):
         assert hasattr(arrowspace, name)
-    assert arrowspace.ArrowSpaceBuilder is asp.ArrowSpaceBuilder
+    # the reference-named module carries the documented graph as its default mode, the package the north_star's
+    assert issubclass(arrowspace.ArrowSpaceBuilder, asp.ArrowSpaceBuilder)
+    assert arrowspace.ArrowSpaceBuilder._mode == asp.REFERENCE_MODE == {"metric": "cosine", "kernel": "rational", "lambda_mode": "item"}
+    assert asp.ArrowSpaceBuilder._mode == asp.NORTH_STAR_MODE == {"metric": "l2", "kernel": "gaussian", "lambda_mode": "item"}
+    assert arrowspace.ArrowSpace is asp.ArrowSpace and arrowspace.GraphLaplacian is asp.GraphLaplacian
     arrowspace.set_debug(True)
     arrowspace.set_debug(False)
 

@@ -2,7 +2,8 @@
 # kernel-trace timeline of the single-query chain: bash tools/gpu_timeline.sh <tag> [bench args]
 set -o pipefail
 TAG=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"   # the repo this script lives in (never an unset variable: `cd ""` stays put)
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 OUT=gpurun_out/tl_$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --steps 200 --warmup 20 "$@" > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
