@@ -51,7 +51,12 @@ struct QInfo {
     int nhit;
     int knn_cnt;      // filter path: appended k-NN candidates
     int sc_cnt;       // filter path: appended scorer candidates
-    int overflow;     // bit0: the k-NN candidate buffer overflowed (-> threshold repair over the kept dots), bit1: the scorer's (-> list path)
+    int overflow;     // bit0: the k-NN candidate buffer overflowed (-> threshold repair over the kept dots), bit1: the scorer's (-> list path),
+                      // bit2: the scan's own scorer candidates overflowed (fused tail -> the threshold chain over the kept dots)
+    // Fused tail (scan-side scorer candidates): counts of rows by cosine bin, bin b = [-1 + b/32, -1 + (b+1)/32) -- the
+    // waves of the scan publish their chunks' best rows here and read it back: the lower edge of the highest bin with at
+    // least M rows at or above it is a lower bound of the M-th largest cosine of the scanned rows
+    unsigned int chist[64];
 };
 
 // everything a search writes into QInfo after the query itself was prepared (norms stay)
@@ -67,6 +72,10 @@ __device__ __forceinline__ void reset_query_state(QInfo* info) {
     info->overflow = 0;
     info->thr32 = 0.0f;
     info->thr64 = 0.0;
+}
+// the cosine histogram of the fused tail: by the 64 lanes of one wave
+__device__ __forceinline__ void reset_query_hist(QInfo* info, int lane) {
+    if (lane < 64) info->chist[lane] = 0u;
 }
 
 struct HostOut {
@@ -136,6 +145,9 @@ struct as_query {
     double stats[4] = {0, 0, 0, 0};
     int crowded = 0;         // > 0: recent queries overflowed the scan's candidate buffer (counts queries since)
     int crowded_direct = 0;  // this query skips the prefilter and takes the threshold repair straight away
+    int fused_tail = 0;      // this search: the scan collects the scorer's candidates, ONE kernel behind it finishes the query
+    int sc_crowded = 0;      // > 0: a recent query's scan-side scorer candidates overflowed (counts queries since): plain chain
+    int no_fused = 0;        // ARROWSPACE_NO_FUSED_TAIL: always the plain chain (A/B runs)
     int* unproven_dev = nullptr;   // build fallback: device counter (caller-owned) of rows that stay unproven
 };
 
@@ -159,6 +171,14 @@ struct PreArgs {
     int host_q = 0;
     float nq32 = 0.0f, inq32 = 0.0f;
     double nq = 0.0, inq = 0.0;
+    // Fused tail: the scan also collects the scorer's candidates, before lambda_q is known.  The lambda term of the
+    // score lies in [(1 - tau) / 2, (1 - tau)] for lambdas in [0, 1], so a row whose cosine is more than
+    // W = (1 - tau) / (2 tau) below the M-th largest cosine cannot be among the M best scores whatever lambda_q turns
+    // out to be.  sc_w = W + slack; rows at or above (bound - sc_w) go to the candidate buffer (sc_idx, QInfo::sc_cnt).
+    int sc_enabled = 0;
+    int sc_m = 0;
+    float sc_w = 0.0f;
+    int* sc_idx = nullptr;
 };
 
 constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats

@@ -461,19 +461,67 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // leave by one coalesced store and the k-NN prefilter runs lane-parallel.
 // All LDS reads and the store are inline asm (see scan_gemm_kernel): nothing the compiler can see may force
 // a vmcnt(0) inside the loop.
-template <int NCH, int NSLOT>
+//
+// SC (fused tail): the scan also collects the SCORER's candidates, before lambda_q exists.  With lambdas in [0, 1] the
+// lambda term of a score lies in [(1 - tau) / 2, 1 - tau], so a row whose cosine is more than W = (1 - tau) / (2 tau)
+// below the M-th largest cosine B cannot be among the M best scores.  B is learned on the way: at every chunk end a wave
+// adds its chunk's best rows (the bins within two of the chunk's maximum, one atomic per bin) to a 64-bin histogram of
+// cosines in QInfo, and reads the histogram back with the next chunk's norms (one more 256-byte DMA, agent scope): the
+// lower edge of the highest bin with >= M rows at or above it bounds B from below whatever subset of rows was
+// published.  Rows at or above (bound - W) wait in a per-wave LDS list, are re-tested against the bound the wave knows
+// at its end and only then go to the candidate buffer -- the first chunks, scanned before any bound exists, leave
+// nothing behind.  A dropped row has score < tau (B - W) + (1 - tau) <= the score of each of the >= M kept rows with
+// cosine >= B: the M best scores are all in the buffer, and the finish kernel's a-posteriori proof applies unchanged.
+constexpr int SC_PEND = 128;   // per-wave list of pending candidates (cosine, row)
+constexpr int SC_BINS = 64;
+__device__ __forceinline__ void lds_write2(unsigned addr, float a, int b) {   // 8-byte aligned
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)(unsigned)b << 32);
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read2(unsigned addr, float& a, int& b) {
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    a = __uint_as_float((unsigned)v);
+    b = (int)(v >> 32);
+}
+__device__ __forceinline__ unsigned lds_read1u(unsigned a) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
+// lower edge of the highest cosine bin with at least m rows at or above it (-2: no such bin yet), and that bin;
+// lane b holds the count of bin b
+__device__ __forceinline__ float sc_bound(unsigned h, int m, int lane, int& jb) {
+    // suffix sums over the lanes: S_b = sum of the bins >= b (6 shuffle steps, once per 64 rows)
+    unsigned sfx = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(sfx, o, 64);
+        if (lane + o < 64) sfx += t;
+    }
+    const unsigned long long ok = __ballot(sfx >= (unsigned)m);
+    jb = ok ? 63 - __builtin_clzll(ok) : -1;
+    return jb >= 0 ? (float)jb * (1.0f / 32.0f) - 1.0f : -2.0f;
+}
+__device__ __forceinline__ int sc_bin(float c) {
+    const int b = (int)floorf((c + 1.0f) * 32.0f);
+    return b < 0 ? 0 : (b > SC_BINS - 1 ? SC_BINS - 1 : b);
+}
+template <int NCH, int NSLOT, bool SC = false>
 __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp,
                                                        int64_t r0, int64_t r1, float* __restrict__ dots, PreArgs pre, int rounds,
                                                        int tail_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RING = NSLOT * NCH * 1024;   // bytes per wave
-    constexpr int WAVE_LDS = RING + 256;       // + the chunk's 64 norms
+    constexpr int WAVE_LDS = RING + 256 + (SC ? 256 + SC_PEND * 8 : 0);   // + the chunk's 64 norms (+ histogram, pending list)
     constexpr int K1 = NCH * (NSLOT - 2);      // DMA operations younger than the oldest row of a full ring
+    constexpr int KB = SC ? 3 : 2;             // operations of a chunk boundary: store + norm DMA (+ histogram DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* myp = smem + wu * WAVE_LDS;
     const unsigned my0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wu * WAVE_LDS;
     const unsigned ax0 = my0 + RING;
+    const unsigned hx0 = ax0 + 256, px0 = hx0 + 256;   // SC: histogram landing area, pending list
     // lanes past the end of a row never receive DMA data: they must read zeros, not stale bits
     for (int i = lane; i < RING / 16; i += 64) *(f32x4*)(myp + i * 16) = f32x4{0, 0, 0, 0};
     f32x4 qv[NCH];
@@ -541,6 +589,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
     int marked = 0;      // rows in flight that have a chunk boundary's store + norm DMA behind them in the queue
     int full = 0;
     bool first = true;
+    int npend = 0;       // SC: entries of the wave's pending list
     for (int t = 0; t <= rounds; ++t) {
         int64_t base;
         int cnt;
@@ -548,6 +597,9 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         if (cnt <= 0) continue;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),   // padded: readable
                                          (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
+        if (SC)   // the histogram as the other waves have left it (sc1: past this XCD's L2), consumed at the chunk's end
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.info->chist + lane),
+                                             (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 16);
         marked = first ? 0 : inflight;   // the first chunk has only the norm DMA behind its rows: assume nothing
         first = false;
         float mydot = 0.0f;
@@ -555,7 +607,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             // operations retire in issue order: the oldest row has landed once at most (rows behind it) * NCH
             // (+ 2 for a chunk boundary behind it) operations are outstanding
             if (inflight == NSLOT - 1) {
-                if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + 2) : "memory");
+                if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -593,8 +645,91 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             store_dword_issued(dots + row, mydot);
             prefilter_f32(pre, row, mydot, aux, nq32, inq32, full);
         }
+        if (SC) {
+            int jb;
+            const float bedge = sc_bound(lds_read1u(hx0 + lane * 4), pre.sc_m, lane, jb);
+            const float thr = bedge - pre.sc_w;
+            const bool valid = lane < cnt && row < pre.n;
+            const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
+            const float c = mydot * inr * inq32;
+            // publish the chunk's best rows: the bins within two of the chunk's maximum that lie above the bound's
+            float cm = valid && c == c ? c : -2.0f;   // (a NaN cosine neither publishes nor bounds)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+            const int mybin = valid && c == c ? sc_bin(c) : -1;
+            const int bmax = cm > -2.0f ? sc_bin(cm) : -1;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int b = bmax - u;
+                const int nb_ = __popcll(__ballot(mybin == b && b >= 0));
+                if (lane == u && b > jb && nb_ > 0) atomicAdd(&pre.infow->chist[b], (unsigned)nb_);
+            }
+            // candidates: !(c < thr), so that a NaN cosine is kept for the finish kernel to deal with, as the plain chain does
+            const bool pass = valid && !(c < thr);
+            const unsigned long long pm = __ballot(pass);
+            const int np = __popcll(pm);
+            if (npend + np > SC_PEND) {
+                // re-test the list against the bound known now (rows kept before a bound existed); flush what is left
+                int keep = 0;
+                for (int e0 = 0; e0 < npend; e0 += 64) {
+                    float ce = 0.0f;
+                    int re = 0;
+                    if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
+                    const bool kp = e0 + lane < npend && !(ce < thr);
+                    const unsigned long long km = __ballot(kp);
+                    // in place: the entries written are at or before the entries read by this or an earlier trip
+                    if (kp) lds_write2(px0 + (unsigned)(keep + __popcll(km & ((1ull << lane) - 1))) * 8, ce, re);
+                    AS_LDS_FENCE();
+                    keep += __popcll(km);
+                }
+                npend = keep;
+                if (npend + np > SC_PEND) {
+                    int gbase = 0;
+                    if (lane == 0) gbase = atomicAdd(&pre.infow->sc_cnt, npend);
+                    gbase = __shfl(gbase, 0, 64);
+                    for (int e0 = 0; e0 < npend; e0 += 64) {
+                        float ce = 0.0f;
+                        int re = 0;
+                        if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
+                        if (e0 + lane < npend && gbase + e0 + lane < CAND_CAP) pre.sc_idx[gbase + e0 + lane] = re;
+                    }
+                    npend = 0;
+                }
+            }
+            if (pass) lds_write2(px0 + (unsigned)(npend + __popcll(pm & ((1ull << lane) - 1))) * 8, c, (int)row);
+            AS_LDS_FENCE();
+            npend += np;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (SC && npend > 0) {
+        // the wave's last word: the histogram as it stands now, the list re-tested against it, the survivors to the buffer
+        int jb;
+        const unsigned h = __hip_atomic_load(&pre.info->chist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+        int keep = 0;
+        for (int e0 = 0; e0 < npend; e0 += 64) {
+            float ce = 0.0f;
+            int re = 0;
+            if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
+            const bool kp = e0 + lane < npend && !(ce < thr);
+            const unsigned long long km = __ballot(kp);
+            if (kp) lds_write2(px0 + (unsigned)(keep + __popcll(km & ((1ull << lane) - 1))) * 8, ce, re);
+            AS_LDS_FENCE();
+            keep += __popcll(km);
+        }
+        if (keep > 0) {
+            int gbase = 0;
+            if (lane == 0) gbase = atomicAdd(&pre.infow->sc_cnt, keep);
+            gbase = __shfl(gbase, 0, 64);
+            for (int e0 = 0; e0 < keep; e0 += 64) {
+                float ce = 0.0f;
+                int re = 0;
+                if (e0 + lane < keep) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
+                if (e0 + lane < keep && gbase + e0 + lane < CAND_CAP) pre.sc_idx[gbase + e0 + lane] = re;
+            }
+        }
+    }
 #undef AS_ISSUE_ROW
 #undef AS_CHUNK
 }
@@ -702,7 +837,7 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
 }
 
 static constexpr size_t gemm_lds(int nbuf) { return sizeof(float) * ((size_t)4 * nbuf * 1024 + 4 * 3 * 64 * 4 + 4 * 64); }
-static constexpr size_t dma_lds(int nch, int nslot) { return 4 * ((size_t)nslot * nch * 1024 + 256); }
+static constexpr size_t dma_lds(int nch, int nslot, bool sc = false) { return 4 * ((size_t)nslot * nch * 1024 + 256 + (sc ? 256 + SC_PEND * 8 : 0)); }
 
 // The dynamic-LDS opt-in is a per-device attribute of a kernel: set it for every scan kernel on the device a
 // workspace is created on (query_alloc), not once per process -- a second device would never be opted in.
@@ -718,6 +853,10 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_dma_kernel<2, 4>), dma_lds(2, 4));
     AS_ATTR((scan_dma_kernel<3, 5>), dma_lds(3, 5));
     AS_ATTR((scan_dma_kernel<4, 4>), dma_lds(4, 4));
+    AS_ATTR((scan_dma_kernel<1, 8, true>), dma_lds(1, 8, true));
+    AS_ATTR((scan_dma_kernel<2, 4, true>), dma_lds(2, 4, true));
+    AS_ATTR((scan_dma_kernel<3, 5, true>), dma_lds(3, 5, true));
+    AS_ATTR((scan_dma_kernel<4, 4, true>), dma_lds(4, 4, true));
 #undef AS_ATTR
     return AS_OK;
 }
@@ -816,9 +955,12 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int tail_rows = (int)((rem + NW - 1) / NW);
 #define AS_DSCAN(N, S)                                                                                                 \
     do {                                                                                                               \
-        const size_t lds = dma_lds(N, S);                                                                              \
-        hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), lds, st, sp->x32, q->q32_src, sp->dp, q->r0, \
-                           q->r1, q->dots32, pre, rounds, tail_rows);                                                  \
+        if (pre.sc_enabled && (N != 2 || S == 4))                                                                      \
+            hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), true), st, \
+                               sp->x32, q->q32_src, sp->dp, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), dma_lds(N, S), st, sp->x32, q->q32_src, sp->dp, \
+                               q->r0, q->r1, q->dots32, pre, rounds, tail_rows);                                       \
     } while (0)
             switch (nch) {
                 case 1: AS_DSCAN(1, 8); break;
