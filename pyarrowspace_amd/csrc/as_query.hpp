@@ -17,6 +17,7 @@ constexpr int MAX_TOPK = 1024;  // largest topk
 constexpr int MS_MAX = MAX_TOPK + 64;  // widest scorer candidate list (topk + margin, rounded to 64)
 constexpr int HIT_CAP = 8 * (MAX_TOPK + 1) + 8;  // hit records hits_final accepts (ranks x (topk + 1))
 constexpr int QB = 8;           // queries per VALU batched scan launch (query fragments live in registers)
+constexpr int SC_WCAP = 64;      // fused tail: words of a scan wave's report (the count + up to 63 candidate rows)
 constexpr int GQ = 32;          // queries per MFMA (GEMM-shaped) batched scan pass == slots of the batched workspace
 
 // Batched searches run GQ independent query "slots" side by side: every per-query buffer is
@@ -53,11 +54,16 @@ struct QInfo {
     int sc_cnt;       // filter path: appended scorer candidates
     int overflow;     // bit0: the k-NN candidate buffer overflowed (-> threshold repair over the kept dots), bit1: the scorer's (-> list path),
                       // bit2: the scan's own scorer candidates overflowed (fused tail -> the threshold chain over the kept dots)
-    // Fused tail (scan-side scorer candidates): counts of rows by cosine bin, bin b = [-1 + b/32, -1 + (b+1)/32) -- the
-    // waves of the scan publish their chunks' best rows here and read it back: the lower edge of the highest bin with at
-    // least M rows at or above it is a lower bound of the M-th largest cosine of the scanned rows
-    unsigned int chist[64];
 };
+
+// Fused tail (scan-side scorer candidates): counts of rows by cosine bin, bin b = [-1 + b/32, -1 + (b+1)/32) -- the waves
+// of the scan publish their chunks' best rows here and read it back: the lower edge of the highest bin with at least M
+// rows at or above it is a lower bound of the M-th largest cosine of the scanned rows.  SC_COPIES identical copies,
+// SC_HSTRIDE words apart (different memory channels): a publisher adds to all of them (one posted atomic per lane), a
+// reader takes copy (wave % SC_COPIES) -- the reads go past the L2 (agent scope), and thousands of waves reading ONE
+// 256-byte line at the end of a short scan queued up for 40 us.
+constexpr int SC_COPIES = 16;
+constexpr int SC_HSTRIDE = 1088;
 
 // everything a search writes into QInfo after the query itself was prepared (norms stay)
 __device__ __forceinline__ void reset_query_state(QInfo* info) {
@@ -73,9 +79,10 @@ __device__ __forceinline__ void reset_query_state(QInfo* info) {
     info->thr32 = 0.0f;
     info->thr64 = 0.0;
 }
-// the cosine histogram of the fused tail: by the 64 lanes of one wave
-__device__ __forceinline__ void reset_query_hist(QInfo* info, int lane) {
-    if (lane < 64) info->chist[lane] = 0u;
+// the cosine histograms of the fused tail, by the threads of one block
+__device__ __forceinline__ void reset_query_hist(unsigned int* hist, int tid, int nthreads) {
+    if (hist)
+        for (int i = tid; i < SC_COPIES * 64; i += nthreads) hist[(i >> 6) * SC_HSTRIDE + (i & 63)] = 0u;
 }
 
 struct HostOut {
@@ -134,6 +141,9 @@ struct as_query {
     int* cidx_k = nullptr;
     void* ckey_s = nullptr;
     int* cidx_s = nullptr;
+    int* sc_widx = nullptr;  // fused tail: the scan's scorer candidates, a report of SC_WCAP words per wave of the scan
+    unsigned int* sc_hist = nullptr;   // SC_COPIES x SC_HSTRIDE words, zero between searches
+    int sc_nw = 0;           // waves of the last fused scan
     void* gmin = nullptr;    // group minima of the scorer key
     as::RSel* rsel = nullptr; // state of the exact global selection
     as_knn_rec* knn = nullptr;
@@ -148,6 +158,7 @@ struct as_query {
     int fused_tail = 0;      // this search: the scan collects the scorer's candidates, ONE kernel behind it finishes the query
     int sc_crowded = 0;      // > 0: a recent query's scan-side scorer candidates overflowed (counts queries since): plain chain
     int no_fused = 0;        // ARROWSPACE_NO_FUSED_TAIL: always the plain chain (A/B runs)
+    double tau_cur = 1.0;    // the tau of the search being launched (the scan's cosine window depends on it)
     int* unproven_dev = nullptr;   // build fallback: device counter (caller-owned) of rows that stay unproven
 };
 
@@ -178,7 +189,9 @@ struct PreArgs {
     int sc_enabled = 0;
     int sc_m = 0;
     float sc_w = 0.0f;
-    int* sc_idx = nullptr;
+    int* sc_idx = nullptr;   // [waves of the scan][SC_WCAP]: a wave's report -- [0] its number of candidates (-1: more than fit), [1 ..] their rows
+    unsigned int* sc_hist = nullptr;   // SC_COPIES cosine histograms
+    int sc_dbg = 0;          // measurement only (ARROWSPACE_SC_DBG): 1 no publication, 2 no histogram read, 4 no candidates
 };
 
 constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats

@@ -515,7 +515,6 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
     constexpr int RING = NSLOT * NCH * 1024;   // bytes per wave
     constexpr int WAVE_LDS = RING + 256 + (SC ? 256 + SC_PEND * 8 : 0);   // + the chunk's 64 norms (+ histogram, pending list)
     constexpr int K1 = NCH * (NSLOT - 2);      // DMA operations younger than the oldest row of a full ring
-    constexpr int KB = SC ? 3 : 2;             // operations of a chunk boundary: store + norm DMA (+ histogram DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* myp = smem + wu * WAVE_LDS;
@@ -590,6 +589,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
     int full = 0;
     bool first = true;
     int npend = 0;       // SC: entries of the wave's pending list
+    int sc_over = 0;     // SC: the list overflowed (the wave reports -1 candidates: the host takes the threshold chain)
     for (int t = 0; t <= rounds; ++t) {
         int64_t base;
         int cnt;
@@ -597,17 +597,23 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         if (cnt <= 0) continue;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),   // padded: readable
                                          (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
-        if (SC)   // the histogram as the other waves have left it (sc1: past this XCD's L2), consumed at the chunk's end
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.info->chist + lane),
+        // SC: the histogram as the other waves have left it (sc1: past this XCD's L2), consumed at the chunk's end -- from
+        // the wave's third chunk on: a read issued at the start of the second chunk arrives right behind the burst of
+        // publications that ends every wave's first chunk, and queues behind it (in order in front of the row DMAs)
+        const bool hread = SC && t >= 2 && !(pre.sc_dbg & 2);
+        if (hread)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
                                              (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 16);
         marked = first ? 0 : inflight;   // the first chunk has only the norm DMA behind its rows: assume nothing
+        const bool hmark = hread;        // (the chunk boundary behind the marked rows holds the histogram DMA as well)
         first = false;
         float mydot = 0.0f;
         for (int r = 0; r < cnt; ++r) {
             // operations retire in issue order: the oldest row has landed once at most (rows behind it) * NCH
             // (+ 2 for a chunk boundary behind it) operations are outstanding
             if (inflight == NSLOT - 1) {
-                if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB) : "memory");
+                if (marked > 0 && hmark) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + 3) : "memory");
+                else if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + 2) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -647,25 +653,43 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         }
         if (SC) {
             int jb;
-            const float bedge = sc_bound(lds_read1u(hx0 + lane * 4), pre.sc_m, lane, jb);
+            const float bedge = sc_bound(hread ? lds_read1u(hx0 + lane * 4) : 0u, pre.sc_m, lane, jb);
             const float thr = bedge - pre.sc_w;
             const bool valid = lane < cnt && row < pre.n;
             const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
             const float c = mydot * inr * inq32;
-            // publish the chunk's best rows: the bins within two of the chunk's maximum that lie above the bound's
-            float cm = valid && c == c ? c : -2.0f;   // (a NaN cosine neither publishes nor bounds)
+            // Publish the chunk's best rows: the bins within two of the chunk's maximum that lie above the bound's -- but
+            // only rows that stand out of their own chunk (more than 4 standard deviations above its mean), or every
+            // 16th chunk unconditionally.  Any subset of the rows bounds B from below; the rule keeps the atomics few:
+            // a posted atomic is cheap for its wave, but every wave's next histogram read (past the L2, in order in front
+            // of its row DMAs) queues behind the atomics in flight on that line -- 2 048 chunks publishing at once made
+            // the whole launch 35 % slower.  A query's near neighbours are outliers of their chunks; smooth cosine
+            // distributions are covered by the unconditional chunks.
+            const bool fin = valid && c == c;           // (a NaN cosine neither publishes nor bounds)
+            float cm = fin ? c : -2.0f;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
-            const int mybin = valid && c == c ? sc_bin(c) : -1;
+            const float nv = (float)__popcll(__ballot(fin));
+            const float mean = wave_sum_dpp(fin ? c : 0.0f) / fmaxf(nv, 1.0f);
+            const float var = fmaxf(wave_sum_dpp(fin ? (c - mean) * (c - mean) : 0.0f) / fmaxf(nv, 1.0f), 0.0f);
+            const bool every = (((int)gw + t) & 31) == 0;
+            const int bfloor = every ? -1 : sc_bin(mean + 4.0f * sqrtf(var));
+            const int mybin = fin ? sc_bin(c) : -1;
             const int bmax = cm > -2.0f ? sc_bin(cm) : -1;
+            int nb3[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < 3; ++u) nb3[u] = __popcll(__ballot(mybin == bmax - u && bmax - u >= 0));
+            {   // lane = copy * 3 + u: bin bmax - u of histogram copy `copy`
+                const int u = lane % 3, copy = lane / 3;
                 const int b = bmax - u;
-                const int nb_ = __popcll(__ballot(mybin == b && b >= 0));
-                if (lane == u && b > jb && nb_ > 0) atomicAdd(&pre.infow->chist[b], (unsigned)nb_);
+                const int nb_ = u == 0 ? nb3[0] : (u == 1 ? nb3[1] : nb3[2]);
+                // (a wave of one or two chunks does not publish its last one: nobody is left to read it but the waves'
+                // final reads, which would queue behind it)
+                if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0 && (t < rounds || rounds >= 2) && !(pre.sc_dbg & 1))
+                    atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
             }
-            // candidates: !(c < thr), so that a NaN cosine is kept for the finish kernel to deal with, as the plain chain does
-            const bool pass = valid && !(c < thr);
+            // candidates: c >= thr -- a NaN cosine (a poisoned row) never qualifies, as under the plain chain's `key <= thr`
+            const bool pass = valid && c >= thr && !(pre.sc_dbg & 4);
             const unsigned long long pm = __ballot(pass);
             const int np = __popcll(pm);
             if (npend + np > SC_PEND) {
@@ -675,7 +699,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
                     float ce = 0.0f;
                     int re = 0;
                     if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
-                    const bool kp = e0 + lane < npend && !(ce < thr);
+                    const bool kp = e0 + lane < npend && ce >= thr;
                     const unsigned long long km = __ballot(kp);
                     // in place: the entries written are at or before the entries read by this or an earlier trip
                     if (kp) lds_write2(px0 + (unsigned)(keep + __popcll(km & ((1ull << lane) - 1))) * 8, ce, re);
@@ -683,16 +707,8 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
                     keep += __popcll(km);
                 }
                 npend = keep;
-                if (npend + np > SC_PEND) {
-                    int gbase = 0;
-                    if (lane == 0) gbase = atomicAdd(&pre.infow->sc_cnt, npend);
-                    gbase = __shfl(gbase, 0, 64);
-                    for (int e0 = 0; e0 < npend; e0 += 64) {
-                        float ce = 0.0f;
-                        int re = 0;
-                        if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
-                        if (e0 + lane < npend && gbase + e0 + lane < CAND_CAP) pre.sc_idx[gbase + e0 + lane] = re;
-                    }
+                if (npend + np > SC_PEND) {   // more than the list holds even under the current bound: this query is not for the fused tail
+                    sc_over = 1;
                     npend = 0;
                 }
             }
@@ -702,33 +718,29 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (SC && npend > 0) {
-        // the wave's last word: the histogram as it stands now, the list re-tested against it, the survivors to the buffer
-        int jb;
-        const unsigned h = __hip_atomic_load(&pre.info->chist[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+    if (SC) {
+        // The wave's last word: the histogram as it stands now, the list re-tested against it, the survivors into the
+        // wave's OWN region of the candidate buffer (SC_WCAP words: the count, then the rows -- one 16-byte load tells the
+        // finish kernel the count and the first three) -- plain stores: a returning atomic per wave on one counter, all
+        // waves ending together, cost the launch 20 us.
         int keep = 0;
-        for (int e0 = 0; e0 < npend; e0 += 64) {
-            float ce = 0.0f;
-            int re = 0;
-            if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
-            const bool kp = e0 + lane < npend && !(ce < thr);
-            const unsigned long long km = __ballot(kp);
-            if (kp) lds_write2(px0 + (unsigned)(keep + __popcll(km & ((1ull << lane) - 1))) * 8, ce, re);
-            AS_LDS_FENCE();
-            keep += __popcll(km);
-        }
-        if (keep > 0) {
-            int gbase = 0;
-            if (lane == 0) gbase = atomicAdd(&pre.infow->sc_cnt, keep);
-            gbase = __shfl(gbase, 0, 64);
-            for (int e0 = 0; e0 < keep; e0 += 64) {
+        int* region = pre.sc_idx + gw * SC_WCAP;   // [0] = number of candidates (-1: more than the region holds), [1 ..] = their rows
+        if (npend > 0 && !sc_over) {
+            int jb;
+            const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+            for (int e0 = 0; e0 < npend; e0 += 64) {
                 float ce = 0.0f;
                 int re = 0;
-                if (e0 + lane < keep) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
-                if (e0 + lane < keep && gbase + e0 + lane < CAND_CAP) pre.sc_idx[gbase + e0 + lane] = re;
+                if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
+                const bool kp = e0 + lane < npend && ce >= thr;
+                const unsigned long long km = __ballot(kp);
+                const int pos = keep + __popcll(km & ((1ull << lane) - 1));
+                if (kp && pos < SC_WCAP - 1) region[1 + pos] = re;
+                keep += __popcll(km);
             }
         }
+        if (lane == 0) region[0] = sc_over || keep > SC_WCAP - 1 ? -1 : keep;
     }
 #undef AS_ISSUE_ROW
 #undef AS_CHUNK
@@ -832,6 +844,17 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     if (q->host_q) {
         p.nq = q->h_nq; p.inq = q->h_inq;
         p.nq32 = (float)q->h_nq; p.inq32 = q->h_nq > 0.0 ? (float)(1.0 / sqrt(q->h_nq)) : 0.0f;
+    }
+    if (q->fused_tail && enabled) {
+        // window of the cosine bound + slack for the fp32 cosine of the scan against the fp64-over-fp32-dot cosine of the
+        // finish kernel's keys (a few ulp of fp32 each way)
+        p.sc_enabled = 1;
+        p.sc_m = q->Ms;
+        p.sc_w = (float)((1.0 - q->tau_cur) / (2.0 * q->tau_cur) + 1.0e-5);
+        p.sc_idx = q->sc_widx;
+        p.sc_hist = q->sc_hist;
+        static const int dbg = getenv("ARROWSPACE_SC_DBG") ? atoi(getenv("ARROWSPACE_SC_DBG")) : 0;
+        p.sc_dbg = dbg;
     }
     return p;
 }
@@ -950,6 +973,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int bpc = nch <= 2 ? (geom ? geom / 10 : 4) : 2;
             const int64_t nblk = std::min<int64_t>(want, bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
+            q->sc_nw = (int)NW;
             const int rounds = (int)(rows / (NW * 64));
             const int64_t rem = rows - (int64_t)rounds * NW * 64;
             const int tail_rows = (int)((rem + NW - 1) / NW);

@@ -24,8 +24,10 @@ __device__ unsigned long long g_stamps[32];
     do {                                                                      \
         if (threadIdx.x == 0 && blockIdx.z == 0) g_stamps[i] = wall_clock64(); \
     } while (0)
+#define AS_STAMP_VAL(i, v) do { g_stamps[i] = (unsigned long long)(v); } while (0)
 #else
 #define AS_STAMP(i) do {} while (0)
+#define AS_STAMP_VAL(i, v) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------ small helpers
@@ -100,8 +102,9 @@ static double host_query_norm(const double* q, int64_t d) {
 }
 
 // the per-search state of QInfo, cleared behind a finished search so that the next one starts without a launch for it
-__global__ void reset_info_kernel(QInfo* info) {
+__global__ void reset_info_kernel(QInfo* info, unsigned int* sc_hist) {
     if (threadIdx.x == 0 && blockIdx.x == 0) reset_query_state(info);
+    if (blockIdx.x == 0) reset_query_hist(sc_hist, threadIdx.x, blockDim.x);
 }
 
 __global__ void q_from_row_kernel(const float* __restrict__ x32, const double* __restrict__ x64, int64_t d, int64_t dp,
@@ -757,6 +760,7 @@ constexpr int Q_LDS_MAX = 2048;  // widest query (padded floats) the finish kern
 // rank-select the M smallest (key, idx) of the C buffered candidates into (fk, fi), sorted.
 // Large C (dense neighbourhoods) is first pruned to the candidates at or below the M-th
 // smallest key by a radix select, so the quadratic ranking only ever sees ~M entries.
+// ckey == nullptr: the caller has filled (sk, si) itself.
 template <typename T>
 __device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx, int C, int M, T* sk, int* si, T* pk, int* pi,
                                                   T* fk, int* fi, int* fcount) {
@@ -764,10 +768,11 @@ __device__ __forceinline__ void select_candidates(const T* ckey, const int* cidx
     __shared__ unsigned int hist[256];
     __shared__ U s_prefix;
     __shared__ int s_rank, s_cnt;
-    for (int t = threadIdx.x; t < C; t += blockDim.x) {
-        sk[t] = ckey[t];
-        si[t] = cidx[t];
-    }
+    if (ckey)
+        for (int t = threadIdx.x; t < C; t += blockDim.x) {
+            sk[t] = ckey[t];
+            si[t] = cidx[t];
+        }
     if (threadIdx.x == 0) {
         *fcount = C < M ? C : M;
         s_cnt = 0;
@@ -1007,6 +1012,7 @@ struct FinishArgs {
     int32_t* o_cnt;
     int* unproven;      // build fallback: counts the rows whose list failed the a-posteriori check even in fp64
     int auto_reset;     // score_finish (fused publish, single query): clear QInfo's per-search state behind a clean search
+    int sc_nw;          // fused tail: waves of the scan, each with a report of SC_WCAP words in ci (count, then rows)
 };
 
 // SPEC S10 given the selected neighbours in LDS in (key, index) rank order; one wave, lane t
@@ -1045,9 +1051,10 @@ __device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist
 
 // k-NN of the query: candidates -> M smallest fp32 keys -> fp64 re-evaluation -> (key64, idx)
 // order, eps, k cap, a-posteriori exactness check; optionally lambda_q in the same launch.
+// qx_pre: the query already staged in LDS by the caller (the fused tail), else staged here behind the work area.
+// Every thread returns from the body (the fused kernel goes on behind it): wave 0 does the ranking and lambda_q alone.
 template <typename T>
-__global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void knn_finish_body(FinishArgs a, char* smem, const double* qx_pre) {
     AS_STAMP(0);
     const int z = blockIdx.z;
     const T* ckey = (const T*)a.ck + (int64_t)z * CAND_CAP;
@@ -1061,8 +1068,8 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     int* pi = (int*)(pk + PRUNE_CAP);
     // the query, read dozens of times by the exact evaluation: once from HBM into LDS (visible behind the barriers
     // of the candidate selection)
-    const double* qx = a.q64;
-    if (a.dp <= Q_LDS_MAX) {
+    const double* qx = qx_pre ? qx_pre : a.q64;
+    if (!qx_pre && a.dp <= Q_LDS_MAX) {
         double* qs = (double*)(pi + PRUNE_CAP) + CAND_CAP;
         for (int64_t c = threadIdx.x; c < a.dp; c += blockDim.x) qs[c] = a.q64[c];
         qx = qs;
@@ -1151,7 +1158,7 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
         }
     }
     __syncthreads();
-    if (w != 0) return;
+    if (w != 0) return;   // (of the body: the other waves have nothing to do with the ranking)
     AS_STAMP(3);
     // rank by (key64, idx): one candidate per lane
     const bool have = lane < Mp;
@@ -1224,6 +1231,12 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
     AS_STAMP(6);
 }
 
+template <typename T>
+__global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    knn_finish_body<T>(a, smem, nullptr);
+}
+
 // SPEC S10 from m candidate records (this shard's, or all shards' all-gathered).  blockIdx.x = query slot: the
 // all-gathered buffer is [rank][slot][per] records, a slot's m records are `per` from every rank, `rstride` apart.
 __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs_all, int64_t m, int64_t per, int64_t rstride,
@@ -1275,9 +1288,12 @@ __device__ __forceinline__ void publish(HostOut* out, int64_t seq) {
     out->seq = seq;
 }
 
+// scan_dots (fused tail, T = double): the candidate buffer holds the ROWS the scan kept by its cosine bound (QInfo::sc_cnt of
+// them in a.ci); their keys -- the mixed form of score_key<double>: fp32 dot, everything else fp64 -- are formed here, now
+// that lambda_q exists.  The M smallest of them are the M smallest keys of all scanned rows (scan_dma_kernel, SC), so
+// what follows is what follows the threshold filter.  qx_pre: the query already staged in LDS by the caller.
 template <typename T>
-__global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double coef_s) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void score_finish_body(FinishArgs a, double coef_s, char* smem, const double* qx_pre, const float* scan_dots, int sc_total) {
     AS_STAMP(16);
     const int z = blockIdx.z;
     const T* ckey = (const T*)a.ck + (int64_t)z * CAND_CAP;
@@ -1294,15 +1310,37 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
     double* sk2 = es + MS_MAX;                 // MS_MAX: scratch, then scores in rank order
     T* fk = (T*)(sk2 + MS_MAX);               // MS_MAX best fp32 keys, sorted
     int* fi = (int*)(fk + MS_MAX);
-    const double* qx = a.q64;
-    if (a.dp <= Q_LDS_MAX) {
+    const double* qx = qx_pre ? qx_pre : a.q64;
+    if (!qx_pre && a.dp <= Q_LDS_MAX) {
         double* qs = (double*)(fi + MS_MAX);
         for (int64_t c = threadIdx.x; c < a.dp; c += blockDim.x) qs[c] = a.q64[c];
         qx = qs;
     }
     __shared__ int fcount;
     int total;
-    if (a.from_list) {
+    if (scan_dots) {
+        // the caller (fused_finish_kernel) has gathered the waves' reports: si[t] = row, sk[t] = its cosine over the fp32 dot
+        // (NaN: not formed yet), sc_total of them (-1: they did not fit)
+        const int raw = sc_total < 0 ? CAND_CAP + 1 : sc_total;
+        if (raw > CAND_CAP && threadIdx.x == 0) a.info->overflow |= 4;   // the host reruns the scorer on the threshold chain
+        total = raw <= CAND_CAP ? raw : 0;
+        const double nq_ = a.info->nq, lq_ = a.info->lambda_q;
+        const double rq_ = nq_ > 0.0 ? rsqrt(nq_) : 0.0;
+        for (int t = threadIdx.x; t < total; t += blockDim.x) {
+            const int j = si[t];
+            double cs = sk[t];
+            if (cs != cs) {
+                const double nrow = a.n64[j];
+                cs = nrow > 0.0 ? (double)scan_dots[j] * rsqrt(nrow) * rq_ : 0.0;
+            }
+            const double key = -(a.tau * cs + (1.0 - a.tau) / (1.0 + fabs(lq_ - a.lam64[j])));
+            sk[t] = key == key ? key : key_traits<T>::inf();   // (a NaN key would rank as 0-th: it compares less than nothing)
+        }
+        __syncthreads();
+        AS_STAMP(25);
+        if (threadIdx.x == 0) AS_STAMP_VAL(26, total);
+        select_candidates<T>(nullptr, nullptr, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
+    } else if (a.from_list) {
         merge_partials<T>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
         total = (int)(a.nrows < 0x7fffffff ? a.nrows : 0x7fffffff);
     } else {
@@ -1397,6 +1435,95 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
         }
     }
     AS_STAMP(20);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double coef_s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    score_finish_body<T>(a, coef_s, smem, nullptr, nullptr, 0);
+}
+
+// Fused tail of a single query: ONE launch behind the scan.  Phase 1 = knn_finish (the k nearest of the scan's k-NN
+// candidates, exact, lambda_q); phase 2 = score_finish over the scan's own scorer candidates (scan_dma_kernel, SC).
+// The query is staged in LDS once; the two phases share the rest of the dynamic LDS.  Clears the scan's cosine
+// histogram behind itself (the next scan counts into it from its first wave on).
+__global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs ak, FinishArgs as_, double coef_s, const float* scan_dots, unsigned int* sc_hist) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    AS_STAMP(22);
+    double* qs = (double*)smem;
+    const double* qx = nullptr;
+    if (ak.dp <= Q_LDS_MAX) {
+        for (int64_t c = threadIdx.x; c < ak.dp; c += blockDim.x) qs[c] = ak.q64[c];
+        qx = qs;
+    }
+    char* work = smem + sizeof(double) * Q_LDS_MAX;
+    __shared__ int s_tot, s_ovf;
+    if (threadIdx.x == 0) {
+        s_tot = 0;
+        s_ovf = 0;
+    }
+    knn_finish_body<float>(ak, work, qx ? qx : nullptr);   // (its barriers publish s_tot / s_ovf)
+    if (threadIdx.x >= 64) {
+        // Waves 1..15, while wave 0 ranks the neighbours and forms lambda_q: gather the waves' reports (SC_WCAP words
+        // each: the count, then the rows; mostly empty) into one list in the work area phase 1 no longer uses -- slots by
+        // an LDS atomic, so the order varies, the ranking behind it goes by (key, row) alone -- and form the cosines.
+        // Two dependent round trips for the whole block, not two per report: every thread first loads the heads of all
+        // its reports (count + the first three rows in 16 bytes), then everything their candidates need.
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        double* sk = (double*)work;
+        int* si = (int*)(sk + CAND_CAP);
+        const double nq_ = as_.info->nq;
+        const double rq_ = nq_ > 0.0 ? rsqrt(nq_) : 0.0;
+        constexpr int NREP = 5;                    // reports per thread: up to 16 * 256 + 64 waves over 960 threads
+        const int nthr = (int)blockDim.x - 64, t0 = (int)threadIdx.x - 64;
+        i32x4 head[NREP];
+#pragma unroll
+        for (int i = 0; i < NREP; ++i) {
+            const int w2 = t0 + i * nthr;
+            head[i] = w2 < as_.sc_nw ? *(const i32x4*)(as_.ci + (int64_t)w2 * SC_WCAP) : i32x4{0, 0, 0, 0};
+        }
+        int base[NREP];
+        double nrow[NREP][3];
+        float dt[NREP][3];
+#pragma unroll
+        for (int i = 0; i < NREP; ++i) {
+            const int c2 = head[i][0];
+            base[i] = 0;
+            if (c2 < 0) s_ovf = 1;
+            else if (c2 > 0) base[i] = atomicAdd(&s_tot, c2);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                nrow[i][e] = 0.0;
+                dt[i][e] = 0.0f;
+                if (e < c2 && base[i] + c2 <= CAND_CAP) {
+                    const int j = head[i][1 + e];
+                    nrow[i][e] = as_.n64[j];
+                    dt[i][e] = scan_dots[j];
+                    if (as_.lam64[j] == -1.0) dt[i][e] = 0.0f;   // (never: the load warms the line the key reads behind the barrier)
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NREP; ++i) {
+            const int c2 = head[i][0];
+            if (c2 <= 0 || base[i] + c2 > CAND_CAP) continue;
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (e < c2) {
+                    si[base[i] + e] = head[i][1 + e];
+                    sk[base[i] + e] = nrow[i][e] > 0.0 ? (double)dt[i][e] * rsqrt(nrow[i][e]) * rq_ : 0.0;
+                }
+            const int w2 = t0 + i * nthr;
+            for (int e = 3; e < c2; ++e) {   // a long report: its cosines are left to the whole block behind the barrier
+                si[base[i] + e] = as_.ci[(int64_t)w2 * SC_WCAP + 1 + e];
+                sk[base[i] + e] = __longlong_as_double(0x7ff8000000000000ll);
+            }
+        }
+    }
+    __syncthreads();   // lambda_q, status and the flags wave 0 has filed in QInfo, and the gathered list: visible to the block
+    AS_STAMP(24);
+    reset_query_hist(sc_hist, threadIdx.x, blockDim.x);
+    score_finish_body<double>(as_, coef_s, work, qx ? qx : nullptr, scan_dots, s_ovf || s_tot > CAND_CAP ? -1 : s_tot);
 }
 
 // merge m hit records (own or all-gathered) -> final topk, written to pinned host memory
@@ -1592,6 +1719,26 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lamb
     return AS_OK;
 }
 
+// the fused tail's dynamic LDS: the query once, then the larger of the two phases' work areas (each sized with a query of its own)
+static size_t fused_lds() { return sizeof(double) * Q_LDS_MAX + std::max(finish_lds<float>(), score_lds<double>()) - sizeof(double) * Q_LDS_MAX; }
+
+// Fused tail (single query, fp32 scan with scan-side scorer candidates): ONE launch behind the scan -- knn_finish and
+// score_finish as the two phases of fused_finish_kernel.
+static as_status run_fused(as_query* q, double eps, double tau) {
+    const as_space* sp = q->sp;
+    hipStream_t st = q->stream;
+    FinishArgs fk = make_finish(q);
+    fk.M = q->Mk; fk.epskey = sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps; fk.coef = coef_query(q, false);
+    fk.recs = q->knn; fk.fuse = 1; fk.ck = q->ckey_k; fk.ci = q->cidx_k; fk.from_list = 0;
+    FinishArgs fs = make_finish(q);
+    fs.tau = tau; fs.M = q->Ms; fs.hits = q->hits; fs.fuse = 1; fs.hout = q->hout_dev; fs.seq = q->seq; fs.auto_reset = 1;
+    fs.ck = q->ckey_s; fs.ci = q->sc_widx; fs.from_list = 0; fs.sc_nw = q->sc_nw;
+    const double coef_s = tau * (coef_query(q, false) + 1.0e-14) + 4.0 * 2.220446049250313e-16;   // as launch_score's mixed keys
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(1), dim3(1024), fused_lds(), st, fk, fs, coef_s, (const float*)q->dots32, q->sc_hist);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
 template <typename T, typename U, int PASSES>
 static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_final, const float* dots32 = nullptr) {
     hipStream_t st = q->stream;
@@ -1710,7 +1857,7 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         q->host_q = 1;
         q->q64_src = q->hq_dev;
         q->q32_src = q->hq32_dev;
-        if (!q->info_clean) hipLaunchKernelGGL(reset_info_kernel, dim3(1), dim3(64), 0, st, q->info);
+        if (!q->info_clean) hipLaunchKernelGGL(reset_info_kernel, dim3(1), dim3(64), 0, st, q->info, q->sc_hist);
         q->info_clean = 0;
         if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
         const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !q->crowded_direct);
@@ -1852,6 +1999,8 @@ static as_status query_alloc(as_query* q) {
     AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp * C));
     AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp * C));
     AS_HIP(hipMalloc(&q->info, sizeof(QInfo) * C));
+    // (on the query's own stream: it is non-blocking, a memset on the null stream may run LATER than the first search)
+    AS_HIP(hipMemsetAsync(q->info, 0, sizeof(QInfo) * C, q->stream));
     AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE) * C));
     q->ss.dots = C > 1 ? 32 : sp->np + ROW_TILE;
     q->ss.dots_ts = C > 1 ? 32 * (int64_t)C : 32;
@@ -1867,10 +2016,17 @@ static as_status query_alloc(as_query* q) {
     AS_HIP(hipMalloc(&q->ckey_s, sizeof(double) * CAND_CAP * C));
     AS_HIP(hipMalloc(&q->cidx_s, sizeof(int) * CAND_CAP * C));
     AS_HIP(hipMalloc(&q->gmin, sizeof(double) * CAND_CAP * C));
+    if (C == 1) {   // fused tail: a report of SC_WCAP words per wave of the scan (at most 4 blocks of 4 waves per CU)
+        const size_t nwmax = (size_t)16 * std::max(q->cus, 1) + 64;
+        AS_HIP(hipMalloc(&q->sc_widx, sizeof(int) * nwmax * SC_WCAP));
+        AS_HIP(hipMemsetAsync(q->sc_widx, 0, sizeof(int) * nwmax * SC_WCAP, q->stream));
+        AS_HIP(hipMalloc(&q->sc_hist, sizeof(unsigned int) * SC_COPIES * SC_HSTRIDE));
+        AS_HIP(hipMemsetAsync(q->sc_hist, 0, sizeof(unsigned int) * SC_COPIES * SC_HSTRIDE, q->stream));
+    }
     AS_HIP(hipMalloc(&q->rsel, sizeof(RSel)));
     AS_HIP(hipMalloc(&q->knn, sizeof(as_knn_rec) * q->ss.knn * C));
     AS_HIP(hipMalloc(&q->hits, sizeof(as_hit_rec) * q->ss.hits * C));
-    AS_HIP(hipMemset(q->knn, 0xff, sizeof(as_knn_rec) * q->ss.knn * C));   // idx = -1: empty records
+    AS_HIP(hipMemsetAsync(q->knn, 0xff, sizeof(as_knn_rec) * q->ss.knn * C, q->stream));   // idx = -1: empty records
     AS_HIP(hipHostMalloc(&q->hout, sizeof(HostOut) * C, hipHostMallocMapped | hipHostMallocCoherent));
     AS_HIP(hipHostGetDevicePointer((void**)&q->hout_dev, q->hout, 0));
     memset(q->hout, 0, sizeof(HostOut) * C);
@@ -1880,7 +2036,10 @@ static as_status query_alloc(as_query* q) {
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<double>()));
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<float>()));
     AS_HIP(hipFuncSetAttribute((const void*)hits_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((sizeof(double) + sizeof(int)) * HIT_CAP)));
+    AS_HIP(hipFuncSetAttribute((const void*)fused_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds()));
     AS_TRY(set_scan_attrs());
+    q->no_fused = getenv("ARROWSPACE_NO_FUSED_TAIL") != nullptr;
+    AS_HIP(hipStreamSynchronize(q->stream));   // the fills above: done before a caller can move the query to another stream
     q->r0 = 0;
     q->r1 = sp->n;
     return AS_OK;
@@ -1901,6 +2060,8 @@ void as_query_free(as_query* q) {
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
     hipFree(q->gmin);
+    if (q->sc_widx) hipFree(q->sc_widx);
+    if (q->sc_hist) hipFree(q->sc_hist);
     hipFree(q->rsel);
     if (q->own_records) {
         hipFree(q->knn);
@@ -2151,20 +2312,47 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     // wait later.  Every 64th query probes the plain path again.
     const bool direct = !feature && !q->robust && q->crowded > 0 && (q->crowded++ & 63) != 0;
     q->crowded_direct = direct ? 1 : 0;
+    // Fused tail: the scan collects the scorer's candidates by a cosine bound and ONE kernel finishes the query.  The
+    // bound's window is (1 - tau) / (2 tau) wide in cosine: pointless below tau = 0.4 (every row would qualify).  A query
+    // whose candidates overflow the buffer falls back to the threshold chain over the kept dots, and the following 63
+    // queries take that chain directly.
+    const bool sc_skip = q->sc_crowded > 0 && (q->sc_crowded++ & 63) != 0;
+    const bool fused = !feature && !q->robust && !q->exact && !direct && !q->no_fused && !sc_skip && q->cap == 1 && tau >= 0.4 && tau <= 1.0 &&
+                       q->sp->dp <= 1024 && !(q->scan_variant & 4);
+    q->fused_tail = fused ? 1 : 0;
+    q->tau_cur = tau;
     const as_status qb = query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1);
     q->crowded_direct = 0;
+    q->fused_tail = 0;
     AS_TRY(qb);
-    if (direct) {
+    if (fused) {
+        q->seq += 1;
+        AS_TRY(run_fused(q, q->gr->gp.eps, tau));
+        if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
+        AS_TRY(wait_published(q));
+        q->crowded = (q->hout->overflow & 1) ? 1 : 0;
+        q->sc_crowded = (q->hout->overflow & 4) ? 1 : 0;
+        if ((q->hout->overflow & 4) && !(q->hout->overflow & 1) && !q->hout->knn_inexact) {
+            // the scan's scorer candidates did not fit: lambda_q stands, the scorer runs on the threshold chain
+            AS_HIP(hipMemsetAsync(&q->info->sc_cnt, 0, sizeof(int), q->stream));
+            AS_HIP(hipMemsetAsync(&q->info->overflow, 0, sizeof(int), q->stream));
+            q->seq += 1;
+            AS_TRY(run_score(q, tau, 1));
+            AS_TRY(wait_published(q));
+        }
+    } else if (direct) {
         AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
         AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1));
     } else if (!feature) {
         AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
     }
-    q->seq += 1;
-    AS_TRY(run_score(q, tau, 1));
-    if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
-    AS_TRY(wait_published(q));
-    if (!direct && !feature && !q->robust) q->crowded = (q->hout->overflow & 1) ? 1 : 0;
+    if (!fused) {
+        q->seq += 1;
+        AS_TRY(run_score(q, tau, 1));
+        if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
+        AS_TRY(wait_published(q));
+    }
+    if (!fused && !direct && !feature && !q->robust) q->crowded = (q->hout->overflow & 1) ? 1 : 0;
     if (!direct && !feature && !q->robust && q->hout->knn_inexact && !(q->hout->overflow & 1)) {
         // near-ties at the k-th distance the fp32 keys cannot order (duplicates, near-duplicates): every row inside
         // the eps bound is still in the candidate buffer -- evaluate them all exactly, no second scan

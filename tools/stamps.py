@@ -24,3 +24,8 @@ names_s = ["select_candidates", "exact eval + scores", "rank + hit records", "a-
 print("knn_finish phases (us):", {nm: round(s[i + 1] - s[i], 2) for i, nm in enumerate(names_k)}, "total", round(s[6] - s[0], 2))
 print("score_finish phases (us):", {nm: round(s[17 + i] - s[16 + i], 2) for i, nm in enumerate(names_s)}, "total", round(s[20] - s[16], 2))
 print("knn_finish end -> score_finish start (gmin, pick_thr, filter + boundaries):", round(s[16] - s[6], 2))
+if s[22] > 0:   # fused tail (fused_finish_kernel): one launch, both phases
+    print("fused tail (us): query staging", round(s[0] - s[22], 2), "| knn phase", round(s[6] - s[0], 2), "| barrier behind the gather of the waves' reports", round(s[24] - s[6], 2),
+          "| keys", round(s[25] - s[16], 2), "| select", round(s[17] - s[25], 2),
+          "| exact eval + scores", round(s[18] - s[17], 2), "| rank", round(s[19] - s[18], 2), "| check + publish", round(s[20] - s[19], 2),
+          "| whole kernel", round(s[20] - s[22], 2), "| candidates", np.mean([a_[26] / 0.01 for a_ in acc]))
