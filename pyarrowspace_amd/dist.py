@@ -497,6 +497,18 @@ class HipEngine:
         self._check(self.L.as_lambdas(self.sp, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def csr(self):
+        """(indptr, indices, values) of this rank's rows of the Laplacian, diagonal included, column ids global."""
+        rows, nnz = int(self.L.as_nnodes(self.gr)), int(self.L.as_graph_nnz(self.gr))
+        ip = np.zeros(rows + 1, dtype=np.int64)
+        ix = np.zeros(max(nnz, 1), dtype=np.int64)
+        v = np.zeros(max(nnz, 1), dtype=np.float64)
+        self._check(self.L.as_graph_csr(self.gr, ip.ctypes.data_as(C.c_void_p), ix.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+        return ip, ix[:nnz], v[:nnz]
+
+    def degrees(self):
+        return self._graph_vec(self.L.as_graph_deg_copy).cpu().numpy()
+
     def stats(self):
         out = np.zeros(10, dtype=np.float64)
         self.L.as_build_stats(self.gr, out.ctypes.data_as(C.c_void_p), 10)
@@ -613,10 +625,21 @@ class ShardedIndex:
 
         import torch
 
+        import time
+
         self = cls()
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.rank = dist.get_rank(group) if dist is not None else 0
+        self.phase_s = {}          # seconds per phase of this rank's build (host clock; every phase ends on a host wait)
+        _t = [time.perf_counter()]
+
+        def lap(name):
+            now = time.perf_counter()
+            self.phase_s[name] = self.phase_s.get(name, 0.0) + now - _t[0]
+            _t[0] = now
+
+        self._lap = lap
         check_world_limits(graph_params, self.world)      # before any upload or GPU work
         self.force_collectives = bool(force_collectives) and dist is not None
         self.engine = engine if engine is not None else HipEngine(graph_params)
@@ -681,6 +704,7 @@ class ShardedIndex:
                 X_shard = X_shard.contiguous()
                 self._sync()
                 self.engine.create_space(X_shard)
+                lap("ingest")
                 idx, dst, gy, cnt = self._ring_knn(X_shard)
                 self.scan_rows = (0, rows)               # the space holds this rank's rows only; ids come out global
             if self.replicated:
@@ -706,8 +730,10 @@ class ShardedIndex:
                 # all-gathered (8 B per item each).  Nothing of size N k is replicated.
                 inc = self._exchange_edges(idx, dst, gy, cnt)
                 self._sync()
+                lap("edge_exchange")
                 deg = self.engine.graph_shard_csr(self.n, self.r0, idx, dst, gy, cnt, *inc)
                 del inc
+                lap("graph_csr")
                 deg_g = self._gather_rows(deg.contiguous(), counts).contiguous()
                 n64 = self._gather_rows(self.engine.norms().contiguous(), counts).contiguous()
                 self._sync()
@@ -716,7 +742,9 @@ class ShardedIndex:
                 E_g = self._gather_rows(E.contiguous(), counts).contiguous()
                 self._sync()
                 self.engine.graph_shard_lambdas(E_g)
+                lap("energies_lambdas")
             self.engine.query_open()
+            lap("query_open")
         return self
 
     def _exchange_edges(self, idx, dst, gy, cnt):
@@ -784,12 +812,15 @@ class ShardedIndex:
                 cur ^= 1
 
         import os
+        lap = getattr(self, "_lap", lambda name: None)
         self.ring_symmetric = ring and hasattr(e, "knn_block_pair") and not os.environ.get("ARROWSPACE_RING_FULL")
         if self.ring_symmetric:
             self._ring_round_symmetric(X_shard, bufs, nmax)
         else:
             one_round(lambda h, b, rg, cg: e.knn_block(h, b, rg, cg))
+            lap("ring_blocks")
         nflag = e.knn_merge(nmax)
+        lap("ring_merge")
         if ring:
             t = torch.tensor([nflag], dtype=torch.int64, device=X_shard.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -805,6 +836,7 @@ class ShardedIndex:
                 bufs[0][: X_shard.shape[0]] = X_shard
             one_round(lambda h, b, rg, cg: e.knn_block_band(h, b, rg, cg))
             e.knn_merge(nmax)
+            lap("ring_round2_band")
             # rows whose band did not fit the collection buffers in some block (thousands of duplicates, or of items at one
             # distance): a third round settles them by exact evaluation of every pair -- collective as well
             nover = e.overflowed_rows() if hasattr(e, "overflowed_rows") else 0
@@ -822,6 +854,7 @@ class ShardedIndex:
                 one_round(lambda h, b, rg, cg: e.knn_block_exact(h, b, rg, cg))
                 if nover:
                     e.knn_merge(nmax, final=True)
+                lap("ring_round3_exact")
         out = e.lists()
         if ring:
             del bufs
@@ -851,8 +884,12 @@ class ShardedIndex:
         half = world // 2
         mx = max(max(counts), 1)
         # step 0: the own block, with the hop for step 1 in flight
+        lap = getattr(self, "_lap", lambda name: None)
         pending = self._exchange_start(bufs[0], bufs[1], nxt_rank, prv_rank) if half >= 1 else None
         e.knn_block(e.own_block(), rank, bounds[rank], bounds[rank])
+        if hasattr(torch, "cuda") and X_shard.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        lap("ring_own_block")
         # thresholds of every item from its own block's list: what a visiting item's candidates are admitted with
         U = e.knn_thresholds(max(nmax))
         Upad = torch.full((mx,), float("inf"), dtype=torch.float32, device=U.device)
@@ -860,6 +897,7 @@ class ShardedIndex:
         U_all = self._gather_fixed(Upad).reshape(world, mx)
         if pending is not None:
             self._exchange_wait(pending)
+        lap("ring_thresholds_hop")
         cur = 1
         for s in range(1, half + 1):
             src = (rank - s) % world                 # whose shard is visiting, and where its slice goes home to
@@ -877,9 +915,14 @@ class ShardedIndex:
                     ct0, ct1 = 0, tq // 2
             P = e.knn_block_pair(h, row0, row1, ct0, ct1, bounds[rank], bounds[src], U_all[src][: counts[src]], counts[src])
             e.close_block(h)
+            if X_shard.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            lap("ring_pairs")
             e.fold_slice(self._swap_slices(P, src, dst, counts[rank]), nmax[dst])
+            lap("ring_slice_swap_fold")
             if pending is not None:
                 self._exchange_wait(pending)
+            lap("ring_hop_wait")
             cur ^= 1
 
     def save(self, prefix):
