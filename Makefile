@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := pyarrowspace_amd/csrc
-SRCS := $(CSRC)/as_api.hip $(CSRC)/as_build.hip $(CSRC)/as_feat.hip $(CSRC)/as_scan.hip $(CSRC)/as_search.hip
+SRCS := $(CSRC)/as_api.hip $(CSRC)/as_build.hip $(CSRC)/as_comm.hip $(CSRC)/as_feat.hip $(CSRC)/as_scan.hip $(CSRC)/as_search.hip
 HDRS := $(CSRC)/as_common.hpp $(CSRC)/as_query.hpp include/arrowspace_hip.h
 OBJS := $(SRCS:.hip=.o)
 LIB := pyarrowspace_amd/libarrowspace_hip.so
@@ -14,7 +14,7 @@ all: $(LIB) oracle
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 oracle:
 	$(MAKE) -C oracle -s
 clean:

@@ -283,6 +283,22 @@ as_status as_query_finish_batch(as_query* q, const as_hit_rec* hits_dev, int32_t
  * (knn_inexact: the k-NN buffer, score_inexact: the scorer's). */
 void as_query_set_exact(as_query* q, int32_t flags);
 as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact);
+/* The per-query exchange steps issued by the library itself (RCCL on the query's stream; librccl is taken from the
+ * process or /opt/rocm/lib by dlopen -- as_comm_available() == 0 on a box without it).  The ranks of an index share one
+ * communicator: rank 0 draws an id (as_comm_unique_id: 128 bytes), the host hands it to every rank (any broadcast),
+ * every rank calls as_comm_create (collective).  as_query_set_comm binds a single-query workspace to it;
+ * as_query_search_staged is then ONE host call per query: scan of this rank's rows, all-gather of the k-NN records,
+ * lambda_q, scorer, all-gather of the hit records, merge, and the escalation to the exact paths (every rank with the
+ * same query and tau; same results and errors as as_search on one space holding every item).
+ * Serves PyArrowSpace::search, /root/reference/src/lib.rs:132-174, on a row-sharded index. */
+typedef struct as_comm as_comm;
+int32_t as_comm_available(void);
+as_status as_comm_unique_id(void* out_128_bytes);
+as_status as_comm_create(const void* id_128_bytes, int32_t rank, int32_t world, int32_t device, as_comm** out);
+void as_comm_free(as_comm* c);
+as_status as_query_set_comm(as_query* q, as_comm* c);
+as_status as_query_search_staged(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end, double tau,
+                                 int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
 /* HIP stream (hipStream_t) the query's kernels run on, for event timing / ordering;
  * as_query_set_stream makes them run on the caller's stream (NULL restores the private one),
  * e.g. the stream torch.distributed orders its RCCL collectives against. */

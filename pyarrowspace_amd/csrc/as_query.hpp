@@ -160,6 +160,13 @@ struct as_query {
     int no_fused = 0;        // ARROWSPACE_NO_FUSED_TAIL: always the plain chain (A/B runs)
     double tau_cur = 1.0;    // the tau of the search being launched (the scan's cosine window depends on it)
     int* unproven_dev = nullptr;   // build fallback: device counter (caller-owned) of rows that stay unproven
+    double staged_tau = -1.0;            // as_query_search_staged: the tau of the search whose scan comes next (-1: not announced)
+    int staged_sc = 0;                   // the last as_query_scan collected the scorer's candidates (SC)
+    const as_knn_rec* staged_recs = nullptr;   // the gathered k-NN records as_query_lambda was given
+    int64_t staged_m = 0;
+    struct as_comm* comm = nullptr;      // as_query_set_comm: the library exchanges this query's records itself (as_comm.hip)
+    as_knn_rec* knn_all = nullptr;       // [world][k] gathered k-NN records
+    as_hit_rec* hits_all = nullptr;      // [world][topk + 1] gathered hit records
 };
 
 namespace as {

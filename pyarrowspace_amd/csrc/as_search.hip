@@ -1239,10 +1239,11 @@ __global__ __launch_bounds__(1024) void knn_finish_kernel(FinishArgs a) {
 
 // SPEC S10 from m candidate records (this shard's, or all shards' all-gathered).  blockIdx.x = query slot: the
 // all-gathered buffer is [rank][slot][per] records, a slot's m records are `per` from every rank, `rstride` apart.
-__global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs_all, int64_t m, int64_t per, int64_t rstride,
-                                                      int64_t k, int metric, int kernel, double sigma, double p, double tau0, QInfo* info) {
-    info += blockIdx.x;
-    const as_knn_rec* __restrict__ recs0 = recs_all + (int64_t)blockIdx.x * per;
+// (one wave; `slot` = the query slot, blockIdx.x of q_lambda_kernel)
+__device__ __forceinline__ void q_lambda_body(const as_knn_rec* __restrict__ recs_all, int64_t m, int64_t per, int64_t rstride, int64_t k, int metric,
+                                              int kernel, double sigma, double p, double tau0, QInfo* info, int slot) {
+    info += slot;
+    const as_knn_rec* __restrict__ recs0 = recs_all + (int64_t)slot * per;
 #define recs_at(t) recs0[((t) / per) * rstride + ((t) % per)]
     __shared__ double r_key[REC_CAP];
     __shared__ int r_idx[REC_CAP];
@@ -1281,6 +1282,11 @@ __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restri
 #undef recs_at
     AS_LDS_FENCE();
     lambda_from_sorted(cnt, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
+}
+
+__global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs_all, int64_t m, int64_t per, int64_t rstride,
+                                                      int64_t k, int metric, int kernel, double sigma, double p, double tau0, QInfo* info) {
+    q_lambda_body(recs_all, m, per, rstride, k, metric, kernel, sigma, p, tau0, info, blockIdx.x);
 }
 
 __device__ __forceinline__ void publish(HostOut* out, int64_t seq) {
@@ -1416,7 +1422,8 @@ __device__ __forceinline__ void score_finish_body(FinishArgs a, double coef_s, c
             // trailing flag record: every rank sees every rank's flags after the all-gather
             as_hit_rec r;
             r.idx = -2;
-            r.score = (double)((a.info->knn_inexact ? 1 : 0) | (bad ? 2 : 0) | ((a.info->overflow & 1) ? 4 : 0) | ((a.info->overflow & 2) ? 8 : 0));
+            r.score = (double)((a.info->knn_inexact ? 1 : 0) | (bad ? 2 : 0) | ((a.info->overflow & 1) ? 4 : 0) | ((a.info->overflow & 2) ? 8 : 0) |
+                               ((a.info->overflow & 4) ? 16 : 0));
             a.hits[a.topk] = r;
         }
         if (a.fuse && a.hout) {
@@ -1443,32 +1450,14 @@ __global__ __launch_bounds__(1024) void score_finish_kernel(FinishArgs a, double
     score_finish_body<T>(a, coef_s, smem, nullptr, nullptr, 0);
 }
 
-// Fused tail of a single query: ONE launch behind the scan.  Phase 1 = knn_finish (the k nearest of the scan's k-NN
-// candidates, exact, lambda_q); phase 2 = score_finish over the scan's own scorer candidates (scan_dma_kernel, SC).
-// The query is staged in LDS once; the two phases share the rest of the dynamic LDS.  Clears the scan's cosine
-// histogram behind itself (the next scan counts into it from its first wave on).
-__global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs ak, FinishArgs as_, double coef_s, const float* scan_dots, unsigned int* sc_hist) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    AS_STAMP(22);
-    double* qs = (double*)smem;
-    const double* qx = nullptr;
-    if (ak.dp <= Q_LDS_MAX) {
-        for (int64_t c = threadIdx.x; c < ak.dp; c += blockDim.x) qs[c] = ak.q64[c];
-        qx = qs;
-    }
-    char* work = smem + sizeof(double) * Q_LDS_MAX;
-    __shared__ int s_tot, s_ovf;
-    if (threadIdx.x == 0) {
-        s_tot = 0;
-        s_ovf = 0;
-    }
-    knn_finish_body<float>(ak, work, qx ? qx : nullptr);   // (its barriers publish s_tot / s_ovf)
-    if (threadIdx.x >= 64) {
-        // Waves 1..15, while wave 0 ranks the neighbours and forms lambda_q: gather the waves' reports (SC_WCAP words
-        // each: the count, then the rows; mostly empty) into one list in the work area phase 1 no longer uses -- slots by
-        // an LDS atomic, so the order varies, the ranking behind it goes by (key, row) alone -- and form the cosines.
-        // Two dependent round trips for the whole block, not two per report: every thread first loads the heads of all
-        // its reports (count + the first three rows in 16 bytes), then everything their candidates need.
+// Waves 1..15 of a finish kernel: gather the reports of the scan's waves (SC_WCAP words each: the count, then the rows;
+// mostly empty) into one list in the work area -- slots by an LDS atomic, so the order varies, the ranking behind it
+// goes by (key, row) alone -- and form the cosines.  Two dependent round trips for the whole block, not two per report:
+// every thread first loads the heads of all its reports (count + the first three rows in 16 bytes), then everything
+// their candidates need.
+__device__ __forceinline__ void gather_reports(const FinishArgs& as_, char* work, const float* scan_dots, int* s_tot_p, int* s_ovf_p) {
+    int& s_tot = *s_tot_p;
+    int& s_ovf = *s_ovf_p;
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         double* sk = (double*)work;
         int* si = (int*)(sk + CAND_CAP);
@@ -1519,11 +1508,64 @@ __global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs ak, Finis
                 sk[base[i] + e] = __longlong_as_double(0x7ff8000000000000ll);
             }
         }
+}
+
+// Fused tail of a single query: ONE launch behind the scan.  Phase 1 = knn_finish (the k nearest of the scan's k-NN
+// candidates, exact, lambda_q); phase 2 = score_finish over the scan's own scorer candidates (scan_dma_kernel, SC).
+// The query is staged in LDS once; the two phases share the rest of the dynamic LDS.  Clears the scan's cosine
+// histogram behind itself (the next scan counts into it from its first wave on).
+__global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs ak, FinishArgs as_, double coef_s, const float* scan_dots, unsigned int* sc_hist) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    AS_STAMP(22);
+    double* qs = (double*)smem;
+    const double* qx = nullptr;
+    if (ak.dp <= Q_LDS_MAX) {
+        for (int64_t c = threadIdx.x; c < ak.dp; c += blockDim.x) qs[c] = ak.q64[c];
+        qx = qs;
     }
+    char* work = smem + sizeof(double) * Q_LDS_MAX;
+    __shared__ int s_tot, s_ovf;
+    if (threadIdx.x == 0) {
+        s_tot = 0;
+        s_ovf = 0;
+    }
+    knn_finish_body<float>(ak, work, qx ? qx : nullptr);   // (its barriers publish s_tot / s_ovf)
+    if (threadIdx.x >= 64) gather_reports(as_, work, scan_dots, &s_tot, &s_ovf);   // while wave 0 ranks the neighbours and forms lambda_q
     __syncthreads();   // lambda_q, status and the flags wave 0 has filed in QInfo, and the gathered list: visible to the block
     AS_STAMP(24);
     reset_query_hist(sc_hist, threadIdx.x, blockDim.x);
     score_finish_body<double>(as_, coef_s, work, qx ? qx : nullptr, scan_dots, s_ovf || s_tot > CAND_CAP ? -1 : s_tot);
+}
+
+// Staged (row-sharded) search, the step between the two exchanges, in ONE launch: lambda_q from the all-gathered k-NN
+// records (wave 0, as q_lambda_kernel) while waves 1..15 gather the scan's scorer candidates (the waves' reports of
+// scan_dma_kernel, SC), then the scorer finish over them (score_finish_body: hit records + flags, no publication) --
+// instead of q_lambda, score_gmin, score_pickfilter and score_finish.
+__global__ __launch_bounds__(1024) void staged_score_kernel(FinishArgs as_, double coef_s, const float* scan_dots, unsigned int* sc_hist,
+                                                            const as_knn_rec* recs_all, int64_t m, int64_t k, int metric, int kernel, double sigma,
+                                                            double p, double tau0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* qs = (double*)smem;
+    const double* qx = nullptr;
+    if (as_.dp <= Q_LDS_MAX) {
+        for (int64_t c = threadIdx.x; c < as_.dp; c += blockDim.x) qs[c] = as_.q64[c];
+        qx = qs;
+    }
+    char* work = smem + sizeof(double) * Q_LDS_MAX;
+    __shared__ int s_tot, s_ovf;
+    if (threadIdx.x == 0) {
+        s_tot = 0;
+        s_ovf = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        q_lambda_body(recs_all, m, m, m, k, metric, kernel, sigma, p, tau0, as_.info, 0);
+    } else {
+        gather_reports(as_, work, scan_dots, &s_tot, &s_ovf);
+    }
+    __syncthreads();
+    reset_query_hist(sc_hist, threadIdx.x, blockDim.x);
+    score_finish_body<double>(as_, coef_s, work, qx, scan_dots, s_ovf || s_tot > CAND_CAP ? -1 : s_tot);
 }
 
 // merge m hit records (own or all-gathered) -> final topk, written to pinned host memory
@@ -1576,7 +1618,7 @@ __global__ __launch_bounds__(1024) void hits_final_kernel(const as_hit_rec* __re
         out->status = info->status;
         out->knn_inexact = (info->knn_inexact || (fl & 1)) ? 1 : 0;
         out->score_inexact = (info->score_inexact || (fl & 2)) ? 1 : 0;
-        out->overflow = (info->overflow & 3) | ((fl & 4) ? 1 : 0) | ((fl & 8) ? 2 : 0);
+        out->overflow = (info->overflow & 7) | ((fl & 4) ? 1 : 0) | ((fl & 8) ? 2 : 0) | ((fl & 16) ? 4 : 0);
         publish(out, seq);
     }
 }
@@ -2037,6 +2079,7 @@ static as_status query_alloc(as_query* q) {
     AS_HIP(hipFuncSetAttribute((const void*)score_finish_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_lds<float>()));
     AS_HIP(hipFuncSetAttribute((const void*)hits_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((sizeof(double) + sizeof(int)) * HIT_CAP)));
     AS_HIP(hipFuncSetAttribute((const void*)fused_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds()));
+    AS_HIP(hipFuncSetAttribute((const void*)staged_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds()));
     AS_TRY(set_scan_attrs());
     q->no_fused = getenv("ARROWSPACE_NO_FUSED_TAIL") != nullptr;
     AS_HIP(hipStreamSynchronize(q->stream));   // the fills above: done before a caller can move the query to another stream
@@ -2062,6 +2105,8 @@ void as_query_free(as_query* q) {
     hipFree(q->gmin);
     if (q->sc_widx) hipFree(q->sc_widx);
     if (q->sc_hist) hipFree(q->sc_hist);
+    if (q->knn_all) hipFree(q->knn_all);
+    if (q->hits_all) hipFree(q->hits_all);
     hipFree(q->rsel);
     if (q->own_records) {
         hipFree(q->knn);
@@ -2116,7 +2161,17 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
         AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
         return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
     }
-    AS_TRY(query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1));
+    // Staged search driven by the library (as_query_search_staged announces tau before the scan): the scan collects the
+    // scorer's candidates by its cosine bound, as on one GPU (search_once), and ONE kernel does the step between the two
+    // exchanges (staged_score_kernel).
+    const bool sc = q->staged_tau >= 0.4 && q->staged_tau <= 1.0 && q->gr->lambda_mode != AS_LAMBDA_FEATURE && !q->robust && !q->exact &&
+                    !q->no_fused && q->cap == 1 && q->sc_widx && q->sp->dp <= 1024 && !(q->scan_variant & 4) && !q->crowded_direct;
+    q->fused_tail = sc ? 1 : 0;
+    q->tau_cur = q->staged_tau;
+    const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
+    q->fused_tail = 0;
+    q->staged_sc = sc && qb == AS_OK && row_end > row_begin ? 1 : 0;
+    AS_TRY(qb);
     if (q->gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // lambda_q is already there; the k-NN records stay empty
     return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
@@ -2132,6 +2187,9 @@ as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {
     }
     const as_graph* gr = q->gr;
     if (gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // computed by as_query_scan, identically on every rank
+    q->staged_recs = recs_dev;
+    q->staged_m = m;
+    if (q->staged_sc) return AS_OK;   // lambda_q is formed by staged_score_kernel (as_query_score), in front of the scorer
     hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, q->stream, recs_dev, m, m, m, q->k, gr->metric, gr->kernel,
                        gr->gp.sigma, gr->gp.p, gr->tau0, q->info);
     AS_HIP(hipGetLastError());
@@ -2142,6 +2200,17 @@ as_status as_query_score(as_query* q, double tau) {
     if (!q || !q->gr) {
         set_err("as_query_score: null argument");
         return AS_EINVAL;
+    }
+    if (q->staged_sc && q->staged_recs && q->r1 > q->r0) {
+        const as_graph* gr = q->gr;
+        FinishArgs fs = make_finish(q);
+        fs.tau = tau; fs.M = q->Ms; fs.hits = q->hits; fs.fuse = 0; fs.hout = nullptr; fs.seq = q->seq; fs.auto_reset = 0;
+        fs.ck = q->ckey_s; fs.ci = q->sc_widx; fs.from_list = 0; fs.sc_nw = q->sc_nw;
+        const double coef_s = tau * (coef_query(q, false) + 1.0e-14) + 4.0 * 2.220446049250313e-16;
+        hipLaunchKernelGGL(staged_score_kernel, dim3(1), dim3(1024), fused_lds(), q->stream, fs, coef_s, (const float*)q->dots32, q->sc_hist,
+                           q->staged_recs, q->staged_m, q->k, gr->metric, gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0);
+        AS_HIP(hipGetLastError());
+        return AS_OK;
     }
     return run_score(q, tau, 0);
 }

@@ -384,6 +384,37 @@ class HipEngine:
     def set_mode(self, mode):
         self.L.as_query_set_exact(self.q, int(mode))
 
+    # ---- the two per-query exchange steps issued by the library (RCCL from C++, as_comm.hip): one host call per query
+    def comm_available(self):
+        return bool(self.L.as_comm_available())
+
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        self._check(self.L.as_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def comm_create(self, uid: bytes, rank: int, world: int):
+        """Collective over the ranks of the index.  The query keeps its own record buffers and its own stream."""
+        self.comm = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        self._check(self.L.as_comm_create(C.cast(buf, C.c_void_p), rank, world, int(self.op.device), C.byref(self.comm)))
+        self.qs = C.c_void_p()
+        self._check(self.L.as_query_create(self.sp, self.gr, C.byref(self.qs)))
+        self._check(self.L.as_query_set_comm(self.qs, self.comm))
+        self._sidx = np.empty(max(self.topk, 1), dtype=np.int64)
+        self._ssc = np.empty(max(self.topk, 1), dtype=np.float64)
+
+    def search_staged(self, q, tau, r0, r1):
+        """-> (hits, lambda_q, zero_lambda): scan, both exchanges, merge and escalation behind one call."""
+        qq = np.ascontiguousarray(q, dtype=np.float64)
+        ln, lq = C.c_int64(0), C.c_double(0.0)
+        st = self.L.as_query_search_staged(self.qs, qq.ctypes.data_as(C.c_void_p), qq.shape[0], r0, r1, float(tau),
+                                           self._sidx.ctypes.data_as(C.c_void_p), self._ssc.ctypes.data_as(C.c_void_p), C.byref(ln), C.byref(lq))
+        if st not in (self._lib.AS_OK, self._lib.AS_EZEROLAMBDA):
+            self._check(st)
+        n = ln.value
+        return list(zip(self._sidx[:n].tolist(), self._ssc[:n].tolist())), float(lq.value), st == self._lib.AS_EZEROLAMBDA
+
     def query_scan(self, q, r0, r1):
         self._q = np.ascontiguousarray(q, dtype=np.float64)
         self._check(self.L.as_query_scan(self.q, self._q.ctypes.data_as(C.c_void_p), self._q.shape[0], r0, r1))
@@ -519,12 +550,18 @@ class HipEngine:
     def tau0(self):
         return float(self.L.as_graph_tau0(self.gr))
 
-    def scan_us(self):
+    def scan_us(self, q=None):
         out = np.zeros(3, dtype=np.float64)
-        self.L.as_query_stats(self.q, out.ctypes.data_as(C.c_void_p), 3)
+        self.L.as_query_stats(q if q is not None else self.q, out.ctypes.data_as(C.c_void_p), 3)
         return float(out[0])
 
     def close(self):
+        if getattr(self, "qs", None):
+            self.L.as_query_free(self.qs)
+            self.qs = None
+        if getattr(self, "comm", None):
+            self.L.as_comm_free(self.comm)
+            self.comm = None
         if getattr(self, "qb", None):
             self.L.as_query_free(self.qb)
             self.qb = C.c_void_p()
@@ -542,11 +579,33 @@ class HipEngine:
 class ShardedIndex:
     """Host logic of the row-sharded index; identical results on every rank."""
 
+    library_exchange = True      # single-query searches: the library issues the two exchange steps itself (RCCL from C++)
+
     def __init__(self):
         self.engine = None
         self._gbuf = {}
         self.stream = None
         self.force_collectives = False
+        self._lib_comm = False
+
+    def _setup_library_exchange(self):
+        """A communicator of this index's ranks inside the library (as_comm.hip): search() is then ONE host call per query --
+        no Python between the scan, the two all-gathers and the merge.  Needs real RCCL ranks (one GPU per rank);
+        ARROWSPACE_PY_COLLECTIVES=1 keeps the torch.distributed path (A/B runs)."""
+        import os
+        e = self.engine
+        if not (self.library_exchange and self._collective() and hasattr(e, "comm_create") and e.comm_available()) or os.environ.get("ARROWSPACE_PY_COLLECTIVES"):
+            return
+        if self.dist.get_backend(self.group) != "nccl":
+            return
+        torch = self.torch
+        dev = torch.device("cuda", e.op.device)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))
+        self.dist.broadcast(uid, self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        e.comm_create(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
+        self._lib_comm = True
 
     # ---- collectives
     def _collective(self):
@@ -692,6 +751,7 @@ class ShardedIndex:
                 self.engine.feat_lambdas_global(E, G, self.n, self.r0)
                 self.scan_rows = (0, rows)
                 self.engine.query_open()
+                self._setup_library_exchange()
                 return self
             if self.replicated:
                 X_full = self._gather_rows(X_shard.contiguous(), counts).contiguous()
@@ -744,6 +804,7 @@ class ShardedIndex:
                 self.engine.graph_shard_lambdas(E_g)
                 lap("energies_lambdas")
             self.engine.query_open()
+            self._setup_library_exchange()
             lap("query_open")
         return self
 
@@ -966,6 +1027,7 @@ class ShardedIndex:
             self.r0, self.r1 = self.bounds[self.rank], self.bounds[self.rank + 1]
             self.scan_rows = (self.r0, self.r1) if self.replicated else (0, rows)
             self.engine.query_open()
+            self._setup_library_exchange()
         return self
 
     def _sync(self):
@@ -979,6 +1041,12 @@ class ShardedIndex:
         from . import PanicException
 
         e = self.engine
+        if self._lib_comm:
+            hits, lq, zero = e.search_staged(q, tau, *self.scan_rows)
+            self.last_lambda_q = lq
+            if zero:
+                raise PanicException("The lambdas are zero, check the magnitude of items and eps.")
+            return hits
         ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
         mode = 0
         with ctx:
@@ -1051,7 +1119,7 @@ class ShardedIndex:
         return self._gather_rows(t, self.counts).cpu().numpy()
 
     def last_scan_us(self):
-        return self.engine.scan_us()
+        return self.engine.scan_us(self.engine.qs if self._lib_comm else None)
 
     def build_stats(self):
         return getattr(self.engine, "stats", lambda: {})()
@@ -1067,6 +1135,9 @@ class HostStagedIndex(ShardedIndex):
     form for ranks that SHARE one GPU -- RCCL wants one device per rank -- i.e. the one-GPU rehearsal of an N-rank job
     (bench.py --gpus N on a box with fewer devices, the multi-rank tests of tests/test_gpu_*.py).  Same host logic,
     same kernels, same results; only the transport differs."""
+
+    library_exchange = False      # (gloo ranks sharing a GPU: no RCCL communicator)
+
 
     def _gather_rows(self, t, counts):
         self.torch.cuda.synchronize()

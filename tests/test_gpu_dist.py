@@ -15,6 +15,7 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from conftest import assert_hits_match, calibrate_eps, clustered  # noqa: E402
+from pyarrowspace_amd import PanicException  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -338,12 +339,19 @@ def test_two_ranks_feature_mode_match_oracle(oracle_lib):
     assert out[0][1] == out[1][1]
 
 
-def test_one_rank_rccl_collectives_on_a_side_stream(oracle_lib):
-    """The real N>1 code path (RCCL all_gather_into_tensor ordered against the query kernels on
-    one dedicated stream) with a 1-rank nccl group: every collective is issued, nothing is skipped."""
+@pytest.mark.parametrize("library_exchange", [True, False], ids=["library-rccl", "torch-collectives"])
+def test_one_rank_rccl_collectives_on_a_side_stream(oracle_lib, library_exchange, monkeypatch):
+    """The real N>1 code path with a 1-rank nccl group: every collective is issued, nothing is skipped.
+    library-rccl: the two per-query all-gathers are issued by the library itself (as_query_search_staged: RCCL from C++
+    on the query's stream, one host call per query); torch-collectives: torch.distributed's all_gather_into_tensor
+    ordered against the query kernels on one dedicated stream (ARROWSPACE_PY_COLLECTIVES=1)."""
     import torch
     import torch.distributed as dist
     from pyarrowspace_amd.dist import ShardedIndex
+    if library_exchange:
+        monkeypatch.delenv("ARROWSPACE_PY_COLLECTIVES", raising=False)
+    else:
+        monkeypatch.setenv("ARROWSPACE_PY_COLLECTIVES", "1")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -355,12 +363,48 @@ def test_one_rank_rccl_collectives_on_a_side_stream(oracle_lib):
         X = clustered(n, d, nclust=16, seed=41)
         gp = {"eps": calibrate_eps(X, 10), "k": 10, "topk": 8, "p": 2.0, "sigma": None}
         index = ShardedIndex.build(gp, torch.from_numpy(X).cuda(), dist, force_collectives=True)
+        assert index._lib_comm == library_exchange
         ref = oracle_lib.OracleIndex(X, gp)
         np.testing.assert_allclose(index.lambdas(), ref.lambdas, rtol=1e-9)
         for rep in range(3):                      # repeated: a missing stream dependency shows up as stale records
             for q, tau in _queries(X, n, d):
                 want, lq = ref.search(q, tau)
                 assert_hits_match(index.search(q, tau), want, ref.scores(q, tau, lq))
+                assert abs(index.last_lambda_q - lq) <= 1e-9 * abs(lq)
+        far = np.zeros(d)
+        far[0] = 50.0
+        with pytest.raises(PanicException):       # no neighbour within eps: the reference's zero-lambda assert, on this path too
+            index.search(far, 0.62)
+        Qb = np.stack([q for q, _ in _queries(X, n, d)])
+        assert index.search_batch(Qb, 0.62) == [index.search(np.ascontiguousarray(q), 0.62) for q in Qb]
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_exchange_repairs_a_crowded_neighbourhood(oracle_lib):
+    """eps above the diameter on the library-side exchange path: the escalation of as_query_search_staged (threshold
+    repair over the kept dots, mode 4) is the Python host's (next_mode), step for step."""
+    import torch
+    import torch.distributed as dist
+    from pyarrowspace_amd.dist import ShardedIndex
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, d = 5000, 64
+        X = clustered(n, d, nclust=6, noise=0.4, seed=23)
+        gp = {"eps": 10.0, "k": 25, "topk": 15, "p": 2.0, "sigma": None}
+        index = ShardedIndex.build(gp, torch.from_numpy(X).cuda(), dist, force_collectives=True)
+        assert index._lib_comm
+        ref = oracle_lib.OracleIndex(X, gp)
+        for q, tau in _queries(X, n, d)[:6]:
+            want, lq = ref.search(q, tau)
+            assert_hits_match(index.search(q, tau), want, ref.scores(q, tau, lq), rtol=1e-9)
+            assert abs(index.last_lambda_q - lq) <= 1e-9 * abs(lq)
         index.close()
     finally:
         dist.destroy_process_group()
