@@ -589,6 +589,8 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
     int full = 0;
     bool first = true;
     int npend = 0;       // SC: entries of the wave's pending list
+    float thr_last = -3.0e38f;   // SC: the threshold of the last chunk that read the histogram
+    bool thr_known = false;
     int sc_over = 0;     // SC: the list overflowed (the wave reports -1 candidates: the host takes the threshold chain)
     for (int t = 0; t <= rounds; ++t) {
         int64_t base;
@@ -655,6 +657,10 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             int jb;
             const float bedge = sc_bound(hread ? lds_read1u(hx0 + lane * 4) : 0u, pre.sc_m, lane, jb);
             const float thr = bedge - pre.sc_w;
+            if (hread) {
+                thr_last = thr;
+                thr_known = true;
+            }
             const bool valid = lane < cnt && row < pre.n;
             const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
             const float c = mydot * inr * inq32;
@@ -666,27 +672,28 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             // the whole launch 35 % slower.  A query's near neighbours are outliers of their chunks; smooth cosine
             // distributions are covered by the unconditional chunks.
             const bool fin = valid && c == c;           // (a NaN cosine neither publishes nor bounds)
-            float cm = fin ? c : -2.0f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
-            const float nv = (float)__popcll(__ballot(fin));
-            const float mean = wave_sum_dpp(fin ? c : 0.0f) / fmaxf(nv, 1.0f);
-            const float var = fmaxf(wave_sum_dpp(fin ? (c - mean) * (c - mean) : 0.0f) / fmaxf(nv, 1.0f), 0.0f);
-            const bool every = (((int)gw + t) & 31) == 0;
-            const int bfloor = every ? -1 : sc_bin(mean + 4.0f * sqrtf(var));
             const int mybin = fin ? sc_bin(c) : -1;
-            const int bmax = cm > -2.0f ? sc_bin(cm) : -1;
-            int nb3[3];
+            // (only a row above the bound's bin can raise the bound: once it stands, the chunk statistics below -- 18
+            // cross-lane operations -- are skipped for almost every chunk)
+            if (__ballot(mybin > jb) && (t < rounds || rounds >= 2) && !(pre.sc_dbg & 1)) {
+                float cm = fin ? c : -2.0f;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) nb3[u] = __popcll(__ballot(mybin == bmax - u && bmax - u >= 0));
-            {   // lane = copy * 3 + u: bin bmax - u of histogram copy `copy`
+                for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+                const float nv = (float)__popcll(__ballot(fin));
+                const float mean = wave_sum_dpp(fin ? c : 0.0f) / fmaxf(nv, 1.0f);
+                const float var = fmaxf(wave_sum_dpp(fin ? (c - mean) * (c - mean) : 0.0f) / fmaxf(nv, 1.0f), 0.0f);
+                const bool every = (((int)gw + t) & 31) == 0;
+                const int bfloor = every ? -1 : sc_bin(mean + 4.0f * sqrtf(var));
+                const int bmax = cm > -2.0f ? sc_bin(cm) : -1;
+                int nb3[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) nb3[u] = __popcll(__ballot(mybin == bmax - u && bmax - u >= 0));
+                // lane = copy * 3 + u: bin bmax - u of histogram copy `copy`.  (A wave of one or two chunks does not publish
+                // its last one: nobody is left to read it but the waves' final reads, which would queue behind it.)
                 const int u = lane % 3, copy = lane / 3;
                 const int b = bmax - u;
                 const int nb_ = u == 0 ? nb3[0] : (u == 1 ? nb3[1] : nb3[2]);
-                // (a wave of one or two chunks does not publish its last one: nobody is left to read it but the waves'
-                // final reads, which would queue behind it)
-                if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0 && (t < rounds || rounds >= 2) && !(pre.sc_dbg & 1))
-                    atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
+                if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0) atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
             }
             // candidates: c >= thr -- a NaN cosine (a poisoned row) never qualifies, as under the plain chain's `key <= thr`
             const bool pass = valid && c >= thr && !(pre.sc_dbg & 4);
@@ -726,9 +733,14 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         int keep = 0;
         int* region = pre.sc_idx + gw * SC_WCAP;   // [0] = number of candidates (-1: more than the region holds), [1 ..] = their rows
         if (npend > 0 && !sc_over) {
-            int jb;
-            const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+            // (a wave of three or more chunks has read the histogram with its last chunks: that threshold will do -- a
+            // fresh read past the L2 at every wave's end is two microseconds of every launch's tail)
+            float thr = thr_last;
+            if (!thr_known) {
+                int jb;
+                const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+            }
             for (int e0 = 0; e0 < npend; e0 += 64) {
                 float ce = 0.0f;
                 int re = 0;

@@ -1332,20 +1332,96 @@ __device__ __forceinline__ void score_finish_body(FinishArgs a, double coef_s, c
         total = raw <= CAND_CAP ? raw : 0;
         const double nq_ = a.info->nq, lq_ = a.info->lambda_q;
         const double rq_ = nq_ > 0.0 ? rsqrt(nq_) : 0.0;
-        for (int t = threadIdx.x; t < total; t += blockDim.x) {
-            const int j = si[t];
-            double cs = sk[t];
-            if (cs != cs) {
-                const double nrow = a.n64[j];
-                cs = nrow > 0.0 ? (double)scan_dots[j] * rsqrt(nrow) * rq_ : 0.0;
+        // Keys and selection in one go.  A key is minus a score: tau cos + (1 - tau) L lies in [-1, 1], so the histogram that
+        // prunes the list to about M entries needs no range pass -- 1024 fixed bins over [-1, 1] are filled while the keys are
+        // formed (the generic select_candidates finds the range first: two more barriers, 2.5 us of this kernel).
+        __shared__ unsigned int khist[1024];
+        __shared__ int k_bin, k_cnt;
+        khist[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) k_cnt = 0;
+        __syncthreads();
+        int mybin[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = (int)threadIdx.x + u * (int)blockDim.x;
+            mybin[u] = -1;
+            if (t < total) {
+                const int j = si[t];
+                double cs = sk[t];
+                if (cs != cs) {
+                    const double nrow = a.n64[j];
+                    cs = nrow > 0.0 ? (double)scan_dots[j] * rsqrt(nrow) * rq_ : 0.0;
+                }
+                double key = -(a.tau * cs + (1.0 - a.tau) / (1.0 + fabs(lq_ - a.lam64[j])));
+                key = key == key ? key : key_traits<T>::inf();   // (a NaN key would rank as 0-th: it compares less than nothing)
+                sk[t] = key;
+                const double fb = (key + 1.0) * 512.0;
+                mybin[u] = fb < 0.0 ? 0 : (fb >= 1023.0 ? 1023 : (int)fb);
+                atomicAdd(&khist[mybin[u]], 1u);
             }
-            const double key = -(a.tau * cs + (1.0 - a.tau) / (1.0 + fabs(lq_ - a.lam64[j])));
-            sk[t] = key == key ? key : key_traits<T>::inf();   // (a NaN key would rank as 0-th: it compares less than nothing)
         }
         __syncthreads();
         AS_STAMP(25);
         if (threadIdx.x == 0) AS_STAMP_VAL(26, total);
-        select_candidates<T>(nullptr, nullptr, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
+        if (threadIdx.x < 64) {   // wave 0: 16 bins per lane, inclusive scan over the lanes, the lane whose bins reach M finishes
+            unsigned int hh[16], tot = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                hh[j] = khist[16 * threadIdx.x + j];
+                tot += hh[j];
+            }
+            unsigned int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t2 = __shfl_up(incl, o, 64);
+                if ((int)threadIdx.x >= o) incl += t2;
+            }
+            const unsigned int excl = incl - tot;
+            const unsigned int want_ = (unsigned)(a.M < total ? a.M : total);
+            if (threadIdx.x == 0) k_bin = 1023;
+            if (want_ > 0 && excl < want_ && incl >= want_) {
+                unsigned int run = excl;
+                int b = 16 * (int)threadIdx.x;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    run += hh[j];
+                    if (run >= want_) break;
+                    b += 1;
+                }
+                k_bin = b;
+            }
+        }
+        __syncthreads();
+        const int bsel = k_bin;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = (int)threadIdx.x + u * (int)blockDim.x;
+            if (mybin[u] >= 0 && mybin[u] <= bsel) {
+                const int slot = atomicAdd(&k_cnt, 1);
+                if (slot < PRUNE_CAP) {
+                    pk[slot] = sk[t];
+                    pi[slot] = si[t];
+                }
+            }
+        }
+        __syncthreads();
+        const int R = k_cnt;
+        if (R <= PRUNE_CAP) {
+            if (threadIdx.x == 0) fcount = total < a.M ? total : a.M;
+            for (int t = threadIdx.x; t < R; t += blockDim.x) {
+                const T k = pk[t];
+                const int i = pi[t];
+                int rank = 0;
+                for (int s2 = 0; s2 < R; ++s2) rank += lex_less<T>(pk[s2], pi[s2], k, i) ? 1 : 0;
+                if (rank < a.M) {
+                    fk[rank] = k;
+                    fi[rank] = i;
+                }
+            }
+            __syncthreads();
+        } else {   // the keys pile up in one bin (mass ties): the generic selection sorts it out
+            select_candidates<T>(nullptr, nullptr, total, a.M, sk, si, pk, pi, fk, fi, &fcount);
+        }
     } else if (a.from_list) {
         merge_partials<T>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
         total = (int)(a.nrows < 0x7fffffff ? a.nrows : 0x7fffffff);
@@ -1771,9 +1847,9 @@ static as_status run_fused(as_query* q, double eps, double tau) {
     hipStream_t st = q->stream;
     FinishArgs fk = make_finish(q);
     fk.M = q->Mk; fk.epskey = sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps; fk.coef = coef_query(q, false);
-    fk.recs = q->knn; fk.fuse = 1; fk.ck = q->ckey_k; fk.ci = q->cidx_k; fk.from_list = 0;
+    fk.recs = nullptr; fk.fuse = 1; fk.ck = q->ckey_k; fk.ci = q->cidx_k; fk.from_list = 0;   // (records are the staged path's: nobody reads them here)
     FinishArgs fs = make_finish(q);
-    fs.tau = tau; fs.M = q->Ms; fs.hits = q->hits; fs.fuse = 1; fs.hout = q->hout_dev; fs.seq = q->seq; fs.auto_reset = 1;
+    fs.tau = tau; fs.M = q->Ms; fs.hits = nullptr; fs.fuse = 1; fs.hout = q->hout_dev; fs.seq = q->seq; fs.auto_reset = 1;
     fs.ck = q->ckey_s; fs.ci = q->sc_widx; fs.from_list = 0; fs.sc_nw = q->sc_nw;
     const double coef_s = tau * (coef_query(q, false) + 1.0e-14) + 4.0 * 2.220446049250313e-16;   // as launch_score's mixed keys
     hipLaunchKernelGGL(fused_finish_kernel, dim3(1), dim3(1024), fused_lds(), st, fk, fs, coef_s, (const float*)q->dots32, q->sc_hist);
