@@ -61,12 +61,12 @@ as_status resolve_params(const as_graph_params* gp, as_graph_params* out) {
 
 // Hard limits of the selection kernels, checked before any upload or GPU work (the reference takes any usize,
 // src/helpers.rs:56-63; INTEGRATION.md lists the caps): k-NN candidate lists are one slot per lane of a wave
-// (k + 8 <= 64), scorer lists live in LDS (topk <= 1024).  Both are capped by the number of items first.
+// or two (k + 8 <= 128), scorer lists live in LDS (topk <= 1024).  Both are capped by the number of items first.
 as_status check_limits(const as_graph_params* r, int64_t n, int lambda_mode) {
     const int64_t k = std::min<int64_t>(r->k, std::max<int64_t>(n - 1, 1));
     const int64_t topk = std::min<int64_t>(r->topk, n);
-    if (k > 56 && lambda_mode != AS_LAMBDA_FEATURE) {   // the feature graph ranks whole columns: any k up to D - 1
-        set_err("graph_params['k']=%lld exceeds the supported maximum of 56 for n=%lld", (long long)r->k, (long long)n);
+    if (k > 120 && lambda_mode != AS_LAMBDA_FEATURE) {   // the feature graph ranks whole columns: any k up to D - 1
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 120 for n=%lld", (long long)r->k, (long long)n);
         return AS_EUNSUPPORTED;
     }
     if (topk > 1024) {
@@ -331,7 +331,7 @@ as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_
     AS_TRY(resolve_params(gp, &r));
     const int M = knn_list_width(r.k);
     if (M < 0) {
-        set_err("graph_params['k']=%lld exceeds the supported maximum of 56", (long long)r.k);
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 120", (long long)r.k);
         return AS_EUNSUPPORTED;
     }
     AS_HIP(hipSetDevice(sp->device));
@@ -359,7 +359,7 @@ as_status as_knn_block_pair(const as_space* sp, const as_space* cols, const as_g
     AS_TRY(resolve_params(gp, &r));
     const int M = knn_list_width(r.k);
     if (M < 0) {
-        set_err("graph_params['k']=%lld exceeds the supported maximum of 56", (long long)r.k);
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 120", (long long)r.k);
         return AS_EUNSUPPORTED;
     }
     AS_HIP(hipSetDevice(sp->device));
@@ -381,7 +381,7 @@ as_status as_knn_thresholds(const as_space* sp, const as_graph_params* gp, int64
     AS_TRY(resolve_params(gp, &r));
     const int M = knn_list_width(r.k);
     if (M < 0) {
-        set_err("graph_params['k']=%lld exceeds the supported maximum of 56", (long long)r.k);
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 120", (long long)r.k);
         return AS_EUNSUPPORTED;
     }
     AS_HIP(hipSetDevice(sp->device));

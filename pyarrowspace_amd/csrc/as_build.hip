@@ -1311,6 +1311,7 @@ static int pick_list_width(int64_t k) {
     const int64_t need = k + 8;
     if (need <= 32) return 32;
     if (need <= 64) return 64;
+    if (need <= 128) return 128;
     return -1;
 }
 int knn_list_width(int64_t k) { return pick_list_width(k); }
@@ -2559,7 +2560,7 @@ struct BlockExactArgs {
     float* p_t32;
 };
 
-constexpr int EXACT_K = 64;   // >= the widest k (56)
+constexpr int EXACT_K = 128;   // >= the widest k (120)
 
 __global__ __launch_bounds__(256) void knn_block_exact_kernel(BlockExactArgs a) {
     __shared__ double sk[4][EXACT_K], sd[4][EXACT_K], sg[4][EXACT_K];

@@ -17,7 +17,8 @@ constexpr int WAVE = 64;
 constexpr int ROW_TILE = 256;   // rows of the item matrix are padded to a multiple of this
 constexpr int COL_PAD = 32;     // feature dimension is padded to a multiple of this (floats)
 constexpr double TAU_MIN = 1e-12;
-constexpr int MAX_LIST = 64;    // widest wave-resident candidate list (one slot per lane)
+constexpr int MAX_LIST = 64;    // widest wave-resident candidate list of one slot per lane (WaveList; WaveList2 holds two)
+constexpr int MAX_KLIST = 128;  // widest k-NN candidate list (k + 8 <= 128)
 
 // ---------------------------------------------------------------- errors
 std::string& err_slot();
@@ -255,6 +256,68 @@ struct WaveList {
             }
             mask &= mask - 1;
             // drop lanes that no longer beat the tightened threshold
+            pass = pass && lex_less<T>(ck, ci, tk, ti);
+            mask &= __ballot(pass);
+        }
+    }
+};
+
+// 128-slot variant (k up to 120): slot t in (key, idx), slot 64 + t in (key2, idx2); same contract as WaveList.
+template <typename T>
+struct WaveList2 {
+    T key, key2;
+    int idx, idx2;
+    __device__ __forceinline__ void init() {
+        key = key2 = key_traits<T>::inf();
+        idx = idx2 = 0x7fffffff;
+    }
+    __device__ __forceinline__ void thr(int m, T& tk, int& ti) const {
+        if (m <= 64) {
+            tk = bcast_lane(key, m - 1);
+            ti = bcast_lane(idx, m - 1);
+        } else {
+            tk = bcast_lane(key2, m - 65);
+            ti = bcast_lane(idx2, m - 65);
+        }
+    }
+    __device__ __forceinline__ void insert(T ck, int ci) {
+        const int lane = lane_id();
+        const int pos = __popcll(__ballot(lex_less<T>(key, idx, ck, ci))) + __popcll(__ballot(lex_less<T>(key2, idx2, ck, ci)));
+        const T pk = __shfl_up(key, 1, 64), pk2 = __shfl_up(key2, 1, 64);
+        const int pi = __shfl_up(idx, 1, 64), pi2 = __shfl_up(idx2, 1, 64);
+        const T lk = bcast_lane(key, 63);      // slot 63 moves up into slot 64
+        const int li = bcast_lane(idx, 63);
+        const int g2 = 64 + lane;
+        if (g2 == pos) {
+            key2 = ck;
+            idx2 = ci;
+        } else if (g2 > pos) {
+            key2 = lane == 0 ? lk : pk2;
+            idx2 = lane == 0 ? li : pi2;
+        }
+        if (lane == pos) {
+            key = ck;
+            idx = ci;
+        } else if (lane > pos) {
+            key = pk;
+            idx = pi;
+        }
+    }
+    __device__ __forceinline__ void offer(int m, T ck, int ci, bool valid) {
+        T tk;
+        int ti;
+        thr(m, tk, ti);
+        bool pass = valid && lex_less<T>(ck, ci, tk, ti);
+        unsigned long long mask = __ballot(pass);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            const T bk = bcast_lane(ck, src);
+            const int bi = bcast_lane(ci, src);
+            if (lex_less<T>(bk, bi, tk, ti)) {
+                insert(bk, bi);
+                thr(m, tk, ti);
+            }
+            mask &= mask - 1;
             pass = pass && lex_less<T>(ck, ci, tk, ti);
             mask &= __ballot(pass);
         }

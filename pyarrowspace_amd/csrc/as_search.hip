@@ -677,13 +677,31 @@ __global__ __launch_bounds__(256) void rsel_filter_kernel(SelArgs<T> a, const RS
 }
 
 // ------------------------------------------------------------------ list path (overflow fallback): wavefront-shuffle partial lists
+// W = 1: lists of 64 slots (WaveList), W = 2: of 128 (WaveList2; k above 56)
+template <typename T, int W>
+struct wave_list_of { typedef WaveList<T> type; };
 template <typename T>
+struct wave_list_of<T, 2> { typedef WaveList2<T> type; };
+template <typename T>
+__device__ __forceinline__ void list_store(const WaveList<T>& l, T* k, int* i, size_t at, int lane) {
+    k[at * 64 + lane] = l.key;
+    i[at * 64 + lane] = l.idx;
+}
+template <typename T>
+__device__ __forceinline__ void list_store(const WaveList2<T>& l, T* k, int* i, size_t at, int lane) {
+    k[at * 128 + lane] = l.key;
+    i[at * 128 + lane] = l.idx;
+    k[at * 128 + 64 + lane] = l.key2;
+    i[at * 128 + 64 + lane] = l.idx2;
+}
+
+template <typename T, int W>
 __global__ __launch_bounds__(256) void knn_partial_kernel(SelArgs<T> a) {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     const double nq = a.info->nq;
-    WaveList<T> lst;
+    typename wave_list_of<T, W>::type lst;
     lst.init();
     int npass = 0;
     for (int64_t base = a.r0 + gw * 64; base < a.r1; base += nw * 64) {
@@ -701,8 +719,7 @@ __global__ __launch_bounds__(256) void knn_partial_kernel(SelArgs<T> a) {
     }
     npass = wave_sum(npass);
     if (lane == 0 && npass) atomicAdd(&a.info_w->knn_total, npass);
-    a.pkey[gw * 64 + lane] = lst.key;
-    a.pidx[gw * 64 + lane] = lst.idx;
+    list_store(lst, a.pkey, a.pidx, (size_t)gw, lane);
 }
 
 template <typename T>
@@ -723,32 +740,38 @@ __global__ __launch_bounds__(256) void score_partial_kernel(SelArgs<T> a) {
     a.pidx[gw * 64 + lane] = lst.idx;
 }
 
-// merge nlists partial lists (64 slots each) down to one sorted list in LDS (fk, fi)
-template <typename T>
+// merge nlists partial lists (64 W slots each) down to one sorted list in LDS (fk, fi)
+template <typename T, int W = 1>
 __device__ __forceinline__ void merge_partials(const T* pkey, const int* pidx, int nlists, int M, T* wk, int* wi, T* fk,
                                                int* fi, int* fcount) {
     const int lane = lane_id(), w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    WaveList<T> lst;
+    typename wave_list_of<T, W>::type lst;
     lst.init();
     for (int p = w; p < nlists; p += nwv) {
-        const T k = pkey[(size_t)p * 64 + lane];
-        const int i = pidx[(size_t)p * 64 + lane];
-        lst.offer(M, k, i, i != 0x7fffffff);
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const T k = pkey[(size_t)p * 64 * W + 64 * u + lane];
+            const int i = pidx[(size_t)p * 64 * W + 64 * u + lane];
+            lst.offer(M, k, i, i != 0x7fffffff);
+        }
     }
-    wk[w * 64 + lane] = lst.key;
-    wi[w * 64 + lane] = lst.idx;
+    list_store(lst, wk, wi, (size_t)w, lane);
     __syncthreads();
     if (w == 0) {
-        WaveList<T> fin;
+        typename wave_list_of<T, W>::type fin;
         fin.init();
         for (int p = 0; p < nwv; ++p) {
-            const T k = wk[p * 64 + lane];
-            const int i = wi[p * 64 + lane];
-            fin.offer(M, k, i, i != 0x7fffffff);
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                const T k = wk[p * 64 * W + 64 * u + lane];
+                const int i = wi[p * 64 * W + 64 * u + lane];
+                fin.offer(M, k, i, i != 0x7fffffff);
+            }
         }
-        fk[lane] = fin.key;
-        fi[lane] = fin.idx;
-        const int c = __popcll(__ballot(lane < M && fin.idx != 0x7fffffff));
+        list_store(fin, fk, fi, 0, lane);
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < W; ++u) c += __popcll(__ballot(64 * u + lane < M && fi[64 * u + lane] != 0x7fffffff));
         if (lane == 0) *fcount = c;
     }
     __syncthreads();
@@ -1020,25 +1043,25 @@ struct FinishArgs {
 __device__ __forceinline__ void lambda_from_sorted(int cnt, const double* s_dist, const double* s_gy, const double* s_deg,
                                                    const double* s_ny, int metric, int kernel, double sigma, double p,
                                                    double tau0, QInfo* info) {
+    // lane t owns neighbours t and 64 + t (k up to 120); every sum adds a lane's two terms, then runs the fixed butterfly
     const int lane = lane_id();
     const double nq = info->nq;
     const double nyq = metric == AS_METRIC_L2 ? nq : (nq > 0.0 ? 1.0 : 0.0);
-    const bool on = lane < cnt;
-    const double at = on ? edge_weight(s_dist[lane], sigma, p, kernel) : 0.0;
-    const double degq = wave_sum(at);
+    const bool on0 = lane < cnt, on1 = 64 + lane < cnt;
+    const double at0 = on0 ? edge_weight(s_dist[lane], sigma, p, kernel) : 0.0;
+    const double at1 = on1 ? edge_weight(s_dist[64 + lane], sigma, p, kernel) : 0.0;
+    const double degq = wave_sum(at0 + at1);
     double lam = 0.0;
     if (cnt > 0 && nyq > 0.0 && degq > 0.0) {
-        double ev = 0.0;
-        if (on) {
-            const double dj = s_deg[lane] + at;
-            ev = edge_energy(at, metric, s_dist[lane], s_gy[lane], degq, dj, nyq, s_ny[lane]);
-        }
-        const double S = wave_sum(ev);
+        double ev0 = 0.0, ev1 = 0.0;
+        if (on0) ev0 = edge_energy(at0, metric, s_dist[lane], s_gy[lane], degq, s_deg[lane] + at0, nyq, s_ny[lane]);
+        if (on1) ev1 = edge_energy(at1, metric, s_dist[64 + lane], s_gy[64 + lane], degq, s_deg[64 + lane] + at1, nyq, s_ny[64 + lane]);
+        const double S = wave_sum(ev0 + ev1);
         const double Eq = 0.5 * S / nyq;
         double Gq = 0.0;
         if (S > 0.0) {
-            const double r = ev / S;
-            Gq = wave_sum(r * r);
+            const double r0 = ev0 / S, r1 = ev1 / S;
+            Gq = wave_sum(r0 * r0 + r1 * r1);
             Gq = Gq < 0.0 ? 0.0 : (Gq > 1.0 ? 1.0 : Gq);
         }
         lam = tau0 * (Eq / (Eq + tau0)) + (1.0 - tau0) * Gq;
@@ -1074,15 +1097,17 @@ __device__ __forceinline__ void knn_finish_body(FinishArgs a, char* smem, const 
         for (int64_t c = threadIdx.x; c < a.dp; c += blockDim.x) qs[c] = a.q64[c];
         qx = qs;
     }
-    __shared__ T fk[64];
-    __shared__ int fi[64];
-    __shared__ double ek[64], ed[64], eg[64], sk2[64];
-    __shared__ double l_dist[64], l_gy[64], l_deg[64], l_ny[64];
+    constexpr int KL = MAX_KLIST;   // widest list: 128 candidates (k up to 120), two per lane where a wave owns the list
+    __shared__ T fk[KL];
+    __shared__ int fi[KL];
+    __shared__ double ek[KL], ed[KL], eg[KL], sk2[KL];
+    __shared__ double l_dist[KL], l_gy[KL], l_deg[KL], l_ny[KL];
     __shared__ int fcount;
     const int lane = lane_id(), w = threadIdx.x >> 6;
     int total;
     if (a.from_list) {
-        merge_partials<T>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
+        if (a.M > 64) merge_partials<T, 2>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
+        else merge_partials<T, 1>(ckey, cidx, a.nlists, a.M, sk, si, fk, fi, &fcount);
         total = a.info->knn_total;
     } else {
         const int raw = a.info->knn_cnt;
@@ -1097,7 +1122,7 @@ __device__ __forceinline__ void knn_finish_body(FinishArgs a, char* smem, const 
     bool complete = false;   // the list below was chosen among ALL candidates by their exact keys: nothing to prove
     if (a.exhaustive && !a.from_list && !a.thresholded && a.info->knn_cnt <= CAND_CAP && total > a.M) {
         // Every row inside the eps bound is in the buffer.  Evaluate them all exactly, 64 per round, and keep the
-        // (up to) 64 smallest by (key64, index): the answer cannot depend on how fp32 ordered near-ties.
+        // (up to) KL smallest by (key64, index): the answer cannot depend on how fp32 ordered near-ties.
         double* xk = (double*)(pi + PRUNE_CAP);   // CAND_CAP exact keys
         __shared__ double t_sq[64], t_dot[64];
         __shared__ int s_npass;
@@ -1125,25 +1150,30 @@ __device__ __forceinline__ void knn_finish_body(FinishArgs a, char* smem, const 
             np_l += 1;
             int rank = 0;
             for (int s2 = 0; s2 < total; ++s2) rank += lex_less<double>(xk[s2], si[s2], kk, si[t]) ? 1 : 0;
-            if (rank < 64) fi[rank] = si[t];
+            if (rank < KL) fi[rank] = si[t];
         }
         if (np_l) atomicAdd(&s_npass, np_l);
         __syncthreads();
-        if (threadIdx.x == 0) fcount = s_npass < 64 ? s_npass : 64;
+        if (threadIdx.x == 0) fcount = s_npass < KL ? s_npass : KL;
         __syncthreads();
         complete = true;
     }
     const int Mp = fcount;
     // the selected candidates' degrees / norms: in flight under the exact evaluation instead of behind it
-    double pre_deg = 0.0, pre_ny = 0.0;
-    if (w == 0 && lane < Mp) {
-        pre_deg = a.deg ? a.deg[fi[lane] + a.goff] : 0.0;
-        pre_ny = a.ny ? a.ny[fi[lane] + a.goff] : 0.0;
+    double pre_deg[2] = {0.0, 0.0}, pre_ny[2] = {0.0, 0.0};
+    if (w == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (64 * u + lane < Mp) {
+                pre_deg[u] = a.deg ? a.deg[fi[64 * u + lane] + a.goff] : 0.0;
+                pre_ny[u] = a.ny ? a.ny[fi[64 * u + lane] + a.goff] : 0.0;
+            }
     }
-    exact_eval_all(a.x32, a.x64, qx, a.d, a.dp, fi, Mp, ek, eg);
+    exact_eval_all(a.x32, a.x64, qx, a.d, a.dp, fi, Mp < 64 ? Mp : 64, ek, eg);
+    if (Mp > 64) exact_eval_all(a.x32, a.x64, qx, a.d, a.dp, fi + 64, Mp - 64, ek + 64, eg + 64);   // (block-uniform)
     __syncthreads();
     AS_STAMP(2);
-    if (threadIdx.x < Mp) {
+    if ((int)threadIdx.x < Mp) {
         const int t = threadIdx.x;
         const double sq = ek[t], dot = eg[t];
         if (a.metric == AS_METRIC_L2) {
@@ -1160,17 +1190,26 @@ __device__ __forceinline__ void knn_finish_body(FinishArgs a, char* smem, const 
     __syncthreads();
     if (w != 0) return;   // (of the body: the other waves have nothing to do with the ranking)
     AS_STAMP(3);
-    // rank by (key64, idx): one candidate per lane
-    const bool have = lane < Mp;
-    const double myk = have ? ek[lane] : 0.0;
-    const int myi = have ? fi[lane] : 0x7fffffff;
-    int rank = 0;
-    for (int s = 0; s < Mp; ++s) rank += lex_less<double>(ek[s], fi[s], myk, myi) ? 1 : 0;
-    if (have) sk2[rank] = myk;
-    const bool pass = have && myk <= a.epskey;
-    const int npass = __popcll(__ballot(pass));
+    // rank by (key64, idx): candidates lane and 64 + lane per lane
+    bool have[2], sel[2];
+    double myk[2], mydeg[2], myny[2];
+    int myi[2], rank[2];
+    int npass = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = 64 * u + lane;
+        have[u] = t < Mp;
+        myk[u] = have[u] ? ek[t] : 0.0;
+        myi[u] = have[u] ? fi[t] : 0x7fffffff;
+        rank[u] = 0;
+        for (int s = 0; s < Mp; ++s) rank[u] += lex_less<double>(ek[s], fi[s], myk[u], myi[u]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (have[u]) sk2[rank[u]] = myk[u];
+        npass += __popcll(__ballot(have[u] && myk[u] <= a.epskey));
+    }
     const int cnt = npass < a.k ? npass : (int)a.k;
-    const bool sel = pass && rank < a.k;
     if (a.recs) {
         for (int64_t t = lane; t < a.k; t += 64) {
             as_knn_rec r;
@@ -1182,34 +1221,42 @@ __device__ __forceinline__ void knn_finish_body(FinishArgs a, char* smem, const 
     }
     if (a.o_idx)
         for (int64_t t = lane; t < a.k; t += 64) a.o_idx[t] = -1;
-    const double mydeg = sel ? pre_deg : 0.0;
-    const double myny = sel ? pre_ny : 0.0;
-    if (sel) {
-        if (a.recs) {
-            as_knn_rec r;
-            r.idx = myi + a.goff;
-            r.key = myk;
-            r.dist = ed[lane];
-            r.gy = eg[lane];
-            r.deg = mydeg;
-            r.ny = myny;
-            a.recs[rank] = r;
-        }
-        if (a.o_idx) {
-            a.o_idx[rank] = myi;
-            a.o_key[rank] = myk;
-            a.o_dist[rank] = ed[lane];
-            a.o_gy[rank] = eg[lane];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = 64 * u + lane;
+        sel[u] = have[u] && myk[u] <= a.epskey && rank[u] < a.k;
+        mydeg[u] = sel[u] ? pre_deg[u] : 0.0;
+        myny[u] = sel[u] ? pre_ny[u] : 0.0;
+        if (sel[u]) {
+            if (a.recs) {
+                as_knn_rec r;
+                r.idx = myi[u] + a.goff;
+                r.key = myk[u];
+                r.dist = ed[t];
+                r.gy = eg[t];
+                r.deg = mydeg[u];
+                r.ny = myny[u];
+                a.recs[rank[u]] = r;
+            }
+            if (a.o_idx) {
+                a.o_idx[rank[u]] = myi[u];
+                a.o_key[rank[u]] = myk[u];
+                a.o_dist[rank[u]] = ed[t];
+                a.o_gy[rank[u]] = eg[t];
+            }
         }
     }
     AS_STAMP(4);
-    if (a.fuse && sel) {
-        // lane order of the sums below = (key64, index) rank: fixed by the data alone, like the ascending-index order
-        // it replaces (64 readlane/ballot rounds, 2.3 us), and the same in q_lambda_kernel
-        l_dist[rank] = ed[lane];
-        l_gy[rank] = eg[lane];
-        l_deg[rank] = mydeg;
-        l_ny[rank] = myny;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (a.fuse && sel[u]) {
+            // order of the sums below = (key64, index) rank: fixed by the data alone, and the same in q_lambda_kernel
+            const int t = 64 * u + lane;
+            l_dist[rank[u]] = ed[t];
+            l_gy[rank[u]] = eg[t];
+            l_deg[rank[u]] = mydeg[u];
+            l_ny[rank[u]] = myny[u];
+        }
     }
     AS_LDS_FENCE();
     if (lane == 0) {
@@ -1247,8 +1294,8 @@ __device__ __forceinline__ void q_lambda_body(const as_knn_rec* __restrict__ rec
 #define recs_at(t) recs0[((t) / per) * rstride + ((t) % per)]
     __shared__ double r_key[REC_CAP];
     __shared__ int r_idx[REC_CAP];
-    __shared__ double l_dist[64], l_gy[64], l_deg[64], l_ny[64];
-    __shared__ int l_pos[64];
+    __shared__ double l_dist[MAX_KLIST], l_gy[MAX_KLIST], l_deg[MAX_KLIST], l_ny[MAX_KLIST];
+    __shared__ int l_pos[MAX_KLIST];
     const int lane = lane_id();
     const int mm = (int)(m < REC_CAP ? m : REC_CAP);
     for (int t = lane; t < mm; t += 64) {
@@ -1264,7 +1311,7 @@ __device__ __forceinline__ void q_lambda_body(const as_knn_rec* __restrict__ rec
         if (r_idx[t] == 0x7fffffff) continue;
         int rank = 0;
         for (int s = 0; s < mm; ++s) rank += lex_less<double>(r_key[s], r_idx[s], r_key[t], r_idx[t]) ? 1 : 0;
-        if (rank < k && rank < 64) {
+        if (rank < k && rank < MAX_KLIST) {
             l_pos[rank] = t;
             cnt_l += 1;
         }
@@ -1272,12 +1319,12 @@ __device__ __forceinline__ void q_lambda_body(const as_knn_rec* __restrict__ rec
     const int cnt = wave_sum(cnt_l);
     AS_LDS_FENCE();
     // lane order = (key, index) rank, as in knn_finish_kernel
-    if (lane < cnt) {
-        const as_knn_rec r = recs_at(l_pos[lane]);
-        l_dist[lane] = r.dist;
-        l_gy[lane] = r.gy;
-        l_deg[lane] = r.deg;
-        l_ny[lane] = r.ny;
+    for (int t = lane; t < cnt; t += 64) {
+        const as_knn_rec r = recs_at(l_pos[t]);
+        l_dist[t] = r.dist;
+        l_gy[t] = r.gy;
+        l_deg[t] = r.deg;
+        l_ny[t] = r.ny;
     }
 #undef recs_at
     AS_LDS_FENCE();
@@ -1711,6 +1758,7 @@ static int list_width(int64_t k) {
     const int64_t need = k + 8;
     if (need <= 32) return 32;
     if (need <= 64) return 64;
+    if (need <= MAX_KLIST) return MAX_KLIST;   // two candidates per lane where one wave owns a list (k up to 120)
     return -1;
 }
 
@@ -1816,13 +1864,15 @@ static as_status run_knn(as_query* q, double eps, int64_t exclude, int fuse_lamb
         if (q->exact) {
             SelArgs<double> a = make_sel<double>(q, q->dots64, q->Mk, exclude);
             a.epskey = epskey; a.coef = f.coef;
-            hipLaunchKernelGGL(knn_partial_kernel<double>, dim3(grid), dim3(256), 0, st, a);
+            if (q->Mk > 64) hipLaunchKernelGGL((knn_partial_kernel<double, 2>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((knn_partial_kernel<double, 1>), dim3(grid), dim3(256), 0, st, a);
             f.ck = q->pkey; f.ci = q->pidx;
             hipLaunchKernelGGL(knn_finish_kernel<double>, dim3(1), dim3(1024), finish_lds<double>(), st, f);
         } else {
             SelArgs<float> a = make_sel<float>(q, q->dots32, q->Mk, exclude);
             a.epskey = epskey; a.coef = f.coef;
-            hipLaunchKernelGGL(knn_partial_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+            if (q->Mk > 64) hipLaunchKernelGGL((knn_partial_kernel<float, 2>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((knn_partial_kernel<float, 1>), dim3(grid), dim3(256), 0, st, a);
             f.ck = q->pkey; f.ci = q->pidx;
             hipLaunchKernelGGL(knn_finish_kernel<float>, dim3(1), dim3(1024), finish_lds<float>(), st, f);
         }
@@ -2127,8 +2177,8 @@ static as_status query_alloc(as_query* q) {
     q->ss.qin = sp->d;
     q->ss.knn = std::max<int64_t>(q->k, 1);
     q->ss.hits = q->topk + 1;
-    AS_HIP(hipMalloc(&q->pkey, sizeof(double) * (size_t)q->nwaves * 64));
-    AS_HIP(hipMalloc(&q->pidx, sizeof(int) * (size_t)q->nwaves * 64));
+    AS_HIP(hipMalloc(&q->pkey, sizeof(double) * (size_t)q->nwaves * MAX_KLIST));
+    AS_HIP(hipMalloc(&q->pidx, sizeof(int) * (size_t)q->nwaves * MAX_KLIST));
     AS_HIP(hipMalloc(&q->ckey_k, sizeof(double) * CAND_CAP * C));
     AS_HIP(hipMalloc(&q->cidx_k, sizeof(int) * CAND_CAP * C));
     AS_HIP(hipMalloc(&q->ckey_s, sizeof(double) * CAND_CAP * C));

@@ -40,7 +40,7 @@ def shard_bounds(n: int, world: int) -> list[int]:
 
 def check_world_limits(graph_params, world: int):
     """A query merges world * k neighbour records and world * (topk + 1) hit records in one workgroup: refuse a
-    combination beyond the library's capacities (512 and 8 208: e.g. k = 56 on 10 ranks) before anything is built."""
+    combination beyond the library's capacities (512 and 8 208: e.g. k = 120 on 5 ranks) before anything is built."""
     from . import _lib
     L = _lib.load()
     gp = graph_params or {}
@@ -139,7 +139,7 @@ class HipEngine:
         torch = self.torch
         self.M = int(self.L.as_knn_list_width(int(self.gp.k)))
         if self.M < 0:
-            raise ValueError(f"graph_params['k']={int(self.gp.k)} exceeds the supported maximum of 56")
+            raise ValueError(f"graph_params['k']={int(self.gp.k)} exceeds the supported maximum of 120")
         dev = torch.device("cuda", self.op.device)
         rows, M = max(self.n, 1), self.M
         self.p_key = torch.zeros((2, rows, M), dtype=torch.float64, device=dev)
@@ -594,12 +594,18 @@ class ShardedIndex:
         ARROWSPACE_PY_COLLECTIVES=1 keeps the torch.distributed path (A/B runs)."""
         import os
         e = self.engine
-        if not (self.library_exchange and self._collective() and hasattr(e, "comm_create") and e.comm_available()) or os.environ.get("ARROWSPACE_PY_COLLECTIVES"):
+        if not (self.library_exchange and self._collective() and hasattr(e, "comm_create")) or os.environ.get("ARROWSPACE_PY_COLLECTIVES"):
             return
         if self.dist.get_backend(self.group) != "nccl":
             return
         torch = self.torch
         dev = torch.device("cuda", e.op.device)
+        # as_comm_create is collective: every rank must be able to take part (a rank without librccl would leave the others
+        # waiting in ncclCommInitRank) -- agree first
+        ok = torch.tensor([1 if e.comm_available() else 0], dtype=torch.int32, device=dev)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            return
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         if self.rank == 0:
             uid.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))

@@ -158,7 +158,7 @@ def test_limits_are_reported_as_value_errors():
     a, g = asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 5, "topk": 2000, "p": 2.0}, X)   # topk > nitems is clamped
     assert len(a.search(np.ascontiguousarray(X[0]), g, 1.0)) == 300
     with pytest.raises(ValueError, match="k"):
-        asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 80, "topk": 5, "p": 2.0}, X)
+        asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 130, "topk": 5, "p": 2.0}, X)
     Y = clustered(1500, 16, nclust=3, seed=1)
     with pytest.raises(ValueError, match="topk"):   # refused before any upload or GPU work, not at the first search
         asp.ArrowSpaceBuilder.build({"eps": 0.8, "k": 5, "topk": 1300, "p": 2.0}, Y)

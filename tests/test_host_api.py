@@ -113,11 +113,11 @@ def test_sharded_index_refuses_record_counts_beyond_the_merge_capacity(asp):
 def test_slice_message_sections_tile_the_flat_buffer():
     """The symmetric ring's slice message is ONE flat fp64 buffer whose sections (keys, distances, y.y, ids, counts,
     bounds) the library writes in place: contiguous views that do not overlap, cover the buffer, and are 8-byte aligned,
-    for odd row counts and both list widths."""
+    for odd row counts and all list widths."""
     import torch
 
     from pyarrowspace_amd.dist import HipEngine
-    for M in (32, 64):
+    for M in (32, 64, 128):
         for n in (1, 2, 3, 7, 128, 1001):
             e = HipEngine.__new__(HipEngine)
             e.torch, e.M = torch, M

@@ -39,7 +39,7 @@ def make(rng, n, d):
         D = 1 - np.maximum(0, (S @ S.T) / np.outer(nn, nn))
     dv = D[np.triu_indices(m, 1)]
     eps = float(np.quantile(dv, float(rng.choice([0.0005, 0.002, 0.01, 0.05, 0.3])))) + 1e-12
-    k = int(rng.choice([1, 4, 10, 25, 40, 56]))
+    k = int(rng.choice([1, 4, 10, 25, 40, 56, 100]))
     gp = {"eps": eps, "k": k, "topk": int(rng.choice([1, 5, 15, 64, 200])), "p": float(rng.choice([1.0, 2.0])),
           "sigma": None if rng.random() < 0.5 else eps * float(rng.uniform(0.3, 2.0)), "metric": metric,
           "kernel": str(rng.choice(["gaussian", "rational"]))}

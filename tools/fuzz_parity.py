@@ -26,10 +26,10 @@ def gen_case(rng, case):
         d = int(rng.choice([3, 16, 32, 64]))
     metric = str(rng.choice(["l2", "cosine"]))
     kernel = str(rng.choice(["gaussian", "rational"]))
-    k = int(rng.integers(1, min(30, n) + 1)) if rng.random() < 0.9 else int(min(56, n))
+    k = int(rng.integers(1, min(30, n) + 1)) if rng.random() < 0.9 else int(min(int(rng.choice([56, 57, 100, 120])), n))
     topk = int(rng.integers(1, 41)) if rng.random() < 0.9 else int(rng.choice([57, 100, 200, 1024]))
     if edgy:
-        k = int(rng.choice([1, min(n - 1, 55), min(n, 56)])) if n > 1 else 1
+        k = int(rng.choice([1, min(n - 1, 55), min(n, 56), min(n, 57), min(n, 120)])) if n > 1 else 1
         topk = int(rng.choice([1, 56, 57, 64, 65, 511, 512, 513, n - 1, n, n + 1, 1023, 1024]))
         topk = max(1, min(topk, 1024))
     p = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
