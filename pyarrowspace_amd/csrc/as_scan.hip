@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
     int npend = 0;       // SC: entries of the wave's pending list
     float thr_last = -3.0e38f;   // SC: the threshold of the last chunk that read the histogram
     bool thr_known = false;
+    int jb_last = -1;
     int sc_over = 0;     // SC: the list overflowed (the wave reports -1 candidates: the host takes the threshold chain)
     for (int t = 0; t <= rounds; ++t) {
         int64_t base;
@@ -602,7 +603,10 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         // SC: the histogram as the other waves have left it (sc1: past this XCD's L2), consumed at the chunk's end -- from
         // the wave's third chunk on: a read issued at the start of the second chunk arrives right behind the burst of
         // publications that ends every wave's first chunk, and queues behind it (in order in front of the row DMAs)
-        const bool hread = SC && t >= 2 && !(pre.sc_dbg & 2);
+        // ... and then ever more rarely (chunks 2, 3, 5, 9, 17, ...): the read comes back later than a row's DMA and every
+        // operation behind it retires behind it -- six reads per wave cost the 1M x 768 scan 8 us, and the bound hardly
+        // moves once the first quarter of the rows has been seen
+        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0) && !(pre.sc_dbg & 2);
         if (hread)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
                                              (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 16);
@@ -654,13 +658,13 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             prefilter_f32(pre, row, mydot, aux, nq32, inq32, full);
         }
         if (SC) {
-            int jb;
-            const float bedge = sc_bound(hread ? lds_read1u(hx0 + lane * 4) : 0u, pre.sc_m, lane, jb);
-            const float thr = bedge - pre.sc_w;
-            if (hread) {
-                thr_last = thr;
+            int jb = jb_last;
+            if (hread) {   // (between reads the wave keeps the bound of its last one)
+                thr_last = sc_bound(lds_read1u(hx0 + lane * 4), pre.sc_m, lane, jb) - pre.sc_w;
+                jb_last = jb;
                 thr_known = true;
             }
+            const float thr = thr_last;
             const bool valid = lane < cnt && row < pre.n;
             const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
             const float c = mydot * inr * inq32;

@@ -1202,7 +1202,8 @@ __device__ __forceinline__ void knn_finish_body(FinishArgs a, char* smem, const 
         myk[u] = have[u] ? ek[t] : 0.0;
         myi[u] = have[u] ? fi[t] : 0x7fffffff;
         rank[u] = 0;
-        for (int s = 0; s < Mp; ++s) rank[u] += lex_less<double>(ek[s], fi[s], myk[u], myi[u]) ? 1 : 0;
+        if (64 * u < Mp)   // (wave-uniform: lists of up to 64 candidates skip the second half altogether)
+            for (int s = 0; s < Mp; ++s) rank[u] += lex_less<double>(ek[s], fi[s], myk[u], myi[u]) ? 1 : 0;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
