@@ -610,8 +610,17 @@ class ShardedIndex:
         if self.rank == 0:
             uid.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))
         self.dist.broadcast(uid, self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-        e.comm_create(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
-        self._lib_comm = True
+        try:
+            e.comm_create(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
+            made = 1
+        except (RuntimeError, ValueError) as err:   # a rank that cannot join: every rank must learn it
+            made = 0
+            if self.rank == 0:
+                import sys
+                print("[pyarrowspace] library-side exchange not available (%s): torch.distributed collectives stay" % err, file=sys.stderr)
+        ok.fill_(made)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
+        self._lib_comm = int(ok.item()) == 1     # all ranks or none: the two paths issue different collectives
 
     # ---- collectives
     def _collective(self):
