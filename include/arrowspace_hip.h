@@ -133,13 +133,16 @@ as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_
  * bound of what was turned away (-inf when its buffer overflowed: the item fails its proof and takes the second
  * round).  as_knn_thresholds derives such thresholds from a rank's folded list (an upper bound of each row's M-th
  * smallest fp32 key over all columns: its M-th exact key so far + the error bound; +inf while the list is not full);
- * nmax_all = the largest squared norm of the whole index.  Scratch: the visiting block is taken in chunks of column
+ * nmax_all = the largest squared norm of the whole index.  row_thr_dev (may be NULL): the same kind of thresholds for the
+ * OWN rows, indexed by the row's number in sp ([nitems]) -- a row then starts every unit from min(eps bound, threshold)
+ * instead of the eps bound (an eps that admits every pair leaves only the thresholds to prune with).  Scratch: the
+ * visiting block is taken in chunks of column
  * tiles whose transposed buffers (8 KiB per item at M = 64) fit in an eighth of the free memory, at most 16 GB. */
 as_status as_knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
                             int64_t col_tile_begin, int64_t col_tile_end, int64_t row_goff, int64_t col_goff,
-                            const float* col_thr_dev, double* p_key_dev, double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev,
-                            int32_t* p_cnt_dev, float* p_t32_dev, double* q_key_dev, double* q_dist_dev, double* q_gy_dev,
-                            int32_t* q_idx_dev, int32_t* q_cnt_dev, float* q_t32_dev);
+                            const float* col_thr_dev, const float* row_thr_dev, double* p_key_dev, double* p_dist_dev, double* p_gy_dev,
+                            int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev, double* q_key_dev, double* q_dist_dev,
+                            double* q_gy_dev, int32_t* q_idx_dev, int32_t* q_cnt_dev, float* q_t32_dev);
 as_status as_knn_thresholds(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, double nmax_all,
                             const double* r_key_dev, const int32_t* r_cnt_dev, float* out_thr_dev);
 as_status as_knn_merge(const as_space* sp, const as_graph_params* gp, int64_t row_begin, int64_t row_end, int32_t nblocks,

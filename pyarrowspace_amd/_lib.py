@@ -110,7 +110,7 @@ def load():
         "as_knn_block": (i32, [vp, vp, pgp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
         "as_record_capacity": (i32, [i32]),
         "as_knn_block_exact": (i32, [vp, vp, pgp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]),
-        "as_knn_block_pair": (i32, [vp, vp, pgp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "as_knn_block_pair": (i32, [vp, vp, pgp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "as_knn_thresholds": (i32, [vp, pgp, i64, i64, f64, vp, vp, vp]),
         "as_knn_merge": (i32, [vp, pgp, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
         "as_knn_fold": (i32, [vp, pgp, i64, i64, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -344,7 +344,7 @@ as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_
 
 as_status as_knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
                             int64_t col_tile_begin, int64_t col_tile_end, int64_t row_goff, int64_t col_goff, const float* col_thr_dev,
-                            double* p_key_dev, double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev,
+                            const float* row_thr_dev, double* p_key_dev, double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev,
                             double* q_key_dev, double* q_dist_dev, double* q_gy_dev, int32_t* q_idx_dev, int32_t* q_cnt_dev, float* q_t32_dev) {
     if (!sp || !cols || !p_key_dev || !p_dist_dev || !p_gy_dev || !p_idx_dev || !p_cnt_dev || !p_t32_dev || !q_key_dev || !q_dist_dev ||
         !q_gy_dev || !q_idx_dev || !q_cnt_dev || !q_t32_dev) {
@@ -364,7 +364,7 @@ as_status as_knn_block_pair(const as_space* sp, const as_space* cols, const as_g
     }
     AS_HIP(hipSetDevice(sp->device));
     const double t0 = now_s();
-    const as_status s = knn_block_pair(sp, cols, &r, row_begin, row_end, col_tile_begin, col_tile_end, row_goff, col_goff, col_thr_dev, M,
+    const as_status s = knn_block_pair(sp, cols, &r, row_begin, row_end, col_tile_begin, col_tile_end, row_goff, col_goff, col_thr_dev, row_thr_dev, M,
                                        p_key_dev, p_dist_dev, p_gy_dev, p_idx_dev, p_cnt_dev, p_t32_dev, q_key_dev, q_dist_dev, q_gy_dev,
                                        q_idx_dev, q_cnt_dev, q_t32_dev);
     sp->kstats[1] += now_s() - t0;

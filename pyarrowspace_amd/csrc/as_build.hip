@@ -2281,7 +2281,7 @@ as_status knn_thresholds(const as_space* sp, int64_t r0, int64_t r1, int M, doub
 // pair_chunk: the column tiles [ca, cb) of the visiting block -- its scratch (transposed buffers of 16 M entries per
 // visiting item, 8 KiB each at M = 64) covers the chunk's items only.
 static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ca,
-                            int64_t cb, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
+                            int64_t cb, int64_t row_goff, int64_t col_goff, const float* col_thr, const float* row_thr, int M, double* p_key, double* p_dist,
                             double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
                             int32_t* q_idx, int32_t* q_cnt, float* q_t32) {
     hipStream_t st = sp->stream;
@@ -2334,6 +2334,7 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     ka.units = d_units; ka.nunits = units; ka.unit_ctr = (int*)tr_cnt + ncc; ka.t_cnt = (int*)tr_cnt - j0;
     ka.t_key = (float*)tr_key - (size_t)j0 * T_CAP; ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP; ka.t_cap = T_CAP;
     ka.t_all = 1; ka.thr_col = col_thr;
+    ka.thr0 = row_thr;   // the own rows' thresholds (their own-block lists' bounds): what a tighter start rejects lies beyond the row's M-th key
     const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
     if (metric == AS_METRIC_L2) {
         AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
@@ -2383,7 +2384,7 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
 }
 
 as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ct0,
-                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
+                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, const float* row_thr, int M, double* p_key, double* p_dist,
                          double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
                          int32_t* q_idx, int32_t* q_cnt, float* q_t32) {
     AS_TRY(block_check(sp, cols, r0, r1, "as_knn_block_pair"));
@@ -2416,7 +2417,7 @@ as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_grap
     }
     const int64_t nchunk = (ct1 - ct0 + chunk - 1) / chunk;
     if (nchunk <= 1)
-        return pair_chunk(sp, cols, gp, r0, r1, ct0, ct1, row_goff, col_goff, col_thr, M, p_key, p_dist, p_gy, p_idx, p_cnt, p_t32, q_key, q_dist,
+        return pair_chunk(sp, cols, gp, r0, r1, ct0, ct1, row_goff, col_goff, col_thr, row_thr, M, p_key, p_dist, p_gy, p_idx, p_cnt, p_t32, q_key, q_dist,
                           q_gy, q_idx, q_cnt, q_t32);
     chunk = (ct1 - ct0 + nchunk - 1) / nchunk;   // even pieces
     dev_tmp<double> c_key, c_dist, c_gy;
@@ -2431,7 +2432,7 @@ as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_grap
     AS_HIP(hipMemsetAsync(p_cnt, 0, sizeof(int32_t) * rows, st));   // an empty running slice: no entries, nothing dropped
     for (int64_t ca = ct0; ca < ct1; ca += chunk) {
         const int64_t cb = std::min(ct1, ca + chunk);
-        AS_TRY(pair_chunk(sp, cols, gp, r0, r1, ca, cb, row_goff, col_goff, col_thr, M, c_key, c_dist, c_gy, c_idx, c_cnt, c_t32, q_key, q_dist,
+        AS_TRY(pair_chunk(sp, cols, gp, r0, r1, ca, cb, row_goff, col_goff, col_thr, row_thr, M, c_key, c_dist, c_gy, c_idx, c_cnt, c_t32, q_key, q_dist,
                           q_gy, q_idx, q_cnt, q_t32));
         // NOT the fold's error term: the chunk's bound is a raw fp32 key, as a block slice's is -- the caller's fold
         // subtracts the error once.  Here only the lists are merged and the smaller raw bound is kept.

@@ -378,8 +378,8 @@ as_status knn_block_exact(const as_space* sp, const as_space* cols, const as_gra
                           int64_t col_goff, int M, const int32_t* flag, double* p_key, double* p_dist, double* p_gy, int32_t* p_idx,
                           int32_t* p_cnt, float* p_t32);
 as_status knn_block_pair(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t ct0,
-                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, int M, double* p_key, double* p_dist,
-                         double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
+                         int64_t ct1, int64_t row_goff, int64_t col_goff, const float* col_thr, const float* row_thr, int M, double* p_key,
+                         double* p_dist, double* p_gy, int32_t* p_idx, int32_t* p_cnt, float* p_t32, double* q_key, double* q_dist, double* q_gy,
                          int32_t* q_idx, int32_t* q_cnt, float* q_t32);
 as_status knn_thresholds(const as_space* sp, int64_t r0, int64_t r1, int M, double nmax_all, const double* r_key, const int32_t* r_cnt,
                          float* out_thr);

@@ -212,7 +212,7 @@ class HipEngine:
         w = n * self.M
         return (3 * w + (w + 1) // 2 + 2 * ((n + 1) // 2),)
 
-    def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols):
+    def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols, row_thr=None):
         """Own rows [row0, row1) x the visiting block's column tiles [ct0, ct1): the own rows' slice is folded here; returns
         the visiting items' slice, packed for the way home (one flat fp64 tensor: _slice_sections)."""
         torch = self.torch
@@ -222,12 +222,15 @@ class HipEngine:
         qi.fill_(-1)
         qt.fill_(float("inf"))
         thr = col_thr.contiguous() if col_thr is not None else None
+        rthr = row_thr.contiguous() if row_thr is not None else None     # the own rows' thresholds: [self.n] fp32
+        assert rthr is None or (rthr.dtype == torch.float32 and rthr.shape[0] == self.n)
         self._fills_done()
         if self.n > 0 and ncols > 0:
             sl = [C.c_void_p(t[1].data_ptr() + row0 * t[1].stride(0) * t.element_size()) for t in
                   (self.p_key, self.p_dist, self.p_gy, self.p_idx, self.p_cnt, self.p_t32)]
             self._check(self.L.as_knn_block_pair(self.sp, h, C.byref(self.gp), row0, row1, ct0, ct1, row_goff, col_goff,
-                                                 C.c_void_p(thr.data_ptr()) if thr is not None else C.c_void_p(), *sl,
+                                                 C.c_void_p(thr.data_ptr()) if thr is not None else C.c_void_p(),
+                                                 C.c_void_p(rthr.data_ptr()) if rthr is not None else C.c_void_p(), *sl,
                                                  *[C.c_void_p(t.data_ptr()) for t in (qk, qd, qg, qi, qc, qt)]))
             if row1 > row0:
                 self._fold_rows(row0, row1, self.block_nmax(h), 1)
@@ -989,7 +992,7 @@ class ShardedIndex:
                     row0 = min(counts[q], (tq // 2) * 128)
                 else:
                     ct0, ct1 = 0, tq // 2
-            P = e.knn_block_pair(h, row0, row1, ct0, ct1, bounds[rank], bounds[src], U_all[src][: counts[src]], counts[src])
+            P = e.knn_block_pair(h, row0, row1, ct0, ct1, bounds[rank], bounds[src], U_all[src][: counts[src]], counts[src], row_thr=U)
             e.close_block(h)
             if X_shard.is_cuda:
                 torch.cuda.current_stream().synchronize()

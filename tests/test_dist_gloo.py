@@ -102,7 +102,7 @@ class OracleEngine:
     def slice_shape(self, nrows):
         return (nrows, 3 * self.prm["k"] + self._wi() // 2)
 
-    def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols):
+    def knn_block_pair(self, h, row0, row1, ct0, ct1, row_goff, col_goff, col_thr, ncols, row_thr=None):
         import torch
         k, ek = self.prm["k"], self.o._eps_key(self.prm["eps"], self.prm["metric"])
         j0, j1 = (0, ncols) if ct0 < 0 else (min(ncols, ct0 * 128), min(ncols, ct1 * 128))

@@ -137,7 +137,7 @@ def _symmetric_ring_lists(X, gp, cuts, dup_round=True):
                 else:
                     ct0, ct1 = 0, tq // 2
             h = e.open_block(blocks[src])
-            out[(r, src)] = e.knn_block_pair(h, row0, row1, ct0, ct1, cuts[r], cuts[src], U[src], counts[src])
+            out[(r, src)] = e.knn_block_pair(h, row0, row1, ct0, ct1, cuts[r], cuts[src], U[src], counts[src], row_thr=U[r])
             e.close_block(h)
         for (r, src), P in out.items():
             eng[src].fold_slice(P, nmax[r])          # the slice of src's rows that rank r computed goes home

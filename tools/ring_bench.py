@@ -11,6 +11,9 @@ from pyarrowspace_amd.dist import HipEngine, shard_bounds
 n, d, G = [int(v) for v in (sys.argv[1:4] + ["1000000", "768", "4"][len(sys.argv) - 1:])]
 X = bench.make_data(n, d, 42, torch.device("cuda", 0))
 gp = {"eps": bench.calibrate_eps(X, 25), "k": 25, "topk": 15, "p": 2.0, "sigma": None}
+if os.environ.get("RING_BENCH_EPS_ALL"):   # the reference's `eps: 10` under the cosine distance (tests/test_3_beir.py:194-200): every pair inside
+    gp = {"eps": 10.0, "k": 25, "topk": 15, "p": 2.0, "sigma": None, "metric": "cosine", "kernel": "rational"}
+seed_rows = not os.environ.get("RING_BENCH_NO_ROW_THR")
 b = shard_bounds(n, G)
 counts = [b[i + 1] - b[i] for i in range(G)]
 for mode in ("full", "symmetric"):
@@ -37,7 +40,7 @@ for mode in ("full", "symmetric"):
             if 2 * s == G:
                 tq = (counts[src] + 255) // 256 * 256 // 128
                 ct0, ct1 = 0, tq // 2
-            e.knn_block_pair(h, row0, row1, ct0, ct1, 0, b[src], U[src][: counts[src]], counts[src])
+            e.knn_block_pair(h, row0, row1, ct0, ct1, 0, b[src], U[src][: counts[src]], counts[src], row_thr=U[0] if seed_rows else None)
         e.close_block(h)
     torch.cuda.synchronize()
     t_rest = time.perf_counter() - t1
