@@ -84,6 +84,64 @@ def visible_devices():
     return n
 
 
+def live_traffic(workload_argv, timeout_s=300):
+    """HBM-side bytes per launch of the roofline kernels, measured NOW rather than read from a committed profile: two
+    child runs of this file (a short pass of the same workload: the build, 22 searches, the batched passes) under
+    rocprofv3, one --pmc pass per counter (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md's HBM section prescribes,
+    summarised and corrected by profiles/summarise.py (the x2 of 16-byte-per-lane streaming reads on gfx950).  Called
+    before this process touches the GPU; the children have the card to themselves.  Returns (dict kernel -> bytes per
+    launch, note) -- (None, why) when rocprofv3 is not on this box, is already around this process, or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already under a profiler"
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import summarise
+
+    tmp = tempfile.mkdtemp(prefix="as_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        csvs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-probe", "--no-cpu-baseline", "--steps", "20", "--warmup", "2"] + list(workload_argv)
+            with open(os.path.join(tmp, counter + ".log"), "w") as log:
+                try:
+                    rc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, timeout=timeout_s).returncode
+                except subprocess.TimeoutExpired:
+                    return None, "%s pass timed out after %d s" % (counter, timeout_s)
+            if rc != 0:
+                print("bench.py: live traffic pass (%s) failed:\n%s" % (counter, open(os.path.join(tmp, counter + ".log")).read()[-600:]), file=sys.stderr)
+                return None, "%s pass exited with %d" % (counter, rc)
+            csvs[counter] = os.path.join(tmp, counter + ".csv")
+            with open(os.devnull, "w") as null:
+                stdout, sys.stdout = sys.stdout, null
+                try:
+                    summarise.pmc(out, counter, csvs[counter])
+                finally:
+                    sys.stdout = stdout
+        with open(os.devnull, "w") as null:
+            stdout, sys.stdout = sys.stdout, null
+            try:
+                summarise.traffic(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], 0, 0, os.path.join(tmp, "traffic.json"))
+            finally:
+                sys.stdout = stdout
+        doc = json.load(open(os.path.join(tmp, "traffic.json")))
+        got = {k: v["bytes_per_launch"] for k, v in doc.items() if isinstance(v, dict) and "bytes_per_launch" in v}
+        return (got, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload run by this bench.py (2 x FETCH_SIZE KiB + WRITE_SIZE KiB, "
+                     "MI355X_MICROARCH.md HBM section)") if got else (None, "no kernel of the path in the counter output")
+    except Exception as e:      # noqa: BLE001 -- a broken profiler must not cost the measurement
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 PARITY = {
     "status": "partial",
     "pinned_by_reference": "scorer form only: README 3x3 scores to 1e-12 (README.md:69), tests/test_0.py tau=1.0 order (:28-32), "
@@ -197,11 +255,22 @@ def main():
     ap.add_argument("--cpu-build-n", type=int, nargs="*", default=[20000, 100000],
                     help="item counts the CPU all-pairs build is timed at (SURVEY section 8d: 20k and 100k)")
     ap.add_argument("--cpu-build-budget", type=float, default=90.0, help="skip a CPU build size predicted to take longer (s)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/traffic.json (when it is of this workload) instead of two rocprofv3 --pmc passes run now")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the short child pass live_traffic() profiles
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: be the launcher (nothing in this process has touched the GPU yet, and nothing will)
         sys.exit(launch(args.gpus, sys.argv[1:]))
+
+    live, live_note = None, "not attempted"
+    if "WORLD_SIZE" not in os.environ and not (args.no_live_traffic or args.traffic_probe):
+        # before this process touches the GPU: the two counter passes (children under rocprofv3) have the card to themselves
+        wl = []
+        for name in ("n", "d", "k", "topk", "tau", "eps", "metric", "kernel", "lambda_mode"):
+            wl += ["--" + name.replace("_", "-"), str(getattr(args, name))]
+        live, live_note = live_traffic(wl)
 
     import torch
 
@@ -298,7 +367,7 @@ def main():
     # (tools/staged_overhead.py: one of ~37 ms some 140 ms after the first search, torch's NCCL watchdog waking up).  They
     # are run here, outside both the build time and the W + K steps -- on EVERY path, the single-GPU one included (which
     # shows no such stall), so that the values at N = 1 and N > 1 come out of one protocol.
-    primed = 300
+    primed = 0 if args.traffic_probe else 300
     for i in range(primed):
         searcher(Q[i % len(Q)])
     for i in range(args.warmup):
@@ -377,20 +446,28 @@ def main():
     mfma_peak = MFMA_F64_PEAK_TF if feature else MFMA_F32_PEAK_TF
     build_kernel = "gram_f64_kernel" if feature else "knn_mfma_dma8_kernel<%s>" % args.metric
 
-    # HBM-side traffic per launch: not measurable inside this process (PMC counters need rocprofv3 around it) --
-    # taken from the committed profile of the same workload, profiles/traffic.json (profiles/collect.sh), and
-    # labelled so; null for any other workload
+    # HBM-side traffic per launch: PMC counters need rocprofv3 around the process -- measured by live_traffic() in two
+    # child passes at the start of this run; when that was not possible (no rocprofv3, --no-live-traffic, N > 1) taken
+    # from the committed profile of the same workload, profiles/traffic.json (profiles/collect.sh), and labelled so;
+    # null for any other workload
     traffic_scan = traffic_mfma = traffic_batch = None
+    traffic_source = None
     # rows up to 1024 floats take the LDS-DMA ring scan, wider rows the register-staged one
     scan_kernel = "scan_dma_kernel" if d <= 1024 and os.environ.get("ARROWSPACE_SCAN_VARIANT", "0") in ("", "0") else "scan_dots_f32_kernel"
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if tj["workload"] == {"n": n, "d": d} and world == 1 and args.metric == "l2" and not feature:
-            traffic_scan = tj.get(scan_kernel, {}).get("bytes_per_launch")
-            traffic_mfma = tj.get("knn_mfma_kernel", {}).get("bytes_per_launch")
-            traffic_batch = tj.get("scan_gemm_kernel", {}).get("bytes_per_launch")
-    except (OSError, KeyError, ValueError):
-        pass
+    if live:
+        traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), live.get("knn_mfma_kernel"), live.get("scan_gemm_kernel")
+        traffic_source = live_note
+    else:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj["workload"] == {"n": n, "d": d} and world == 1 and args.metric == "l2" and not feature:
+                traffic_scan = tj.get(scan_kernel, {}).get("bytes_per_launch")
+                traffic_mfma = tj.get("knn_mfma_kernel", {}).get("bytes_per_launch")
+                traffic_batch = tj.get("scan_gemm_kernel", {}).get("bytes_per_launch")
+                traffic_source = ("profiles/traffic.json (rocprofv3 --pmc passes of this workload, profiles/collect.sh); live passes: %s"
+                                  % live_note)
+        except (OSError, KeyError, ValueError):
+            pass
 
     out = {
         "metric": "queries/sec (single-query search, B=1) at N=%dx D=%d fp32; index-build sec alongside" % (n, d),
@@ -426,7 +503,7 @@ def main():
         "build_fallback_rows": bstats["fallback_rows"],
         "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
-                     "traffic_source": None if traffic_scan is None else "profiles/traffic.json (rocprofv3 --pmc passes of this workload, profiles/collect.sh)",
+                     "traffic_source": traffic_source if traffic_scan is not None else "none (live passes: %s)" % live_note,
                      "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes},
         "roofline_query": {"bound": "hbm", "achieved": query_bytes / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -11,7 +11,7 @@ for ARGS in "--n 1000000 --d 768" "--n 400000 --d 384 --k 4 --topk 2" "--n 20000
     for which in new old; do
       if [ $which = new ]; then cp gpurun_out/lib_new.so $L; else cp pyarrowspace_amd/libarrowspace_hip_old.so $L; fi
       echo -n "$ARGS $which: "
-      timeout -k 10 300 python bench.py --no-cpu-baseline --steps 400 $ARGS 2>gpurun_out/ab.err | tail -1 | python -c "$S" || { cp gpurun_out/lib_new.so $L; exit 1; }
+      timeout -k 10 300 python bench.py --no-cpu-baseline --no-live-traffic --steps 400 $ARGS 2>gpurun_out/ab.err | tail -1 | python -c "$S" || { cp gpurun_out/lib_new.so $L; exit 1; }
     done
   done
 done

@@ -4,7 +4,7 @@ set -e
 mkdir -p gpurun_out
 out=gpurun_out/sweep.jsonl
 : > $out
-run() { timeout -k 10 400 python bench.py --no-cpu-baseline --steps 100 --warmup 10 "$@" 2>/dev/null | grep '^{"metric"' >> $out; }
+run() { timeout -k 10 400 python bench.py --no-cpu-baseline --no-live-traffic --steps 100 --warmup 10 "$@" 2>/dev/null | grep '^{"metric"' >> $out; }
 run --n 400000 --d 384 --k 4 --topk 2
 run --n 200000 --d 768
 run --n 1000000 --d 768 --topk 100
