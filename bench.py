@@ -367,7 +367,7 @@ def main():
     # (tools/staged_overhead.py: one of ~37 ms some 140 ms after the first search, torch's NCCL watchdog waking up).  They
     # are run here, outside both the build time and the W + K steps -- on EVERY path, the single-GPU one included (which
     # shows no such stall), so that the values at N = 1 and N > 1 come out of one protocol.
-    primed = 0 if args.traffic_probe else 300
+    primed = 0 if args.traffic_probe else int(os.environ.get("ARROWSPACE_BENCH_PRIME", "300"))
     for i in range(primed):
         searcher(Q[i % len(Q)])
     for i in range(args.warmup):

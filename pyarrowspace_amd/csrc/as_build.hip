@@ -1376,10 +1376,22 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     const char* ev_tcap = getenv("ARROWSPACE_SYM_TCAP");
     const bool publish = !getenv("ARROWSPACE_SYM_NO_PUBLISH");
     int T_CAP = ev_tcap ? atoi(ev_tcap) : 16 * M;
-    size_t mfree = 0, mtotal = 0;
-    if (sym && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)n * T_CAP * 8.0 > 0.25 * (double)mfree) sym = false;
+    // The transposed buffers (T_CAP entries of 8 bytes per item: 8 KiB at M = 64) must fit a quarter of the free memory.
+    // When those of all items do not -- a shard of 8M rows, 64M x 768 over 8 GPUs: 64 GB -- the main pass runs in
+    // column chunks (whole pieces of L tiles, at most 7), each with the buffers of its own items only; beyond 7 chunks
+    // the full pass.
+    size_t mfree = 0;
+    auto free_now = [&]() {   // (asked again where it matters: the candidate lists below are 33 GB at 8M rows)
+        size_t f = 0, t = 0;
+        mfree = hipMemGetInfo(&f, &t) == hipSuccess ? f : 0;
+        // (rehearsal of a rank that holds five shards: pretend that little is free)
+        if (const char* ev = getenv("ARROWSPACE_SYM_FREE_GB")) mfree = std::min<size_t>(mfree, (size_t)(atof(ev) * 1e9));
+    };
+    if (sym) free_now();
+    if (sym && mfree && (double)n * T_CAP * 8.0 > 7.0 * 0.25 * (double)mfree) sym = false;
+    int Lpiece = 0, npiece = 1, nchunk = 1;
     std::vector<int4> hunits;
-    dev_tmp<int4> d_units;
+    dev_tmp<int4> d_units, d_units2;
     dev_tmp<int> tr_cnt, tr_idx;
     dev_tmp<float> tr_key, thr0;
     double sym_tiles = 0, thr_tiles = 0;
@@ -1390,7 +1402,15 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
         for (int rb = 0; rb < nrb; ++rb) total += std::max(0, ntile - rb * per);
         int L = (int)std::max<double>(8.0, std::ceil(total / (dev_cus * 16.0)));
         if ((ntile + L - 1) / L > 7) L = (ntile + 6) / 7;   // at most 7 own segments + the transposed one
+        {   // as many pieces as the main pass may need column chunks (sized for the larger buffers: the sample decides later)
+            int want = mfree ? (int)std::ceil((double)n * 32 * M * 8.0 / (0.25 * (double)mfree)) : 1;
+            if (const char* ev_ch = getenv("ARROWSPACE_SYM_CHUNKS")) want = std::max(want, atoi(ev_ch));
+            want = std::max(1, std::min(want, 7));
+            if (want > 1) L = std::max(1, std::min(L, (ntile + want - 1) / want));
+        }
         S = (ntile + L - 1) / L + 1;
+        Lpiece = L;
+        npiece = S - 1;
         for (int rb = 0; rb < nrb; ++rb) {
             const int tlo = rb * per;
             int seg = 0;
@@ -1459,30 +1479,92 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 dbg("knn_rows: threshold pass at every %dth tile: %d of %lld rows would overflow %d-entry buffers", tstride, risky,
                     (long long)rows, T_CAP);
                 if ((double)risky <= 0.005 * (double)rows) break;
-                // (when the larger buffers do not fit, the rows that overflow go to the band pass instead)
-                if (mfree && (double)n * 32 * M * 8.0 > 0.25 * (double)mfree) break;
+                // (when the larger buffers do not fit even in 7 column chunks, the rows that overflow go to the band pass instead)
+                free_now();
+                if (mfree && (double)n * 32 * M * 8.0 > 7.0 * 0.25 * (double)mfree) break;
                 tstride = 16;
                 T_CAP = 32 * M;
             }
-            AS_HIP(tr_key.alloc((size_t)n * T_CAP));
-            AS_HIP(tr_idx.alloc((size_t)n * T_CAP));
-            ka.t_key = tr_key; ka.t_idx = tr_idx; ka.t_cap = T_CAP;
+            // column chunks of the main pass: whole pieces, as few as hold their items' buffers in a quarter of the free memory
+            free_now();
+            if (mfree) nchunk = (int)std::ceil((double)n * T_CAP * 8.0 / (0.25 * (double)mfree));
+            if (const char* ev_ch = getenv("ARROWSPACE_SYM_CHUNKS")) nchunk = atoi(ev_ch);
+            nchunk = std::max(1, std::min(nchunk, npiece));
+            std::vector<int> cfirst(nchunk + 1, 0), cpiece(nchunk + 1, 0);
+            for (int c = 0; c <= nchunk; ++c) cpiece[c] = (int)((int64_t)npiece * c / nchunk);
+            cfirst[nchunk] = (int)hunits.size();
+            if (nchunk > 1) {
+                // a chunk's units must not reach into the next chunk's columns: pieces aligned to multiples of L (not to the
+                // row block's diagonal); a row block's segments count from its first piece -- at most npiece of them, as before
+                const int per = BM / BN;
+                std::vector<std::vector<int4>> byc(nchunk);
+                for (int rb = 0; rb < nrb; ++rb) {
+                    const int tlo = rb * per;
+                    if (tlo >= ntile) continue;
+                    const int p0 = tlo / Lpiece;
+                    for (int pj = p0; pj < npiece; ++pj) {
+                        const int ta = std::max(tlo, pj * Lpiece), tb = std::min(ntile, (pj + 1) * Lpiece);
+                        if (ta >= tb) continue;
+                        int c = 0;
+                        while (cpiece[c + 1] <= pj) ++c;
+                        byc[c].push_back(make_int4(rb, ta, tb, pj - p0));
+                    }
+                }
+                hunits.clear();
+                sym_tiles = 0;
+                for (int c = 0; c < nchunk; ++c) {
+                    std::stable_sort(byc[c].begin(), byc[c].end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
+                    cfirst[c] = (int)hunits.size();
+                    for (const int4& u : byc[c]) {
+                        hunits.push_back(u);
+                        sym_tiles += u.z - u.y;
+                    }
+                }
+                cfirst[nchunk] = (int)hunits.size();
+                AS_HIP(hipStreamSynchronize(st));   // (the first upload of the units is done with its source)
+                AS_HIP(d_units2.alloc(hunits.size() + 1));
+                AS_HIP(hipMemcpyAsync(d_units2, hunits.data(), sizeof(int4) * hunits.size(), hipMemcpyHostToDevice, st));
+                dbg("knn_rows: symmetric pass in %d column chunks (%.1f GB of transposed buffers for all items, %.1f GB free)", nchunk,
+                    (double)n * T_CAP * 8.0 / 1e9, (double)mfree / 1e9);
+            }
+            int64_t cmax = 0;   // items of the largest chunk
+            for (int c = 0; c < nchunk; ++c)
+                cmax = std::max<int64_t>(cmax, std::min<int64_t>(n, (int64_t)cpiece[c + 1] * Lpiece * BN) - std::min<int64_t>(n, (int64_t)cpiece[c] * Lpiece * BN));
+            if (nchunk == 1) cmax = n;
+            AS_HIP(tr_key.alloc((size_t)cmax * T_CAP));
+            AS_HIP(tr_idx.alloc((size_t)cmax * T_CAP));
+            ka.t_cap = T_CAP;
             AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));   // the pass above left its counts there
             ka.thr0 = thr0;
             ka.thr_col = thr0;
             ka.thr_pub = publish ? (float*)thr0 : nullptr;
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-            if (metric == AS_METRIC_L2)
-                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-            else
-                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-            AS_HIP(hipGetLastError());
-            // the transposed buffers become segment S - 1 of every row's candidate lists
             const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
             AS_HIP(hipFuncSetAttribute((const void*)transposed_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
-            hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt,
-                               (const float*)tr_key, (const int*)tr_idx, T_CAP, rows, S, S - 1, M, (float*)ckey, (int*)cidx, (int*)ccnt);
+            for (int c = 0; c < nchunk; ++c) {
+                // the chunk's items [j0, j1): their transposed buffers, indexed by item as if all items had one
+                const int64_t j0 = nchunk == 1 ? 0 : std::min<int64_t>(n, (int64_t)cpiece[c] * Lpiece * BN);
+                const int64_t j1 = nchunk == 1 ? n : std::min<int64_t>(n, (int64_t)cpiece[c + 1] * Lpiece * BN);
+                const int cunits = cfirst[c + 1] - cfirst[c];
+                if (cunits <= 0 || j1 <= j0) continue;
+                ka.units = (nchunk > 1 ? (int4*)d_units2 : (int4*)d_units) + cfirst[c];
+                ka.nunits = cunits;
+                ka.t_key = (float*)tr_key - (size_t)j0 * T_CAP;
+                ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP;
+                if (c) AS_HIP(hipMemsetAsync(ka.unit_ctr, 0, sizeof(int), st));
+                const int lgrid = std::min(std::min(cunits, dev_cus), grid);
+                if (metric == AS_METRIC_L2)
+                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(lgrid), dim3(512), lds8, st, ka);
+                else
+                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(lgrid), dim3(512), lds8, st, ka);
+                AS_HIP(hipGetLastError());
+                // the transposed buffers become segment S - 1 of their rows' candidate lists
+                hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((j1 - j0 + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt + j0,
+                                   (const float*)tr_key, (const int*)tr_idx, T_CAP, j1 - j0, S, S - 1, M, (float*)ckey + (size_t)j0 * S * M,
+                                   (int*)cidx + (size_t)j0 * S * M, (int*)ccnt + (size_t)j0 * S);
+                AS_HIP(hipGetLastError());
+            }
         } else if (metric == AS_METRIC_L2)
             hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
         else
@@ -1548,7 +1630,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     // caller's arrays are rows x gp->k; we write the first k slots and pad the rest
     const int M = pick_list_width(k);
     if (M < 0) {
-        set_err("graph_params['k']=%lld exceeds the supported maximum of 56 for n=%lld", (long long)gp->k, (long long)n);
+        set_err("graph_params['k']=%lld exceeds the supported maximum of 120 for n=%lld", (long long)gp->k, (long long)n);
         return AS_EUNSUPPORTED;
     }
     hipStream_t st = sp->stream;

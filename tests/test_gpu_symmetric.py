@@ -13,17 +13,25 @@ from conftest import calibrate_eps, clustered
 pytestmark = pytest.mark.gpu
 
 
-def _build(X, gp, sym):
+def _build(X, gp, sym, chunks=None):
+    """chunks: the symmetric main pass in that many column chunks (ARROWSPACE_SYM_CHUNKS), each with the transposed buffers
+    of its own items only -- what a shard whose buffers do not fit the free memory gets."""
     from pyarrowspace_amd import ArrowSpaceBuilder
     old = os.environ.pop("ARROWSPACE_NO_SYM", None)
+    oldc = os.environ.pop("ARROWSPACE_SYM_CHUNKS", None)
     if not sym:
         os.environ["ARROWSPACE_NO_SYM"] = "1"
+    if chunks is not None:
+        os.environ["ARROWSPACE_SYM_CHUNKS"] = str(chunks)
     try:
         aspace, gl = ArrowSpaceBuilder.build(gp, X)
     finally:
         os.environ.pop("ARROWSPACE_NO_SYM", None)
+        os.environ.pop("ARROWSPACE_SYM_CHUNKS", None)
         if old is not None:
             os.environ["ARROWSPACE_NO_SYM"] = old
+        if oldc is not None:
+            os.environ["ARROWSPACE_SYM_CHUNKS"] = oldc
     return aspace, gl, gl.build_stats()
 
 
@@ -109,3 +117,34 @@ def test_symmetric_pass_with_zero_rows_duplicates_and_unrepresentable_items(metr
     sym, full = _build(X, gp, True), _build(X, gp, False)
     _same_index(sym, full)
     assert sym[2]["mfma_flops"] < full[2]["mfma_flops"] and sym[2]["fallback_rows"] == full[2]["fallback_rows"]
+
+
+@pytest.mark.parametrize("metric,kernel", [("l2", "gaussian"), ("cosine", "rational")])
+@pytest.mark.parametrize("n,d,k", [(5000, 96, 10), (20000, 64, 10), (41000, 48, 25)])
+def test_column_chunked_symmetric_pass_is_bitwise_the_same(metric, kernel, n, d, k):
+    """The main pass in 2, 3 and 7 column chunks (a shard of 8M rows takes 2: DESIGN.md section 6): the units are cut at
+    multiples of the piece length instead of at each row block's diagonal, a chunk's transposed buffers hold its own
+    items only -- same graph and lambdas bit for bit, same triangle of tiles."""
+    X = clustered(n, d, nclust=8, seed=4)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
+    one = _build(X, gp, True)
+    for chunks in (2, 3, 7):
+        got = _build(X, gp, True, chunks)
+        _same_index(got, one)
+        # (the triangle's tiles are the same; which rows a band pass settles afterwards depends on how the lists are segmented)
+        assert abs(got[2]["mfma_flops"] - one[2]["mfma_flops"]) < 0.05 * one[2]["mfma_flops"] and got[2]["fallback_rows"] == 0
+
+
+def test_column_chunks_with_overflowing_buffers_and_a_loose_eps():
+    """The two hard cases of this file again, chunked: 900 copies of one item (buffers overflow -> band pass) and eps = 10."""
+    n, d, k = 6000, 64, 12
+    X = clustered(n, d, nclust=12, seed=8, normalise=False)
+    X[5100:6000] = X[5100]
+    gp = {"eps": calibrate_eps(X[:5000], k), "k": k, "topk": 5, "p": 2.0, "sigma": None}
+    one, got = _build(X, gp, True), _build(X, gp, True, 3)
+    _same_index(got, one)
+    assert got[2]["band_rows"] >= 100 and got[2]["fallback_rows"] == 0
+    X = clustered(9000, 64, nclust=6, seed=2)
+    for metric in ("l2", "cosine"):
+        gp = {"eps": 10.0, "k": 8, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
+        _same_index(_build(X, gp, True, 4), _build(X, gp, True))
