@@ -363,11 +363,16 @@ def main():
     build_s = float(bt.item())
 
     # ---------------- search: W warmup + K timed steps
-    # The first few hundred sharded searches after a build see one-off stalls of the collective layer
-    # (tools/staged_overhead.py: one of ~37 ms some 140 ms after the first search, torch's NCCL watchdog waking up).  They
-    # are run here, outside both the build time and the W + K steps -- on EVERY path, the single-GPU one included (which
-    # shows no such stall), so that the values at N = 1 and N > 1 come out of one protocol.
-    primed = 0 if args.traffic_probe else int(os.environ.get("ARROWSPACE_BENCH_PRIME", "300"))
+    # CPython's cyclic collector, not the GPU: the first full collection after `import torch` and a build walks everything
+    # they left behind -- one search of 32-60 ms, at the 171st staged search exactly, whatever the wall time, with torch's
+    # process group alive or destroyed (tools/stall_probe.py; rounds 1-2 blamed the collective layer's watchdog and ran 300
+    # untimed "priming" searches to get past it).  A serving process freezes what the build left behind (gc.freeze(): out
+    # of the collector's sight, later collections are short) -- so does this one, on every path; no priming searches.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    primed = 0 if args.traffic_probe else int(os.environ.get("ARROWSPACE_BENCH_PRIME", "0"))   # (A/B knob: tools/prime_ab.sh)
     for i in range(primed):
         searcher(Q[i % len(Q)])
     for i in range(args.warmup):

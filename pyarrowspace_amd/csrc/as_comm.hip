@@ -2,8 +2,8 @@
 // k-NN records and of the hit records on the query's own stream, and the whole staged search -- scan, exchange,
 // lambda_q, scorer, exchange, merge, the escalation to the exact paths -- behind ONE host call
 // (as_query_search_staged).  The host language above (pyarrowspace_amd/dist.py) used to issue the two collectives
-// through torch.distributed: ~100 us of host time per query and a stall of the collective layer's watchdog some 140 ms
-// after the first search -- more than an 8-GPU scan (58 us at 1M x 768 / 8).
+// through torch.distributed: ~100 us of host time per query -- more than an 8-GPU scan (58 us at
+// 1M x 768 / 8).
 //
 // RCCL is not linked: librccl is taken from the process (the copy torch.distributed has loaded, when it has) or from
 // /opt/rocm/lib, by dlopen -- the library keeps working, single-GPU, on a box without it.
