@@ -964,6 +964,9 @@ class ShardedIndex:
         mx = max(max(counts), 1)
         # step 0: the own block, with the hop for step 1 in flight
         lap = getattr(self, "_lap", lambda name: None)
+        if X_shard.is_cuda:
+            torch.cuda.empty_cache()      # (the library sizes the symmetric pass's scratch by what the driver reports free; before
+                                          # the hop starts: freeing memory waits for the device)
         pending = self._exchange_start(bufs[0], bufs[1], nxt_rank, prv_rank) if half >= 1 else None
         e.knn_block(e.own_block(), rank, bounds[rank], bounds[rank])
         if hasattr(torch, "cuda") and X_shard.is_cuda:
