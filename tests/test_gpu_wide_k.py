@@ -126,3 +126,35 @@ def test_ring_second_and_third_round_at_wide_k(oracle_lib):
         lo, hi = cuts[b], cuts[b + 1]
         np.testing.assert_array_equal(res[b][3], ref.knn_cnt[lo:hi])
         np.testing.assert_array_equal(res[b][0], ref.knn_idx[lo:hi])
+
+
+def test_wide_k_at_200k_items_properties():
+    """200 000 x 256, k = 100, topk = 50 (lists of 128, symmetric pass, 3 x the headline's list traffic) -- past what the
+    oracle finishes in seconds, so by properties (tests/test_gpu_fullsize.py): Laplacian identities, sampled rows' k-NN
+    against an independent fp64 brute force (torch), scores recomputed from the accessors, no left-out item beats the
+    last hit, batched == single."""
+    import torch
+
+    import pyarrowspace_amd as asp
+    from conftest import gpu_clustered
+    from test_gpu_fullsize import check_laplacian, check_sampled_knn, check_search
+    n, d, k, topk = 200_000, 256, 100, 50
+    X = gpu_clustered(n, d, 11, nclust=512)
+    import bench
+    eps = bench.calibrate_eps(X, k)
+    gp = {"eps": eps, "k": k, "topk": topk, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build_from_device(gp, X.data_ptr(), "float32", n, d, d)
+    st = gl.build_stats()
+    assert st["unproven_rows"] == 0
+    csr = gl.to_csr()
+    assert int(np.diff(csr[0]).max()) - 1 > 56          # rows with more than 56 neighbours exist: the wide lists were needed
+    check_laplacian(csr, gl.degrees(), n, k)
+    check_sampled_knn(X, csr, "l2", eps, k, nsample=48)
+    lam = np.asarray(aspace.lambdas())
+    rows = np.random.default_rng(3).integers(0, n, 5)
+    for tau in (1.0, 0.62):
+        check_search(X, aspace, gl, lam, tau, topk, rows)
+    Q = np.stack([X[int(i)].double().cpu().numpy() * 1.01 for i in rows])
+    assert aspace.search_batch(Q, gl, 0.62) == [aspace.search(q, gl, 0.62) for q in Q]
+    del aspace, gl
+    torch.cuda.empty_cache()
