@@ -2129,7 +2129,7 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     q->Mk = list_width(std::min<int64_t>(q->k, sp->n));
     q->Ms = score_width(q->topk);
     if (q->Mk < 0 || q->Ms < 0) {
-        set_err("k=%lld exceeds the supported maximum of 56, or topk=%lld the maximum of 1024", (long long)q->k, (long long)q->topk);
+        set_err("k=%lld exceeds the supported maximum of 120, or topk=%lld the maximum of 1024", (long long)q->k, (long long)q->topk);
         delete q;
         return AS_EUNSUPPORTED;
     }
@@ -2619,7 +2619,7 @@ as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, in
     ws->k = gp->k;
     ws->Mk = list_width(std::min<int64_t>(gp->k, sp->n));
     if (ws->Mk < 0) {
-        set_err("k=%lld exceeds the supported maximum of 56", (long long)gp->k);
+        set_err("k=%lld exceeds the supported maximum of 120", (long long)gp->k);
         return AS_EUNSUPPORTED;
     }
     ws->exact = 1;
