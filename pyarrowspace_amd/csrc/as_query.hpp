@@ -12,7 +12,7 @@ namespace as {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CAND_CAP = 4096;  // candidate buffer of the filter path
-constexpr int REC_CAP = 512;    // k-NN records q_lambda accepts (ranks x k)
+constexpr int REC_CAP = 1024;   // k-NN records q_lambda accepts (ranks x k: k = 120 on 8 ranks)
 constexpr int MAX_TOPK = 1024;  // largest topk
 constexpr int MS_MAX = MAX_TOPK + 64;  // widest scorer candidate list (topk + margin, rounded to 64)
 constexpr int HIT_CAP = 8 * (MAX_TOPK + 1) + 8;  // hit records hits_final accepts (ranks x (topk + 1))

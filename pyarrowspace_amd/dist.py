@@ -40,7 +40,7 @@ def shard_bounds(n: int, world: int) -> list[int]:
 
 def check_world_limits(graph_params, world: int):
     """A query merges world * k neighbour records and world * (topk + 1) hit records in one workgroup: refuse a
-    combination beyond the library's capacities (512 and 8 208: e.g. k = 120 on 5 ranks) before anything is built."""
+    combination beyond the library's capacities (1 024 and 8 208: e.g. k = 120 on 9 ranks) before anything is built."""
     from . import _lib
     L = _lib.load()
     gp = graph_params or {}

@@ -158,3 +158,45 @@ def test_wide_k_at_200k_items_properties():
     assert aspace.search_batch(Q, gl, 0.62) == [aspace.search(q, gl, 0.62) for q in Q]
     del aspace, gl
     torch.cuda.empty_cache()
+
+
+def test_eight_ranks_worth_of_records_at_k_120(oracle_lib):
+    """k = 120 on 8 ranks is 960 neighbour records per query (the merge takes 1 024): the staged steps of the C ABI driven
+    for eight row ranges of one space in one process -- every range's scan leaves its k records, lambda_q is formed from
+    all of them, every range scores against it, the hit records are merged -- against the oracle."""
+    import torch
+    from pyarrowspace_amd.dist import ShardedIndex, shard_bounds
+    n, d, k, topk, G = 4000, 48, 120, 12, 8
+    X = clustered(n, d, nclust=3, seed=77)
+    gp = {"eps": calibrate_eps(X, k), "k": k, "topk": topk, "p": 2.0, "sigma": None}
+    ref = oracle_lib.OracleIndex(X, gp)
+    index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())      # one rank holds every row; the ranges below play eight
+    e = index.engine
+    b = shard_bounds(n, G)
+    rng = np.random.default_rng(9)
+    try:
+        for _ in range(3):
+            q = np.ascontiguousarray(X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d))
+            for tau in (1.0, 0.62):
+                e.set_mode(0)
+                recs = []
+                for r in range(G):
+                    e.query_scan(q, b[r], b[r + 1])
+                    torch.cuda.synchronize()
+                    recs.append(e.knn_local.clone())
+                knn_all = torch.cat(recs).contiguous()
+                assert knn_all.shape[0] == G * k == 960
+                hits = []
+                for r in range(G):
+                    e.query_scan(q, b[r], b[r + 1])
+                    e.query_lambda(knn_all)
+                    e.query_score(tau)
+                    torch.cuda.synchronize()
+                    hits.append(e.hits_local.clone())
+                got, lq, zero, inexact, overflow = e.query_finish(torch.cat(hits).contiguous())
+                assert not zero and not inexact and not overflow
+                want, lq_ref = ref.search(q, tau)
+                assert abs(lq - lq_ref) <= RTOL * abs(lq_ref)
+                assert_hits_match(got, want, ref.scores(q, tau, lq_ref), rtol=RTOL)
+    finally:
+        index.close()

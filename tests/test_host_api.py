@@ -97,14 +97,15 @@ def test_product_never_imports_the_oracle():
 
 
 def test_sharded_index_refuses_record_counts_beyond_the_merge_capacity(asp):
-    """world * k neighbour records and world * (topk + 1) hit records are merged by one workgroup per query (512 and
+    """world * k neighbour records and world * (topk + 1) hit records are merged by one workgroup per query (1 024 and
     8 208): a combination beyond that is refused before anything is built, not at the first search."""
     from pyarrowspace_amd.dist import check_world_limits
-    gp = {"eps": 1.0, "k": 56, "topk": 15, "p": 2.0, "sigma": None}
-    check_world_limits(gp, 8)                                   # 448 records
+    gp = {"eps": 1.0, "k": 120, "topk": 15, "p": 2.0, "sigma": None}
+    check_world_limits(gp, 8)                                   # 960 records
     with pytest.raises(ValueError, match="neighbour records"):
-        check_world_limits(gp, 10)                              # 560
+        check_world_limits(gp, 9)                               # 1 080
     check_world_limits(dict(gp, lambda_mode="feature"), 10)    # no neighbour records in feature mode
+    check_world_limits(dict(gp, k=56), 18)                     # 1 008
     check_world_limits(dict(gp, k=25, topk=1024), 8)           # 8 200 hit records
     with pytest.raises(ValueError, match="hit records"):
         check_world_limits(dict(gp, k=25, topk=1024), 9)
