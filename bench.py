@@ -84,7 +84,7 @@ def visible_devices():
     return n
 
 
-def live_traffic(workload_argv, timeout_s=300):
+def live_traffic(workload_argv, timeout_s=150):
     """HBM-side bytes per launch of the roofline kernels, measured NOW rather than read from a committed profile: two
     child runs of this file (a short pass of the same workload: the build, 22 searches, the batched passes) under
     rocprofv3, one --pmc pass per counter (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md's HBM section prescribes,
