@@ -112,9 +112,18 @@ def live_traffic(workload_argv, timeout_s=150):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--traffic-probe", "--no-cpu-baseline", "--steps", "20", "--warmup", "2"] + list(workload_argv)
             with open(os.path.join(tmp, counter + ".log"), "w") as log:
+                # (its own process group: a pass that runs out of time is ended with everything it started -- the profiled
+                # child must not keep the GPU busy under the measurement that follows)
+                proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
                 try:
-                    rc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, timeout=timeout_s).returncode
+                    rc = proc.wait(timeout=timeout_s)
                 except subprocess.TimeoutExpired:
+                    import signal
+                    try:
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    proc.wait()
                     return None, "%s pass timed out after %d s" % (counter, timeout_s)
             if rc != 0:
                 print("bench.py: live traffic pass (%s) failed:\n%s" % (counter, open(os.path.join(tmp, counter + ".log")).read()[-600:]), file=sys.stderr)

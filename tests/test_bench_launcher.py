@@ -107,3 +107,30 @@ def test_live_traffic_reports_a_failing_pass(monkeypatch, tmp_path):
     for k in [k for k in os.environ if k.startswith("ROCPROF")]:
         monkeypatch.delenv(k)
     assert bench.live_traffic([], timeout_s=30) == (None, "FETCH_SIZE pass exited with 3")
+
+
+def test_live_traffic_ends_a_pass_that_runs_out_of_time(monkeypatch, tmp_path):
+    """The stand-in profiler starts a grandchild and sleeps: after the timeout both are gone (one process group)."""
+    import stat
+    import time
+
+    import bench
+    pidfile = tmp_path / "grandchild.pid"
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\nsleep 60 &\necho $! > %s\nsleep 60\n" % pidfile)
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    for k in [k for k in os.environ if k.startswith("ROCPROF")]:
+        monkeypatch.delenv(k)
+    t0 = time.time()
+    assert bench.live_traffic([], timeout_s=2) == (None, "FETCH_SIZE pass timed out after 2 s")
+    assert time.time() - t0 < 20
+    pid = int(pidfile.read_text())
+    for _ in range(50):
+        try:
+            os.kill(pid, 0)
+        except OSError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the pass's grandchild survived the timeout")
