@@ -42,7 +42,25 @@ def _bounds(n, world, uneven):
     return [0] + [int(c) for c in cuts]
 
 
-def _worker(rank, world, port, n, d, uneven, metric, kernel, out):
+def _check_own_rows_knn(X, ip, ix, lo, metric, eps, k, rows, rel=1e-9):
+    """check_sampled_knn (tests/test_gpu_fullsize.py) for rows of ONE rank's CSR (local row pointers, global column ids)."""
+    import torch
+    from conftest import brute_keys
+    epskey = eps * eps if metric == "l2" else eps
+    keys = brute_keys(X, rows, metric)
+    vals, idx = torch.topk(keys, k + 8, dim=1, largest=False)
+    vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+    margin = rel * (float((X[:4096].double() ** 2).sum(1).max().item()) if metric == "l2" else 1.0)
+    for t, i in enumerate(rows):
+        cols = ix[ip[i - lo]:ip[i - lo + 1]]
+        cols = set(cols[cols != i].tolist())
+        inside = [int(j) for v, j in zip(vals[t][:k], idx[t][:k]) if v <= epskey - margin and (vals[t][k] - v) > margin]
+        assert set(inside) <= cols, (i, set(inside) - cols)
+        for v, j in zip(vals[t], idx[t]):
+            assert not (v > epskey + margin and int(j) in cols), (i, int(j), v)
+
+
+def _worker(rank, world, port, n, d, uneven, metric, kernel, out, single=True):
     import time
 
     import torch
@@ -57,12 +75,18 @@ def _worker(rank, world, port, n, d, uneven, metric, kernel, out):
         from test_gpu_fullsize import check_sampled_knn
 
         X = gpu_clustered(n, d, 42)
-        eps = bench.calibrate_eps(X, K, metric)
+        if single:
+            eps = bench.calibrate_eps(X, K, metric)
+        else:   # (full size: the calibration's temporaries are 3 x the items -- one rank at a time is enough)
+            box = [bench.calibrate_eps(X, K, metric) if rank == 0 else None]
+            torch.cuda.empty_cache()
+            dist.broadcast_object_list(box, 0)
+            eps = box[0]
         gp = {"eps": eps, "k": K, "topk": TOPK, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
         b = _bounds(n, world, uneven)
         lo, hi = b[rank], b[rank + 1]
         shard = X[lo:hi].clone()
-        if rank != 0:
+        if rank != 0 or not single:
             del X
             torch.cuda.empty_cache()
         dist.barrier()
@@ -91,8 +115,9 @@ def _worker(rank, world, port, n, d, uneven, metric, kernel, out):
         # ---- searches: staged single + batched, tau sweep of tests/test_4_msmarco_tau_sweep.py:18-22
         qrng = np.random.default_rng(5)
         if rank == 0:
-            qrows = qrng.integers(0, n, 6)
-            Q = np.stack([X[int(i)].double().cpu().numpy() * 1.01 + 0.002 * qrng.standard_normal(d) / np.sqrt(d) for i in qrows])
+            qrows = qrng.integers(0, n, 6) if single else qrng.integers(lo, hi, 6)     # (full size: rank 0 holds its shard only)
+            rowvec = (lambda i: X[int(i)]) if single else (lambda i: shard[int(i) - lo])
+            Q = np.stack([rowvec(i).double().cpu().numpy() * 1.01 + 0.002 * qrng.standard_normal(d) / np.sqrt(d) for i in qrows])
             qt = torch.from_numpy(Q)
         else:
             qt = torch.empty((6, d), dtype=torch.float64)
@@ -117,6 +142,18 @@ def _worker(rank, world, port, n, d, uneven, metric, kernel, out):
                         cos = float(x @ q) / np.sqrt(float(x @ x) * float(q @ q))
                         assert abs(s - (tau * cos + (1 - tau) / (1 + abs(lq - lam_all[j])))) < 1e-12
 
+        if not single:
+            # full size (tools/config4_fullsize.py): no single-space build to compare with -- sampled rows of rank 0 against an
+            # independent fp64 brute force over all items (regenerated now that the ring's buffers are gone)
+            if rank == 0:
+                X = gpu_clustered(n, d, 42)
+                _check_own_rows_knn(X, ip, ix, lo, metric, eps, K, np.random.default_rng(1).choice(np.arange(lo, hi), 32, replace=False))
+                del X
+            dist.barrier()
+            out[rank] = dict(build_s=build_s, phases=dict(index.phase_s), stats=index.build_stats(), search_ms=search_s * 1e3,
+                             flagged=getattr(index, "ring_flagged", 0), single_s=float("nan"), rows=hi - lo)
+            index.close()
+            return
         # ---- against ONE space holding every item (rank 0 builds it; the other ranks wait): bit-identical rows
         tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "as_multirank_%d" % port)
         if rank == 0:
@@ -159,7 +196,7 @@ def _worker(rank, world, port, n, d, uneven, metric, kernel, out):
         dist.destroy_process_group()
 
 
-def _run(world, n, d, uneven, metric="l2", kernel="gaussian"):
+def _run(world, n, d, uneven, metric="l2", kernel="gaussian", single=True):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -167,7 +204,7 @@ def _run(world, n, d, uneven, metric="l2", kernel="gaussian"):
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, n, d, uneven, metric, kernel, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, d, uneven, metric, kernel, out, single), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
     for r in range(world):
         o = out[r]
