@@ -518,7 +518,10 @@ def main():
         "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
                      "traffic_source": traffic_source if traffic_scan is not None else "none (live passes: %s)" % live_note,
-                     "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes},
+                     "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes,
+                     "note": "round 3: this launch also collects the scorer's candidates (fused tail, DESIGN.md 5.4) -- 4-14 us more than "
+                             "round 2's plain scan on the same box, for 3 launches and ~14 us less behind it; ARROWSPACE_NO_FUSED_TAIL=1 "
+                             "runs the plain kernel (tools/scan_ab.sh)"},
         "roofline_query": {"bound": "hbm", "achieved": query_bytes / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "note": "whole query, host-visible latency, per GPU"},
