@@ -15,10 +15,12 @@ run --n 131072 --d 2048
 run --n 65536 --d 4096
 run --n 20000 --d 768
 python - <<'PY'
-import json
+import json, re
 for l in open("gpurun_out/sweep.jsonl"):
     d = json.loads(l)
     c = d["config"]
-    print(f"n={c['n']:>8} d={c['d']:>5} {c['workload'].split('fp32, ')[1].split(' eps')[0]:28s} q/s={d['value']:9.1f} scan={d['roofline']['frac']:.3f} query={d['roofline_query']['frac']:.3f} "
-          f"build={d['index_build_sec']:.2f}s mfma={d['roofline_build']['frac']:.3f} batched={d['batched_queries_per_sec'] or 0:.0f}")
+    m = re.search(r"k=(\d+) topk=(\d+) tau=([0-9.]+)", c["workload"])
+    print(f"n={c['n']:>8} d={c['d']:>5} k={m.group(1):>3} topk={m.group(2):>4} tau={m.group(3)} q/s={d['value']:9.1f} scan={d['roofline']['frac']:.3f} query={d['roofline_query']['frac']:.3f} "
+          f"in-dist q/s={d['in_distribution_queries']['value']:9.1f} build={d['index_build_sec']:.2f}s mfma={d['roofline_build']['frac']:.3f} batched={d['batched_queries_per_sec'] or 0:.0f} "
+          f"(batch frac {d['roofline_batch']['frac'] if d['roofline_batch'] else 0:.3f})")
 PY
