@@ -110,6 +110,8 @@ struct as_query {
     int nwaves = 0;
     int reuse = 0;           // staged path: the next scan call repairs the previous scan's overflow from its dots
     int cap = 1;             // query slots (GQ for the batched workspace)
+    int half_enabled = 1;    // batched MFMA scan: keep the 32 slots' cosines as fp16 instead of their dots as fp32 (ARROWSPACE_BATCH_F32_DOTS=1: off)
+    int dots_half = 0;       // ... and that is what the last batched scan wrote
     int gemm_variant = 0;    // batched MFMA scan (ARROWSPACE_GEMM_VARIANT): 1 = ring of 3 slabs, 2 = default cache policy, 16 = no MFMA (timing only)
     int nb = 1;              // active slots of the current launch sequence
     as::SlotStride ss{};

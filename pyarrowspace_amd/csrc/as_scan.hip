@@ -242,6 +242,16 @@ __device__ __forceinline__ void store_dword_issued(float* p, float v) {
 __device__ __forceinline__ void store_x4_issued(float* p, f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_x2_issued(void* p, u32x2 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+// two floats -> two fp16 (round to nearest even) in one dword
+__device__ __forceinline__ unsigned int pack_half2(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned int, v);
+}
 // s_nop: the hazard recogniser does not look inside asm, and an MFMA result may be the operand
 __device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
     asm volatile("s_nop 15\n\ts_nop 3\n\tds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
@@ -255,10 +265,30 @@ __device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
 // and cost the per-slot selection kernels their cache hits.  The cost is per byte, not per instruction or per
 // episode: 16 dword stores per row block, 4 dwordx4 stores, or the stores of 4 row blocks issued together all
 // measure the same (0.60 ms): 134 MB of write-backs among 3 GB of streamed reads cost what 0.9 GB of reads would.
-template <int NBUF, int DIAG = 0, int AUX = 2>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// eight fp32 values -> their bf16 head and the bf16 of what the head leaves: v = hi + lo + r, |r| <= 2^-16 |v| (two
+// roundings to nearest of 2^-8 each: bf16 carries 8 significant bits; the subtraction is exact).  A non-finite value keeps its head and gets a zero tail (inf - inf would be NaN).
+__device__ __forceinline__ void split_bf16(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        hi[t] = (__bf16)a[t];
+        hi[4 + t] = (__bf16)b[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float ra = a[t] - (float)hi[t], rb = b[t] - (float)hi[4 + t];
+        lo[t] = (__bf16)(ra == ra ? ra : 0.0f);
+        lo[4 + t] = (__bf16)(rb == rb ? rb : 0.0f);
+    }
+}
+
+// BF3: the products on the bf16 matrix pipe (16 x the fp32 rate), each operand as head + tail: q.x ~ qh.xh + qh.xl + ql.xh --
+// three v_mfma_f32_32x32x16_bf16 per 16 columns instead of eight v_mfma_f32_32x32x2_f32; bf16 x bf16 is exact in the fp32
+// accumulator, what is dropped (ql.xl and the two remainders) is at most 3 * 2^-16 |q_k x_k| per term (coef_query).
+template <int NBUF, int DIAG, int AUX, bool BF3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
     const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
-    int64_t ts, PreArgs pre, int nb) {
+    int64_t ts, PreArgs pre, int nb, int half_dots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     float* St = (float*)smem;   // per wave: NBUF slabs x [32 rows][32 floats]; Ex[owner wave][3 senders][64 lanes][4]; Ax[wave][64]
@@ -279,6 +309,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float nqv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) nqv[e] = pre.metric == AS_METRIC_L2 ? pre.info[e + 8 * wu + 4 * h].nq32 : pre.info[e + 8 * wu + 4 * h].inq32;
+    float iqv[4];   // 1/|q| of the same queries: the stored value is the cosine (half_dots)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) iqv[e] = pre.info[e + 8 * wu + 4 * h].inq32;
     // the loads above complete here, once: otherwise the compiler has to assume they are still pending inside
     // the loop and puts a vmcnt(0) -- which also waits for the whole prefetch ring -- in front of their first use
 #pragma unroll
@@ -287,6 +320,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[ks][s]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(nqv[e]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(iqv[e]));
+    bf16x8 qh[GEMM_NSW][2], ql[GEMM_NSW][2];
+    if (BF3) {
+#pragma unroll
+        for (int ks = 0; ks < GEMM_NSW; ++ks) {
+            split_bf16(qf[ks][0], qf[ks][1], qh[ks][0], ql[ks][0]);
+            split_bf16(qf[ks][2], qf[ks][3], qh[ks][1], ql[ks][1]);
+        }
+    }
     float* my = St + wu * NBUF * 1024;
     const unsigned my0 = lds0 + wu * NBUF * 4096;
     const int drow = lane >> 3;
@@ -363,14 +406,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
                     continue;
                 }
+                if (BF3) {
+                    // lane (row l31, half h) holds the same 8 + 8 columns of its query and of its item: the order of the
+                    // columns inside an instruction is free as long as both operands agree
+                    bf16x8 bh0, bl0, bh1, bl1;
+                    split_bf16(x0, x1, bh0, bl0);
+                    split_bf16(x2, x3, bh1, bl1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[ks][0], bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[ks][1], bh1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[ks][0], bl0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[ks][1], bl1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[ks][0], bh0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[ks][1], bh1, acc, 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][0][t], x0[t], acc, 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][0][t], x0[t], acc, 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][1][t], x1[t], acc, 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][1][t], x1[t], acc, 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][2][t], x2[t], acc, 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][2][t], x2[t], acc, 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][3][t], x3[t], acc, 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ks][3][t], x3[t], acc, 0, 0, 0);
+                }
                 cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
             }
         }
@@ -403,7 +460,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // (np + ROW_TILE rows are allocated), idle slots have their places in every tile.  Tile layout
             // [slot quad][32 rows][4 slots]: the lane's four values (slots 8 wu + 4 h + {0..3} of row l31) are 16
             // contiguous bytes, the wave's ONE dwordx4 store fills 1 KiB of the row block's contiguous 4 KiB
-            store_x4_issued(dots + (row >> 5) * ts + ((2 * wu + h) * 32 + (row & 31)) * 4, mine);
+            // half_dots: the same places, two bytes each -- the cosines (in [-1, 1]: no range problem whatever the items'
+            // magnitudes) rounded to fp16; 67 MB of write-backs per pass instead of 134, and the selection kernels behind
+            // read half as much and need no norms.  The neighbour prefilter below keeps the fp32 dots in registers.
+            if (half_dots) {
+                const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
+                u32x2 pk;
+                pk[0] = pack_half2(mine[0] * inr * iqv[0], mine[1] * inr * iqv[1]);
+                pk[1] = pack_half2(mine[2] * inr * iqv[2], mine[3] * inr * iqv[3]);
+                store_x2_issued((char*)dots + ((row >> 5) * ts + ((2 * wu + h) * 32 + (row & 31)) * 4) * 2, pk);
+            } else {
+                store_x4_issued(dots + (row >> 5) * ts + ((2 * wu + h) * 32 + (row & 31)) * 4, mine);
+            }
             x0 += 1;
             x1 += 1;
             x2 += 1;
@@ -843,7 +911,14 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
 double coef_query(const as_query* q, bool exact) {
     const double u = exact ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
     const int64_t dp = q->sp->dp;
-    if (!exact && q->cap > 1 && dp <= 4 * GEMM_NSW * 32) return (double)(2 * (((dp / 32 + 3) / 4) * 32) + 3 + 24) * u;
+    if (!exact && q->cap > 1 && dp <= 4 * GEMM_NSW * 32) {
+        // the batched MFMA pass.  fp32 pipe: two roundings per term of a wave's quarter of the columns.  bf16 pipe (BF3, with
+        // the fp16 cosines): three exact products per column -- three times the accumulated terms -- and the operands' dropped
+        // remainders, 3 * 2^-16 of |q_k x_k| per term, at most that of |q| |x| in the sum (Cauchy-Schwarz)
+        const int64_t kw = ((dp / 32 + 3) / 4) * 32;
+        if (q->half_enabled && q->ss.dots_rs == 4) return (double)(6 * kw + 3 + 24) * u + 3.0 * 1.52587890625e-5 * 1.01;   // 3 * 2^-16
+        return (double)(2 * kw + 3 + 24) * u;
+    }
     return (double)(dp / 64 + 24) * u;
 }
 
@@ -886,6 +961,9 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_gemm_kernel<4, 0, 0>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<4, 1, 2>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<4, 0, 2>), gemm_lds(4));
+    AS_ATTR((scan_gemm_kernel<3, 0, 2, true>), gemm_lds(3));
+    AS_ATTR((scan_gemm_kernel<4, 0, 0, true>), gemm_lds(4));
+    AS_ATTR((scan_gemm_kernel<4, 0, 2, true>), gemm_lds(4));
     AS_ATTR((scan_dma_kernel<1, 8>), dma_lds(1, 8));
     AS_ATTR((scan_dma_kernel<2, 8>), dma_lds(2, 8));
     AS_ATTR((scan_dma_kernel<2, 5>), dma_lds(2, 5));
@@ -905,6 +983,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
     const int64_t rows = q->r1 - q->r0;
     if (rows <= 0) return AS_OK;
     hipStream_t st = q->stream;
+    q->dots_half = 0;   // (only the batched MFMA pass below writes fp16 cosines)
     if (q->exact) {
         if (!q->dots64) AS_HIP(hipMalloc(&q->dots64, sizeof(double) * (sp->np + ROW_TILE)));
         const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, 4096);
@@ -919,9 +998,14 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
         const size_t lds = gemm_lds(NB_);                                                                              \
         const int64_t nrb = (rows + 31) / 32;                                                                          \
         const unsigned grid = (unsigned)std::min<int64_t>(nrb, 2 * q->cus);                                            \
-        hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
-                           q->dots32, q->ss.dots_ts, pre, q->nb);                                                                     \
+        if (q->dots_half && DG == 0)                                                                                   \
+            hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX, true>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
+                               q->r1, q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);                                     \
+        else                                                                                                           \
+            hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
+                               q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);                                            \
     } while (0)
+            q->dots_half = q->half_enabled && q->ss.dots_rs == 4 ? 1 : 0;
             if (q->gemm_variant == 1) AS_GSCAN(3, 0, 2);
             else if (q->gemm_variant == 2) AS_GSCAN(4, 0, 0);
             else if (q->gemm_variant == 16) AS_GSCAN(4, 1, 2);

@@ -470,10 +470,12 @@ struct BatchSel {
     const float* dots32;      // slot 0
     const double* n64;
     const double* lam64;
+    const float* lam32;       // (half: the keys are coarse anyway -- fp32 arithmetic, 4 bytes of lambda per row)
     const QInfo* info;        // [NS]
     QInfo* info_w;
     int64_t r0, r1, sd, ts;
     int rs;                   // SlotStride::dots_rs
+    int half;                 // the scan left fp16 cosines in the dots' places (as_query::dots_half), not fp32 dots
     double tau;
     double* gmin;             // [NS][CAND_CAP]
     double* ckey;             // [NS][CAND_CAP]
@@ -481,15 +483,46 @@ struct BatchSel {
     int ns;
 };
 
+// wave-wide minimum on the DPP crossbar (as wave_sum_dpp of as_scan.hip: no LDS round trips); the same value in every lane
+__device__ __forceinline__ float wave_min_dpp(float v) {
+#define AS_MIN_DPP(ctrl, rmask) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xF, false)))
+    AS_MIN_DPP(0xB1, 0xF);    // quad_perm [1,0,3,2]
+    AS_MIN_DPP(0x4E, 0xF);    // quad_perm [2,3,0,1]
+    AS_MIN_DPP(0x141, 0xF);   // row_half_mirror
+    AS_MIN_DPP(0x140, 0xF);   // row_mirror
+    AS_MIN_DPP(0x142, 0xA);   // row_bcast15 -> rows 1, 3
+    AS_MIN_DPP(0x143, 0xC);   // row_bcast31 -> rows 2, 3
+#undef AS_MIN_DPP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// the coarse key of the fp16-cosine workspace, in fp32 (see batch_key)
+__device__ __forceinline__ float batch_key32(float t32, float cs, float lrow, float lq) {
+    return -(t32 * cs + (1.0f - t32) * __builtin_amdgcn_rcpf(1.0f + fabsf(lq - lrow)));
+}
 // rn = 1/|x_row|, rq = 1/|q_s|: no square root or division for the cosine; one reciprocal for the lambda term
 __device__ __forceinline__ double batch_key(const BatchSel& a, float dot, double rn, double lrow, double rq, double lq) {
-    return -(a.tau * ((double)dot * rn * rq) + (1.0 - a.tau) / (1.0 + fabs(lq - lrow)));
+    if (a.half) {
+        // the stored value is the cosine itself, good to 2^-11: the rest in fp32 (a dozen roundings of values below 1 and a
+        // reciprocal good to an ulp: under 1e-6 in all, launch_score's e_key32)
+        return (double)batch_key32((float)a.tau, dot, (float)lrow, (float)lq);
+    }
+    const double cs = (double)dot * rn * rq;
+    return -(a.tau * cs + (1.0 - a.tau) / (1.0 + fabs(lq - lrow)));
 }
 // the dots of slots [s0, s0 + NSW) of one row: two dwordx4 in the batched workspace's [slot quad][32 rows][4] tiles
 template <int NSW>
 __device__ __forceinline__ void batch_dots(const BatchSel& a, int s0, int64_t row, float (&dv)[NSW]) {
     const float* __restrict__ t = a.dots32 + (row >> 5) * a.ts;
-    if (a.rs == 4) {
+    if (a.half) {   // [slot quad][32 rows][4 slots] of fp16: a row's four slots are one 8-byte load
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const _Float16* __restrict__ th = (const _Float16*)a.dots32 + (row >> 5) * a.ts;
+#pragma unroll
+        for (int g = 0; g < NSW / 4; ++g) {
+            const h4 v = *(const h4*)(th + ((s0 >> 2) + g) * 128 + (row & 31) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[4 * g + e] = (float)v[e];
+        }
+    } else if (a.rs == 4) {
 #pragma unroll
         for (int g = 0; g < NSW / 4; ++g) {
             const f32x4 v = *(const f32x4*)(t + ((s0 >> 2) + g) * 128 + (row & 31) * 4);
@@ -518,12 +551,41 @@ __global__ __launch_bounds__(256) void score_gmin_batch_kernel(BatchSel a, int64
     if (g >= ngroups) return;
     const int64_t lo = a.r0 + g * G;
     const int64_t hi = lo + G < a.r1 ? lo + G : a.r1;
+    if (a.half) {
+        // fp16 cosines: fp32 keys, fp32 minima, the wave's minimum over the DPP crossbar (the fp64 butterfly below is 96
+        // ds_bpermute per wave -- as long as the wave's four trips over its rows)
+        float m32[NSW];
+        const float t32 = (float)a.tau;
+        float lq32[NSW];
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) {
+            m32[s] = __int_as_float(0x7f800000);
+            lq32[s] = (float)s_lq[s];
+        }
+        for (int64_t row = lo + lane; row < hi; row += 64) {
+            const float lrow = a.lam32[row];
+            float dv[NSW];
+            batch_dots<NSW>(a, s0, row, dv);
+#pragma unroll
+            for (int s = 0; s < NSW; ++s) m32[s] = fminf(m32[s], batch_key32(t32, dv[s], lrow, lq32[s]));
+        }
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) {
+            const float v = wave_min_dpp(m32[s]);
+            if (lane == s && s0 + s < a.ns) a.gmin[(int64_t)(s0 + s) * CAND_CAP + g] = (double)v;
+        }
+        return;
+    }
     double m[NSW];
 #pragma unroll
     for (int s = 0; s < NSW; ++s) m[s] = key_traits<double>::inf();
     for (int64_t row = lo + lane; row < hi; row += 64) {
-        const double nrow = a.n64[row], lrow = a.lam64[row];
-        const double rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
+        const double lrow = a.half ? (double)a.lam32[row] : a.lam64[row];
+        double rn = 0.0;
+        if (!a.half) {
+            const double nrow = a.n64[row];
+            rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
+        }
         float dv[NSW];
         batch_dots<NSW>(a, s0, row, dv);
 #pragma unroll
@@ -556,27 +618,32 @@ __global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a, int
         s_thr[threadIdx.x] = s0 + (int)threadIdx.x < a.ns ? a.info[s0 + threadIdx.x].thr64 : -key_traits<double>::inf();
     }
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned int full = 0;   // bit s: the slot has overflowed its candidate buffer (mass ties): stop adding to its counter
-    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1; row += stride) {
-        // a group whose minimum key is above a slot's threshold holds nothing for that slot: a wave (64 consecutive rows,
-        // one group: G is a multiple of 64) reads its rows only for the slots that can still take some -- a few per cent
-        // of the (group, slot) pairs
-        const int64_t g = (row - a.r0) / G;
-        bool act[NSW], any = false;
-#pragma unroll
-        for (int s = 0; s < NSW; ++s) {
-            act[s] = a.gmin[(int64_t)(s0 + s) * CAND_CAP + g] <= s_thr[s];
-            any = any || act[s];
+    // A wave takes 64 consecutive rows -- one group: G is a multiple of 64 -- and asks ONCE which of its NSW slots can still
+    // take rows of that group (lanes 0 .. NSW-1 read the slots' group minima, a ballot spreads the answer): a group whose
+    // minimum key is above a slot's threshold holds nothing for that slot, and for nearly every (group, slot octet) nothing at
+    // all -- the wave moves on without touching the rows.  (Every thread used to read the NSW minima for its own row.)
+    const int lane = lane_id();
+    const int64_t nchunk = (a.r1 - a.r0 + 63) / 64;
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t ch = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < nchunk; ch += nwave) {
+        const int64_t g = (ch * 64) / G;
+        const bool mine = lane < NSW && a.gmin[(int64_t)(s0 + lane) * CAND_CAP + g] <= s_thr[lane < NSW ? lane : 0];
+        const unsigned int actm = (unsigned int)__ballot(mine);
+        if (!actm) continue;
+        const int64_t row = a.r0 + ch * 64 + lane;
+        if (row >= a.r1) continue;
+        const double lrow = a.half ? (double)a.lam32[row] : a.lam64[row];
+        double rn = 0.0;
+        if (!a.half) {
+            const double nrow = a.n64[row];
+            rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
         }
-        if (!any) continue;
-        const double nrow = a.n64[row], lrow = a.lam64[row];
-        const double rn = nrow > 0.0 ? rsqrt(nrow) : 0.0;
         float dv[NSW];
         batch_dots<NSW>(a, s0, row, dv);
 #pragma unroll
         for (int s = 0; s < NSW; ++s) {
-            if (!act[s]) continue;
+            if (!((actm >> s) & 1u)) continue;
             const double k = batch_key(a, dv[s], rn, lrow, s_rq[s], s_lq[s]);
             if (k <= s_thr[s] && !((full >> s) & 1u)) {
                 const int slot = atomicAdd(&a.info_w[s0 + s].sc_cnt, 1);
@@ -1914,7 +1981,11 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
     f.M = q->Ms; f.hits = q->hits; f.fuse = fuse_final; f.hout = q->hout_dev; f.seq = q->seq;
     f.auto_reset = fuse_final && q->cap == 1 ? 1 : 0;
     // mixed (fp32 dots, fp64 keys): the only error of a key is the dot's, scaled by tau
-    const double coef_s = dots32 ? f.tau * (coef_query(q, false) + 1.0e-14) + 4.0 * 2.220446049250313e-16 : coef_query(q, sizeof(T) == 8);
+    // fp16 cosines (batched MFMA pass): the rounding to nearest of a value in [-1, 1] (2^-11 relative), the fp32 reciprocal
+    // norms and their products in front of it (a few ulp of fp32), on top of the dot's own error
+    const double e_half = q->dots_half && dots32 ? 4.8828125e-4 + 1.0e-6 : 0.0;
+    const double e_key32 = q->dots_half && dots32 ? 1.5e-6 : 0.0;   // the coarse keys' fp32 evaluation (batch_key): not scaled by tau
+    const double coef_s = dots32 ? f.tau * (coef_query(q, false) + 1.0e-14 + e_half) + e_key32 + 4.0 * 2.220446049250313e-16 : coef_query(q, sizeof(T) == 8);
     if (q->robust && q->Ms > MAX_LIST) {
         // wide lists: exact global selection, then the filter-path finish kernel on exactly M rows
         const int64_t rows = q->r1 - q->r0;
@@ -1956,9 +2027,9 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
             // batched workspace: every slot's keys from one read of a row's norm and lambda (all GQ slots: idle ones hold
             // zero queries and cost nothing but their share of the dots)
             BatchSel b;
-            b.dots32 = dots32; b.n64 = q->sp->n64; b.lam64 = q->sp->lam64; b.info = q->info; b.info_w = q->info;
+            b.dots32 = dots32; b.n64 = q->sp->n64; b.lam64 = q->sp->lam64; b.lam32 = q->sp->lam32; b.info = q->info; b.info_w = q->info;
             b.r0 = q->r0; b.r1 = q->r1; b.sd = q->ss.dots; b.ts = q->ss.dots_ts; b.rs = q->ss.dots_rs; b.tau = f.tau;
-            b.gmin = (double*)q->gmin; b.ckey = (double*)q->ckey_s; b.cidx = q->cidx_s; b.ns = q->nb;
+            b.gmin = (double*)q->gmin; b.ckey = (double*)q->ckey_s; b.cidx = q->cidx_s; b.ns = q->nb; b.half = q->dots_half;
             constexpr int NSW = 8;   // slots per wave: a row's norm and lambda are read GQ / NSW times instead of GQ
             const unsigned ny = (unsigned)((q->nb + NSW - 1) / NSW);
             hipLaunchKernelGGL((score_gmin_batch_kernel<NSW>), dim3((unsigned)((ng + 3) / 4), ny), dim3(256), 0, st, b, G, ng);
@@ -2148,6 +2219,7 @@ static as_status query_alloc(as_query* q) {
     q->nwaves = 4096;
     if (const char* ev = getenv("ARROWSPACE_SCAN_VARIANT")) q->scan_variant = atoi(ev) & 7;
     if (const char* ev = getenv("ARROWSPACE_GEMM_VARIANT")) q->gemm_variant = atoi(ev);
+    q->half_enabled = getenv("ARROWSPACE_BATCH_F32_DOTS") ? 0 : 1;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) q->cus = prop.multiProcessorCount;
@@ -2593,7 +2665,7 @@ as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, in
         AS_TRY(wait_published(q, b));
         crowded = crowded || (q->hout[b].overflow & 1);
     }
-    if (crowded) {
+    if (crowded && !q->dots_half) {   // (fp16 cosines cannot repair a neighbourhood: those slots go to the single-query path below)
         // some neighbourhood overflowed its candidate buffer: threshold repair of every slot over the kept dots
         AS_TRY(knn_repair(q, q->gr->gp.eps, -1));
         AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1));
