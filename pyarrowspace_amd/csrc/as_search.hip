@@ -2224,7 +2224,22 @@ static as_status query_alloc(as_query* q) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) q->cus = prop.multiProcessorCount;
     }
-    AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));
+    if (C > 1) {
+        // Batched workspaces come in pairs whose passes are meant to overlap (as_search_batch) -- which they only do on
+        // DIFFERENT hardware queues, and the runtime multiplexes a process's streams over 4 of them (GPU_MAX_HW_QUEUES): the
+        // pair shared one and ran strictly one kernel after the other (tools/hwq_ab.sh: 0.655 ms per pass, 0.61-0.62 with 8
+        // queues).  Streams of different priorities never share a queue: every other batched workspace asks for the high one.
+        static std::atomic<int> nbatch{0};
+        int lo_prio = 0, hi_prio = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+        const int prio = (nbatch.fetch_add(1) & 1) ? hi_prio : (lo_prio + hi_prio) / 2;
+        if (hipStreamCreateWithPriority(&q->own_stream, hipStreamNonBlocking, prio) != hipSuccess) {
+            (void)hipGetLastError();
+            AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));
+        }
+    } else {
+        AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));
+    }
     q->stream = q->own_stream;
     {   // (dp doubles at least: the host-prepared fast path reads the zero padding behind the d elements)
         const size_t hq_n = std::max<size_t>((size_t)sp->d * C, (size_t)sp->dp);
