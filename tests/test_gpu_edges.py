@@ -353,3 +353,45 @@ def test_build_from_device_with_a_leading_dimension(oracle_lib, dtype):
     q = np.ascontiguousarray(X[9] * 1.01)
     want, lq = ref.search(q, 0.62)
     assert_hits_match(aspace.search(q, gl, 0.62), want, ref.scores(q, 0.62, lq), rtol=RTOL)
+
+
+@pytest.mark.parametrize("metric,kernel", [("l2", "gaussian"), ("cosine", "rational")])
+def test_batched_pass_bf16_products_and_fp32_products_agree(metric, kernel):
+    """The batched pass forms its products on the bf16 matrix pipe (every operand as head + tail) and keeps fp16 cosines
+    (DESIGN.md 5.5); ARROWSPACE_BATCH_F32_DOTS=1 is round 2's fp32 form.  Both are proven exact behind their own error
+    terms: same hits as each other and as the single-query search -- on normalised items, on items whose rows span six
+    orders of magnitude, and on rows with one dominant component (the bf16 tails carry everything else)."""
+    import os
+
+    import pyarrowspace_amd as asp
+    from conftest import calibrate_eps, clustered
+    n, d, k, topk = 12000, 768, 12, 10
+    rng = np.random.default_rng(8)
+    base = clustered(n, d, nclust=24, seed=6)
+    spiky = base.copy()
+    spiky[:, 5] += 40.0                                   # one component 1 000 x the others
+    spread = base * np.exp(rng.uniform(-7, 7, n))[:, None]  # row norms from 1e-3 to 1e3
+    for X in (base, spiky, spread):
+        gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": topk, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
+        Q = None
+        got = {}
+        for form in ("bf16", "fp32"):
+            old = os.environ.pop("ARROWSPACE_BATCH_F32_DOTS", None)
+            if form == "fp32":
+                os.environ["ARROWSPACE_BATCH_F32_DOTS"] = "1"
+            try:
+                aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)     # (the workspace reads the switch when it is created)
+                if Q is None:   # queries next to items that have neighbours (an isolated item's lambda is 0: the zero-lambda panic)
+                    rows = rng.choice(np.flatnonzero(gl.degrees() > 0), 40, replace=False)
+                    Q = np.stack([X[i] * 1.01 + 0.01 * np.abs(X[i]).mean() * rng.standard_normal(d) for i in rows])
+                res = {}
+                for tau in (1.0, 0.62, 0.42):
+                    res[tau] = aspace.search_batch(Q, gl, tau)
+                    assert res[tau] == [aspace.search(q, gl, tau) for q in Q], (form, tau)
+                got[form] = res
+            finally:
+                os.environ.pop("ARROWSPACE_BATCH_F32_DOTS", None)
+                if old is not None:
+                    os.environ["ARROWSPACE_BATCH_F32_DOTS"] = old
+        assert got["bf16"] == got["fp32"]
+        assert all(len(h) == topk for h in got["bf16"][0.62])
