@@ -530,7 +530,9 @@ def main():
             "achieved": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
             "traffic": traffic_batch,
-            "note": "whole 32-query pass, host-visible, per GPU; N*(D+2)*4 bytes per pass; fp32 MFMA work 2*32*N*D flops"},
+            "note": "whole 32-query pass, host-visible, per GPU; N*(D+2)*4 bytes per pass; products on the bf16 matrix pipe, every operand as "
+                    "bf16 head + tail (3 x 2*32*N*D flops, error bound in the prefilter's and the proof's coefficients: DESIGN.md 5.5), "
+                    "fp16 cosines kept per slot; ARROWSPACE_BATCH_F32_DOTS=1 is the fp32 form"},
         "roofline_build": {"kernel": build_kernel, "bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak,
                            "unit": "TFLOP/s", "frac": mfma_tf / mfma_peak, "traffic": traffic_mfma,
                            "flops_issued": bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"],
