@@ -1,6 +1,6 @@
 // K7a of the search chain on gfx950: dots[i] = x_i . q over the fp32 item matrix, with the k-NN prefilter fused
 // into the epilogue (DESIGN.md sections 5.4, 5.5).  One HBM pass per query (scan_dma_kernel, scan_dots_f32_kernel)
-// or per 32 queries (scan_gemm_kernel, fp32 MFMA).  Replaces the scan inside `search_lambda_aware` and
+// or per 32 queries (scan_gemm_kernel: bf16 head + tail products on the matrix pipe, or fp32 MFMA).  Replaces the scan inside `search_lambda_aware` and
 // `prepare_query_item` (/root/reference/src/lib.rs:154,173).
 #include "as_query.hpp"
 
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void scan_dots_batch_kernel(const float* __res
     }
 }
 
-// Batched scan as a GEMM (rows up to 768 floats): dots[GQ x rows] = Q . X^T on fp32 MFMA
-// (v_mfma_f32_32x32x2_f32, A = 32 queries, B = 32 item rows).  A block is a team of 4 waves
+// Batched scan as a GEMM (rows up to 768 floats): dots[GQ x rows] = Q . X^T on the matrix pipe -- fp32
+// (v_mfma_f32_32x32x2_f32, A = 32 queries, B = 32 item rows) or, by default, bf16 head + tail (BF3, below).  A block is a team of 4 waves
 // that splits K: wave w keeps the Q fragments of its quarter of the columns in registers for the
 // whole launch (<= 6 slabs of 32 floats -> 96 VGPRs) and streams the matching quarter of every
 // 32-row block by LDS-DMA into a private ring of NBUF XOR-swizzled slabs (same image as
@@ -992,7 +992,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
     } else {
         const int nch = (int)((sp->dp + 255) / 256);
         if (q->cap > 1 && sp->dp <= 4 * GEMM_NSW * 32) {
-            // batched pass, GEMM-shaped: fp32 MFMA, K split over the 4 waves of a block, 2 blocks per CU
+            // batched pass, GEMM-shaped: matrix pipe (bf16 head + tail with the fp16 cosines, else fp32), K split over the 4 waves of a block, 2 blocks per CU
 #define AS_GSCAN(NB_, DG, AX)                                                                                                \
     do {                                                                                                               \
         const size_t lds = gemm_lds(NB_);                                                                              \
