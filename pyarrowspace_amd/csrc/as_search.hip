@@ -475,7 +475,8 @@ struct BatchSel {
     QInfo* info_w;
     int64_t r0, r1, sd, ts;
     int rs;                   // SlotStride::dots_rs
-    int half;                 // the scan left fp16 cosines in the dots' places (as_query::dots_half), not fp32 dots
+    int half;                 // the scan left fp16 cosines in the dots' places (as_query::dots_half), not fp32 dots: 1 = the keys in
+                              // fp32 too, 2 = the lambda term in fp64 (small tau: the scores are all lambda term, an fp32 one costs the proof)
     double tau;
     double* gmin;             // [NS][CAND_CAP]
     double* ckey;             // [NS][CAND_CAP]
@@ -501,12 +502,12 @@ __device__ __forceinline__ float batch_key32(float t32, float cs, float lrow, fl
 }
 // rn = 1/|x_row|, rq = 1/|q_s|: no square root or division for the cosine; one reciprocal for the lambda term
 __device__ __forceinline__ double batch_key(const BatchSel& a, float dot, double rn, double lrow, double rq, double lq) {
-    if (a.half) {
+    if (a.half == 1) {
         // the stored value is the cosine itself, good to 2^-11: the rest in fp32 (a dozen roundings of values below 1 and a
         // reciprocal good to an ulp: under 1e-6 in all, launch_score's e_key32)
         return (double)batch_key32((float)a.tau, dot, (float)lrow, (float)lq);
     }
-    const double cs = (double)dot * rn * rq;
+    const double cs = a.half ? (double)dot : (double)dot * rn * rq;
     return -(a.tau * cs + (1.0 - a.tau) / (1.0 + fabs(lq - lrow)));
 }
 // the dots of slots [s0, s0 + NSW) of one row: two dwordx4 in the batched workspace's [slot quad][32 rows][4] tiles
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void score_gmin_batch_kernel(BatchSel a, int64
     if (g >= ngroups) return;
     const int64_t lo = a.r0 + g * G;
     const int64_t hi = lo + G < a.r1 ? lo + G : a.r1;
-    if (a.half) {
+    if (a.half == 1) {
         // fp16 cosines: fp32 keys, fp32 minima, the wave's minimum over the DPP crossbar (the fp64 butterfly below is 96
         // ds_bpermute per wave -- as long as the wave's four trips over its rows)
         float m32[NSW];
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256) void score_gmin_batch_kernel(BatchSel a, int64
 #pragma unroll
     for (int s = 0; s < NSW; ++s) m[s] = key_traits<double>::inf();
     for (int64_t row = lo + lane; row < hi; row += 64) {
-        const double lrow = a.half ? (double)a.lam32[row] : a.lam64[row];
+        const double lrow = a.half == 1 ? (double)a.lam32[row] : a.lam64[row];
         double rn = 0.0;
         if (!a.half) {
             const double nrow = a.n64[row];
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a, int
         if (!actm) continue;
         const int64_t row = a.r0 + ch * 64 + lane;
         if (row >= a.r1) continue;
-        const double lrow = a.half ? (double)a.lam32[row] : a.lam64[row];
+        const double lrow = a.half == 1 ? (double)a.lam32[row] : a.lam64[row];
         double rn = 0.0;
         if (!a.half) {
             const double nrow = a.n64[row];
@@ -1984,7 +1985,11 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
     // fp16 cosines (batched MFMA pass): the rounding to nearest of a value in [-1, 1] (2^-11 relative), the fp32 reciprocal
     // norms and their products in front of it (a few ulp of fp32), on top of the dot's own error
     const double e_half = q->dots_half && dots32 ? 4.8828125e-4 + 1.0e-6 : 0.0;
-    const double e_key32 = q->dots_half && dots32 ? 1.5e-6 : 0.0;   // the coarse keys' fp32 evaluation (batch_key): not scaled by tau
+    // the coarse keys' fp32 evaluation (batch_key) is not scaled by tau: below tau = 0.05 -- where the scores are nearly all
+    // lambda term and differ in its last digits -- the lambda term stays in fp64 (tau = 0: 42 000 queries/s against 6 600,
+    // every slot failing its proof by 1.5e-6 and going to the single-query path)
+    const int half_mode = q->dots_half && dots32 ? (f.tau < 0.05 ? 2 : 1) : 0;
+    const double e_key32 = half_mode == 1 ? 1.5e-6 : 0.0;
     const double coef_s = dots32 ? f.tau * (coef_query(q, false) + 1.0e-14 + e_half) + e_key32 + 4.0 * 2.220446049250313e-16 : coef_query(q, sizeof(T) == 8);
     if (q->robust && q->Ms > MAX_LIST) {
         // wide lists: exact global selection, then the filter-path finish kernel on exactly M rows
@@ -2029,7 +2034,7 @@ static void launch_score(as_query* q, const T* dots, FinishArgs f, int fuse_fina
             BatchSel b;
             b.dots32 = dots32; b.n64 = q->sp->n64; b.lam64 = q->sp->lam64; b.lam32 = q->sp->lam32; b.info = q->info; b.info_w = q->info;
             b.r0 = q->r0; b.r1 = q->r1; b.sd = q->ss.dots; b.ts = q->ss.dots_ts; b.rs = q->ss.dots_rs; b.tau = f.tau;
-            b.gmin = (double*)q->gmin; b.ckey = (double*)q->ckey_s; b.cidx = q->cidx_s; b.ns = q->nb; b.half = q->dots_half;
+            b.gmin = (double*)q->gmin; b.ckey = (double*)q->ckey_s; b.cidx = q->cidx_s; b.ns = q->nb; b.half = half_mode;
             constexpr int NSW = 8;   // slots per wave: a row's norm and lambda are read GQ / NSW times instead of GQ
             const unsigned ny = (unsigned)((q->nb + NSW - 1) / NSW);
             hipLaunchKernelGGL((score_gmin_batch_kernel<NSW>), dim3((unsigned)((ng + 3) / 4), ny), dim3(256), 0, st, b, G, ng);
