@@ -6,11 +6,9 @@
 #include <chrono>
 #include <vector>
 
-#include "as_query.hpp"
+#include "as_knn.hpp"
 
 namespace as {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -20,7 +18,38 @@ double err_coef(int64_t dp) {
     // |fl32(n_i + n_j - 2 G32) - (exact)| <= coef * (n_i + n_j): k-ordered fp32 fma chain of
     // length dp (gamma_dp), rounded norms, two adds and the fp32 rounding of the inputs.
     const double u = 5.9604644775390625e-8;  // 2^-24
-    return (double)(dp + 16) * u;
+    if (!k2_bf16_enabled()) return (double)(dp + 16) * u;
+    // bf16 head + tail products (as_k2bf.hip): G32 sums xh.yh + xh.yl + xl.yh -- 3 dp exact products, each addition
+    // charged 2^-23 (a matrix core that truncates instead of rounding is covered) --, and what is dropped (xl.yl and
+    // the two remainders, |r| <= 2^-16 |x|) is at most 3.03 * 2^-16 |x_k y_k| per term, hence <= 3.03 * 2^-16 |x||y|
+    // in the sum (Cauchy-Schwarz) and, doubled in the key, <= 3.03 * 2^-16 (n_i + n_j).
+    return (double)(6 * dp + 32) * u + 3.03 * 0x1p-16;
+}
+
+// The operand of the k-NN kernels for this space's items: the fp32 matrix, or (default) its bf16 head + tail image,
+// made on first use and kept with the space.
+static as_status k2_items(const as_space* sp, const float** out) {
+    if (!k2_bf16_enabled()) {
+        *out = sp->x32;
+        return AS_OK;
+    }
+    if (!sp->xs) {
+        const int64_t rows_alloc = sp->np + ROW_TILE;
+        float* xs = nullptr;
+        AS_HIP(hipMalloc(&xs, sizeof(float) * rows_alloc * sp->dp));
+        as_status s = split_rows_bf16(sp->x32, xs, rows_alloc, sp->dp, sp->stream);
+        if (s == AS_OK && hipStreamSynchronize(sp->stream) != hipSuccess) {   // the kernels may run on another space's stream
+            set_err("split_rows_bf16 failed: %s", hipGetErrorString(hipGetLastError()));
+            s = AS_EHIP;
+        }
+        if (s != AS_OK) {
+            (void)hipFree(xs);
+            return s;
+        }
+        sp->xs = xs;
+    }
+    *out = sp->xs;
+    return AS_OK;
 }
 
 // ------------------------------------------------------------------ K0 ingest
@@ -153,65 +182,6 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
 // the candidate bookkeeping of a row never crosses waves.  Candidates that beat the row's
 // running bound are appended to a per-row buffer in HBM scratch; a full buffer is compacted
 // to its M smallest (key, idx) and the bound tightened.
-constexpr int BM = 256, BN = 128, BK = 32, CAP = 256;
-
-struct KnnArgs {
-    const float* x32;
-    const float* n32;
-    const float* inorm32;
-    int64_t n, dp;
-    int64_t r0, r1;
-    int nrb, S, ntile, M, metric;
-    float epskey, coef, nmax;
-    float* buf_key;
-    int* buf_idx;
-    float* out_key;  // [(r1-r0)][S][M]
-    int* out_idx;
-    int* out_cnt;    // [(r1-r0)][S]: count | dropped<<30 | overflowed<<31 (collect mode)
-    // Row side (A operand) and column side (B operand = x32 / n32 / inorm32 / n above) are separate: the same space
-    // for a single-GPU build, this rank's shard against a visiting shard on the ring.  Item ids
-    // are global: row id = row_goff + row, stored column id = col_goff + column.
-    const float* xa;
-    const float* a_n32;
-    const float* a_inorm32;
-    int64_t row_goff, col_goff;
-    // collect mode (second pass over the rows the first could not prove exact): the A rows are a gathered copy
-    // [r1][dp] of those rows (r0 = 0), with their own norms, global ids (self exclusion) and FIXED per-row
-    // thresholds -- every column whose fp32 key is inside the threshold is kept, nothing is compacted away
-    const int* a_ids;
-    const float* a_thr;
-    // symmetric mode (whole-index builds with an eps that admits few pairs): only the column tiles at or above a row
-    // block's own rows are computed -- half the MFMA work.  A unit is (row block, tile range, segment) taken from a
-    // list sorted by length through an atomic cursor; a key d(i, j) computed above the diagonal also serves row j:
-    // when it is inside j's static eps bound it is appended to j's transposed buffer (t_cap entries per row, counter
-    // may exceed it: the row is then flagged), which the host compacts into one more segment of j's candidate lists.
-    const int4* units = nullptr;   // (row block, first tile, end tile, segment)
-    int nunits = 0;
-    int* unit_ctr = nullptr;
-    int* t_cnt = nullptr;          // [n]
-    float* t_key = nullptr;        // [n][t_cap]
-    int* t_idx = nullptr;
-    int t_cap = 0;
-    // Per-item thresholds: thr0[i] is an upper bound of the M-th smallest fp32 key of item i over ALL columns (the
-    // M-th smallest over a sample of the columns is one), or +inf.  A row starts from min(eps bound, thr0) instead of
-    // the eps bound alone (what that rejects is beyond the M-th smallest, like what a compaction drops), and the
-    // transposed appends of the symmetric mode use the column item's.  out_thr: the row bounds a pass ends with.
-    // Column tiles visited: tile index * tstride + tphase (a strided sample of the columns for the threshold pass).
-    const float* thr0 = nullptr;
-    const float* thr_col = nullptr;   // the column items' thresholds (== thr0 in a self build; a visiting block's on the ring)
-    int t_all = 0;                    // block pairs: every tile is "above the diagonal" (rows and columns are different items)
-    float* thr_pub = nullptr;   // == thr0 when the running bounds are published back during the symmetric main pass
-    float* out_thr = nullptr;
-    int tstride = 1, tphase = 0;
-};
-
-__device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int ld_l2(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Cross-lane hand-offs through LDS inside one wave: the hardware keeps a wave's LDS
-// operations in order, the compiler only needs to be told that memory changed.
-#define AS_CBAR() asm volatile("" ::: "memory")
-
 // keep the M smallest (key, idx) of the row's cnt buffered candidates; wave-cooperative
 __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, float* ck, int* ci, int* s_cur,
                                             float* s_thr, int* s_drop, int tstride = 1, float* pub = nullptr) {
@@ -248,8 +218,6 @@ __device__ __forceinline__ void compact_row(int rl, int M, float* bk, int* bi, f
     AS_CBAR();
 }
 
-constexpr int DROW = 32;                       // floats per row of a DMA slab (no padding)
-constexpr int DSLAB = (BM + BN) * DROW;        // floats per slab buffer: A rows then B rows
 
 #ifdef AS_ABLATION   // the A/B ladder of DESIGN.md 5.2 (tools/knn_variants.py); the product library holds one kernel per metric
 constexpr int LROW = 36;   // padded LDS row of the register-staged kernels
@@ -956,6 +924,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// The fused X.X^T + k-smallest kernel, every mode: bf16 head + tail products (default; ka.x32 / ka.xa are split images,
+// k2_items) or the fp32 matrix pipe (ARROWSPACE_K2_FP32=1).
+static as_status launch_k2(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st) {
+    if (k2_bf16_enabled()) return launch_k2_bf16(ka, metric, collect, sym, grid, st);
+    const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
+#define AS_K2(MM, CC, SS)                                                                                               \
+    do {                                                                                                                \
+        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<MM, CC, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); \
+        hipLaunchKernelGGL((knn_mfma_dma8_kernel<MM, CC, SS>), dim3(grid), dim3(512), lds8, st, ka);                    \
+    } while (0)
+    if (metric == AS_METRIC_L2) {
+        if (collect) AS_K2(AS_METRIC_L2, true, false);
+        else if (sym) AS_K2(AS_METRIC_L2, false, true);
+        else AS_K2(AS_METRIC_L2, false, false);
+    } else {
+        if (collect) AS_K2(AS_METRIC_COSINE, true, false);
+        else if (sym) AS_K2(AS_METRIC_COSINE, false, true);
+        else AS_K2(AS_METRIC_COSINE, false, false);
+    }
+#undef AS_K2
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
 // ------------------------------------------------------------------ K2b fp64 refinement
 // One wave per row: merge the S segment lists to the M smallest fp32 keys, evaluate those
 // M pairs exactly in fp64, order by (key64, idx), apply eps and the k cap, and prove a
@@ -1434,14 +1426,17 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     AS_HIP(cidx.alloc((size_t)rows * S * M));
     AS_HIP(ccnt.alloc((size_t)rows * S));
     KnnArgs& ka = c.ka;
-    ka.x32 = sp->x32; ka.n32 = sp->n32; ka.inorm32 = sp->inorm32;
+    const float* items = nullptr;   // fp32 rows, or their bf16 head + tail image
+    if ((variant & 48) == 48) AS_TRY(k2_items(sp, &items));
+    else items = sp->x32;
+    ka.x32 = items; ka.n32 = sp->n32; ka.inorm32 = sp->inorm32;
     ka.n = n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
     ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
     ka.epskey = (float)epskey; ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(sp->nmax * 1.0000002);
     // round the fp32 bound ingredients up so the device-side bound is never tighter than the fp64 one
     ka.epskey = nextafterf(ka.epskey, INFINITY);
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-    ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff; ka.a_ids = nullptr; ka.a_thr = nullptr;
+    ka.xa = items; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff; ka.a_ids = nullptr; ka.a_thr = nullptr;
     ka.units = nullptr; ka.nunits = 0; ka.unit_ctr = nullptr; ka.t_cnt = nullptr; ka.t_key = nullptr; ka.t_idx = nullptr; ka.t_cap = 0;
     if (sym) {   // (the transposed buffers are allocated once the threshold pass has settled their size)
         ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + n; ka.t_cnt = tr_cnt;
@@ -1450,9 +1445,6 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     AS_HIP(ev.create());
     hipEvent_t e0 = ev.e[0], e1 = ev.e[1];
     if ((variant & 48) == 48) {
-        const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
         AS_HIP(hipEventRecord(e0, st));
         if (sym) {
             // threshold pass: every row against every tstride-th column tile (S = 1; the lists are not used): the
@@ -1463,11 +1455,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 k0.units = nullptr; k0.nunits = 0; k0.unit_ctr = nullptr; k0.t_cnt = nullptr; k0.t_key = nullptr; k0.t_idx = nullptr; k0.t_cap = 0;
                 k0.S = 1; k0.tstride = tstride; k0.tphase = 0; k0.ntile = (ntile + tstride - 1) / tstride; k0.thr0 = nullptr; k0.out_thr = thr0;
                 thr_tiles += (double)nrb * k0.ntile;
-                if (metric == AS_METRIC_L2)
-                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
-                else
-                    hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(nrb, dev_cus)), dim3(512), lds8, st, k0);
-                AS_HIP(hipGetLastError());
+                AS_TRY(launch_k2(k0, metric, false, false, std::min(nrb, dev_cus), st));
                 if (attempt == 1 || ev_stride || ev_tcap || tstride <= 16) break;
                 // rows whose sampled count says their transposed buffer would not hold what the main pass sends
                 hipLaunchKernelGGL(sym_risk_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const int*)ccnt, rows,
@@ -1538,8 +1526,6 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
             ka.thr0 = thr0;
             ka.thr_col = thr0;
             ka.thr_pub = publish ? (float*)thr0 : nullptr;
-            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-            AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             const size_t ldst = (sizeof(float) + sizeof(int)) * 4 * (size_t)T_CAP;
             AS_HIP(hipFuncSetAttribute((const void*)transposed_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
             for (int c = 0; c < nchunk; ++c) {
@@ -1554,21 +1540,15 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP;
                 if (c) AS_HIP(hipMemsetAsync(ka.unit_ctr, 0, sizeof(int), st));
                 const int lgrid = std::min(std::min(cunits, dev_cus), grid);
-                if (metric == AS_METRIC_L2)
-                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(lgrid), dim3(512), lds8, st, ka);
-                else
-                    hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(lgrid), dim3(512), lds8, st, ka);
-                AS_HIP(hipGetLastError());
+                AS_TRY(launch_k2(ka, metric, false, true, lgrid, st));
                 // the transposed buffers become segment S - 1 of their rows' candidate lists
                 hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((j1 - j0 + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt + j0,
                                    (const float*)tr_key, (const int*)tr_idx, T_CAP, j1 - j0, S, S - 1, M, (float*)ckey + (size_t)j0 * S * M,
                                    (int*)cidx + (size_t)j0 * S * M, (int*)ccnt + (size_t)j0 * S);
                 AS_HIP(hipGetLastError());
             }
-        } else if (metric == AS_METRIC_L2)
-            hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_L2>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
-        else
-            hipLaunchKernelGGL(knn_mfma_dma8_kernel<AS_METRIC_COSINE>, dim3(std::min(units, dev_cus)), dim3(512), lds8, st, ka);
+        } else
+            AS_TRY(launch_k2(ka, metric, false, false, std::min(units, dev_cus), st));
     } else {
 #ifdef AS_ABLATION
         const size_t lds = sizeof(float) * (BM + BN) * LROW * (((variant & 2) && !(variant & 16)) ? 2 : 1) + sizeof(float) * 4 * BM +
@@ -1719,7 +1699,8 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             AS_HIP(c2cnt.alloc((size_t)nfp * S2));
             AS_HIP(hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
             AS_HIP(hipMemsetAsync(xa, 0, sizeof(float) * (size_t)(nfp + BM) * sp->dp, st));
-            hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, sp->x32, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
+            // (ka.x32 is the operand the first pass ran on: the rows are gathered from the same image)
+            hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, ka.x32, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
                                (const int*)d_ids, nf, (const double*)bandB, metric, coef, sp->nmax, (float*)xa, (float*)a_n32, (float*)a_inorm,
                                (int*)a_ids, (float*)a_thr, (int64_t)0);
             AS_HIP(hipGetLastError());
@@ -1729,7 +1710,6 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             kb.r0 = 0; kb.r1 = nf; kb.nrb = nrb2; kb.S = S2; kb.M = CAP;
             kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
             kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr;
-            const size_t lds8c = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
             const int g2 = std::min(nrb2 * S2, dev_cus);
             // per-block append buffers: the first pass sized them for ITS grid
             dev_tmp<float> bkey2;
@@ -1740,14 +1720,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
                 kb.buf_key = bkey2;
                 kb.buf_idx = bidx2;
             }
-            if (metric == AS_METRIC_L2) {
-                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8c));
-                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, true>), dim3(g2), dim3(512), lds8c, st, kb);
-            } else {
-                AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8c));
-                hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, true>), dim3(g2), dim3(512), lds8c, st, kb);
-            }
-            AS_HIP(hipGetLastError());
+            AS_TRY(launch_k2(kb, metric, true, false, g2, st));
             BandArgs ba;
             ba.x32 = sp->x32; ba.x64 = sp->x64; ba.n64 = sp->n64; ba.d = sp->d; ba.dp = sp->dp; ba.r0 = r0;
             ba.S = S2; ba.CW = CAP; ba.metric = metric; ba.nf = nf; ba.k = kk; ba.epskey = epskey;
@@ -2214,23 +2187,6 @@ static as_status knn_fold_raw(const as_space* sp, int64_t rows, int M, double* r
     return fold_launch(sp, 0, rows, M, 0, 1, 0.0, nullptr, r_key, r_dist, r_gy, r_idx, r_cnt, r_t32, b_key, b_dist, b_gy, b_idx, b_cnt, b_t32);
 }
 
-// the fused MFMA kernel on (rows of sp) x (columns of cols), normal or collect mode
-static as_status launch_k2(const KnnArgs& ka, int metric, bool collect, int grid, hipStream_t st) {
-    const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
-#define AS_K2(MM, CC)                                                                                                   \
-    do {                                                                                                                \
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<MM, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); \
-        hipLaunchKernelGGL((knn_mfma_dma8_kernel<MM, CC>), dim3(grid), dim3(512), lds8, st, ka);                        \
-    } while (0)
-    if (metric == AS_METRIC_L2 && !collect) AS_K2(AS_METRIC_L2, false);
-    else if (metric == AS_METRIC_L2) AS_K2(AS_METRIC_L2, true);
-    else if (!collect) AS_K2(AS_METRIC_COSINE, false);
-    else AS_K2(AS_METRIC_COSINE, true);
-#undef AS_K2
-    AS_HIP(hipGetLastError());
-    return AS_OK;
-}
-
 static int device_cus(int device) {
     hipDeviceProp_t prop;
     return hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -2295,13 +2251,16 @@ as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_par
     AS_HIP(ccnt.alloc((size_t)rows * S));
     const double nmax = std::max(sp->nmax, cols->nmax);
     KnnArgs ka;
-    ka.x32 = cols->x32; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+    const float *items_a = nullptr, *items_b = nullptr;
+    AS_TRY(k2_items(sp, &items_a));
+    AS_TRY(k2_items(cols, &items_b));
+    ka.x32 = items_b; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
     ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
     ka.epskey = nextafterf((float)epskey, INFINITY); ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(nmax * 1.0000002);
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-    ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff + 0; ka.col_goff = col_goff;
+    ka.xa = items_a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff + 0; ka.col_goff = col_goff;
     ka.a_ids = nullptr; ka.a_thr = nullptr;
-    AS_TRY(launch_k2(ka, metric, false, grid, st));
+    AS_TRY(launch_k2(ka, metric, false, false, grid, st));
     BlockRefineArgs ra;
     ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = cols->x32; ra.xb64 = cols->x64; ra.na64 = sp->n64; ra.nb64 = cols->n64;
     ra.d = sp->d; ra.dp = sp->dp; ra.r0 = r0; ra.r1 = r1; ra.col_goff = col_goff; ra.S = S; ra.M = M; ra.metric = metric;
@@ -2405,11 +2364,14 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));
     const double nmax = std::max(sp->nmax, cols->nmax);
     KnnArgs ka;
-    ka.x32 = cols->x32; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+    const float *items_a = nullptr, *items_b = nullptr;
+    AS_TRY(k2_items(sp, &items_a));
+    AS_TRY(k2_items(cols, &items_b));
+    ka.x32 = items_b; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
     ka.nrb = nrb; ka.S = S; ka.ntile = ntile_all; ka.M = M; ka.metric = metric;
     ka.epskey = nextafterf((float)epskey, INFINITY); ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(nmax * 1.0000002);
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-    ka.xa = sp->x32; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff;
+    ka.xa = items_a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff;
     ka.a_ids = nullptr; ka.a_thr = nullptr;
     // the kernel addresses the transposed buffers by the item's number inside the block: bases moved back by the chunk's
     // first item (only items of the chunk's tiles are ever addressed)
@@ -2417,15 +2379,7 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     ka.t_key = (float*)tr_key - (size_t)j0 * T_CAP; ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP; ka.t_cap = T_CAP;
     ka.t_all = 1; ka.thr_col = col_thr;
     ka.thr0 = row_thr;   // the own rows' thresholds (their own-block lists' bounds): what a tighter start rejects lies beyond the row's M-th key
-    const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
-    if (metric == AS_METRIC_L2) {
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-        hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_L2, false, true>), dim3(grid), dim3(512), lds8, st, ka);
-    } else {
-        AS_HIP(hipFuncSetAttribute((const void*)knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-        hipLaunchKernelGGL((knn_mfma_dma8_kernel<AS_METRIC_COSINE, false, true>), dim3(grid), dim3(512), lds8, st, ka);
-    }
-    AS_HIP(hipGetLastError());
+    AS_TRY(launch_k2(ka, metric, false, true, grid, st));
     // own rows: as in knn_block
     BlockRefineArgs ra;
     ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = cols->x32; ra.xb64 = cols->x64; ra.na64 = sp->n64; ra.nb64 = cols->n64;
@@ -2596,17 +2550,20 @@ as_status knn_block_band(const as_space* sp, const as_space* cols, const as_grap
     AS_HIP(hipMemsetAsync(xa, 0, sizeof(float) * (size_t)(nfp + BM) * sp->dp, st));
     AS_HIP(hipMemsetAsync(over, 0, sizeof(int), st));
     const double nmax = std::max(sp->nmax, cols->nmax);
-    hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, sp->x32, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
+    const float *items_a = nullptr, *items_b = nullptr;
+    AS_TRY(k2_items(sp, &items_a));
+    AS_TRY(k2_items(cols, &items_b));
+    hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, items_a, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
                        (const int*)d_ids, nf, B, metric, coef, nmax, (float*)xa, (float*)a_n32, (float*)a_inorm, (int*)a_ids, (float*)a_thr,
                        row_goff);
     AS_HIP(hipGetLastError());
     KnnArgs kb;
-    kb.x32 = cols->x32; kb.n32 = cols->n32; kb.inorm32 = cols->inorm32; kb.n = cols->n; kb.dp = sp->dp; kb.r0 = 0; kb.r1 = nf;
+    kb.x32 = items_b; kb.n32 = cols->n32; kb.inorm32 = cols->inorm32; kb.n = cols->n; kb.dp = sp->dp; kb.r0 = 0; kb.r1 = nf;
     kb.nrb = nrb2; kb.S = S2; kb.ntile = ntile; kb.M = CAP; kb.metric = metric;
     kb.epskey = 0; kb.coef = 0; kb.nmax = 0;
     kb.buf_key = bkey; kb.buf_idx = bidx; kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
     kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr; kb.row_goff = 0; kb.col_goff = col_goff;
-    AS_TRY(launch_k2(kb, metric, true, g2, st));
+    AS_TRY(launch_k2(kb, metric, true, false, g2, st));
     BlockBandArgs ba;
     ba.xa32 = sp->x32; ba.xa64 = sp->x64; ba.xb32 = cols->x32; ba.xb64 = cols->x64; ba.na64 = sp->n64; ba.nb64 = cols->n64;
     ba.d = sp->d; ba.dp = sp->dp; ba.r0 = r0; ba.col_goff = col_goff; ba.S = S2; ba.CW = CAP; ba.M = M; ba.metric = metric; ba.nf = nf;

@@ -50,6 +50,7 @@ struct as_space {
     int device = 0;
     int64_t n = 0, d = 0, np = 0, dp = 0;
     float* x32 = nullptr;     // [np][dp]
+    mutable float* xs = nullptr;  // [np][dp] bf16 head + tail image of x32 (as_k2bf.hip), made by the first k-NN pass; null until then
     double* x64 = nullptr;    // [n][d] or null when the items are exactly fp32-representable
     double* n64 = nullptr;    // [n] squared norms (fp64, from the fp64 items)
     float* n32 = nullptr;     // [np] squared norms rounded to fp32 (0 on pad rows)

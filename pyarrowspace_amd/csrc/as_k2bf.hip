@@ -1,0 +1,466 @@
+// K2 on the bf16 matrix pipe: the fused X.X^T + streaming k-smallest kernel of as_build.hip with every operand as
+// bf16 head + tail (x = xh + xl + r, |r| <= 2^-16 |x|) and x_i.x_j ~ xh_i.xh_j + xh_i.xl_j + xl_i.xh_j -- three
+// v_mfma_f32_32x32x16_bf16 per 16 columns instead of eight v_mfma_f32_32x32x2_f32 (the bf16 pipe runs at 16 x the
+// fp32 rate on gfx950).  The items are split ONCE (split_rows_bf16: per row and 32-column slab 32 heads then 32
+// tails, the bytes and the stride of the fp32 slab row), so the LDS-DMA image, its XOR swizzle and the fragment
+// addresses are those of the fp32 kernel: 16-byte chunk c of a slab row holds heads (c < 4) or tails (c >= 4) of
+// columns 8 (c & 3) .. 8 (c & 3) + 7 -- exactly one lane's operand of a 16-column k-step.
+//
+// With the matrix time cut to a fifth, the kernel lives on its staging pipeline: a ring of RING = 3 slab buffers,
+// slabs issued two ahead of the MFMAs, one raw s_barrier per slab, counted vmcnt (never 0 in the loop) -- and every
+// LDS access of the steady state through inline asm, because the compiler orders any LDS access it can see behind ALL
+// outstanding LDS-DMA (vmcnt(0)), which would drain the ring.  Candidate bookkeeping, symmetric mode, collect mode and
+// every output are those of knn_mfma_dma8_kernel; what the dropped products cost is in
+// err_coef (as_build.hip).  Replaces the distance block of the crate call at /root/reference/src/lib.rs:278-289.
+#include <cstdlib>
+
+#include "as_knn.hpp"
+
+namespace as {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int RING = 3;             // slab buffers
+constexpr int NPIECE = 6;           // DMA pieces per wave and slab: 4 x 8 A rows of its 32, 2 x 8 B rows of its 16
+constexpr int SN = 4;               // column-side norm / threshold lines kept (tiles in flight: see the WAR note below)
+
+bool k2_bf16_enabled() {
+    const char* e = getenv("ARROWSPACE_K2_FP32");
+    return !(e && atoi(e) != 0);
+}
+
+// ------------------------------------------------------------------ split image
+// 8 consecutive floats -> 8 heads (16 B) at the same place of the slab's first half, 8 tails in its second half.
+// A non-finite value keeps its head and gets a zero tail (inf - inf would be NaN).
+__global__ void split_bf16_kernel(const float* __restrict__ x32, float* __restrict__ xs, int64_t groups) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        const f32x4 a = *(const f32x4*)(x32 + 8 * g), b = *(const f32x4*)(x32 + 8 * g + 4);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            hi[t] = (__bf16)a[t];
+            hi[4 + t] = (__bf16)b[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float ra = a[t] - (float)hi[t], rb = b[t] - (float)hi[4 + t];
+            lo[t] = (__bf16)(ra == ra ? ra : 0.0f);
+            lo[4 + t] = (__bf16)(rb == rb ? rb : 0.0f);
+        }
+        char* slab = (char*)xs + (g >> 2) * 128 + (g & 3) * 16;
+        *(bf16x8*)slab = hi;
+        *(bf16x8*)(slab + 64) = lo;
+    }
+}
+
+as_status split_rows_bf16(const float* x32, float* xs, int64_t rows, int64_t dp, hipStream_t st) {
+    const int64_t groups = rows * dp / 8;
+    if (groups <= 0) return AS_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((groups + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, st, x32, xs, groups);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+// ------------------------------------------------------------------ LDS through inline asm
+// Each block waits for its own reads before it ends: no register the compiler may copy or reuse holds data in flight.
+__device__ __forceinline__ void lds_frag5(unsigned aa, unsigned ab, f32x4& a, f32x4& b0, f32x4& b1, f32x4& b2, f32x4& b3) {
+    asm volatile(
+        "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %6 offset:8192\n\t"
+        "ds_read_b128 %4, %6 offset:12288\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(a), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+        : "v"(aa), "v"(ab)
+        : "memory");
+}
+__device__ __forceinline__ void lds_read_b128x8(unsigned a0, f32x4 (&v)[8]) {
+    // rows 4h + {0..3} + 8g, g = 0..3, of the wave's (bound, norm) pairs: 32 B per group, 64 B between groups
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:80\n\t"
+        "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:144\n\tds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:208\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(a0)
+        : "memory");
+}
+__device__ __forceinline__ void lds_read_b32x4(unsigned a0, float& v0, float& v1, float& v2, float& v3) {
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:128\n\tds_read_b32 %2, %4 offset:256\n\tds_read_b32 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(a0)
+                 : "memory");
+}
+__device__ __forceinline__ int lds_read_i32(unsigned a) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write_i32(unsigned a, int v) {
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(a), "v"(v) : "memory");
+}
+// s_waitcnt vmcnt(n) for the wave-uniform counts the ring produces; anything else waits for everything (always correct)
+__device__ __forceinline__ void ring_wait(int n) {
+    if (n == NPIECE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == NPIECE + 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == NPIECE + 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// keep the M smallest (key, idx) of the row's cnt <= CAP buffered candidates -- the ranks of compact_row (as_build.hip),
+// formed in registers: a lane holds entries lane + 64 u and meets every entry through v_readlane (no LDS scratch:
+// the ring takes the room).  Only called with the DMA ring's state irrelevant (it drains it: compiler-visible loads).
+__device__ __forceinline__ void compact_row_reg(int M, float* bk, int* bi, int cnt, float* s_thr, int* s_cur_row, int* s_drop_row, float* pub) {
+    const int lane = lane_id();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float k[4];
+    int id[4], rank[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = lane + 64 * u;
+        k[u] = t < cnt ? ld_l2(bk + t) : __int_as_float(0x7f800000);
+        id[u] = t < cnt ? ld_l2(bi + t) : 0x7fffffff;
+        rank[u] = 0;
+    }
+#pragma unroll
+    for (int us = 0; us < 4; ++us) {
+        const int lim = min(64, cnt - 64 * us);
+        for (int l = 0; l < lim; ++l) {
+            const float ks = bcast_lane(k[us], l);
+            const int is = bcast_lane(id[us], l);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank[u] += lex_less<float>(ks, is, k[u], id[u]) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (lane + 64 * u < cnt && rank[u] < M) {
+            bk[rank[u]] = k[u];
+            bi[rank[u]] = id[u];
+            if (rank[u] == M - 1) {
+                *s_thr = k[u];
+                // symmetric mode: the row's new bound is published for the blocks that hold this item as a column
+                if (pub) atomicMin((int*)pub, __float_as_int(fmaxf(k[u], 0.0f)));
+            }
+        }
+    }
+    if (lane == 0) {
+        *s_cur_row = M;
+        *s_drop_row = 1;
+    }
+    AS_CBAR();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------ the kernel
+// Block = 8 waves (two per SIMD), tile 256 rows x 128 columns; wave w owns rows [32w, 32w+32) as 1x4 accumulators.
+template <int METRIC, bool COLLECT, bool SYM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_bf16_kernel(KnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Sl = (float*)smem;                     // RING slab buffers: A rows then B rows, 128 B per row
+    float2* s_ta = (float2*)(Sl + RING * DSLAB);  // per row: (running bound, n_i or 1/|x_i|)
+    int* s_cur = (int*)(s_ta + BM);
+    int* s_drop = s_cur + BM;
+    int* s_id = s_drop + BM;                      // collect mode: global item id of every A row
+    float* s_n = (float*)(s_id + BM);             // [SN][2][BN]: the column items' norms and thresholds of the tiles in flight
+    int* s_unit = (int*)(s_n + SN * 2 * BN);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* __restrict__ bkey = a.buf_key + (size_t)blockIdx.x * BM * CAP;
+    int* __restrict__ bidx = a.buf_idx + (size_t)blockIdx.x * BM * CAP;
+    const int units = a.nrb * a.S;
+    const int nslab = (int)(a.dp / BK);
+    const float finf = __int_as_float(0x7f800000);
+    const int drow = lane >> 3;
+    const int csw0 = (lane & 7) ^ ((lane >> 4) & 7);
+    const int csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+    const unsigned lo0 = (unsigned)((drow * a.dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * a.dp + csw1 * 4) * 4);
+    // fragment addresses inside a slab buffer: chunk 2 q + h of the lane's row (q = 0, 1: heads of k-step q; q = 2, 3: tails)
+    unsigned aoff[4], boff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned sw = (unsigned)(((2 * q + h) ^ ((l31 >> 1) & 7)) << 4);
+        aoff[q] = lds0 + (unsigned)((w * 32 + l31) * DROW * 4) + sw;
+        boff[q] = lds0 + (unsigned)((BM + l31) * DROW * 4) + sw;
+    }
+    const unsigned ta0 = lds0 + (unsigned)(RING * DSLAB * 4) + (unsigned)((w * 32 + 4 * h) * 8);
+    const unsigned cur0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8);
+    const unsigned sn0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8 + 3 * BM * 4);
+    const bool late = wu >= 4;   // wave-uniform: the second-dispatched half issues its DMA mid-slab
+    // vector-memory operations a wave adds to the first slab of a tile: the column items' norms (and thresholds)
+    const int nextra = wu < 2 ? (SYM ? 2 : 1) : 0;
+    const float* __restrict__ cnorm = METRIC == AS_METRIC_L2 ? a.n32 : a.inorm32;
+    const float* __restrict__ cthr = a.thr_col ? a.thr_col : a.n32;
+
+    for (int u = blockIdx.x;; u += gridDim.x) {
+        int rb, cs, t0, t1;
+        if (SYM) {
+            // longest units first, handed out through an atomic cursor (the triangle's units differ in length)
+            if (tid == 0) *s_unit = atomicAdd(a.unit_ctr, 1);
+            __syncthreads();   // the previous unit ended with a barrier: nobody still reads the old value
+            u = *s_unit;
+            if (u >= a.nunits) break;
+            const int4 ud = a.units[u];
+            rb = ud.x; t0 = ud.y; t1 = ud.z; cs = ud.w;
+        } else {
+            if (u >= units) break;
+            rb = u / a.S;
+            cs = u % a.S;
+            t0 = (int)((int64_t)a.ntile * cs / a.S);
+            t1 = (int)((int64_t)a.ntile * (cs + 1) / a.S);
+        }
+        const int64_t rowbase = a.r0 + (int64_t)rb * BM;
+        if (tid < BM) {
+            const int64_t rg = rowbase + tid;
+            const bool valid = rg < a.r1;
+            if (COLLECT) {
+                s_ta[tid] = make_float2(valid ? a.a_thr[rg] : -finf, valid ? (METRIC == AS_METRIC_L2 ? a.a_n32[rg] : a.a_inorm32[rg]) : 0.0f);
+                s_id[tid] = valid ? a.a_ids[rg] : -1;
+                s_drop[tid] = 0;
+            } else {
+                const float ni = valid ? a.a_n32[rg] : 0.0f;
+                float bound = METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (ni + a.nmax) : a.epskey + a.coef;
+                int dropped = 0;
+                if (a.thr0 && valid) {
+                    const float t0r = ld_l2(a.thr0 + rg);   // possibly tightened by other units of this row since the threshold pass
+                    if (t0r < bound) {   // what the tighter start rejects is beyond the row's M-th smallest key: a drop
+                        bound = t0r;
+                        dropped = 1;
+                    }
+                }
+                s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.a_inorm32[rg]) : 0.0f);
+                s_drop[tid] = dropped;
+            }
+            s_cur[tid] = 0;
+        }
+        const char* pa0 = (const char*)(a.xa + (size_t)(rowbase + wu * 32) * a.dp);
+        // prefetch cursor: (tile, slab) of the next slab to issue, RING - 1 slabs ahead of the MFMAs
+        int pct = t0, pks = 0, pbuf = 0, inflight = 0;
+        bool young_first = false;   // the youngest slab in flight opens a tile (it carries the wave's extra operations)
+        // (a macro, not a lambda: the by-reference closure of a lambda this size is left in scratch memory)
+#define K2_ISSUE()                                                                                                          \
+    do {                                                                                                                    \
+        if (pct < t1) {                                                                                                     \
+            const int64_t cb_ = ((int64_t)pct * a.tstride + a.tphase) * BN;                                                 \
+            const char* sa_ = pa0 + pks * (BK * 4);                                                                         \
+            const char* sb_ = (const char*)(a.x32 + (size_t)(cb_ + wu * 16) * a.dp) + pks * (BK * 4);                       \
+            float* dst_ = Sl + pbuf * DSLAB;                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa_ + (size_t)(8 * j) * a.dp * 4 + ((j & 1) ? lo1 : lo0)), \
+                                                 (__attribute__((address_space(3))) void*)(dst_ + (wu * 32 + 8 * j) * DROW), 16, 0, 0);          \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb_ + (size_t)(8 * j) * a.dp * 4 + ((j & 1) ? lo1 : lo0)), \
+                                                 (__attribute__((address_space(3))) void*)(dst_ + BM * DROW + (wu * 16 + 8 * j) * DROW), 16, 0, 0); \
+            young_first = pks == 0;                                                                                         \
+            if (pks == 0 && wu < 2) {                                                                                       \
+                /* always issued, addresses clamped instead of lanes masked: the ring's counts assume the operation */      \
+                const int64_t cg_ = cb_ + wu * 64 + lane;                                                                   \
+                float* sn_ = s_n + (pct & (SN - 1)) * 2 * BN + wu * 64;                                                     \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cnorm + cg_),              \
+                                                 (__attribute__((address_space(3))) void*)sn_, 4, 0, 0);                    \
+                if (SYM)                                                                                                    \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cthr + (cg_ < a.n ? cg_ : a.n - 1)), \
+                                                     (__attribute__((address_space(3))) void*)(sn_ + BN), 4, 0, 0);         \
+            }                                                                                                               \
+            pbuf = pbuf + 1 == RING ? 0 : pbuf + 1;                                                                         \
+            if (++pks == nslab) {                                                                                           \
+                pks = 0;                                                                                                    \
+                ++pct;                                                                                                      \
+            }                                                                                                               \
+            ++inflight;                                                                                                     \
+        }                                                                                                                   \
+    } while (0)
+        // the previous unit's last reads of the ring and of s_n are behind its closing barrier
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) K2_ISSUE();
+        AS_LDS_FENCE();
+        __builtin_amdgcn_s_barrier();   // s_ta / s_cur / s_drop of this unit are in place (no vmcnt(0): the ring is filling)
+        unsigned cbuf = 0;   // byte offset of the slab buffer the MFMAs read next
+        for (int ct = t0; ct < t1; ++ct) {
+            const int64_t colbase = ((int64_t)ct * a.tstride + a.tphase) * BN;
+            f32x16 acc[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nn][r] = 0.0f;
+            for (int ks = 0; ks < nslab; ++ks) {
+                // the slab has landed once only the younger slab's operations are outstanding (operations retire in
+                // issue order; anything else in flight -- appends -- only makes the wait stricter)
+                ring_wait(inflight >= 2 ? NPIECE + (young_first ? nextra : 0) : 0);
+                __builtin_amdgcn_s_barrier();   // everybody's pieces are in, everybody is done with the buffer issued into next
+                --inflight;
+                if (!late) K2_ISSUE();
+                f32x4 fa, fb[4], ga, gb[4];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    lds_frag5(aoff[s] + cbuf, boff[s] + cbuf, fa, fb[0], fb[1], fb[2], fb[3]);          // heads of k-step s
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn)
+                        acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb[nn]), acc[nn], 0, 0, 0);
+                    lds_frag5(aoff[2 + s] + cbuf, boff[2 + s] + cbuf, ga, gb[0], gb[1], gb[2], gb[3]);  // tails
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn)
+                        acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, gb[nn]), acc[nn], 0, 0, 0);
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn)
+                        acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga), __builtin_bit_cast(bf16x8, fb[nn]), acc[nn], 0, 0, 0);
+                    if (s == 0 && late) K2_ISSUE();
+                }
+                cbuf = cbuf + DSLAB * 4 == RING * DSLAB * 4 ? 0 : cbuf + DSLAB * 4;
+            }
+            // ---- epilogue: keys, bound test, append (32 rows per wave).  The tile's norm line was issued with its first
+            // slab and waited for with it; a tile of one slab has not met a later wait yet.
+            float nj[4], tj[4] = {finf, finf, finf, finf};
+            int cj[4];
+            {
+                const unsigned sna = sn0 + (unsigned)(((ct & (SN - 1)) * 2 * BN + l31) * 4);
+                lds_read_b32x4(sna, nj[0], nj[1], nj[2], nj[3]);
+                if (SYM) lds_read_b32x4(sna + BN * 4, tj[0], tj[1], tj[2], tj[3]);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) cj[nn] = (int)(colbase + nn * 32 + l31);
+            }
+            {
+                const int mycnt = lds_read_i32(cur0 + (unsigned)((w * 32 + l31) * 4));
+                unsigned long long need = __ballot(lane < 32 && mycnt > CAP - BN);
+                if (COLLECT) {
+                    // nothing may be dropped here: a row whose band does not fit stops collecting and is reported
+                    if (need) {
+                        const int rl = w * 32 + l31;
+                        if (lane < 32 && s_cur[rl] > CAP - BN) {
+                            s_ta[rl].x = -finf;
+                            s_drop[rl] = 2;
+                        }
+                        AS_LDS_FENCE();
+                    }
+                    need = 0;
+                }
+                while (need) {
+                    const int r = __ffsll((long long)need) - 1;
+                    const unsigned rr = w * 32 + r;
+                    compact_row_reg(a.M, bkey + rr * CAP, bidx + rr * CAP, s_cur[rr], &s_ta[rr].x, s_cur + rr, s_drop + rr,
+                                    SYM && a.thr_pub ? a.thr_pub + (rowbase + rr) : nullptr);
+                    need &= need - 1;
+                }
+            }
+            f32x4 tav[8];   // (bound, norm) of rows 4 h + {0..3} + 8 g: tav[2 g] = rows +0, +1; tav[2 g + 1] = rows +2, +3
+            lds_read_b128x8(ta0, tav);
+            const int64_t colg = a.col_goff + colbase, rowg = a.row_goff + rowbase;   // global ids of the tile's corner
+            const bool edge = COLLECT || colbase + BN > a.n || (colg < rowg + BM && colg + BN > rowg);
+            // symmetric mode: tiles strictly above the row block also serve the column items' rows (the diagonal tiles
+            // hold both (i, j) and (j, i) themselves)
+            const bool transp = SYM && a.t_cnt && (a.t_all || colbase >= rowbase + BM);
+            float cb[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                cb[nn] = !transp || cj[nn] >= (int)a.n ? -finf : (METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (nj[nn] + a.nmax) : a.epskey + a.coef);
+                if (transp && a.thr_col && cj[nn] < (int)a.n) cb[nn] = fminf(cb[nn], tj[nn]);   // as of the tile's first slab: a stale bound is only less tight
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const f32x4 tq = tav[2 * (r >> 2) + ((r & 3) >> 1)];
+                const float thr = (r & 1) ? tq[2] : tq[0], ai = (r & 1) ? tq[3] : tq[1];
+                float key[4];
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    const float gg = acc[nn][r];
+                    key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * (ai * nj[nn]));
+                }
+                bool any_t = false;
+                if (transp) {
+                    const bool rowok = rowbase + rl < a.r1;
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) any_t = any_t || (rowok && key[nn] <= cb[nn]);
+                }
+                if (transp && __ballot(any_t)) {
+                    const int rg = (int)(rowg + rl);
+                    const bool rowok = rowbase + rl < a.r1;
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn)
+                        if (rowok && key[nn] <= cb[nn]) {
+                            const int slot = atomicAdd(a.t_cnt + cj[nn], 1);
+                            if (slot < a.t_cap) {
+                                a.t_key[(size_t)cj[nn] * a.t_cap + slot] = key[nn];
+                                a.t_idx[(size_t)cj[nn] * a.t_cap + slot] = rg;
+                            }
+                        }
+                }
+                if (edge) {  // wave-uniform: only tiles on the diagonal or at the padded tail pay for the exclusions
+                    // collect mode: an excluded entry must fail `key <= thr` even against an infinite band: NaN
+                    const float excl = COLLECT ? __int_as_float(0x7fc00000) : finf;
+                    const int rg = COLLECT ? s_id[rl] : (int)(rowg + rl);
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn)
+                        if (cj[nn] >= (int)a.n || cj[nn] + (int)a.col_goff == rg) key[nn] = excl;
+                }
+                const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
+                if (__ballot(kmin <= thr)) {
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) {
+                        const bool p = key[nn] <= thr;
+                        const unsigned long long mk = __ballot(p);
+                        if (!mk) continue;
+                        const unsigned hm = h ? (unsigned)(mk >> 32) : (unsigned)mk;
+                        const int base = s_cur[rl];
+                        if (p) {
+                            const unsigned slot = (unsigned)rl * CAP + base + __popc(hm & ((1u << l31) - 1u));
+                            bkey[slot] = key[nn];
+                            bidx[slot] = cj[nn] + (int)a.col_goff;
+                        }
+                        AS_CBAR();
+                        s_cur[rl] = base + __popc(hm);
+                        AS_CBAR();
+                    }
+                }
+            }
+        }
+        // ---- finalize this unit's rows (each wave: its 32 rows); the ring is empty
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        AS_CBAR();
+        for (int r = 0; r < 32; ++r) {
+            const unsigned rl = w * 32 + r;
+            const int64_t rg = rowbase + rl;
+            if (rg >= a.r1) break;
+            if (!COLLECT && s_cur[rl] > a.M)
+                compact_row_reg(a.M, bkey + rl * CAP, bidx + rl * CAP, s_cur[rl], &s_ta[rl].x, s_cur + rl, s_drop + rl,
+                                SYM && a.thr_pub ? a.thr_pub + rg : nullptr);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int cnt = s_cur[rl];
+            const size_t ob = ((size_t)(rg - a.r0) * a.S + cs) * a.M;
+            for (int t = lane; t < cnt; t += 64) {
+                a.out_key[ob + t] = ld_l2(bkey + rl * CAP + t);
+                a.out_idx[ob + t] = ld_l2(bidx + rl * CAP + t);
+            }
+            if (lane == 0) {
+                a.out_cnt[(size_t)(rg - a.r0) * a.S + cs] = (int)((unsigned)cnt | ((unsigned)s_drop[rl] << 30));
+                if (!COLLECT && a.out_thr) a.out_thr[rg] = s_ta[rl].x;   // M-th smallest key seen (or the start bound): threshold pass, S = 1
+            }
+        }
+        __syncthreads();
+#undef K2_ISSUE
+    }
+}
+
+constexpr size_t K2BF_LDS = sizeof(float) * RING * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + sizeof(float) * SN * 2 * BN + 16;
+
+as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st) {
+#define AS_K2B(MM, CC, SS)                                                                                                        \
+    do {                                                                                                                          \
+        AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<MM, CC, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \
+        hipLaunchKernelGGL((knn_bf16_kernel<MM, CC, SS>), dim3(grid), dim3(512), K2BF_LDS, st, ka);                                \
+    } while (0)
+    if (metric == AS_METRIC_L2) {
+        if (collect) AS_K2B(AS_METRIC_L2, true, false);
+        else if (sym) AS_K2B(AS_METRIC_L2, false, true);
+        else AS_K2B(AS_METRIC_L2, false, false);
+    } else {
+        if (collect) AS_K2B(AS_METRIC_COSINE, true, false);
+        else if (sym) AS_K2B(AS_METRIC_COSINE, false, true);
+        else AS_K2B(AS_METRIC_COSINE, false, false);
+    }
+#undef AS_K2B
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+}  // namespace as
