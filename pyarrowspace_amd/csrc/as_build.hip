@@ -46,6 +46,9 @@ static as_status k2_items(const as_space* sp, const float** out) {
             (void)hipFree(xs);
             return s;
         }
+#ifdef AS_ABLATION
+        if (getenv("ARROWSPACE_K2_ZERO")) (void)hipMemset(xs, 0, sizeof(float) * rows_alloc * sp->dp);   // clock experiments: all-zero operands
+#endif
         sp->xs = xs;
     }
     *out = sp->xs;
@@ -1308,6 +1311,55 @@ static int pick_list_width(int64_t k) {
 }
 int knn_list_width(int64_t k) { return pick_list_width(k); }
 
+// Gang order of a symmetric pass's units (bf16 kernel; KnnArgs::xoff; opt-in: ARROWSPACE_K2_GANG_GC = column pieces per
+// gang).  Every block streams 48 KB per tile and slab from beyond its XCD's L2 (17 % hits in the plain order) -- so the
+// units are dealt to the eight XCDs in GANGS: GR consecutive row blocks x GC column pieces (GR GC <= 32, the blocks of an
+// XCD): the XCD's blocks then work on 32 / GC row blocks, whose rows (768 KB each at 768 columns) stay in its 4 MB L2 from
+// tile to tile.  Pieces are aligned (tile0 + multiples of Lp) so that the units of a gang walk the same tiles.  Gangs go
+// to the XCD with the least work so far, longest first; xoff[0..8] are the lists' bounds.  Measured:
+// L2 hits 17 -> 48 %, fabric fetch -35 %, the memory side alone 0.111 -> 0.079 s at 262144 x 768 -- and the kernel no
+// faster: on random operands it is held by the chip's power management, not by its memory side.  Kept for shapes and
+// chips where that changes; off by default (GC + 1 candidate segments per row cost the refinement 0.05 -> 0.15 s).
+static int gang_pieces() {   // GC: column pieces of a gang (and of a row: the gang spans all columns)
+    const char* e = getenv("ARROWSPACE_K2_GANG_GC");
+    const int gc = e ? atoi(e) : 16;
+    return std::max(1, std::min(gc, 16));
+}
+static void gang_plan(std::vector<int4>& units, int Lp, int tile0, int xoff[9]) {
+    int npieces = 1;
+    for (const int4& u : units) npieces = std::max(npieces, (u.y - tile0) / Lp + 1);
+    const int GC = std::min(gang_pieces(), npieces), GR = std::max(1, 32 / GC);
+    const int ngc = (npieces + GC - 1) / GC;
+    struct Gang { long long key; long long work; std::vector<int4> us; };
+    std::vector<Gang> gangs;
+    std::vector<std::pair<long long, int>> order(units.size());
+    for (size_t i = 0; i < units.size(); ++i)
+        order[i] = std::make_pair((long long)(units[i].x / GR) * ngc + ((units[i].y - tile0) / Lp) / GC, (int)i);
+    std::sort(order.begin(), order.end());
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (gangs.empty() || gangs.back().key != order[i].first) gangs.push_back(Gang{order[i].first, 0, {}});
+        const int4& u = units[order[i].second];
+        gangs.back().us.push_back(u);
+        gangs.back().work += u.z - u.y;
+    }
+    std::stable_sort(gangs.begin(), gangs.end(), [](const Gang& x, const Gang& y) { return x.work > y.work; });
+    std::vector<std::vector<int4>> lists(8);
+    long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const Gang& g : gangs) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x)
+            if (load[x] < load[best]) best = x;
+        load[best] += g.work;
+        lists[best].insert(lists[best].end(), g.us.begin(), g.us.end());
+    }
+    units.clear();
+    for (int x = 0; x < 8; ++x) {
+        xoff[x] = (int)units.size();
+        units.insert(units.end(), lists[x].begin(), lists[x].end());
+    }
+    xoff[8] = (int)units.size();
+}
+
 // First pass of the k-NN stage for the rows [r0, r1) of a space against all of its items: the candidate lists
 // c.ckey / c.cidx / c.ccnt ([rows][c.S][M], ids global: column + col_goff) that a refinement turns into exact lists.
 // A whole-space pass runs in symmetric mode (threshold pass, upper-triangle tiles, transposed buffers as one more
@@ -1382,7 +1434,11 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     if (sym) free_now();
     if (sym && mfree && (double)n * T_CAP * 8.0 > 7.0 * 0.25 * (double)mfree) sym = false;
     int Lpiece = 0, npiece = 1, nchunk = 1;
+    // bf16 kernel: units in gang order on per-XCD lists (gang_plan); pieces aligned to multiples of L, eight per row
+    const bool gang = sym && (variant & 48) == 48 && k2_bf16_enabled() && getenv("ARROWSPACE_K2_GANG_GC") != nullptr;
     std::vector<int4> hunits;
+    std::vector<int> hxoff;   // gang order: [chunk][9] list bounds, relative to the chunk's first unit
+    dev_tmp<int> d_xoff, d_xcur;
     dev_tmp<int4> d_units, d_units2;
     dev_tmp<int> tr_cnt, tr_idx;
     dev_tmp<float> tr_key, thr0;
@@ -1394,6 +1450,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
         for (int rb = 0; rb < nrb; ++rb) total += std::max(0, ntile - rb * per);
         int L = (int)std::max<double>(8.0, std::ceil(total / (dev_cus * 16.0)));
         if ((ntile + L - 1) / L > 7) L = (ntile + 6) / 7;   // at most 7 own segments + the transposed one
+        if (gang) L = std::max(8, (ntile + gang_pieces() - 1) / gang_pieces());   // gang order: GC aligned pieces, one gang row spans all columns
         {   // as many pieces as the main pass may need column chunks (sized for the larger buffers: the sample decides later)
             int want = mfree ? (int)std::ceil((double)n * 32 * M * 8.0 / (0.25 * (double)mfree)) : 1;
             if (const char* ev_ch = getenv("ARROWSPACE_SYM_CHUNKS")) want = std::max(want, atoi(ev_ch));
@@ -1406,7 +1463,11 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
         for (int rb = 0; rb < nrb; ++rb) {
             const int tlo = rb * per;
             int seg = 0;
-            for (int t = tlo; t < ntile; t += L, ++seg) hunits.push_back(make_int4(rb, t, std::min(ntile, t + L), seg));
+            if (gang) {   // aligned pieces (rebuilt per column chunk below: only the count matters here)
+                for (int pj = tlo / L; pj < S - 1; ++pj, ++seg)
+                    if (std::max(tlo, pj * L) < std::min(ntile, (pj + 1) * L)) hunits.push_back(make_int4(rb, std::max(tlo, pj * L), std::min(ntile, (pj + 1) * L), seg));
+            } else
+                for (int t = tlo; t < ntile; t += L, ++seg) hunits.push_back(make_int4(rb, t, std::min(ntile, t + L), seg));
         }
         std::stable_sort(hunits.begin(), hunits.end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
         for (const int4& u : hunits) sym_tiles += u.z - u.y;
@@ -1481,7 +1542,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
             std::vector<int> cfirst(nchunk + 1, 0), cpiece(nchunk + 1, 0);
             for (int c = 0; c <= nchunk; ++c) cpiece[c] = (int)((int64_t)npiece * c / nchunk);
             cfirst[nchunk] = (int)hunits.size();
-            if (nchunk > 1) {
+            if (nchunk > 1 || gang) {
                 // a chunk's units must not reach into the next chunk's columns: pieces aligned to multiples of L (not to the
                 // row block's diagonal); a row block's segments count from its first piece -- at most npiece of them, as before
                 const int per = BM / BN;
@@ -1500,8 +1561,10 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 }
                 hunits.clear();
                 sym_tiles = 0;
+                hxoff.assign((size_t)nchunk * 9, 0);
                 for (int c = 0; c < nchunk; ++c) {
-                    std::stable_sort(byc[c].begin(), byc[c].end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
+                    if (gang) gang_plan(byc[c], Lpiece, 0, hxoff.data() + (size_t)c * 9);
+                    else std::stable_sort(byc[c].begin(), byc[c].end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
                     cfirst[c] = (int)hunits.size();
                     for (const int4& u : byc[c]) {
                         hunits.push_back(u);
@@ -1512,7 +1575,12 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 AS_HIP(hipStreamSynchronize(st));   // (the first upload of the units is done with its source)
                 AS_HIP(d_units2.alloc(hunits.size() + 1));
                 AS_HIP(hipMemcpyAsync(d_units2, hunits.data(), sizeof(int4) * hunits.size(), hipMemcpyHostToDevice, st));
-                dbg("knn_rows: symmetric pass in %d column chunks (%.1f GB of transposed buffers for all items, %.1f GB free)", nchunk,
+                if (gang) {
+                    AS_HIP(d_xoff.alloc(hxoff.size()));
+                    AS_HIP(d_xcur.alloc(8 * 16));
+                    AS_HIP(hipMemcpyAsync(d_xoff, hxoff.data(), sizeof(int) * hxoff.size(), hipMemcpyHostToDevice, st));
+                }
+                if (nchunk > 1) dbg("knn_rows: symmetric pass in %d column chunks (%.1f GB of transposed buffers for all items, %.1f GB free)", nchunk,
                     (double)n * T_CAP * 8.0 / 1e9, (double)mfree / 1e9);
             }
             int64_t cmax = 0;   // items of the largest chunk
@@ -1534,8 +1602,13 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 const int64_t j1 = nchunk == 1 ? n : std::min<int64_t>(n, (int64_t)cpiece[c + 1] * Lpiece * BN);
                 const int cunits = cfirst[c + 1] - cfirst[c];
                 if (cunits <= 0 || j1 <= j0) continue;
-                ka.units = (nchunk > 1 ? (int4*)d_units2 : (int4*)d_units) + cfirst[c];
+                ka.units = (nchunk > 1 || gang ? (int4*)d_units2 : (int4*)d_units) + cfirst[c];
                 ka.nunits = cunits;
+                if (gang) {
+                    ka.xoff = (const int*)d_xoff + (size_t)c * 9;
+                    ka.xcur = d_xcur;
+                    AS_HIP(hipMemsetAsync(d_xcur, 0, sizeof(int) * 8 * 16, st));
+                }
                 ka.t_key = (float*)tr_key - (size_t)j0 * T_CAP;
                 ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP;
                 if (c) AS_HIP(hipMemsetAsync(ka.unit_ctr, 0, sizeof(int), st));
@@ -2338,6 +2411,8 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     // units: every row block's tiles in pieces of at most L, one segment per piece
     int L = (int)std::max<double>(8.0, std::ceil((double)nrb * ntile / (dev_cus * 16.0)));
     if ((ntile + L - 1) / L > 8) L = (ntile + 7) / 8;
+    const bool gang = k2_bf16_enabled() && getenv("ARROWSPACE_K2_GANG_GC") != nullptr;
+    if (gang) L = std::max(8, (ntile + gang_pieces() - 1) / gang_pieces());   // one gang row spans the chunk's columns (gang_plan)
     const int S = (ntile + L - 1) / L;
     std::vector<int4> hunits;
     for (int rb = 0; rb < nrb; ++rb) {
@@ -2345,8 +2420,11 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
         for (int t = (int)ca; t < cb; t += L, ++seg) hunits.push_back(make_int4(rb, t, (int)std::min<int64_t>(cb, t + L), seg));
     }
     std::stable_sort(hunits.begin(), hunits.end(), [](const int4& x, const int4& y) { return x.z - x.y > y.z - y.y; });
+    int hxoff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (gang) gang_plan(hunits, L, (int)ca, hxoff);
     const int units = (int)hunits.size(), grid = std::min(units, dev_cus);
     const int T_CAP = 16 * M;
+    dev_tmp<int> d_xo;   // gang order: 9 list bounds, then the 8 cursors 16 ints apart
     dev_tmp<int4> d_units;
     dev_tmp<float> bkey, ckey, tr_key, c2key, gate, t_bound;
     dev_tmp<int> bidx, cidx, ccnt, tr_cnt, tr_idx, c2idx, c2cnt;
@@ -2377,6 +2455,13 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     // first item (only items of the chunk's tiles are ever addressed)
     ka.units = d_units; ka.nunits = units; ka.unit_ctr = (int*)tr_cnt + ncc; ka.t_cnt = (int*)tr_cnt - j0;
     ka.t_key = (float*)tr_key - (size_t)j0 * T_CAP; ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP; ka.t_cap = T_CAP;
+    if (gang) {
+        AS_HIP(d_xo.alloc(16 + 8 * 16));
+        AS_HIP(hipMemsetAsync(d_xo, 0, sizeof(int) * (16 + 8 * 16), st));
+        AS_HIP(hipMemcpyAsync(d_xo, hxoff, sizeof(int) * 9, hipMemcpyHostToDevice, st));
+        ka.xoff = d_xo;
+        ka.xcur = (int*)d_xo + 16;
+    }
     ka.t_all = 1; ka.thr_col = col_thr;
     ka.thr0 = row_thr;   // the own rows' thresholds (their own-block lists' bounds): what a tighter start rejects lies beyond the row's M-th key
     AS_TRY(launch_k2(ka, metric, false, true, grid, st));

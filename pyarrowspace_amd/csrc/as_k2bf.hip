@@ -24,6 +24,10 @@ constexpr int RING = 3;             // slab buffers
 constexpr int NPIECE = 6;           // DMA pieces per wave and slab: 4 x 8 A rows of its 32, 2 x 8 B rows of its 16
 constexpr int SN = 4;               // column-side norm / threshold lines kept (tiles in flight: see the WAR note below)
 
+// Timing skeletons (make ABLATION=1; ARROWSPACE_K2_DIAG, wrong results): bit 0 no MFMA, 1 no DMA / ring waits, 2 no
+// epilogue, 3 no fragment reads, 4 no slab barrier.  The product library compiles none of it.
+#define K2_DIAG(bit) ((DIAG & (bit)) != 0)
+
 bool k2_bf16_enabled() {
     const char* e = getenv("ARROWSPACE_K2_FP32");
     return !(e && atoi(e) != 0);
@@ -152,7 +156,7 @@ __device__ __forceinline__ void compact_row_reg(int M, float* bk, int* bi, int c
 
 // ------------------------------------------------------------------ the kernel
 // Block = 8 waves (two per SIMD), tile 256 rows x 128 columns; wave w owns rows [32w, 32w+32) as 1x4 accumulators.
-template <int METRIC, bool COLLECT, bool SYM>
+template <int METRIC, bool COLLECT, bool SYM, int DIAG = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_bf16_kernel(KnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Sl = (float*)smem;                     // RING slab buffers: A rows then B rows, 128 B per row
@@ -187,6 +191,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned cur0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8);
     const unsigned sn0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8 + 3 * BM * 4);
     const bool late = wu >= 4;   // wave-uniform: the second-dispatched half issues its DMA mid-slab
+    int xcc = 0;                 // the XCD this block runs on (L2 affinity of the unit lists: speed only)
+    if (SYM) {
+        unsigned xr;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xr));
+        xcc = (int)(xr & 7u);
+    }
     // vector-memory operations a wave adds to the first slab of a tile: the column items' norms (and thresholds)
     const int nextra = wu < 2 ? (SYM ? 2 : 1) : 0;
     const float* __restrict__ cnorm = METRIC == AS_METRIC_L2 ? a.n32 : a.inorm32;
@@ -195,8 +205,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = blockIdx.x;; u += gridDim.x) {
         int rb, cs, t0, t1;
         if (SYM) {
-            // longest units first, handed out through an atomic cursor (the triangle's units differ in length)
-            if (tid == 0) *s_unit = atomicAdd(a.unit_ctr, 1);
+            // longest units first, handed out through atomic cursors (the triangle's units differ in length): the list of
+            // this block's XCD first -- its neighbours there work on the same row blocks and column pieces --, then the others'
+            if (tid == 0) {
+                if (a.xoff) {
+                    int got = a.nunits;
+                    for (int y = 0; y < 8 && got == a.nunits; ++y) {
+                        const int x = (xcc + y) & 7;
+                        const int len = a.xoff[x + 1] - a.xoff[x];
+                        if (ld_l2(a.xcur + 16 * x) >= len) continue;   // (an empty list's cursor is left alone)
+                        const int j = atomicAdd(a.xcur + 16 * x, 1);
+                        if (j < len) got = a.xoff[x] + j;
+                    }
+                    *s_unit = got;
+                } else {
+                    *s_unit = atomicAdd(a.unit_ctr, 1);
+                }
+            }
             __syncthreads();   // the previous unit ended with a barrier: nobody still reads the old value
             u = *s_unit;
             if (u >= a.nunits) break;
@@ -286,27 +311,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int ks = 0; ks < nslab; ++ks) {
                 // the slab has landed once only the younger slab's operations are outstanding (operations retire in
                 // issue order; anything else in flight -- appends -- only makes the wait stricter)
-                ring_wait(inflight >= 2 ? NPIECE + (young_first ? nextra : 0) : 0);
-                __builtin_amdgcn_s_barrier();   // everybody's pieces are in, everybody is done with the buffer issued into next
+                if (!K2_DIAG(2)) ring_wait(inflight >= 2 ? NPIECE + (young_first ? nextra : 0) : 0);
+                if (!K2_DIAG(16)) __builtin_amdgcn_s_barrier();   // everybody's pieces are in, everybody is done with the buffer issued into next
                 --inflight;
-                if (!late) K2_ISSUE();
+                if (!late && !K2_DIAG(2)) K2_ISSUE();
                 f32x4 fa, fb[4], ga, gb[4];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    lds_frag5(aoff[s] + cbuf, boff[s] + cbuf, fa, fb[0], fb[1], fb[2], fb[3]);          // heads of k-step s
+                    if (!K2_DIAG(8)) {
+                        lds_frag5(aoff[s] + cbuf, boff[s] + cbuf, fa, fb[0], fb[1], fb[2], fb[3]);          // heads of k-step s
+                        lds_frag5(aoff[2 + s] + cbuf, boff[2 + s] + cbuf, ga, gb[0], gb[1], gb[2], gb[3]);  // tails
+                    } else {
+                        asm volatile("" : "=v"(fa), "=v"(fb[0]), "=v"(fb[1]), "=v"(fb[2]), "=v"(fb[3]));
+                        asm volatile("" : "=v"(ga), "=v"(gb[0]), "=v"(gb[1]), "=v"(gb[2]), "=v"(gb[3]));
+                    }
+                    if (!K2_DIAG(1)) {
 #pragma unroll
-                    for (int nn = 0; nn < 4; ++nn)
-                        acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb[nn]), acc[nn], 0, 0, 0);
-                    lds_frag5(aoff[2 + s] + cbuf, boff[2 + s] + cbuf, ga, gb[0], gb[1], gb[2], gb[3]);  // tails
+                        for (int nn = 0; nn < 4; ++nn)   // xh . yh
+                            acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb[nn]), acc[nn], 0, 0, 0);
 #pragma unroll
-                    for (int nn = 0; nn < 4; ++nn)
-                        acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, gb[nn]), acc[nn], 0, 0, 0);
+                        for (int nn = 0; nn < 4; ++nn)   // xh . yl
+                            acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, gb[nn]), acc[nn], 0, 0, 0);
 #pragma unroll
-                    for (int nn = 0; nn < 4; ++nn)
-                        acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga), __builtin_bit_cast(bf16x8, fb[nn]), acc[nn], 0, 0, 0);
-                    if (s == 0 && late) K2_ISSUE();
+                        for (int nn = 0; nn < 4; ++nn)   // xl . yh
+                            acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga), __builtin_bit_cast(bf16x8, fb[nn]), acc[nn], 0, 0, 0);
+                    } else {
+                        acc[0][0] += fa[0] + fb[0][0] + fb[1][1] + fb[2][2] + fb[3][3] + ga[0] + gb[0][0] + gb[1][1] + gb[2][2] + gb[3][3];
+                    }
+                    if (s == 0 && late && !K2_DIAG(2)) K2_ISSUE();
                 }
                 cbuf = cbuf + DSLAB * 4 == RING * DSLAB * 4 ? 0 : cbuf + DSLAB * 4;
+            }
+            if (K2_DIAG(4)) {
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) asm volatile("" ::"v"(acc[nn]));
+                continue;
             }
             // ---- epilogue: keys, bound test, append (32 rows per wave).  The tile's norm line was issued with its first
             // slab and waited for with it; a tile of one slab has not met a later wait yet.
@@ -444,6 +483,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr size_t K2BF_LDS = sizeof(float) * RING * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + sizeof(float) * SN * 2 * BN + 16;
 
 as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st) {
+#ifdef AS_ABLATION
+    if (const char* e = getenv("ARROWSPACE_K2_DIAG")) {   // timing skeletons of the symmetric L2 kernel
+        const int dg = atoi(e);
+        if (dg && sym && metric == AS_METRIC_L2) {
+#define AS_K2D(DD)                                                                                                                 \
+    case DD:                                                                                                                       \
+        AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<AS_METRIC_L2, false, true, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \
+        hipLaunchKernelGGL((knn_bf16_kernel<AS_METRIC_L2, false, true, DD>), dim3(grid), dim3(512), K2BF_LDS, st, ka);             \
+        break;
+            switch (dg) {
+                AS_K2D(4) AS_K2D(5) AS_K2D(6) AS_K2D(12) AS_K2D(13) AS_K2D(14) AS_K2D(15) AS_K2D(30) AS_K2D(22) AS_K2D(20)
+                default:
+                    set_err("ARROWSPACE_K2_DIAG=%d is not compiled", dg);
+                    return AS_EINVAL;
+            }
+#undef AS_K2D
+            AS_HIP(hipGetLastError());
+            return AS_OK;
+        }
+    }
+#endif
 #define AS_K2B(MM, CC, SS)                                                                                                        \
     do {                                                                                                                          \
         AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<MM, CC, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \

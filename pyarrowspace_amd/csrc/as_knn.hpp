@@ -61,6 +61,12 @@ struct KnnArgs {
     float* thr_pub = nullptr;   // == thr0 when the running bounds are published back during the symmetric main pass
     float* out_thr = nullptr;
     int tstride = 1, tphase = 0;
+    // Gang order (bf16 kernel, symmetric mode): units[] is eight lists, one per XCD -- xoff[x] .. xoff[x + 1] -- and a
+    // block takes its units from the list of the XCD it runs on (xcur[16 x]: that list's cursor), other lists once its
+    // own is empty.  Consecutive entries of a list are GR row blocks x GC column pieces that share operands: run side by
+    // side on one XCD they are served by its L2 instead of the fabric (as_build.hip, gang_plan).  Speed only: any block may run any unit.
+    const int* xoff = nullptr;
+    int* xcur = nullptr;
 };
 
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
