@@ -47,17 +47,65 @@ def launch(n_ranks, argv, child=None):
     ndev = int(os.environ.get("ARROWSPACE_BENCH_NDEV", "0")) or visible_devices()
     shared = ndev < n_ranks
     cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)]
+    import signal
+    import time
+
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(ndev, 1)), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if shared:
             env["ARROWSPACE_BENCH_SHARED_GPU"] = str(max(ndev, 1))
-        procs.append(subprocess.Popen(cmd + list(argv), env=env))
+        # a session (= process group) of its own per rank: what it started dies with it when the group is signalled
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, start_new_session=True))
+
+    def code(rc):
+        return rc if rc >= 0 else 128 - rc
+
+    def stop_all(grace_s=10.0):
+        """SIGTERM to every live rank's process group, SIGKILL to what is still there after the grace period."""
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            live = [p for p in procs if p.poll() is None]
+            if not live:
+                return
+            for p in live:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.monotonic() + grace_s
+            while time.monotonic() < t_end and any(p.poll() is None for p in live):
+                time.sleep(0.05)
+
+    # All ranks are polled together: the first one that fails takes the others down (they would otherwise sit in a
+    # rendezvous or a collective their peer never enters) and its code is the launch's; so does an interrupt or the
+    # overall time limit (ARROWSPACE_BENCH_LAUNCH_TIMEOUT seconds, 0 = none).
+    limit = float(os.environ.get("ARROWSPACE_BENCH_LAUNCH_TIMEOUT", "0") or 0)
+    t0 = time.monotonic()
     worst = 0
-    for p in procs:
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            failed = [code(rc) for rc in rcs if rc is not None and rc != 0]
+            if failed:
+                worst = max(failed)
+                stop_all()
+                break
+            if all(rc is not None for rc in rcs):
+                break
+            if limit and time.monotonic() - t0 > limit:
+                print("bench.launch: ranks still running after %.0f s: stopping them" % limit, file=sys.stderr, flush=True)
+                stop_all()
+                worst = 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all()
+        worst = 130
+    for p in procs:   # (every rank has exited or been killed: reap, and fold in codes that arrived meanwhile)
         rc = p.wait()
-        worst = max(worst, rc if rc >= 0 else 128 - rc)
+        if rc > 0:   # ranks this launcher signalled itself (negative codes) do not outrank the failure that caused it
+            worst = max(worst, rc)
     return worst
 
 
@@ -279,7 +327,13 @@ def main():
         wl = []
         for name in ("n", "d", "k", "topk", "tau", "eps", "metric", "kernel", "lambda_mode"):
             wl += ["--" + name.replace("_", "-"), str(getattr(args, name))]
-        live, live_note = live_traffic(wl)
+        # each pass is a whole build plus a few searches: sized by the build this workload implies (2.6 s at 1M x 768 on
+        # the item graph, quadratic in n); beyond two minutes of build per pass the committed profile is the fallback
+        build_s = 0.05 if args.lambda_mode == "feature" else 2.6 * (args.n / 1e6) ** 2 * (args.d / 768.0)
+        if build_s > 120.0:
+            live, live_note = None, "skipped: a counter pass would rebuild the index (%.0f s predicted) twice" % build_s
+        else:
+            live, live_note = live_traffic(wl, timeout_s=int(150 + 4 * build_s))
 
     import torch
 

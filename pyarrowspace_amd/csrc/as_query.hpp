@@ -112,7 +112,7 @@ struct as_query {
     int cap = 1;             // query slots (GQ for the batched workspace)
     int half_enabled = 1;    // batched MFMA scan: keep the 32 slots' cosines as fp16 instead of their dots as fp32 (ARROWSPACE_BATCH_F32_DOTS=1: off)
     int dots_half = 0;       // ... and that is what the last batched scan wrote
-    int gemm_variant = 0;    // batched MFMA scan (ARROWSPACE_GEMM_VARIANT): 1 = ring of 3 slabs, 2 = default cache policy, 16 = no MFMA (timing only)
+    int gemm_variant = 0;    // batched MFMA scan (ARROWSPACE_GEMM_VARIANT): 1 = ring of 3 slabs, 2 = default cache policy, 16 = no MFMA (timing only; -DAS_ABLATION builds)
     int nb = 1;              // active slots of the current launch sequence
     as::SlotStride ss{};
     int cus = 256;
@@ -200,7 +200,7 @@ struct PreArgs {
     float sc_w = 0.0f;
     int* sc_idx = nullptr;   // [waves of the scan][SC_WCAP]: a wave's report -- [0] its number of candidates (-1: more than fit), [1 ..] their rows
     unsigned int* sc_hist = nullptr;   // SC_COPIES cosine histograms
-    int sc_dbg = 0;          // measurement only (ARROWSPACE_SC_DBG): 1 no publication, 2 no histogram read, 4 no candidates
+    int sc_dbg = 0;          // measurement only, -DAS_ABLATION builds (ARROWSPACE_SC_DBG): 1 no publication, 2 no histogram read, 4 no candidates
 };
 
 constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats

@@ -4,6 +4,14 @@
 // `prepare_query_item` (/root/reference/src/lib.rs:154,173).
 #include "as_query.hpp"
 
+// ARROWSPACE_SC_DBG (1 no publication, 2 no histogram read, 4 no candidates: the fused tail's cost breakdown, WRONG results)
+// is compiled into `make ABLATION=1` builds only; the product library's kernels do not test it.
+#ifdef AS_ABLATION
+#define AS_SC_DBG(bit) (pre.sc_dbg & (bit))
+#else
+#define AS_SC_DBG(bit) 0
+#endif
+
 namespace as {
 
 // ------------------------------------------------------------------ K7a scan: dots[i] = x_i . q  (+ k-NN prefilter)
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         // ... and then ever more rarely (chunks 2, 3, 5, 9, 17, ...): the read comes back later than a row's DMA and every
         // operation behind it retires behind it -- six reads per wave cost the 1M x 768 scan 8 us, and the bound hardly
         // moves once the first quarter of the rows has been seen
-        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0) && !(pre.sc_dbg & 2);
+        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0) && !AS_SC_DBG(2);
         if (hread)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
                                              (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 16);
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             const int mybin = fin ? sc_bin(c) : -1;
             // (only a row above the bound's bin can raise the bound: once it stands, the chunk statistics below -- 18
             // cross-lane operations -- are skipped for almost every chunk)
-            if (__ballot(mybin > jb) && (t < rounds || rounds >= 2) && !(pre.sc_dbg & 1)) {
+            if (__ballot(mybin > jb) && (t < rounds || rounds >= 2) && !AS_SC_DBG(1)) {
                 float cm = fin ? c : -2.0f;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
                 if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0) atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
             }
             // candidates: c >= thr -- a NaN cosine (a poisoned row) never qualifies, as under the plain chain's `key <= thr`
-            const bool pass = valid && c >= thr && !(pre.sc_dbg & 4);
+            const bool pass = valid && c >= thr && !AS_SC_DBG(4);
             const unsigned long long pm = __ballot(pass);
             const int np = __popcll(pm);
             if (npend + np > SC_PEND) {
@@ -944,8 +952,10 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
         p.sc_w = (float)((1.0 - q->tau_cur) / (2.0 * q->tau_cur) + 1.0e-5);
         p.sc_idx = q->sc_widx;
         p.sc_hist = q->sc_hist;
+#ifdef AS_ABLATION   // measurement switches that return wrong answers exist in `make ABLATION=1` builds only
         static const int dbg = getenv("ARROWSPACE_SC_DBG") ? atoi(getenv("ARROWSPACE_SC_DBG")) : 0;
         p.sc_dbg = dbg;
+#endif
     }
     return p;
 }
@@ -959,7 +969,9 @@ as_status set_scan_attrs() {
 #define AS_ATTR(KERN, BYTES) AS_HIP(hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
     AS_ATTR((scan_gemm_kernel<3, 0, 2>), gemm_lds(3));
     AS_ATTR((scan_gemm_kernel<4, 0, 0>), gemm_lds(4));
+#ifdef AS_ABLATION
     AS_ATTR((scan_gemm_kernel<4, 1, 2>), gemm_lds(4));
+#endif
     AS_ATTR((scan_gemm_kernel<4, 0, 2>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<3, 0, 2, true>), gemm_lds(3));
     AS_ATTR((scan_gemm_kernel<4, 0, 0, true>), gemm_lds(4));
@@ -1008,7 +1020,9 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             q->dots_half = q->half_enabled && q->ss.dots_rs == 4 ? 1 : 0;
             if (q->gemm_variant == 1) AS_GSCAN(3, 0, 2);
             else if (q->gemm_variant == 2) AS_GSCAN(4, 0, 0);
+#ifdef AS_ABLATION   // the no-MFMA skeleton (timing only, wrong results) is not in the product library
             else if (q->gemm_variant == 16) AS_GSCAN(4, 1, 2);
+#endif
             else AS_GSCAN(4, 0, 2);
 #undef AS_GSCAN
             AS_HIP(hipGetLastError());
@@ -1070,7 +1084,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             // (ring of 4 two-KiB slots, or of 8 one-KiB slots) -- 400k x 384: 105 -> 99 us, x 256: 78.5 -> 75.7, x 512: 141 -> 137.
             // (measurement: ARROWSPACE_SCAN_GEOM=<blocks per CU><ring slots> for rows up to 512 floats, e.g. 28 = the old form)
             static const int geom = getenv("ARROWSPACE_SCAN_GEOM") ? atoi(getenv("ARROWSPACE_SCAN_GEOM")) : 0;
-            const int bpc = nch <= 2 ? (geom ? geom / 10 : 4) : 2;
+            const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : 4, 4)) : 2;   // (<= 4: the wave reports are sized for 16 waves per CU)
             const int64_t nblk = std::min<int64_t>(want, bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
             q->sc_nw = (int)NW;
@@ -1079,7 +1093,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int tail_rows = (int)((rem + NW - 1) / NW);
 #define AS_DSCAN(N, S)                                                                                                 \
     do {                                                                                                               \
-        if (pre.sc_enabled && (N != 2 || S == 4))                                                                      \
+        if (pre.sc_enabled)   /* (rows of up to 512 floats: the fused form exists with the ring of 4 only) */               \
             hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), true), st, \
                                sp->x32, q->q32_src, sp->dp, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);          \
         else                                                                                                           \

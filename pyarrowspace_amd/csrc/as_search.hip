@@ -1655,8 +1655,10 @@ __device__ __forceinline__ void gather_reports(const FinishArgs& as_, char* work
         int* si = (int*)(sk + CAND_CAP);
         const double nq_ = as_.info->nq;
         const double rq_ = nq_ > 0.0 ? rsqrt(nq_) : 0.0;
-        constexpr int NREP = 5;                    // reports per thread: up to 16 * 256 + 64 waves over 960 threads
-        const int nthr = (int)blockDim.x - 64, t0 = (int)threadIdx.x - 64;
+        constexpr int NREP = 5;                    // reports per thread and pass: 16 * 256 + 64 waves over 960 threads in one pass
+        const int nthr = (int)blockDim.x - 64;
+        // (as many passes as the scan had waves: a device with more than 296 CUs, or another scan geometry, takes a second one)
+        for (int t0 = (int)threadIdx.x - 64; t0 < as_.sc_nw; t0 += NREP * nthr) {
         i32x4 head[NREP];
 #pragma unroll
         for (int i = 0; i < NREP; ++i) {
@@ -1699,6 +1701,7 @@ __device__ __forceinline__ void gather_reports(const FinishArgs& as_, char* work
                 si[base[i] + e] = as_.ci[(int64_t)w2 * SC_WCAP + 1 + e];
                 sk[base[i] + e] = __longlong_as_double(0x7ff8000000000000ll);
             }
+        }
         }
 }
 

@@ -134,3 +134,45 @@ def test_live_traffic_ends_a_pass_that_runs_out_of_time(monkeypatch, tmp_path):
         time.sleep(0.1)
     else:
         raise AssertionError("the pass's grandchild survived the timeout")
+
+
+HANG_CHILD = ("import os, sys, time\n"
+              "r = int(os.environ['RANK'])\n"
+              "open(os.path.join(sys.argv[-1], 'pid%d' % r), 'w').write(str(os.getpid()))\n"
+              "if r == 1:\n"
+              "    time.sleep(0.5); sys.exit(7)\n"
+              "time.sleep(600)\n")   # the peers of a dead rank: stuck in a rendezvous / collective it never enters
+
+
+def test_a_failed_rank_takes_the_others_down(tmp_path):
+    """One rank dies (import error, out of memory, RCCL init): the launcher returns ITS code within seconds instead of
+    waiting on ranks blocked in a collective, and no rank outlives it (each rank is its own process group)."""
+    import time
+    code = ("import sys, bench\n"
+            "sys.exit(bench.launch(3, [%r], child=[sys.executable, '-c', %r]))\n" % (str(tmp_path), HANG_CHILD))
+    env = dict(os.environ, ARROWSPACE_BENCH_NDEV="1", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 7, (p.returncode, p.stderr[-500:])
+    assert time.monotonic() - t0 < 60
+    for r in range(3):
+        pid = int(open(tmp_path / ("pid%d" % r)).read())
+        gone = False
+        for _ in range(100):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                gone = True
+                break
+            time.sleep(0.05)
+        assert gone, "rank %d (pid %d) survived the launcher" % (r, pid)
+
+
+def test_launch_time_limit(tmp_path):
+    code = ("import sys, bench\n"
+            "sys.exit(bench.launch(2, [%r], child=[sys.executable, '-c', 'import time; time.sleep(600)']))\n" % str(tmp_path))
+    env = dict(os.environ, ARROWSPACE_BENCH_NDEV="1", PYTHONPATH=ROOT, ARROWSPACE_BENCH_LAUNCH_TIMEOUT="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124 and "still running" in p.stderr

@@ -5,7 +5,9 @@ available offline).  Same size-independent properties as tests/test_gpu_fullsize
             x100-scaled items (:74), ~1 % exact duplicate rows (the dataset is duplicate questions)
   config 3: 200k x 768, k = 25, topk = 15, sigma = None (/root/reference/tests/test_3_beir.py:194-200), x100 (:190)
   config 4: one rank's slice of 8.8M x 768 on 4 GPUs: the whole item matrix resident (27 GB fp32), exact k-NN lists
-            of one 64k-row range against all 8.8M columns (as_knn_rows, what a rank computes per step), staged search
+            of one 64k-row range against all 8.8M columns (as_knn_rows, what a rank computes per step).  The staged
+            and batched SEARCH of that configuration is not here: tests/test_gpu_multirank.py runs it with 4 ranks at
+            2M x 768, tools/config4_fullsize.py at the full 8.8M (a builder-run log, profiles/r03_config4_full.log)
 The harness values of eps (0.5 and 10) are rectified-cosine distances (GRAPH_VARIABLES.md:7): they are used as
 written under metric='cosine', and replaced by a calibrated eps under the north_star's L2 metric, where 0.5 / 10 on
 x100-scaled items admit no edge / mean nothing."""

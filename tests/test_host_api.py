@@ -134,3 +134,18 @@ def test_slice_message_sections_tile_the_flat_buffer():
                 s.fill_(v + 1)
             assert all(bool((s == v + 1).all()) for v, s in enumerate(sec))
             assert e.slice_shape(0) == e.slice_shape(1)
+
+
+def test_product_library_has_no_wrong_answer_switches():
+    """Measurement switches that make kernels return wrong results (ARROWSPACE_SC_DBG: the fused tail's cost breakdown;
+    ARROWSPACE_GEMM_VARIANT=16 and ARROWSPACE_K2_DIAG: no-MFMA / no-DMA timing skeletons; ARROWSPACE_K2_ZERO: all-zero
+    operands) are compiled into `make ABLATION=1` builds only: the product library does not even know their names, so a
+    stray environment variable cannot turn a serving process's answers into garbage."""
+    import os
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pyarrowspace_amd", "libarrowspace_hip.so")
+    blob = open(lib, "rb").read()
+    for name in (b"ARROWSPACE_SC_DBG", b"ARROWSPACE_K2_DIAG", b"ARROWSPACE_K2_ZERO", b"ARROWSPACE_KNN_VARIANT_ABLATION"):
+        assert name not in blob, name.decode() + " is compiled into the product library (was it built with ABLATION=1?)"
+    assert b"ARROWSPACE_K2_FP32" in blob     # (the names of the switches that DO exist are in there: the scan is meaningful)
+    # the batched scan's no-MFMA skeleton is an extra kernel instantiation of ablation builds
+    assert b"scan_gemm_kernelILi4ELi1ELi2E" not in blob
