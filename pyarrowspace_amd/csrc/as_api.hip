@@ -665,9 +665,9 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
     const int64_t topk = std::min<int64_t>(gr->gp.topk, sp->n);
     std::lock_guard<std::mutex> lock(sp->qmu);
     AS_HIP(hipSetDevice(sp->device));
-    // the batched pass serves QUERY_BATCH queries per read of the items (MFMA pass for rows up to 768 floats,
-    // register-resident VALU pass up to 1024): fp32 fast path only
-    const bool batched = sp->dp <= 1024 && !sp->opts.force_exact && (sp->opts.search_mode & 3) == 0 && b > 1;
+    // the batched pass serves QUERY_BATCH queries per read of the items (MFMA pass; rows wider than 768 floats in
+    // K-chunk passes of the same kernel): fp32 fast path only
+    const bool batched = !sp->opts.force_exact && (sp->opts.search_mode & 3) == 0 && b > 1;
     if (batched) {
         if (sp->qcache_b && sp->qcache_b_gr != gr) {
             as_query_free(sp->qcache_b);

@@ -136,6 +136,7 @@ struct as_query {
     float* q32 = nullptr;    // [dp]
     as::QInfo* info = nullptr;
     float* dots32 = nullptr; // [np]
+    float* part32 = nullptr; // batched workspace of rows wider than 768 floats: [K-chunk pass][slots x np] fp32 partial dots (as_scan.hip, gemm_chunks)
     double* dots64 = nullptr;
     void* pkey = nullptr;    // list path: [nwaves][64] keys (sized for double)
     int* pidx = nullptr;
@@ -204,7 +205,9 @@ struct PreArgs {
 };
 
 constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats
+constexpr int GEMM_NSW_WIDE = 8;   // ... of the instantiation for wider rows (bf16 products): 1024 columns per K-chunk pass
 double coef_query(const as_query* q, bool exact);
+int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products);
 PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
 as_status launch_scan(as_query* q, const PreArgs& pre);
 as_status set_scan_attrs();   // per-device dynamic-LDS opt-in of the scan kernels

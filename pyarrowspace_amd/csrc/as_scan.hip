@@ -293,10 +293,16 @@ __device__ __forceinline__ void split_bf16(const f32x4& a, const f32x4& b, bf16x
 // BF3: the products on the bf16 matrix pipe (16 x the fp32 rate), each operand as head + tail: q.x ~ qh.xh + qh.xl + ql.xh --
 // three v_mfma_f32_32x32x16_bf16 per 16 columns instead of eight v_mfma_f32_32x32x2_f32; bf16 x bf16 is exact in the fp32
 // accumulator, what is dropped (ql.xl and the two remainders) is at most 3 * 2^-16 |q_k x_k| per term (coef_query).
-template <int NBUF, int DIAG, int AUX, bool BF3 = false>
+template <int NBUF, int DIAG, int AUX, bool BF3 = false, int NSW = GEMM_NSW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
     const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
-    int64_t ts, PreArgs pre, int nb, int half_dots) {
+    int64_t ts, PreArgs pre, int nb, int half_dots, int64_t kbase_, int64_t kcols_, int raw, int npass, int64_t pstride) {
+    // A wave keeps the query fragments of NSW slabs in registers: 4 * NSW * 32 columns per launch (768 at NSW = 6; the
+    // bf16 form also exists with NSW = 8: 1024).  Wider rows are scanned in K-CHUNK passes: a launch covers the columns
+    // [kbase, kbase + kcols) and, `raw`, leaves its fp32 partial dots in `dots` (tile-major, no epilogue);
+    // gemm_combine_kernel adds the passes' partials and does the epilogue.  The npass passes of a wide row share ONE launch
+    // (block b works on pass b % npass: one ramp instead of npass, and the passes balance each other's tails): pass p covers
+    // the columns [p kcols_, ...) and writes the partial buffer p (pstride floats apart).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     float* St = (float*)smem;   // per wave: NBUF slabs x [32 rows][32 floats]; Ex[owner wave][3 senders][64 lanes][4]; Ax[wave][64]
@@ -304,15 +310,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned ex0 = lds0 + 4 * NBUF * 4096, ax0 = ex0 + 4 * 3 * 64 * 16;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nslab = (int)(dp / 32), nsw = (nslab + 3) / 4;
+    const int pz = npass > 1 ? (int)(blockIdx.x % (unsigned)npass) : 0;
+    const int64_t bx = npass > 1 ? blockIdx.x / (unsigned)npass : blockIdx.x, gx = npass > 1 ? gridDim.x / (unsigned)npass : gridDim.x;
+    const int64_t kbase = kbase_ + (int64_t)pz * kcols_;
+    const int64_t kcols = min(kcols_, dp - kbase);
+    dots += (int64_t)pz * pstride;
+    const int nslab = (int)(kcols / 32), nsw = (nslab + 3) / 4;
     const int ks0 = wu * nsw;
     const int myns = max(0, min(nsw, nslab - ks0));
-    f32x4 qf[GEMM_NSW][4];
+    f32x4 qf[NSW][4];
 #pragma unroll
-    for (int ks = 0; ks < GEMM_NSW; ++ks)
+    for (int ks = 0; ks < NSW; ++ks)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            qf[ks][s] = ks < myns ? *(const f32x4*)(q32 + (int64_t)l31 * dp + (ks0 + ks) * 32 + (2 * s + h) * 4) : f32x4{0, 0, 0, 0};
+            qf[ks][s] = ks < myns ? *(const f32x4*)(q32 + (int64_t)l31 * dp + kbase + (ks0 + ks) * 32 + (2 * s + h) * 4) : f32x4{0, 0, 0, 0};
     // per-query constants of the prefilter, for the 4 queries this lane finishes: b = e + 8 wu + 4 h
     float nqv[4];
 #pragma unroll
@@ -323,17 +334,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the loads above complete here, once: otherwise the compiler has to assume they are still pending inside
     // the loop and puts a vmcnt(0) -- which also waits for the whole prefetch ring -- in front of their first use
 #pragma unroll
-    for (int ks = 0; ks < GEMM_NSW; ++ks)
+    for (int ks = 0; ks < NSW; ++ks)
 #pragma unroll
         for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[ks][s]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(nqv[e]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(iqv[e]));
-    bf16x8 qh[GEMM_NSW][2], ql[GEMM_NSW][2];
+    bf16x8 qh[NSW][2], ql[NSW][2];
     if (BF3) {
 #pragma unroll
-        for (int ks = 0; ks < GEMM_NSW; ++ks) {
+        for (int ks = 0; ks < NSW; ++ks) {
             split_bf16(qf[ks][0], qf[ks][1], qh[ks][0], ql[ks][0]);
             split_bf16(qf[ks][2], qf[ks][3], qh[ks][1], ql[ks][1]);
         }
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t nrb = (r1 - r0 + 31) / 32;
     const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
     // prefetch cursor: the wave's slab sequence (row block, k slab), NBUF-1 slabs ahead of the MFMAs
-    int64_t prb = myns > 0 ? (int64_t)blockIdx.x : nrb;
+    int64_t prb = myns > 0 ? bx : nrb;
     int pks = 0, pbuf = 0, inflight = 0;
     // x0/x1/x2: vector-memory operations other than slab DMAs issued after the oldest / 2nd / 3rd slab in
     // flight -- a lower bound: the norm DMA and the 4 dot stores of each row block (rare appends add more and
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     do {                                                                                                                  \
         if (prb < nrb) {                                                                                                  \
             /* 4 x 1 KiB pieces per 32-row slab: piece j = rows [8j, 8j+8) */                                             \
-            const char* base_ = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + (ks0 + pks) * 32);                     \
+            const char* base_ = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + kbase + (ks0 + pks) * 32);             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
                 const char* src_ = base_ + (size_t)(8 * j) * dp * 4 + ((j & 1) ? lo1 : lo0);                              \
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                     \
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;                                                                       \
             if (++pks == myns) {                                                                                          \
                 pks = 0;                                                                                                  \
-                prb += gridDim.x;                                                                                         \
+                prb += gx;                                                                                                \
             }                                                                                                             \
             if (inflight == 0) x0 = 0;                                                                                    \
             else if (inflight == 1) x1 = 0;                                                                               \
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < NBUF - 1; ++i) AS_ISSUE_SLAB();
     unsigned cur = 0;   // byte offset of the slab the MFMAs read next
     int full = 0;       // bit e: query e of this lane has overflowed its candidate buffer (see prefilter_f32)
-    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    for (int64_t rb = bx; rb < nrb; rb += gx) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             x2 += 1;
         }
 #pragma unroll
-        for (int ks = 0; ks < GEMM_NSW; ++ks) {
+        for (int ks = 0; ks < NSW; ++ks) {
             if (ks < myns) {
                 // slab `cur` has landed once at most inflight-1 newer slabs (4 DMA ops each) are outstanding:
                 // loads retire in order, so the count is conservative whatever else is in flight
@@ -463,6 +474,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the norms: older than the slabs in flight when those were all issued inside this row block
         wait_vmcnt(myns >= NBUF - 1 ? 4 * inflight : 0);
         const float aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
+        if (raw) {   // a K-chunk pass: the partial dots of this chunk, fp32, in the tile layout (gemm_combine_kernel finishes)
+            store_x4_issued(dots + (row >> 5) * ts + ((2 * wu + h) * 32 + (row & 31)) * 4, mine);
+            x0 += 1;
+            x1 += 1;
+            x2 += 1;
+            continue;
+        }
         {
             // the store is issued whatever the lane holds: rows past r1 land in the padding behind the last tile
             // (np + ROW_TILE rows are allocated), idle slots have their places in every tile.  Tile layout
@@ -911,21 +929,82 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
     }
 }
 
+// K-chunk passes of the batched scan (rows wider than 768 floats): the passes' fp32 partial dots -> the epilogue of
+// scan_gemm_kernel: cosines as fp16 (or the dots as fp32) in the slot buffers and the fused k-NN prefilter.  A thread takes
+// 4 slots of one row (16 contiguous bytes of every partial tile); 32 x N x 4 B per pass read once: 8 % of the item bytes.
+__global__ __launch_bounds__(256) void gemm_combine_kernel(const float* __restrict__ part, int npass, int64_t pstride, int64_t r0, int64_t r1,
+                                                           float* __restrict__ dots, int64_t ts, PreArgs pre, int nb, int half_dots) {
+    const int64_t tile = blockIdx.x;
+    const int quad = threadIdx.x >> 5, r = threadIdx.x & 31;
+    const int64_t row = r0 + tile * 32 + r;
+    const int64_t off = (row >> 5) * ts + (quad * 32 + (row & 31)) * 4;
+    f32x4 mine = *(const f32x4*)(part + off);
+    for (int p = 1; p < npass; ++p) mine += *(const f32x4*)(part + (int64_t)p * pstride + off);   // pass order: one summation order per launch geometry
+    const float aux = pre.metric == AS_METRIC_L2 ? pre.n32[row] : pre.inorm32[row];   // padded arrays: readable past r1
+    if (half_dots) {
+        const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
+        u32x2 pk;
+        pk[0] = pack_half2(mine[0] * inr * pre.info[4 * quad].inq32, mine[1] * inr * pre.info[4 * quad + 1].inq32);
+        pk[1] = pack_half2(mine[2] * inr * pre.info[4 * quad + 2].inq32, mine[3] * inr * pre.info[4 * quad + 3].inq32);
+        *(u32x2*)((char*)dots + off * 2) = pk;
+    } else {
+        *(f32x4*)(dots + off) = mine;
+    }
+    if (!(pre.enabled && row < r1 && row < pre.n && row != pre.exclude)) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int b = 4 * quad + e;
+        if (b >= nb) continue;   // idle slot
+        const float nq = pre.metric == AS_METRIC_L2 ? pre.info[b].nq32 : pre.info[b].inq32;
+        float key, bound;
+        if (pre.metric == AS_METRIC_L2) {
+            key = fmaf(-2.0f, mine[e], aux + nq);
+            bound = ((float)pre.epskey + (float)pre.coef * (aux + nq)) * 1.000001f;
+        } else {
+            key = 1.0f - fmaxf(0.0f, mine[e] * aux * nq);
+            bound = ((float)pre.epskey + (float)pre.coef) * 1.000001f;
+        }
+        // (a full buffer is left alone: the counter only has to exceed the capacity -- a million atomics on one word cost 7 ms)
+        if (key <= bound && __hip_atomic_load(&pre.infow[b].knn_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= CAND_CAP) {
+            const int slot = atomicAdd(&pre.infow[b].knn_cnt, 1);
+            if (slot < CAND_CAP) {
+                ((float*)pre.ckey)[(int64_t)b * CAND_CAP + slot] = key;
+                pre.cidx[(int64_t)b * CAND_CAP + slot] = (int)row;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 // fp32/fp64 error coefficient of one dot product: (terms in the longest rounding chain + slack) * u.
 // Wave-per-row scans sum dp/64 fused terms per lane before a 6-level butterfly; the MFMA pass
 // accumulates a quarter of the columns in sequence (two roundings per term, in case the matrix
 // core rounds the products) and adds four partials.
+// K-chunk passes of the batched MFMA scan: a wave keeps the query fragments of GEMM_NSW slabs in registers, a block of 4
+// waves covers 4 * GEMM_NSW * 32 = 768 columns per pass -- 4 * GEMM_NSW_WIDE * 32 = 1024 in the kernel instantiated for wide
+// rows (bf16 products only: the fp32 fragments of 8 slabs do not fit) --; wider rows take P = ceil(dp / cap) passes of even
+// width (whole slabs).  Returns P; *chunk = columns of a pass (the last one takes what is left).
+int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products) {
+    const int64_t cap = 4 * (dp > 4 * GEMM_NSW * 32 && bf16_products ? GEMM_NSW_WIDE : GEMM_NSW) * 32;
+    const int P = (int)((dp + cap - 1) / cap);
+    *chunk = ((dp + P - 1) / P + 31) / 32 * 32;
+    return P;
+}
+
 double coef_query(const as_query* q, bool exact) {
     const double u = exact ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
     const int64_t dp = q->sp->dp;
-    if (!exact && q->cap > 1 && dp <= 4 * GEMM_NSW * 32) {
+    if (!exact && q->cap > 1) {
         // the batched MFMA pass.  fp32 pipe: two roundings per term of a wave's quarter of the columns.  bf16 pipe (BF3, with
         // the fp16 cosines): three exact products per column -- three times the accumulated terms -- and the operands' dropped
         // remainders, 3 * 2^-16 of |q_k x_k| per term, at most that of |q| |x| in the sum (Cauchy-Schwarz)
-        const int64_t kw = ((dp / 32 + 3) / 4) * 32;
-        if (q->half_enabled && q->ss.dots_rs == 4) return (double)(6 * kw + 3 + 24) * u + 3.0 * 1.52587890625e-5 * 1.01;   // 3 * 2^-16
-        return (double)(2 * kw + 3 + 24) * u;
+        // Rows wider than 768 floats take P K-chunk passes (gemm_chunks): every pass's error is that of its own columns --
+        // sum_p |q_p||x_p| <= |q||x| -- and gemm_combine_kernel's P - 1 fp32 additions of the partials come on top.
+        int64_t chunk = dp;
+        const int P = gemm_chunks(dp, &chunk, q->half_enabled && q->ss.dots_rs == 4);
+        const int64_t kw = ((chunk / 32 + 3) / 4) * 32;
+        if (q->half_enabled && q->ss.dots_rs == 4) return (double)(6 * kw + 3 + 24 + P) * u + 3.0 * 1.52587890625e-5 * 1.01;   // 3 * 2^-16
+        return (double)(2 * kw + 3 + 24 + P) * u;
     }
     return (double)(dp / 64 + 24) * u;
 }
@@ -976,6 +1055,7 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_gemm_kernel<3, 0, 2, true>), gemm_lds(3));
     AS_ATTR((scan_gemm_kernel<4, 0, 0, true>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<4, 0, 2, true>), gemm_lds(4));
+    AS_ATTR((scan_gemm_kernel<4, 0, 2, true, GEMM_NSW_WIDE>), gemm_lds(4));
     AS_ATTR((scan_dma_kernel<1, 8>), dma_lds(1, 8));
     AS_ATTR((scan_dma_kernel<2, 8>), dma_lds(2, 8));
     AS_ATTR((scan_dma_kernel<2, 5>), dma_lds(2, 5));
@@ -1003,8 +1083,19 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
                            q->r1, q->dots64, pre);
     } else {
         const int nch = (int)((sp->dp + 255) / 256);
-        if (q->cap > 1 && sp->dp <= 4 * GEMM_NSW * 32) {
+        if (q->cap > 1 && q->ss.dots_rs == 4) {
             // batched pass, GEMM-shaped: matrix pipe (bf16 head + tail with the fp16 cosines, else fp32), K split over the 4 waves of a block, 2 blocks per CU
+            int64_t chunk = sp->dp;
+            q->dots_half = q->half_enabled && q->ss.dots_rs == 4 ? 1 : 0;
+            const int npass = gemm_chunks(sp->dp, &chunk, q->dots_half != 0);
+            if (npass > 1 && !q->part32) {
+                set_err("launch_scan: the workspace has no partial buffer for rows of %lld floats", (long long)sp->dp);
+                return AS_EINVAL;
+            }
+            const int64_t pstride = (sp->np + ROW_TILE) * (int64_t)q->cap;   // floats between the passes' partial buffers
+            int64_t kbase = 0, kcols = sp->dp;
+            float* gdst = q->dots32;
+            int graw = 0;
 #define AS_GSCAN(NB_, DG, AX)                                                                                                \
     do {                                                                                                               \
         const size_t lds = gemm_lds(NB_);                                                                              \
@@ -1012,12 +1103,44 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
         const unsigned grid = (unsigned)std::min<int64_t>(nrb, 2 * q->cus);                                            \
         if (q->dots_half && DG == 0)                                                                                   \
             hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX, true>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, \
-                               q->r1, q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);                                     \
+                               q->r1, gdst, q->ss.dots_ts, pre, q->nb, q->dots_half, kbase, kcols, graw, 1, (int64_t)0);       \
         else                                                                                                           \
             hipLaunchKernelGGL((scan_gemm_kernel<NB_, DG, AX>), dim3(grid), dim3(256), lds, st, sp->x32, q->q32, sp->dp, q->r0, q->r1, \
-                               q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);                                            \
+                               gdst, q->ss.dots_ts, pre, q->nb, q->dots_half, kbase, kcols, graw, 1, (int64_t)0);              \
     } while (0)
-            q->dots_half = q->half_enabled && q->ss.dots_rs == 4 ? 1 : 0;
+            if (chunk > 4 * GEMM_NSW * 32) {
+                // rows wider than 768 floats on the bf16 pipe: 1024 columns per pass (8 slabs per wave), the K-chunk passes of
+                // wider rows side by side in ONE launch (block b: pass b % npass), then the combine + epilogue launch
+                const size_t lds = gemm_lds(4);
+                const int64_t nrb = (rows + 31) / 32;
+                const int64_t per = std::max<int64_t>(1, std::min<int64_t>(nrb, (2 * q->cus) / npass));
+                hipLaunchKernelGGL((scan_gemm_kernel<4, 0, 2, true, GEMM_NSW_WIDE>), dim3((unsigned)(per * npass)), dim3(256), lds, st, sp->x32, q->q32, sp->dp,
+                                   q->r0, q->r1, npass > 1 ? q->part32 : q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half, (int64_t)0, chunk,
+                                   npass > 1 ? 1 : 0, npass, pstride);
+                AS_HIP(hipGetLastError());
+                if (npass > 1) {
+                    hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)nrb), dim3(256), 0, st, (const float*)q->part32, npass, pstride, q->r0, q->r1,
+                                       q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);
+                    AS_HIP(hipGetLastError());
+                }
+                return AS_OK;
+            }
+            if (npass > 1) {
+                // K-chunk passes: raw fp32 partials per pass, then one combine + epilogue launch over 32 x rows partial dots
+                graw = 1;
+                for (int p = 0; p < npass; ++p) {
+                    kbase = (int64_t)p * chunk;
+                    kcols = std::min<int64_t>(chunk, sp->dp - kbase);
+                    gdst = q->part32 + (int64_t)p * pstride;
+                    AS_GSCAN(4, 0, 2);
+                    AS_HIP(hipGetLastError());
+                }
+                const int64_t nrb = (rows + 31) / 32;
+                hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)nrb), dim3(256), 0, st, (const float*)q->part32, npass, pstride, q->r0, q->r1,
+                                   q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);
+                AS_HIP(hipGetLastError());
+                return AS_OK;
+            }
             if (q->gemm_variant == 1) AS_GSCAN(3, 0, 2);
             else if (q->gemm_variant == 2) AS_GSCAN(4, 0, 0);
 #ifdef AS_ABLATION   // the no-MFMA skeleton (timing only, wrong results) is not in the product library

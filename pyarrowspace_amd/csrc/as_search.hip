@@ -2266,6 +2266,11 @@ static as_status query_alloc(as_query* q) {
     // (on the query's own stream: it is non-blocking, a memset on the null stream may run LATER than the first search)
     AS_HIP(hipMemsetAsync(q->info, 0, sizeof(QInfo) * C, q->stream));
     AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE) * C));
+    if (C > 1 && C % 4 == 0) {   // batched workspace: the K-chunk passes' partial dots of rows wider than 768 floats
+        int64_t chunk = 0;
+        const int npass = gemm_chunks(sp->dp, &chunk, false);   // (sized for the fp32 form: the most passes either form takes)
+        if (npass > 1) AS_HIP(hipMalloc(&q->part32, sizeof(float) * (sp->np + ROW_TILE) * C * npass));
+    }
     q->ss.dots = C > 1 ? 32 : sp->np + ROW_TILE;
     q->ss.dots_ts = C > 1 ? 32 * (int64_t)C : 32;
     q->ss.dots_rs = C > 1 && C % 4 == 0 ? 4 : 1;
@@ -2321,7 +2326,7 @@ void as_query_free(as_query* q) {
     if (q->stream) hipStreamSynchronize(q->stream);
     if (q->hq) hipHostFree(q->hq);
     if (q->hq32) hipHostFree(q->hq32);
-    hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32);
+    hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32); hipFree(q->part32);
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
     hipFree(q->gmin);
@@ -2461,11 +2466,7 @@ as_status as_query_finish(as_query* q, const as_hit_rec* hits_dev, int64_t m, in
 // ---- batched staged search: up to as_query_slots(q) queries per pass over this rank's rows; the record buffers hold
 // [slot][k] / [slot][topk + 1] records, the all-gathered ones [rank][slot][...] (one collective per step and pass)
 as_status as_query_create_batch(const as_space* sp, const as_graph* gr, as_query** out) {
-    if (sp && sp->dp > 1024) {
-        set_err("as_query_create_batch: rows wider than 1024 floats are searched query by query");
-        return AS_EUNSUPPORTED;
-    }
-    return query_create(sp, gr, QUERY_BATCH, out);
+    return query_create(sp, gr, QUERY_BATCH, out);   // (any row width: rows beyond 768 floats are scanned in K-chunk passes)
 }
 int32_t as_query_slots(const as_query* q) { return q ? q->cap : 0; }
 

@@ -1101,7 +1101,7 @@ class ShardedIndex:
         Q = np.ascontiguousarray(Q, dtype=np.float64)
         if Q.ndim != 2:
             raise TypeError("items must be a 2-D float64 array")
-        if not hasattr(e, "query_scan_batch") or getattr(e, "d", 0) > 1024:
+        if not hasattr(e, "query_scan_batch"):
             return [self.search(np.ascontiguousarray(q), tau) for q in Q]
         nranks = self.world if self._collective() else 1
         ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()

@@ -102,10 +102,13 @@ def test_non_fp32_representable_items_keep_fp64(oracle_lib):
     assert [i for i, _ in got] == [i for i, _ in want]
 
 
-@pytest.mark.parametrize("metric,d", [("l2", 200), ("cosine", 200), ("l2", 24), ("cosine", 768), ("l2", 1000)])
+@pytest.mark.parametrize("metric,d", [("l2", 200), ("cosine", 200), ("l2", 24), ("cosine", 768), ("l2", 1000), ("l2", 1024), ("cosine", 1536),
+                                      ("l2", 2048), ("cosine", 3000), ("l2", 4096)])
 def test_search_batch_matches_single_and_oracle(oracle_lib, metric, d):
-    """as_search_batch: 32 query slots per pass over the items (MFMA pass up to 768 columns, K split over
-    4 waves: 7 slabs -> 2,2,2,1; 1 slab -> 1,0,0,0; 24 slabs -> 6 each; VALU pass above), chunks of 32 and 13."""
+    """as_search_batch: 32 query slots per pass over the items (MFMA pass, K split over 4 waves: 7 slabs -> 2,2,2,1;
+    1 slab -> 1,0,0,0; 24 slabs -> 6 each; rows wider than 768 floats on the 8-slabs-per-wave instantiation: 1 024 columns in one
+    launch, beyond that K-chunk passes -- 1536 -> 2 x 768, 2048 -> 2 x 1024, 3008 -> 1024 / 1024 / 960, 4096 -> 4 x 1024 -- whose
+    partial dots gemm_combine_kernel adds), chunks of 32 and 13 queries."""
     import pyarrowspace_amd as asp
     n, k, topk = 3000, 9, 7
     X = clustered(n, d, nclust=10, seed=13)
