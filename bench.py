@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_F64_PEAK_TF = 78.6    # v_mfma_f64_16x16x4_f64: vendor fp64 matrix peak (half the fp32 rate; not in the guide's table)
+MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (never the 2:1 sparsity figure)
 
 
 def launch(n_ranks, argv, child=None):
@@ -484,6 +485,39 @@ def main():
         dist.all_reduce(tin, op=dist.ReduceOp.MAX)
     dt_in = float(tin.item())
 
+    # as_search is re-entrant: T host threads, each issuing B = 1 searches back to back on ONE space -- every
+    # call runs on a pooled workspace and stream of its own, one thread's scan under another's finish kernel and host
+    # turnaround.  Reported BESIDE the headline (which stays the single-thread, single-query number), never as it.
+    threaded = None
+    if single and not args.traffic_probe:
+        import threading
+
+        threaded = {}
+        for nthr in (2, 4):
+            per = max(args.steps, 64)
+            errs = []
+
+            def worker(t, per=per, nthr=nthr):
+                try:
+                    for i in range(per):
+                        searcher(Q[(args.warmup + t * per + i) % len(Q)])
+                except BaseException as e:   # noqa: BLE001 -- reported below, the bench line must still come out
+                    errs.append(repr(e))
+
+            ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
+            for t in range(nthr):           # untimed: lets the pool grow to nthr workspaces
+                searcher(Q[t % len(Q)])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            dth = time.perf_counter() - t0
+            threaded[str(nthr)] = {"value": nthr * per / dth, "unit": "queries/s", "host_threads": nthr, "queries": nthr * per,
+                                   "frac": n * (d + 2) * 4.0 * nthr * per / dth / 1e9 / HBM_PEAK_GBS, "errors": errs[:2]}
+        threaded["pool_size"] = aspace.search_pool_size
+
     # extension, reported next to the headline, never as it: batched search, 32 query
     # slots per pass over the items (GEMM-shaped scan on fp32 MFMA)
     batched_qps = batch_pass_ms = None
@@ -510,9 +544,18 @@ def main():
     scan_bytes = rows_per_gpu * (d + 2) * 4.0          # N x D fp32 items + N reciprocal norms read, N fp32 dots written
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
-    mfma_tf = bstats["mfma_flops"] / max(bstats["knn_mfma_s"], 1e-9) / 1e12
-    mfma_peak = MFMA_F64_PEAK_TF if feature else MFMA_F32_PEAK_TF
-    build_kernel = "gram_f64_kernel" if feature else "knn_mfma_dma8_kernel<%s>" % args.metric
+    # Build kernel: bstats["mfma_flops"] counts 2 * (pairs computed) * D -- the fp32-equivalent work.  The default kernel
+    # (as_k2bf.hip) issues THREE bf16 products per such flop (head x head, head x tail, tail x head): the roofline
+    # fraction is issued bf16 flops / 2.5 PFLOP/s; the fp32-equivalent rate is kept beside it.  ARROWSPACE_K2_FP32=1: the
+    # fp32 matrix pipe (157.3 TFLOP/s), one product per flop.
+    k2_fp32 = os.environ.get("ARROWSPACE_K2_FP32", "0") not in ("", "0")
+    mfma_tf_eq = bstats["mfma_flops"] / max(bstats["knn_mfma_s"], 1e-9) / 1e12
+    if feature:
+        mfma_tf, mfma_peak, build_kernel, build_dtype = mfma_tf_eq, MFMA_F64_PEAK_TF, "gram_f64_kernel", "f64"
+    elif k2_fp32:
+        mfma_tf, mfma_peak, build_kernel, build_dtype = mfma_tf_eq, MFMA_F32_PEAK_TF, "knn_mfma_dma8_kernel<%s>" % args.metric, "f32"
+    else:
+        mfma_tf, mfma_peak, build_kernel, build_dtype = 3.0 * mfma_tf_eq, MFMA_BF16_PEAK_TF, "knn_bf16_kernel<%s>" % args.metric, "bf16 head + tail (3 products per fp32 product)"
 
     # HBM-side traffic per launch: PMC counters need rocprofv3 around the process -- measured by live_traffic() in two
     # child passes at the start of this run; when that was not possible (no rocprofv3, --no-live-traffic, N > 1) taken
@@ -567,8 +610,11 @@ def main():
         "index_build_sec": build_s,
         "priming_queries": primed,
         "batched_queries_per_sec": batched_qps,
+        "threaded_queries_per_sec": threaded,
+        "zero_lambda_rate": zero_in / args.steps,
         "build_stages_sec": {k: bstats[k] for k in ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s")},
         "build_fallback_rows": bstats["fallback_rows"],
+        "build_band_rows": bstats["band_rows"],
         "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
                      "traffic_source": traffic_source if traffic_scan is not None else "none (live passes: %s)" % live_note,
@@ -589,8 +635,12 @@ def main():
                     "fp16 cosines kept per slot; ARROWSPACE_BATCH_F32_DOTS=1 is the fp32 form"},
         "roofline_build": {"kernel": build_kernel, "bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak,
                            "unit": "TFLOP/s", "frac": mfma_tf / mfma_peak, "traffic": traffic_mfma,
-                           "flops_issued": bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"],
-                           "dtype": "f64" if feature else "f32"},
+                           "flops_issued": (1.0 if feature or k2_fp32 else 3.0) * bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"],
+                           "fp32_equivalent_tflops": mfma_tf_eq, "fp32_equivalent_flops": bstats["mfma_flops"],
+                           "frac_of_fp32_mfma_peak": mfma_tf_eq / MFMA_F32_PEAK_TF, "dtype": build_dtype,
+                           "note": "k-NN kernels of the build (threshold pass + symmetric pass: half the distance block); "
+                                   "on random operands the bf16 kernel is held by the chip's power management, not by its "
+                                   "issue structure (all-zero operands: 1.5 x faster, DESIGN.md 5.2)"},
     }
 
     # ---------------- CPU baseline: the oracle (fp64 C/OpenMP restatement) on this box's host cores

@@ -221,9 +221,15 @@ as_status as_feat_lambdas_global(as_space* sp, as_graph* gr, const double* E_dev
 
 /* query: host fp64, contiguous, length d (d != nfeatures -> AS_EINVAL,
  * src/lib.rs:140-146).  out_idx/out_score: capacity >= min(topk, nitems).
- * lambda_q == 0 -> AS_EZEROLAMBDA.  Results: score desc, index asc. */
+ * lambda_q == 0 -> AS_EZEROLAMBDA.  Results: score desc, index asc.
+ * RE-ENTRANT across host threads: every call runs on a workspace of its own -- stream, device buffers, pinned
+ * results -- taken from a pool the space grows on demand (up to 4, ARROWSPACE_SEARCH_POOL); no lock is held while a
+ * search runs, so one thread's scan overlaps another's finish kernel and host turnaround.  The reference holds the GIL
+ * through prepare_query_item + search_lambda_aware (src/lib.rs:132-174): its searches are serialised. */
 as_status as_search(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
                     int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
+/* workspaces the pool of as_search holds at the moment (1 after single-threaded use) */
+int32_t as_search_pool_size(const as_space* sp);
 
 /* B queries, row-major [b][d]; outputs [b][topk]; status per query in out_status
  * (AS_OK / AS_EZEROLAMBDA).  Extension. */

@@ -303,6 +303,12 @@ class ArrowSpace:
         fp64 rounding); the library also says so on stderr the first time.  0 in normal operation."""
         return int(_L.as_unproven_searches(self._h))
 
+    @property
+    def search_pool_size(self) -> int:
+        """Extension: single-query workspaces the library holds for this space -- `search` is re-entrant across host threads
+        (ctypes releases the GIL around the call), each concurrent call runs on a workspace and stream of its own."""
+        return int(_L.as_search_pool_size(self._h))
+
     def save(self, gl: GraphLaplacian, path: str) -> None:
         """Extension: write the built index (items, lambdas, graph) to one file."""
         st = _L.as_index_save(self._h, gl._h, os.fsencode(path))

@@ -102,7 +102,8 @@ int32_t as_device_count(void) {
 void as_free_space(as_space* sp) {
     if (!sp) return;
     hipSetDevice(sp->device);
-    if (sp->qcache) as_query_free(sp->qcache);
+    for (int i = 0; i < as_space::QPOOL; ++i)
+        if (sp->qpool[i]) as_query_free(sp->qpool[i]);
     if (sp->qcache_b) as_query_free(sp->qcache_b);
     if (sp->qcache_b2) as_query_free(sp->qcache_b2);
     if (sp->stream) hipStreamSynchronize(sp->stream);
@@ -572,21 +573,90 @@ as_status as_build(const double* items, int64_t n, int64_t d, int64_t row_stride
 }
 
 // ---------------------------------------------------------------- search
-static as_status get_cached_query(const as_space* sp, const as_graph* gr, as_query** out) {
-    if (sp->qcache && sp->qcache_gr != gr) {
-        as_query_free(sp->qcache);
-        sp->qcache = nullptr;
-    }
-    if (!sp->qcache) {
-        AS_TRY(as_query_create(sp, gr, &sp->qcache));
-        sp->qcache_gr = gr;
-    }
-    *out = sp->qcache;
-    return AS_OK;
+// ---- the pool of single-query workspaces (as_space::qpool).  pool_acquire hands out the lowest free slot -- a single
+// thread always gets slot 0 --, grows the pool by one workspace when every existing one is busy (ARROWSPACE_SEARCH_POOL
+// caps it, 1 .. QPOOL, default QPOOL) and otherwise waits for a release.  A search against ANOTHER graph handle waits for
+// the pool to fall idle and rebuilds it (the workspaces carry the graph's k / topk layout).
+static int pool_limit() {
+    static const int lim = [] {
+        const char* e = getenv("ARROWSPACE_SEARCH_POOL");
+        const int v = e ? atoi(e) : as_space::QPOOL;
+        return std::max(1, std::min(v, (int)as_space::QPOOL));
+    }();
+    return lim;
 }
 
-static as_status search_single_locked(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
-                                      int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
+static as_status pool_acquire(const as_space* sp, const as_graph* gr, int* slot, as_query** out) {
+    std::unique_lock<std::mutex> lk(sp->qmu);
+    for (;;) {
+        bool any = false, busy = false;
+        for (int i = 0; i < as_space::QPOOL; ++i) {
+            any = any || sp->qpool[i] != nullptr;
+            busy = busy || sp->qbusy[i];
+        }
+        if (any && sp->qcache_gr != gr) {
+            if (busy) {
+                sp->qcv.wait(lk);
+                continue;
+            }
+            for (int i = 0; i < as_space::QPOOL; ++i) {
+                if (sp->qpool[i]) as_query_free(sp->qpool[i]);
+                sp->qpool[i] = nullptr;
+            }
+            sp->qcache = nullptr;
+        }
+        for (int i = 0; i < as_space::QPOOL; ++i)
+            if (sp->qpool[i] && !sp->qbusy[i]) {
+                sp->qbusy[i] = true;
+                *slot = i;
+                *out = sp->qpool[i];
+                return AS_OK;
+            }
+        for (int i = 0; i < pool_limit(); ++i)
+            if (!sp->qpool[i] && !sp->qbusy[i]) {
+                sp->qbusy[i] = true;   // reserved while the workspace is being made (allocations: outside the lock)
+                sp->qcache_gr = gr;
+                lk.unlock();
+                as_query* q = nullptr;
+                const as_status s = query_create(sp, gr, 1, &q, i);
+                lk.lock();
+                if (s != AS_OK) {
+                    sp->qbusy[i] = false;
+                    sp->qcv.notify_all();
+                    return s;
+                }
+                sp->qpool[i] = q;
+                if (i == 0) sp->qcache = q;
+                *slot = i;
+                *out = q;
+                return AS_OK;
+            }
+        sp->qcv.wait(lk);
+    }
+}
+
+static void pool_release(const as_space* sp, int slot) {
+    {
+        std::lock_guard<std::mutex> lk(sp->qmu);
+        sp->qbusy[slot] = false;
+    }
+    sp->qcv.notify_all();
+}
+
+static as_status search_single(const as_space* sp, const as_graph* gr, as_query* q, const double* query, int64_t d, double tau,
+                               int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
+
+// one single-query search on a workspace of the pool
+static as_status search_pooled(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau, int64_t* out_idx,
+                               double* out_score, int64_t* out_len, double* out_lambda_q) {
+    AS_HIP(hipSetDevice(sp->device));
+    int slot = -1;
+    as_query* q = nullptr;
+    AS_TRY(pool_acquire(sp, gr, &slot, &q));
+    const as_status s = search_single(sp, gr, q, query, d, tau, out_idx, out_score, out_len, out_lambda_q);
+    pool_release(sp, slot);
+    return s;
+}
 
 // the graph handle belongs to this space: item graphs have one node per item, feature graphs one per column
 static as_status graph_matches(const as_space* sp, const as_graph* gr, const char* who) {
@@ -602,6 +672,14 @@ static as_status graph_matches(const as_space* sp, const as_graph* gr, const cha
     return AS_OK;
 }
 
+int32_t as_search_pool_size(const as_space* sp) {
+    if (!sp) return 0;
+    std::lock_guard<std::mutex> lk(sp->qmu);
+    int n = 0;
+    for (int i = 0; i < as_space::QPOOL; ++i) n += sp->qpool[i] ? 1 : 0;
+    return n;
+}
+
 as_status as_search(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau, int64_t* out_idx,
                     double* out_score, int64_t* out_len, double* out_lambda_q) {
     if (!sp || !gr || !query || !out_idx || !out_score) {
@@ -613,15 +691,12 @@ as_status as_search(const as_space* sp, const as_graph* gr, const double* query,
         return AS_EINVAL;
     }
     AS_TRY(graph_matches(sp, gr, "as_search"));
-    std::lock_guard<std::mutex> lock(sp->qmu);
-    return search_single_locked(sp, gr, query, d, tau, out_idx, out_score, out_len, out_lambda_q);
+    return search_pooled(sp, gr, query, d, tau, out_idx, out_score, out_len, out_lambda_q);
 }
 
-static as_status search_single_locked(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
-                                      int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q) {
-    AS_HIP(hipSetDevice(sp->device));
-    as_query* q = nullptr;
-    AS_TRY(get_cached_query(sp, gr, &q));
+static as_status search_single(const as_space* sp, const as_graph* gr, as_query* q, const double* query, int64_t d, double tau,
+                               int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q) {
+    (void)gr;
     // mode bit0: fp64 end to end, bit1: wavefront-list selection (candidate buffer overflowed)
     int mode = sp->opts.search_mode & 3;  // tests start directly on a fallback path
     as_status s = AS_OK;
@@ -643,6 +718,7 @@ static as_status search_single_locked(const as_space* sp, const as_graph* gr, co
         int ki = 0, si = 0;
         query_flags(q, &ki, &si);
         if (s == AS_OK && ((ki & 1) || (si & 1))) {
+            std::lock_guard<std::mutex> lk(sp->qmu);
             if (sp->unproven_searches++ == 0)
                 fprintf(stderr, "[pyarrowspace] warning: a search result could not be proven exact (ties at the k-th distance or score "
                                 "inside fp64 rounding); see as_unproven_searches()\n");
@@ -663,7 +739,7 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
     }
     AS_TRY(graph_matches(sp, gr, "as_search_batch"));
     const int64_t topk = std::min<int64_t>(gr->gp.topk, sp->n);
-    std::lock_guard<std::mutex> lock(sp->qmu);
+    std::lock_guard<std::mutex> lock(sp->bmu);   // (the batched workspaces; single-query fallbacks below go through the pool)
     AS_HIP(hipSetDevice(sp->device));
     // the batched pass serves QUERY_BATCH queries per read of the items (MFMA pass; rows wider than 768 floats in
     // K-chunk passes of the same kernel): fp32 fast path only
@@ -722,8 +798,7 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
             const int64_t i = i0 + t;
             if (st_chunk[t] == -1) {  // not provably exact on the batched fast path (or batching unavailable)
                 double lq = 0.0;
-                const as_status s1 = search_single_locked(sp, gr, queries + i * d, d, tau, out_idx + i * topk, out_score + i * topk,
-                                                          out_len + i, &lq);
+                const as_status s1 = search_pooled(sp, gr, queries + i * d, d, tau, out_idx + i * topk, out_score + i * topk, out_len + i, &lq);
                 if (out_lambda_q) out_lambda_q[i] = lq;
                 st_chunk[t] = (int32_t)s1;
                 if (s1 != AS_OK && s1 != AS_EZEROLAMBDA) return drain(s1);

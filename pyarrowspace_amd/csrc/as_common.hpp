@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -62,6 +63,14 @@ struct as_space {
     int lossless = 0;         // items exactly representable in fp32
     as_opts opts{};
     hipStream_t stream = nullptr;
+    // as_search is re-entrant across host threads: a pool of single-query workspaces (own stream, buffers, pinned results
+    // each), lazily grown up to QPOOL; a call takes a free one under qmu and runs WITHOUT the lock, so one thread's scan
+    // overlaps another's finish kernel and host turnaround.  qcache == qpool[0] (what a single thread ever uses).
+    static constexpr int QPOOL = 4;
+    mutable as_query* qpool[QPOOL] = {nullptr, nullptr, nullptr, nullptr};
+    mutable bool qbusy[QPOOL] = {false, false, false, false};
+    mutable std::condition_variable qcv;
+    mutable std::mutex bmu;                   // the batched workspaces below (as_search_batch calls are serialised)
     mutable as_query* qcache = nullptr;       // lazily created by as_search
     mutable const as_graph* qcache_gr = nullptr;
     mutable as_query* qcache_b = nullptr;     // batched workspace (QUERY_BATCH slots), lazily created
@@ -405,7 +414,7 @@ as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, in
 as_status search_once(as_query* q, const double* query, int64_t d, double tau, int exact, int64_t* out_idx,
                       double* out_score, int64_t* out_len, double* out_lambda_q);
 void query_flags(const as_query* q, int* knn_inexact, int* score_inexact);
-as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out);
+as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out, int pool_slot = 0);
 as_status search_batch_launch(as_query* q, const double* queries, int nb, int64_t d, double tau);
 as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, int64_t* out_idx, double* out_score, int64_t* out_len,
                                double* out_lambda_q, int32_t* out_status);

@@ -135,6 +135,7 @@ struct as_query {
     double* q64 = nullptr;   // [dp] zero padded
     float* q32 = nullptr;    // [dp]
     as::QInfo* info = nullptr;
+    int pool_slot = 0;       // slot in the space's pool of single-query workspaces (as_search): picks the stream's priority
     float* dots32 = nullptr; // [np]
     float* part32 = nullptr; // batched workspace of rows wider than 768 floats: [K-chunk pass][slots x np] fp32 partial dots (as_scan.hip, gemm_chunks)
     double* dots64 = nullptr;

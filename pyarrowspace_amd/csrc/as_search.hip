@@ -2190,7 +2190,7 @@ int as_debug_stamps(unsigned long long* out) {
 namespace as {
 static as_status query_alloc(as_query* q);
 
-as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out) {
+as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out, int pool_slot) {
     if (!sp || !out) {
         set_err("as_query_create: null argument");
         return AS_EINVAL;
@@ -2198,6 +2198,7 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     AS_HIP(hipSetDevice(sp->device));
     as_query* q = new as_query();
     q->cap = cap;
+    q->pool_slot = pool_slot;
     q->sp = sp;
     q->gr = gr;
     const bool feature = gr && gr->lambda_mode == AS_LAMBDA_FEATURE;
@@ -2241,6 +2242,16 @@ static as_status query_alloc(as_query* q) {
         int lo_prio = 0, hi_prio = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
         const int prio = (nbatch.fetch_add(1) & 1) ? hi_prio : (lo_prio + hi_prio) / 2;
+        if (hipStreamCreateWithPriority(&q->own_stream, hipStreamNonBlocking, prio) != hipSuccess) {
+            (void)hipGetLastError();
+            AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));
+        }
+    } else if (q->pool_slot > 0) {
+        // the workspaces of as_search's pool (concurrent host threads): a stream priority of its own per slot, for the same
+        // reason -- one thread's scan is meant to run under another's finish kernel and host turnaround
+        int lo_prio = 0, hi_prio = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+        const int prio = q->pool_slot % 3 == 1 ? hi_prio : (q->pool_slot % 3 == 2 ? lo_prio : (lo_prio + hi_prio) / 2);
         if (hipStreamCreateWithPriority(&q->own_stream, hipStreamNonBlocking, prio) != hipSuccess) {
             (void)hipGetLastError();
             AS_HIP(hipStreamCreateWithFlags(&q->own_stream, hipStreamNonBlocking));

@@ -34,3 +34,58 @@ print("ok")
 def test_one_hip_runtime_per_process(order):
     out = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT), order], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_search_is_reentrant_across_host_threads(oracle_lib):
+    """as_search from several host threads at once on ONE space.  Every call runs on a pooled workspace (own
+    stream, buffers, pinned results), no lock held while it runs: 4 threads x 60 searches (three taus, the exact-item
+    query, a far query that must raise the zero-lambda panic in its own thread only) return what the oracle returns and
+    what the same searches return single-threaded; the pool has grown to at most 4 workspaces, 1 before the threads ran."""
+    import threading
+
+    import numpy as np
+
+    import pyarrowspace_amd as asp
+    from conftest import assert_hits_match, calibrate_eps, clustered
+    RTOL = 1e-9
+    n, d, k, topk = 6000, 96, 9, 7
+    X = clustered(n, d, nclust=12, seed=23)
+    gp = {"eps": calibrate_eps(X, k, "l2"), "k": k, "topk": topk, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(5)
+    Q = [np.ascontiguousarray(X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d)) for _ in range(60)]
+    Q[7] = np.ascontiguousarray(X[123])
+    far = np.zeros(d)
+    far[0] = 40.0
+    taus = (0.62, 1.0, 0.0)
+    single = [aspace.search(q, gl, taus[i % 3]) for i, q in enumerate(Q)]
+    assert aspace.search_pool_size == 1
+    results = [[None] * len(Q) for _ in range(4)]
+    panics, errors = [0] * 4, []
+
+    def worker(t):
+        try:
+            for i, q in enumerate(Q):
+                if (i + t) % 17 == 0:
+                    try:
+                        aspace.search(far, gl, 0.62)
+                    except asp.PanicException:
+                        panics[t] += 1
+                results[t][i] = aspace.search(q, gl, taus[i % 3])
+        except BaseException as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    assert all(p >= 3 for p in panics)
+    assert 1 <= aspace.search_pool_size <= 4
+    for i, q in enumerate(Q):
+        want, lq = ref.search(q, taus[i % 3])
+        assert_hits_match(single[i], want, ref.scores(q, taus[i % 3], lq), rtol=RTOL)
+        for t in range(4):
+            assert results[t][i] == single[i], (t, i)
