@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--cpu-build-budget", type=float, default=90.0, help="skip a CPU build size predicted to take longer (s)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/traffic.json (when it is of this workload) instead of two rocprofv3 --pmc passes run now")
+    ap.add_argument("--no-threaded", action="store_true", help="skip the 2- and 4-host-thread search runs (kernel-trace profiles: their overlapping kernels stretch each other)")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the short child pass live_traffic() profiles
     args = ap.parse_args()
 
@@ -489,7 +490,7 @@ def main():
     # call runs on a pooled workspace and stream of its own, one thread's scan under another's finish kernel and host
     # turnaround.  Reported BESIDE the headline (which stays the single-thread, single-query number), never as it.
     threaded = None
-    if single and not args.traffic_probe:
+    if single and not args.traffic_probe and not args.no_threaded:
         import threading
 
         threaded = {}
@@ -612,6 +613,9 @@ def main():
         "batched_queries_per_sec": batched_qps,
         "threaded_queries_per_sec": threaded,
         "zero_lambda_rate": zero_in / args.steps,
+        # single-query searches of this run that needed a second pass over the items, by cause (as_search_counters)
+        "fallback_rate": (lambda c: None if c is None else dict(c, rate=c["searches_with_rerun"] / max(c["searches"], 1)))(
+            aspace.search_counters() if single else None),
         "build_stages_sec": {k: bstats[k] for k in ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s")},
         "build_fallback_rows": bstats["fallback_rows"],
         "build_band_rows": bstats["band_rows"],

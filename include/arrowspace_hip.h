@@ -352,6 +352,10 @@ as_status as_query_stats(const as_query* q, double* out, int32_t n);
 void as_enable_search_stats(int32_t enabled);
 /* same, for the workspace as_search keeps inside the space (last as_search call) */
 as_status as_last_search_stats(const as_space* sp, double* out, int32_t n);
+/* single-query searches on this space since it was made: out[0] searches, [1] zero-lambda results (src/lib.rs:156-159),
+ * [2] reruns after a failed k-NN a-posteriori check, [3] after a candidate-buffer overflow, [4] after a failed scorer
+ * check, [5] searches that took at least one rerun.  A rerun costs a second pass over the items. */
+as_status as_search_counters(const as_space* sp, int64_t* out, int32_t n);
 
 /* ---- index persistence (extension; the reference exposes none): one flat file
  * holding the items, lambdas and graph arrays.  Loading re-ingests the items and uploads the

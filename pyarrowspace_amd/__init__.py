@@ -303,6 +303,16 @@ class ArrowSpace:
         fp64 rounding); the library also says so on stderr the first time.  0 in normal operation."""
         return int(_L.as_unproven_searches(self._h))
 
+    def search_counters(self) -> dict:
+        """Extension: what the single-query searches on this space cost so far -- reruns (a second pass over the items) by
+        cause, zero-lambda results."""
+        out = np.zeros(6, dtype=np.int64)
+        st = _L.as_search_counters(self._h, out.ctypes.data_as(C.c_void_p), 6)
+        if st:
+            _raise(st)
+        keys = ("searches", "zero_lambda", "rerun_knn_check", "rerun_overflow", "rerun_score_check", "searches_with_rerun")
+        return dict(zip(keys, (int(v) for v in out)))
+
     @property
     def search_pool_size(self) -> int:
         """Extension: single-query workspaces the library holds for this space -- `search` is re-entrant across host threads

@@ -700,9 +700,18 @@ static as_status search_single(const as_space* sp, const as_graph* gr, as_query*
     // mode bit0: fp64 end to end, bit1: wavefront-list selection (candidate buffer overflowed)
     int mode = sp->opts.search_mode & 3;  // tests start directly on a fallback path
     as_status s = AS_OK;
+    int64_t cnt[6] = {1, 0, 0, 0, 0, 0};
     for (int attempt = 0; attempt < 3; ++attempt) {
         s = search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
         if (s != AS_OK && s != AS_EZEROLAMBDA) break;
+        // lambda_q == 0 (no item within eps, proven: the k-NN check below still escalates an unproven empty list) is the
+        // reference's panic (src/lib.rs:156-159): no result will be returned, so the scorer's flags of such a query --
+        // every item ties at tau = 0 -- must not buy it two more passes over the items
+        if (s == AS_EZEROLAMBDA) {
+            int ki0 = 0, si0 = 0;
+            query_flags(q, &ki0, &si0);
+            if (!(ki0 & 1) && !(query_overflow_bits(q) & 1)) break;
+        }
         int ki = 0, si = 0;
         query_flags(q, &ki, &si);
         int next = mode;
@@ -710,7 +719,16 @@ static as_status search_single(const as_space* sp, const as_graph* gr, as_query*
         if (((ki & 1) || si) && !sp->opts.force_exact) next |= 1;
         if (next == mode) break;
         dbg("search: fast path not provably exact (knn=%d score=%d), rerunning with mode %d", ki, si, next);
+        cnt[2] += (ki & 1) ? 1 : 0;
+        cnt[3] += (ki & 2) ? 1 : 0;
+        cnt[4] += si ? 1 : 0;
+        cnt[5] = 1;
         mode = next;
+    }
+    cnt[1] = s == AS_EZEROLAMBDA ? 1 : 0;
+    {
+        std::lock_guard<std::mutex> lk(sp->qmu);
+        for (int i = 0; i < 6; ++i) sp->scount[i] += cnt[i];
     }
     if (s == AS_OK && out_lambda_q) dbg("search: qlen=%lld, lambda_q=%.6f", (long long)d, *out_lambda_q);  // src/lib.rs:161-165
     {   // the strongest path has run and the answer still fails its a-posteriori check (more near-ties than fp64
@@ -917,6 +935,16 @@ as_status as_last_search_stats(const as_space* sp, double* out, int32_t n) {
         return AS_EINVAL;
     }
     return as_query_stats(sp->qcache, out, n);
+}
+
+as_status as_search_counters(const as_space* sp, int64_t* out, int32_t n) {
+    if (!sp || !out) {
+        set_err("as_search_counters: null argument");
+        return AS_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(sp->qmu);
+    for (int i = 0; i < n && i < 6; ++i) out[i] = sp->scount[i];
+    return AS_OK;
 }
 
 as_status as_build_stats(const as_graph* gr, double* out, int32_t n) {

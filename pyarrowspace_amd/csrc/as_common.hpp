@@ -77,6 +77,10 @@ struct as_space {
     mutable as_query* qcache_b2 = nullptr;    // its twin: passes alternate, one scans while the other finishes
     mutable const as_graph* qcache_b_gr = nullptr;
     mutable std::mutex qmu;
+    // as_search_counters: [0] searches, [1] zero-lambda results, [2] reruns because the k-NN a-posteriori check failed,
+    // [3] reruns because a candidate buffer overflowed, [4] reruns because the scorer's check failed, [5] searches that
+    // took at least one rerun (under qmu)
+    mutable int64_t scount[6] = {0, 0, 0, 0, 0, 0};
     mutable int64_t unproven_searches = 0;   // searches returned although their a-posteriori check failed on the strongest path
     mutable double kstats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // accumulated by as_knn_rows
 };
@@ -414,6 +418,7 @@ as_status exact_row_knn(as_query* ws, const as_graph_params* gp, int64_t row, in
 as_status search_once(as_query* q, const double* query, int64_t d, double tau, int exact, int64_t* out_idx,
                       double* out_score, int64_t* out_len, double* out_lambda_q);
 void query_flags(const as_query* q, int* knn_inexact, int* score_inexact);
+int query_overflow_bits(const as_query* q);
 as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out, int pool_slot = 0);
 as_status search_batch_launch(as_query* q, const double* queries, int nb, int64_t d, double tau);
 as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, int64_t* out_idx, double* out_score, int64_t* out_len,

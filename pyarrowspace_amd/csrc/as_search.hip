@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void score_gmin_kernel(SelArgs<T> a, int64_t G
     const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (KEY == 1 && g == 0 && lane == 0) reset_query_state(a.info_w);   // the search restarts behind the scan
     if (g >= ngroups) return;
+    // lambda_q == 0 is the reference's panic (src/lib.rs:156-159): no scores will be returned, none are formed (at tau = 0
+    // such a query ties with every isolated item: thousands of candidates at the threshold for an answer nobody reads)
+    if (KEY == 0 && a.info->status == AS_EZEROLAMBDA) return;
     const ScoreCtx c = load_ctx(a.info, a.tau);
     const int64_t lo = a.r0 + g * G;
     const int64_t hi = lo + G < a.r1 ? lo + G : a.r1;
@@ -434,6 +437,7 @@ __global__ __launch_bounds__(1024) void pick_thr_kernel(const T* __restrict__ gm
 template <typename T, int KEY>
 __global__ __launch_bounds__(1024) void score_pickfilter_kernel(SelArgs<T> a, int ng, int M) {
     sel_slot(a);
+    if (KEY == 0 && a.info->status == AS_EZEROLAMBDA) return;   // (as score_gmin_kernel: an empty candidate list for the finish kernel)
     const double thr_d = pick_thr_block<T>(a.gmin, ng, M);
     const T thr = (T)thr_d;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -451,6 +455,12 @@ __global__ __launch_bounds__(1024) void score_pickfilter_kernel(SelArgs<T> a, in
     for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1 && !full; row += stride) {
         const T k = sel_key<T, KEY>(a, c, row);
         if (k <= thr && (KEY == 0 || k < key_traits<T>::inf())) {
+            // mass ties at the threshold (tau = 0 with thousands of isolated items at lambda = 0): once the counter has
+            // passed the capacity nobody needs a slot any more -- 100 000 returning atomics on one word cost a millisecond
+            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > CAND_CAP) {
+                full = true;
+                break;
+            }
             const int slot = atomicAdd(counter, 1);
             if (slot < CAND_CAP) {
                 ckey[slot] = k;
@@ -647,6 +657,10 @@ __global__ __launch_bounds__(256) void score_filter_batch_kernel(BatchSel a, int
             if (!((actm >> s) & 1u)) continue;
             const double k = batch_key(a, dv[s], rn, lrow, s_rq[s], s_lq[s]);
             if (k <= s_thr[s] && !((full >> s) & 1u)) {
+                if (__hip_atomic_load(&a.info_w[s0 + s].sc_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > CAND_CAP) {   // (as score_pickfilter_kernel)
+                    full |= 1u << s;
+                    continue;
+                }
                 const int slot = atomicAdd(&a.info_w[s0 + s].sc_cnt, 1);
                 if (slot < CAND_CAP) {
                     a.ckey[(int64_t)(s0 + s) * CAND_CAP + slot] = k;
@@ -2602,6 +2616,8 @@ void query_flags(const as_query* q, int* knn_inexact, int* score_inexact) {
     *score_inexact = q->hout->score_inexact;
     if (q->hout->overflow) *knn_inexact |= 2;
 }
+
+int query_overflow_bits(const as_query* q) { return q->hout->overflow; }   // bit0 k-NN candidates, bit1 scorer's, bit2 the scan's scorer candidates
 
 // one full single-GPU search on q's stream: 6 launches, one host wait
 as_status search_once(as_query* q, const double* query, int64_t d, double tau, int mode, int64_t* out_idx, double* out_score,
