@@ -564,17 +564,18 @@ def main():
     # null for any other workload
     traffic_scan = traffic_mfma = traffic_batch = None
     traffic_source = None
+    k2_fp32_env = os.environ.get("ARROWSPACE_K2_FP32", "0") not in ("", "0")
     # rows up to 1024 floats take the LDS-DMA ring scan, wider rows the register-staged one
     scan_kernel = "scan_dma_kernel" if d <= 1024 and os.environ.get("ARROWSPACE_SCAN_VARIANT", "0") in ("", "0") else "scan_dots_f32_kernel"
     if live:
-        traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), live.get("knn_mfma_kernel"), live.get("scan_gemm_kernel")
+        traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), (live.get("knn_mfma_kernel") if k2_fp32_env else live.get("knn_bf16_kernel")), live.get("scan_gemm_kernel")
         traffic_source = live_note
     else:
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj["workload"] == {"n": n, "d": d} and world == 1 and args.metric == "l2" and not feature:
                 traffic_scan = tj.get(scan_kernel, {}).get("bytes_per_launch")
-                traffic_mfma = tj.get("knn_mfma_kernel", {}).get("bytes_per_launch")
+                traffic_mfma = tj.get("knn_mfma_kernel" if k2_fp32_env else "knn_bf16_kernel", {}).get("bytes_per_launch")
                 traffic_batch = tj.get("scan_gemm_kernel", {}).get("bytes_per_launch")
                 traffic_source = ("profiles/traffic.json (rocprofv3 --pmc passes of this workload, profiles/collect.sh); live passes: %s"
                                   % live_note)

@@ -103,12 +103,16 @@ def traffic(fetch_csv, write_csv, n, d, out):
                        "Valid only for the workload named in 'workload'.",
            "workload": {"n": int(n), "d": int(d)}}
     for key, prefix in (("scan_dma_kernel", "as::scan_dma_kernel"), ("scan_dots_f32_kernel", "as::scan_dots_f32_kernel"),
-                        ("scan_gemm_kernel", "as::scan_gemm_kernel"), ("knn_mfma_kernel", "as::knn_mfma")):
+                        ("scan_gemm_kernel", "as::scan_gemm_kernel"), ("knn_mfma_kernel", "as::knn_mfma"),
+                        ("knn_bf16_kernel", "as::knn_bf16_kernel")):
         fk = [k for k in f if k.startswith(prefix)]
         if not fk:
             continue
-        k = fk[0]
+        k = max(fk, key=lambda name: f[name])   # (the main pass of the build, not its threshold pass)
         doc[key] = {"fetch_kib": f[k], "write_kib": w.get(k, 0.0), "bytes_per_launch": int((2.0 * f[k] + w.get(k, 0.0)) * 1024)}
+    if "knn_bf16_kernel" in doc:
+        doc["knn_bf16_kernel"]["note"] = ("fabric-side requests of the symmetric main pass (bf16 head + tail kernel); Infinity-Cache hits are "
+                                          "counted (MI355X_MICROARCH.md HBM section)")
     if "knn_mfma_kernel" in doc:
         doc["knn_mfma_kernel"]["note"] = ("fabric-side requests of the 8-wave LDS-DMA kernel; Infinity-Cache hits are counted "
                                           "(MI355X_MICROARCH.md HBM section)")

@@ -22,5 +22,8 @@ for l in open("gpurun_out/sweep.jsonl"):
     m = re.search(r"k=(\d+) topk=(\d+) tau=([0-9.]+)", c["workload"])
     print(f"n={c['n']:>8} d={c['d']:>5} k={m.group(1):>3} topk={m.group(2):>4} tau={m.group(3)} q/s={d['value']:9.1f} scan={d['roofline']['frac']:.3f} query={d['roofline_query']['frac']:.3f} "
           f"in-dist q/s={d['in_distribution_queries']['value']:9.1f} build={d['index_build_sec']:.2f}s mfma={d['roofline_build']['frac']:.3f} batched={d['batched_queries_per_sec'] or 0:.0f} "
-          f"(batch frac {d['roofline_batch']['frac'] if d['roofline_batch'] else 0:.3f})")
+          f"(batch frac {d['roofline_batch']['frac'] if d['roofline_batch'] else 0:.3f}) "
+          f"threads 2/4: {d['threaded_queries_per_sec']['2']['value']:.0f} ({d['threaded_queries_per_sec']['2']['frac']:.3f}) / "
+          f"{d['threaded_queries_per_sec']['4']['value']:.0f} ({d['threaded_queries_per_sec']['4']['frac']:.3f}) zero-lambda {d['zero_lambda_rate']:.2f} "
+          f"reruns {d['fallback_rate']['rate']:.3f}")
 PY
