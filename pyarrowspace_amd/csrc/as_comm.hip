@@ -11,6 +11,9 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <string>
+#include <vector>
+
 #include "as_query.hpp"
 
 namespace {
@@ -170,15 +173,41 @@ as_status as_query_search_staged(as_query* q, const double* query_host, int64_t 
     for (int pass = 0; pass < 9; ++pass) {
         as_query_set_exact(q, mode);
         q->staged_tau = sc && mode == 0 ? tau : -1.0;
-        const as_status s0 = as_query_scan(q, query_host, d, row_begin, row_end);
+        // A failure of THIS rank between the collectives (an allocation of the fp64 escalation, a wait that times out) must
+        // not leave the peers blocked in an all-gather it never enters: the pass goes on -- both collectives are issued --,
+        // the trailing hit record carries an error flag every rank merges, and every rank returns after the pass.  (A failing
+        // collective itself is the communicator's failure: nothing further can be exchanged over it.)
+        as_status local = as_query_scan(q, query_host, d, row_begin, row_end);
         q->staged_tau = -1.0;
-        AS_TRY(s0);
+        std::string local_msg = local != AS_OK ? err_slot() : std::string();
         AS_TRY(nccl_check(r->all_gather(q->knn, q->knn_all, sizeof(as_knn_rec) * krec, NCCL_CHAR, c->comm, q->stream), "ncclAllGather (k-NN records)"));
-        AS_TRY(as_query_lambda(q, q->knn_all, krec * c->world));
-        AS_TRY(as_query_score(q, tau));
+        if (local == AS_OK && (local = as_query_lambda(q, q->knn_all, krec * c->world)) != AS_OK) local_msg = err_slot();
+        if (local == AS_OK && (local = as_query_score(q, tau)) != AS_OK) local_msg = err_slot();
+        if (local != AS_OK) {
+            // no hits of this rank (whatever the buffer holds is not this query's), the flag in the trailing record
+            std::vector<as_hit_rec> fail((size_t)hrec);
+            for (auto& h : fail) {
+                h.idx = -1;
+                h.score = 0.0;
+            }
+            fail[(size_t)hrec - 1].idx = -2;
+            fail[(size_t)hrec - 1].score = 32.0;
+            (void)hipMemcpyAsync(q->hits, fail.data(), sizeof(as_hit_rec) * hrec, hipMemcpyHostToDevice, q->stream);
+            (void)hipStreamSynchronize(q->stream);   // (the source is this frame's)
+        }
         AS_TRY(nccl_check(r->all_gather(q->hits, q->hits_all, sizeof(as_hit_rec) * hrec, NCCL_CHAR, c->comm, q->stream), "ncclAllGather (hit records)"));
         st = as_query_finish(q, q->hits_all, hrec * c->world, out_idx, out_score, out_len, out_lambda_q);
         q->staged_sc = 0;
+        if (local != AS_OK) {
+            as_query_set_exact(q, 0);
+            set_err("%s", local_msg.c_str());
+            return local;
+        }
+        if (q->hout->overflow & 8) {
+            as_query_set_exact(q, 0);
+            set_err("as_query_search_staged: another rank of the index failed in this pass");
+            return AS_EHIP;
+        }
         if (st != AS_OK && st != AS_EZEROLAMBDA) return st;
         if (sc && mode == 0) {
             q->sc_crowded = (q->hout->overflow & 4) ? 1 : 0;

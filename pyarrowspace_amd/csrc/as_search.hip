@@ -1827,7 +1827,9 @@ __global__ __launch_bounds__(1024) void hits_final_kernel(const as_hit_rec* __re
         out->status = info->status;
         out->knn_inexact = (info->knn_inexact || (fl & 1)) ? 1 : 0;
         out->score_inexact = (info->score_inexact || (fl & 2)) ? 1 : 0;
-        out->overflow = (info->overflow & 7) | ((fl & 4) ? 1 : 0) | ((fl & 8) ? 2 : 0) | ((fl & 16) ? 4 : 0);
+        // (bit 3: some rank could not finish its part of a staged search -- as_query_search_staged files the flag so that every
+        // rank leaves the pass with the same error instead of waiting for a collective its peer never enters)
+        out->overflow = (info->overflow & 7) | ((fl & 4) ? 1 : 0) | ((fl & 8) ? 2 : 0) | ((fl & 16) ? 4 : 0) | ((fl & 32) ? 8 : 0);
         publish(out, seq);
     }
 }

@@ -597,15 +597,19 @@ class ShardedIndex:
         ARROWSPACE_PY_COLLECTIVES=1 keeps the torch.distributed path (A/B runs)."""
         import os
         e = self.engine
-        if not (self.library_exchange and self._collective() and hasattr(e, "comm_create")) or os.environ.get("ARROWSPACE_PY_COLLECTIVES"):
+        # (what decides here is the same on every rank: the class, the engine type, the group's backend)
+        if not (self.library_exchange and self._collective() and hasattr(e, "comm_create")):
             return
         if self.dist.get_backend(self.group) != "nccl":
             return
         torch = self.torch
         dev = torch.device("cuda", e.op.device)
         # as_comm_create is collective: every rank must be able to take part (a rank without librccl would leave the others
-        # waiting in ncclCommInitRank) -- agree first
-        ok = torch.tensor([1 if e.comm_available() else 0], dtype=torch.int32, device=dev)
+        # waiting in ncclCommInitRank) -- agree first.  Whatever may DIFFER between ranks -- librccl on the box, this rank's
+        # environment (ARROWSPACE_PY_COLLECTIVES) -- goes into the vote, never into a return in front of it: ranks that take
+        # different branches here issue different collectives for every query that follows.
+        mine = e.comm_available() and not os.environ.get("ARROWSPACE_PY_COLLECTIVES")
+        ok = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) == 0:
             return
@@ -1165,8 +1169,24 @@ class HostStagedIndex(ShardedIndex):
         return super()._gather_rows(t.cpu(), counts).cuda()
 
     def _gather_fixed(self, t, persistent=False):
-        self.torch.cuda.synchronize()
-        return super()._gather_fixed(t.cpu()).cuda()
+        torch = self.torch
+        torch.cuda.synchronize()
+        if not (persistent and t.is_cuda and self._collective()):
+            return super()._gather_fixed(t.cpu()).cuda()
+        # the engine's record tensors, gathered for every query: pinned host buffers and the device result are made once
+        key = ("host", t.data_ptr(), tuple(t.shape), t.dtype)
+        bufs = self._gbuf.get(key)
+        if bufs is None:
+            hs = torch.empty(tuple(t.shape), dtype=t.dtype).pin_memory()
+            hr = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype).pin_memory()
+            out = torch.empty(tuple(hr.shape), dtype=t.dtype, device=t.device)
+            bufs = self._gbuf[key] = (hs, hr, out)
+        hs, hr, out = bufs
+        hs.copy_(t)
+        self.dist.all_gather_into_tensor(hr, hs, group=self.group)
+        out.copy_(hr)
+        torch.cuda.synchronize()
+        return out
 
     def _swap_slices(self, P, dst, src, nrows):                  # the symmetric ring's slices
         self.torch.cuda.synchronize()
