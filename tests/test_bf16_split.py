@@ -71,3 +71,67 @@ def test_non_finite_heads_keep_a_zero_tail():
         rem = v - hi
     lo = np.where(rem == rem, rem, np.float32(0))
     assert lo[0] == 0 and lo[1] == 0 and lo[2] == 0 and lo[3] == 0
+
+
+def test_split_image_layout_of_the_build_kernel():
+    """The build kernel's operand (csrc/as_k2bf.hip, split_bf16_kernel): per row and 32-column slab 32 bf16 heads then 32 bf16
+    tails -- the 128 bytes of the fp32 slab row; 16-byte chunk c holds heads (c < 4) or tails (c >= 4) of columns
+    8 (c & 3) .. 8 (c & 3) + 7, one lane's operand of a 16-column k-step of v_mfma_f32_32x32x16_bf16 (lane half h of k-step s
+    reads chunk 2 s + h and 4 + 2 s + h).  Restated here: image -> (head, tail) recovers the split of every element."""
+    rng = np.random.default_rng(3)
+    rows, dp = 5, 96
+    x = rng.standard_normal((rows, dp)).astype(np.float32)
+    hi, lo = split(x)
+    img = np.zeros((rows, dp * 2), dtype=np.uint16)           # 4 bytes per element, as bf16 halves
+    for r in range(rows):
+        for s in range(dp // 32):
+            img[r, 64 * s: 64 * s + 32] = (hi[r, 32 * s: 32 * s + 32].view(np.uint32) >> 16).astype(np.uint16)
+            img[r, 64 * s + 32: 64 * s + 64] = (lo[r, 32 * s: 32 * s + 32].view(np.uint32) >> 16).astype(np.uint16)
+    for r in range(rows):
+        for s in range(dp // 32):
+            for kstep in range(2):
+                for h in range(2):
+                    c_head, c_tail = 2 * kstep + h, 4 + 2 * kstep + h
+                    cols = 32 * s + 16 * kstep + 8 * h + np.arange(8)
+                    got_h = (img[r, 64 * s + 8 * c_head: 64 * s + 8 * c_head + 8].astype(np.uint32) << 16).view(np.float32)
+                    got_l = (img[r, 64 * s + 8 * c_tail: 64 * s + 8 * c_tail + 8].astype(np.uint32) << 16).view(np.float32)
+                    np.testing.assert_array_equal(got_h, hi[r, cols])
+                    np.testing.assert_array_equal(got_l, lo[r, cols])
+
+
+def test_build_kernel_error_coefficient_covers_the_three_product_key():
+    """err_coef of the bf16 build kernel (csrc/as_build.hip): |key32 - key64| <= [(6 Dp + 32) 2^-24 + 3.03 2^-16] (n_i + n_j)
+    for key = n_i + n_j - 2 G with G the fp32-accumulated sum of xh.yh + xh.yl + xl.yh.  Restated with sequential fp32
+    accumulation in the kernel's order (per 16-column k-step: the three products of its columns), on clustered, scaled,
+    near-duplicate and cancelling rows."""
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for trial in range(60):
+        d = int(rng.choice([32, 96, 768]))
+        x = rng.standard_normal(d)
+        y = rng.standard_normal(d)
+        kind = trial % 4
+        if kind == 1:
+            y = x + 1e-3 * y                      # near-duplicates: the key cancels to ~1e-6 of the norms
+        elif kind == 2:
+            x *= 1e3
+            y *= 1e-3
+        elif kind == 3:
+            y = -x + 1e-2 * y
+        x32, y32 = x.astype(np.float32), y.astype(np.float32)
+        xh, xl = split(x32)
+        yh, yl = split(y32)
+        acc = np.float32(0.0)
+        for s in range(0, d, 16):
+            for a, b in ((xh, yh), (xh, yl), (xl, yh)):
+                for c in range(s, min(s + 16, d)):
+                    acc = np.float32(acc + np.float32(a[c]) * np.float32(b[c]))     # bf16 x bf16 is exact in fp32; one rounding per addition
+        ni, nj = np.float32(np.sum(x32.astype(np.float64) ** 2)), np.float32(np.sum(y32.astype(np.float64) ** 2))
+        key32 = np.float32(np.float32(ni + nj) + np.float32(-2.0) * acc)
+        key64 = float(np.sum((x32.astype(np.float64) - y32.astype(np.float64)) ** 2))
+        dp = (d + 31) // 32 * 32
+        coef = (6 * dp + 32) * 2.0 ** -24 + 3.03 * 2.0 ** -16
+        bound = coef * (float(ni) + float(nj))
+        assert abs(float(key32) - key64) <= bound, (trial, kind, abs(float(key32) - key64) / (float(ni) + float(nj)), coef)
+        worst = max(worst, abs(float(key32) - key64) / (float(ni) + float(nj)) / coef)
+    assert worst < 1.0

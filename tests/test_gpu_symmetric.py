@@ -148,3 +148,51 @@ def test_column_chunks_with_overflowing_buffers_and_a_loose_eps():
     for metric in ("l2", "cosine"):
         gp = {"eps": 10.0, "k": 8, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
         _same_index(_build(X, gp, True, 4), _build(X, gp, True))
+
+
+def _build_pipe(X, gp, fp32, **env):
+    """One build on the bf16 head + tail kernel (default) or, ARROWSPACE_K2_FP32=1, on the fp32 matrix pipe."""
+    keys = dict(env, ARROWSPACE_K2_FP32="1" if fp32 else None)
+    old = {k: os.environ.pop(k, None) for k in keys}
+    for k, v in keys.items():
+        if v is not None:
+            os.environ[k] = str(v)
+    try:
+        return _build(X, gp, True)
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
+
+
+@pytest.mark.parametrize("metric,kernel", [("l2", "gaussian"), ("cosine", "rational")])
+@pytest.mark.parametrize("n,d,k", [(6000, 96, 10), (3000, 768, 25), (20000, 64, 10), (1100, 40, 6), (9000, 1000, 57)])
+def test_bf16_build_kernel_gives_the_graphs_of_the_fp32_pipe_bitwise(metric, kernel, n, d, k):
+    """The k-NN block of the build on the bf16 matrix pipe (as_k2bf.hip: every operand as head + tail, three products) is a
+    PREFILTER like the fp32 kernel it replaces: the refinement evaluates what it keeps exactly and proves what it dropped
+    against the wider error term (err_coef) -- so CSR, Laplacian values and lambdas are bit for bit those of the fp32 pipe
+    (ARROWSPACE_K2_FP32=1), symmetric pass, threshold pass and band pass included; also in gang order (per-XCD unit lists)."""
+    X = clustered(n, d, nclust=8, seed=4)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
+    bf, f32 = _build_pipe(X, gp, False), _build_pipe(X, gp, True)
+    _same_index(bf, f32)
+    assert bf[2]["fallback_rows"] == 0 and bf[2]["mfma_flops"] > 0
+    if n >= 6000:
+        _same_index(_build_pipe(X, gp, False, ARROWSPACE_K2_GANG_GC=4), f32)
+
+
+def test_bf16_build_kernel_with_duplicates_zero_rows_and_scaled_items():
+    """What strains the wider error term: groups of exact duplicates (ties at the k-th distance: band pass), zero rows, items
+    scaled by 1e3 and 1e-3 in one index (norms six decades apart), values that do not round-trip through fp32."""
+    rng = np.random.default_rng(9)
+    X = clustered(7000, 128, nclust=6, seed=11, normalise=False)
+    X[100:140] = X[100]            # 40 copies
+    X[2000:2003] = 0.0
+    X[3000:3500] *= 1.0e3
+    X[4000:4500] *= 1.0e-3
+    X[5000:5200] += 1.0e-9 * rng.standard_normal((200, 128))
+    for metric in ("l2", "cosine"):
+        gp = {"eps": calibrate_eps(X, 12, metric), "k": 12, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
+        bf, f32 = _build_pipe(X, gp, False), _build_pipe(X, gp, True)
+        _same_index(bf, f32)
