@@ -14,7 +14,7 @@ static inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-double err_coef(int64_t dp) {
+static double err_coef_dp(int64_t dp) {
     // |fl32(n_i + n_j - 2 G32) - (exact)| <= coef * (n_i + n_j): k-ordered fp32 fma chain of
     // length dp (gamma_dp), rounded norms, two adds and the fp32 rounding of the inputs.
     const double u = 5.9604644775390625e-8;  // 2^-24
@@ -25,6 +25,18 @@ double err_coef(int64_t dp) {
     // in the sum (Cauchy-Schwarz) and, doubled in the key, <= 3.03 * 2^-16 (n_i + n_j).
     return (double)(6 * dp + 32) * u + 3.03 * 0x1p-16;
 }
+
+// int8 two-digit image (as_k2bf.hip, quant_i8_kernel): x = s (q + theta) / 16256 with |theta| <= 1/2 and q = 128 a1 + a2; the
+// kernel forms s_i s_j (16384 a1.b1 + 128 (a1.b2 + a2.b1)) / 16256^2 exactly in int32.  With x~ = s q / 16256:
+//   x_i.x_j - G = x_i.(x_j - x~_j) + (x_i - x~_i).x~_j + s_i s_j a2_i.a2_j / 16256^2,
+//   |.| <= |x_i| s_j |theta_j|_2 / 16256 + |x~_j| s_i |theta_i|_2 / 16256 + s_i s_j |a2_i|_2 |a2_j|_2 / 16256^2   (Cauchy-Schwarz)
+//       <= |x_i||x_j| (2.001 U + V^2),   U = max_i s_i |theta_i|_2 / (16256 |x_i|),  V = max_i s_i |a2_i|_2 / (16256 |x_i|)
+// (the rows' ACTUAL residue and low-digit norms, measured by the quantisation kernel).  Doubled in the key and against
+// n_i + n_j >= 2 |x_i||x_j| the bracket IS the coefficient; the epilogue's fp32 scaling (four roundings) and the rounded norms
+// add 8 * 2^-24.  Clustered unit rows at D = 768: 3.6e-4 (bf16 head + tail: 3.2e-4).
+static double err_coef_i8(double U, double V) { return 2.001 * U + V * V + 8.0 * 5.9604644775390625e-8; }
+
+double err_coef(const as_space* sp) { return sp->k2_i8 ? sp->coef8 : err_coef_dp(sp->dp); }
 
 // The operand of the k-NN kernels for this space's items: the fp32 matrix, or (default) its bf16 head + tail image,
 // made on first use and kept with the space.
@@ -52,6 +64,51 @@ static as_status k2_items(const as_space* sp, const float** out) {
         sp->xs = xs;
     }
     *out = sp->xs;
+    return AS_OK;
+}
+
+// The int8 two-digit image of this space's items and the error coefficient its products carry; made on first use.  False
+// when the image cannot be used: a non-finite item, or a coefficient more than twice the bf16 kernel's (rows dominated by
+// one element: s / |x| near 1) -- the bf16 kernel then.
+static as_status k2_items_i8(const as_space* sp, bool* usable) {
+    *usable = false;
+    if (!sp->x8 && !sp->x8_bad) {
+        const int64_t rows_alloc = sp->np + ROW_TILE;
+        const int64_t dp8 = (sp->dp + 63) / 64 * 64;
+        void* x8 = nullptr;
+        float* fa8 = nullptr;
+        dev_tmp<unsigned int> mx;
+        AS_HIP(mx.alloc(4));
+        AS_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int) * 4, sp->stream));
+        AS_HIP(hipMalloc(&x8, (size_t)rows_alloc * dp8 * 2));
+        if (hipMalloc(&fa8, sizeof(float) * rows_alloc) != hipSuccess) {
+            (void)hipFree(x8);
+            set_err("k2_items_i8: out of memory");
+            return AS_ENOMEM;
+        }
+        as_status s = quant_rows_i8(sp->x32, sp->n32, x8, fa8, rows_alloc, sp->dp, dp8, mx, sp->stream);
+        unsigned int h[4] = {0, 0, 0, 0};
+        if (s == AS_OK && (hipMemcpyAsync(h, mx, sizeof(h), hipMemcpyDeviceToHost, sp->stream) != hipSuccess || hipStreamSynchronize(sp->stream) != hipSuccess)) {
+            set_err("quant_rows_i8 failed: %s", hipGetErrorString(hipGetLastError()));
+            s = AS_EHIP;
+        }
+        if (s != AS_OK) {
+            (void)hipFree(x8);
+            (void)hipFree(fa8);
+            return s;
+        }
+        float U, V;
+        memcpy(&U, &h[0], 4);
+        memcpy(&V, &h[1], 4);
+        const_cast<as_space*>(sp)->dp8 = dp8;
+        sp->x8 = x8;
+        sp->fa8 = fa8;
+        sp->coef8 = err_coef_i8(U, V);
+        sp->x8_bad = h[2] ? 1 : 0;
+        dbg("k2_items_i8: U = %.3e, V = %.3e -> coefficient %.3e (bf16: %.3e)%s", U, V, sp->coef8, err_coef_dp(sp->dp),
+            sp->x8_bad ? ", non-finite items: unusable" : "");
+    }
+    *usable = sp->x8 && !sp->x8_bad && sp->coef8 <= 2.0 * err_coef_dp(sp->dp) && sp->dp <= 131072;
     return AS_OK;
 }
 
@@ -929,8 +986,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // The fused X.X^T + k-smallest kernel, every mode: bf16 head + tail products (default; ka.x32 / ka.xa are split images,
 // k2_items) or the fp32 matrix pipe (ARROWSPACE_K2_FP32=1).
-static as_status launch_k2(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st) {
-    if (k2_bf16_enabled()) return launch_k2_bf16(ka, metric, collect, sym, grid, st);
+static as_status launch_k2(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st, bool i8 = false) {
+    if (k2_bf16_enabled()) return launch_k2_bf16(ka, metric, collect, sym, grid, st, i8);
     const size_t lds8 = sizeof(float) * 2 * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + (sizeof(float) + sizeof(int)) * 8 * CAP;
 #define AS_K2(MM, CC, SS)                                                                                               \
     do {                                                                                                                \
@@ -1116,7 +1173,8 @@ __global__ void band_gather_kernel(const float* __restrict__ x32, const float* _
                                    const double* __restrict__ n64, int64_t dp, int64_t r0, const int* __restrict__ ids, int nf,
                                    const double* __restrict__ B, int metric, double coef, double nmax, float* __restrict__ xa,
                                    float* __restrict__ a_n32, float* __restrict__ a_inorm32, int* __restrict__ a_ids,
-                                   float* __restrict__ a_thr, int64_t goff) {
+                                   float* __restrict__ a_thr, int64_t goff, const float* __restrict__ fa = nullptr,
+                                   float* __restrict__ a_fa = nullptr) {   // (dp: floats per row of the operand IMAGE x32 points at)
     const int f = blockIdx.x;
     if (f >= nf) return;
     const int lr = ids[f];
@@ -1125,6 +1183,7 @@ __global__ void band_gather_kernel(const float* __restrict__ x32, const float* _
     if (threadIdx.x == 0) {
         a_n32[f] = n32[row];
         a_inorm32[f] = inorm32[row];
+        if (fa) a_fa[f] = fa[row];
         a_ids[f] = (int)(goff + row);   // global item id (self exclusion against global column ids)
         const double e = metric == AS_METRIC_L2 ? coef * (n64[row] + nmax) : coef;
         // rounded up twice over: the device-side comparison must never be tighter than the fp64 band
@@ -1369,7 +1428,7 @@ struct KnnCand {
     dev_tmp<int> bidx, cidx, ccnt;
     KnnArgs ka;
     int S = 1, grid = 0, dev_cus = 256, ntile = 0, nrb = 0, units = 0;
-    bool sym = false;
+    bool sym = false, i8 = false;
     double flops = 0, t_mfma = 0;
 };
 
@@ -1379,7 +1438,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     hipStream_t st = sp->stream;
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
-    const double coef = err_coef(sp->dp);
+    const double coef = err_coef(sp);
     const int nrb = (int)((rows + BM - 1) / BM);
     const int ntile = (int)(sp->np / BN);
     // default: 8-wave LDS-DMA kernel (48); 32 = 4-wave LDS-DMA; 0..31 = register-staged kernel and its A/B variants
@@ -1487,9 +1546,12 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     AS_HIP(cidx.alloc((size_t)rows * S * M));
     AS_HIP(ccnt.alloc((size_t)rows * S));
     KnnArgs& ka = c.ka;
-    const float* items = nullptr;   // fp32 rows, or their bf16 head + tail image
-    if ((variant & 48) == 48) AS_TRY(k2_items(sp, &items));
+    const float* items = nullptr;   // fp32 rows, their bf16 head + tail image, or (sp->k2_i8: knn_rows decided) the int8 two-digit image
+    const bool i8 = sp->k2_i8 != 0 && (variant & 48) == 48;
+    if (i8) items = (const float*)sp->x8;
+    else if ((variant & 48) == 48) AS_TRY(k2_items(sp, &items));
     else items = sp->x32;
+    c.i8 = i8;
     ka.x32 = items; ka.n32 = sp->n32; ka.inorm32 = sp->inorm32;
     ka.n = n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
     ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
@@ -1499,6 +1561,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
     ka.xa = items; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff; ka.a_ids = nullptr; ka.a_thr = nullptr;
     ka.units = nullptr; ka.nunits = 0; ka.unit_ctr = nullptr; ka.t_cnt = nullptr; ka.t_key = nullptr; ka.t_idx = nullptr; ka.t_cap = 0;
+    ka.ld = i8 ? sp->dp8 / 2 : sp->dp; ka.nslab = (int)(i8 ? sp->dp8 / 64 : sp->dp / 32); ka.fa = i8 ? sp->fa8 : nullptr; ka.a_fa = ka.fa;
     if (sym) {   // (the transposed buffers are allocated once the threshold pass has settled their size)
         ka.units = d_units; ka.nunits = units; ka.unit_ctr = tr_cnt + n; ka.t_cnt = tr_cnt;
     }
@@ -1516,7 +1579,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 k0.units = nullptr; k0.nunits = 0; k0.unit_ctr = nullptr; k0.t_cnt = nullptr; k0.t_key = nullptr; k0.t_idx = nullptr; k0.t_cap = 0;
                 k0.S = 1; k0.tstride = tstride; k0.tphase = 0; k0.ntile = (ntile + tstride - 1) / tstride; k0.thr0 = nullptr; k0.out_thr = thr0;
                 thr_tiles += (double)nrb * k0.ntile;
-                AS_TRY(launch_k2(k0, metric, false, false, std::min(nrb, dev_cus), st));
+                AS_TRY(launch_k2(k0, metric, false, false, std::min(nrb, dev_cus), st, i8));
                 if (attempt == 1 || ev_stride || ev_tcap || tstride <= 16) break;
                 // rows whose sampled count says their transposed buffer would not hold what the main pass sends
                 hipLaunchKernelGGL(sym_risk_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const int*)ccnt, rows,
@@ -1613,7 +1676,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 ka.t_idx = (int*)tr_idx - (size_t)j0 * T_CAP;
                 if (c) AS_HIP(hipMemsetAsync(ka.unit_ctr, 0, sizeof(int), st));
                 const int lgrid = std::min(std::min(cunits, dev_cus), grid);
-                AS_TRY(launch_k2(ka, metric, false, true, lgrid, st));
+                AS_TRY(launch_k2(ka, metric, false, true, lgrid, st, i8));
                 // the transposed buffers become segment S - 1 of their rows' candidate lists
                 hipLaunchKernelGGL(transposed_compact_kernel, dim3((unsigned)((j1 - j0 + 3) / 4)), dim3(256), ldst, st, (const int*)tr_cnt + j0,
                                    (const float*)tr_key, (const int*)tr_idx, T_CAP, j1 - j0, S, S - 1, M, (float*)ckey + (size_t)j0 * S * M,
@@ -1621,7 +1684,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
                 AS_HIP(hipGetLastError());
             }
         } else
-            AS_TRY(launch_k2(ka, metric, false, false, std::min(units, dev_cus), st));
+            AS_TRY(launch_k2(ka, metric, false, false, std::min(units, dev_cus), st, i8));
     } else {
 #ifdef AS_ABLATION
         const size_t lds = sizeof(float) * (BM + BN) * LROW * (((variant & 2) && !(variant & 16)) ? 2 : 1) + sizeof(float) * 4 * BM +
@@ -1689,7 +1752,6 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     hipStream_t st = sp->stream;
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
-    const double coef = err_coef(sp->dp);
 
     int32_t* t_idx = out_idx;
     double *t_key = out_key, *t_dist = out_dist, *t_gy = out_gy;
@@ -1707,6 +1769,19 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
     double t_mfma = 0, t_ref = 0, t_fb = 0, flops = 0;
     int nflagged = 0, unproven = 0, band_rows = 0;
 
+    // The int8 two-digit image (twice the bf16 matrix rate, half the operand bytes) serves single-space passes whose items
+    // it represents well enough (k2_items_i8); the ring's entry points keep the bf16 image.  err_coef follows sp->k2_i8: set
+    // here for this pass and what it refines, cleared on every way out.
+    struct I8Scope {
+        const as_space* sp;
+        ~I8Scope() { sp->k2_i8 = 0; }
+    } i8_scope{sp};
+    if (!sp->opts.force_exact && k2_bf16_enabled() && !getenv("ARROWSPACE_K2_NO_I8")) {
+        bool usable = false;
+        AS_TRY(k2_items_i8(sp, &usable));
+        sp->k2_i8 = usable ? 1 : 0;
+    }
+    const double coef = err_coef(sp);
     if (!sp->opts.force_exact) {
         KnnCand cand;
         AS_TRY(knn_candidates(sp, gp, r0, r1, M, 0, 0, cand));
@@ -1773,16 +1848,19 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
             AS_HIP(hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
             AS_HIP(hipMemsetAsync(xa, 0, sizeof(float) * (size_t)(nfp + BM) * sp->dp, st));
             // (ka.x32 is the operand the first pass ran on: the rows are gathered from the same image)
-            hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, ka.x32, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
+            dev_tmp<float> a_fa;
+            AS_HIP(a_fa.alloc(nfp));
+            AS_HIP(hipMemsetAsync(a_fa, 0, sizeof(float) * nfp, st));
+            hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, ka.x32, sp->n32, sp->inorm32, sp->n64, ka.ld, r0,
                                (const int*)d_ids, nf, (const double*)bandB, metric, coef, sp->nmax, (float*)xa, (float*)a_n32, (float*)a_inorm,
-                               (int*)a_ids, (float*)a_thr, (int64_t)0);
+                               (int*)a_ids, (float*)a_thr, (int64_t)0, ka.fa, (float*)a_fa);
             AS_HIP(hipGetLastError());
             KnnArgs kb = ka;
             kb.units = nullptr; kb.nunits = 0; kb.unit_ctr = nullptr; kb.t_cnt = nullptr; kb.t_key = nullptr; kb.t_idx = nullptr; kb.t_cap = 0;
             kb.thr0 = nullptr; kb.thr_col = nullptr; kb.thr_pub = nullptr; kb.out_thr = nullptr;
             kb.r0 = 0; kb.r1 = nf; kb.nrb = nrb2; kb.S = S2; kb.M = CAP;
             kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
-            kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr;
+            kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr; kb.a_fa = a_fa;
             const int g2 = std::min(nrb2 * S2, dev_cus);
             // per-block append buffers: the first pass sized them for ITS grid
             dev_tmp<float> bkey2;
@@ -1793,7 +1871,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
                 kb.buf_key = bkey2;
                 kb.buf_idx = bidx2;
             }
-            AS_TRY(launch_k2(kb, metric, true, false, g2, st));
+            AS_TRY(launch_k2(kb, metric, true, false, g2, st, cand.i8));
             BandArgs ba;
             ba.x32 = sp->x32; ba.x64 = sp->x64; ba.n64 = sp->n64; ba.d = sp->d; ba.dp = sp->dp; ba.r0 = r0;
             ba.S = S2; ba.CW = CAP; ba.metric = metric; ba.nf = nf; ba.k = kk; ba.epskey = epskey;
@@ -2235,7 +2313,7 @@ static as_status fold_launch(const as_space* sp, int64_t r0, int64_t r1, int M, 
     if (rows <= 0) return AS_OK;
     FoldArgs fa;
     fa.raw = raw;
-    fa.rows = rows; fa.r0 = r0; fa.M = M; fa.metric = sp->opts.metric; fa.mode = mode; fa.coef = err_coef(sp->dp); fa.nmax_b = block_nmax;
+    fa.rows = rows; fa.r0 = r0; fa.M = M; fa.metric = sp->opts.metric; fa.mode = mode; fa.coef = err_coef(sp); fa.nmax_b = block_nmax;
     fa.na64 = sp->n64; fa.flag = flag;
     fa.r_key = r_key; fa.r_dist = r_dist; fa.r_gy = r_gy; fa.r_idx = r_idx; fa.r_cnt = r_cnt; fa.r_t32 = r_t32;
     fa.b_key = b_key; fa.b_dist = b_dist; fa.b_gy = b_gy; fa.b_idx = b_idx; fa.b_cnt = b_cnt; fa.b_t32 = b_t32;
@@ -2308,7 +2386,7 @@ as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_par
     hipStream_t st = sp->stream;
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
-    const double coef = err_coef(sp->dp);
+    const double coef = err_coef(sp);
     const int dev_cus = device_cus(sp->device);
     const int nrb = (int)((rows + BM - 1) / BM);
     const int ntile = (int)(cols->np / BN);
@@ -2333,6 +2411,7 @@ as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_par
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
     ka.xa = items_a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff + 0; ka.col_goff = col_goff;
     ka.a_ids = nullptr; ka.a_thr = nullptr;
+    ka.ld = sp->dp; ka.nslab = (int)(sp->dp / 32);
     AS_TRY(launch_k2(ka, metric, false, false, grid, st));
     BlockRefineArgs ra;
     ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = cols->x32; ra.xb64 = cols->x64; ra.na64 = sp->n64; ra.nb64 = cols->n64;
@@ -2379,7 +2458,7 @@ as_status knn_thresholds(const as_space* sp, int64_t r0, int64_t r1, int M, doub
     const int64_t rows = r1 - r0;
     if (rows <= 0) return AS_OK;
     hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, sp->stream, r_key, r_cnt, sp->n64, r0, rows,
-                       M, sp->opts.metric, err_coef(sp->dp), std::max(nmax_all, sp->nmax), out_thr);
+                       M, sp->opts.metric, err_coef(sp), std::max(nmax_all, sp->nmax), out_thr);
     AS_HIP(hipGetLastError());
     AS_HIP(hipStreamSynchronize(sp->stream));
     return AS_OK;
@@ -2404,7 +2483,7 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     const int ntile_all = (int)(cols->np / BN);
     const int metric = sp->opts.metric;
     const double epskey = metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps;
-    const double coef = err_coef(sp->dp);
+    const double coef = err_coef(sp);
     const int dev_cus = device_cus(sp->device);
     const int nrb = (int)((rows + BM - 1) / BM);
     const int ntile = (int)(cb - ca);
@@ -2451,6 +2530,7 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
     ka.xa = items_a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff;
     ka.a_ids = nullptr; ka.a_thr = nullptr;
+    ka.ld = sp->dp; ka.nslab = (int)(sp->dp / 32);
     // the kernel addresses the transposed buffers by the item's number inside the block: bases moved back by the chunk's
     // first item (only items of the chunk's tiles are ever addressed)
     ka.units = d_units; ka.nunits = units; ka.unit_ctr = (int*)tr_cnt + ncc; ka.t_cnt = (int*)tr_cnt - j0;
@@ -2580,7 +2660,7 @@ as_status knn_merge(const as_space* sp, const as_graph_params* gp, int64_t r0, i
     ma.folded = nblocks == 0 ? 1 : 0;
     if (nblocks == 0) nblocks = 1;
     ma.rows = rows; ma.k = gp->k; ma.nblocks = nblocks; ma.M = M; ma.metric = sp->opts.metric;
-    ma.epskey = ma.metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps; ma.coef = err_coef(sp->dp);
+    ma.epskey = ma.metric == AS_METRIC_L2 ? gp->eps * gp->eps : gp->eps; ma.coef = err_coef(sp);
     ma.na64 = sp->n64; ma.r0 = r0;
     ma.p_key = p_key; ma.p_dist = p_dist; ma.p_gy = p_gy; ma.p_idx = p_idx; ma.p_cnt = p_cnt; ma.p_t32 = p_t32; ma.nmax = nmax;
     ma.out_idx = out_idx; ma.out_key = out_key; ma.out_dist = out_dist; ma.out_gy = out_gy; ma.out_cnt = out_cnt;
@@ -2610,7 +2690,7 @@ as_status knn_block_band(const as_space* sp, const as_space* cols, const as_grap
     if (rows == 0) return AS_OK;
     hipStream_t st = sp->stream;
     const int metric = sp->opts.metric;
-    const double coef = err_coef(sp->dp);
+    const double coef = err_coef(sp);
     std::vector<int> hflag(rows);
     AS_HIP(hipMemcpy(hflag.data(), flag, sizeof(int) * rows, hipMemcpyDeviceToHost));
     std::vector<int> ids;
@@ -2648,6 +2728,7 @@ as_status knn_block_band(const as_space* sp, const as_space* cols, const as_grap
     kb.epskey = 0; kb.coef = 0; kb.nmax = 0;
     kb.buf_key = bkey; kb.buf_idx = bidx; kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
     kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr; kb.row_goff = 0; kb.col_goff = col_goff;
+    kb.ld = sp->dp; kb.nslab = (int)(sp->dp / 32);
     AS_TRY(launch_k2(kb, metric, true, false, g2, st));
     BlockBandArgs ba;
     ba.xa32 = sp->x32; ba.xa64 = sp->x64; ba.xb32 = cols->x32; ba.xb64 = cols->x64; ba.na64 = sp->n64; ba.nb64 = cols->n64;

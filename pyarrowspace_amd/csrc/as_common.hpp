@@ -52,6 +52,16 @@ struct as_space {
     int64_t n = 0, d = 0, np = 0, dp = 0;
     float* x32 = nullptr;     // [np][dp]
     mutable float* xs = nullptr;  // [np][dp] bf16 head + tail image of x32 (as_k2bf.hip), made by the first k-NN pass; null until then
+    // int8 two-digit image (as_k2bf.hip, quant_rows_i8): x ~ s_i (128 a1 + a2) / 16256, per row and 64-column slab 64 bytes of
+    // a1 then 64 of a2 ([np + 256][dp8 * 2] bytes, dp8 = dp rounded up to 64); fa8[i] = s_i sqrt(128) / 16256; coef8 = the
+    // error coefficient its products carry (from max_i s_i / |x_i| and max_i |x_i|_1 / |x_i|); k2_i8: the k-NN pass in
+    // flight runs on it (set and cleared by knn_rows: err_coef follows it)
+    mutable void* x8 = nullptr;
+    mutable float* fa8 = nullptr;
+    mutable double coef8 = 0.0;
+    mutable int x8_bad = 0;
+    mutable int k2_i8 = 0;
+    int64_t dp8 = 0;
     double* x64 = nullptr;    // [n][d] or null when the items are exactly fp32-representable
     double* n64 = nullptr;    // [n] squared norms (fp64, from the fp64 items)
     float* n32 = nullptr;     // [np] squared norms rounded to fp32 (0 on pad rows)
@@ -357,7 +367,7 @@ as_status resolve_params(const as_graph_params* gp, as_graph_params* out);
 as_status check_limits(const as_graph_params* resolved, int64_t n, int lambda_mode);
 // per-pair fp32 error coefficient: |key32 - key64| <= coef * (n_i + n_j) for L2,
 // <= coef for cosine
-double err_coef(int64_t dp);
+double err_coef(const as_space* sp);
 
 // build stages (as_build.hip)
 as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld);

@@ -67,6 +67,83 @@ as_status split_rows_bf16(const float* x32, float* xs, int64_t rows, int64_t dp,
     return AS_OK;
 }
 
+// ------------------------------------------------------------------ int8 two-digit image
+// x ~ s (128 a1 + a2) / 16256 with s = max |x_c| of the row, q = round(x / s * 16256) in [-16256, 16256], a2 = ((q + 64) mod
+// 128) - 64 in [-64, 63], a1 = (q - a2) / 128 in [-127, 127].  x_i . x_j ~ s_i s_j (16384 a1.b1 + 128 (a1.b2 + a2.b1)) / 16256^2:
+// three int8 products per column on v_mfma_i32_32x32x32_i8 (twice the bf16 rate, half its operand bytes), accumulated
+// EXACTLY in int32 (|sum| <= 127^2 dp < 2^31 up to dp = 133 000).  What is lost: the quantisation residues theta (x = s (q +
+// theta) / 16256, |theta| <= 1/2) and a2.b2 -- bounded by Cauchy-Schwarz through the rows' ACTUAL |theta|_2 and |a2|_2:
+// maxima[0] = max_i s_i |theta_i|_2 / (16256 |x_i|), maxima[1] = max_i s_i |a2_i|_2 / (16256 |x_i|) (err_coef_i8).
+// Per row and 64-column slab: 64 bytes of a1, then 64 of a2 -- the 128-byte slab row of the bf16 image, covering 64 columns.
+__global__ __launch_bounds__(256) void quant_i8_kernel(const float* __restrict__ x32, const float* __restrict__ n32, signed char* __restrict__ x8,
+                                                       float* __restrict__ fa8, int64_t rows, int64_t dp, int64_t dp8, unsigned int* maxima) {
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    float wr = 0.0f, wl = 0.0f;
+    bool bad = false;
+    for (int64_t row = gw; row < rows; row += nw) {
+        const float* x = x32 + row * dp;
+        float m = 0.0f, l1 = 0.0f;
+        for (int64_t c = lane; c < dp; c += 64) {
+            const float v = fabsf(x[c]);
+            m = fmaxf(m, v);
+            l1 += v;
+            bad = bad || !(v <= 3.0e38f);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m = fmaxf(m, __shfl_xor(m, o, 64));
+            l1 += __shfl_xor(l1, o, 64);
+        }
+        const float inv = m > 0.0f ? 16256.0f / m : 0.0f;
+        signed char* dst = x8 + row * dp8 * 2;
+        float st2 = 0.0f, sa2 = 0.0f;
+        for (int64_t c = lane; c < dp8; c += 64) {
+            const float v = c < dp ? x[c] : 0.0f;
+            const float sc = v * inv;
+            int q = (int)rintf(sc);
+            q = q > 16256 ? 16256 : (q < -16256 ? -16256 : q);
+            const int a2 = ((q + 64 + (1 << 20)) & 127) - 64;
+            const int a1 = (q - a2) >> 7;
+            const int64_t slab = c >> 6, k = c & 63;
+            dst[slab * 128 + k] = (signed char)a1;
+            dst[slab * 128 + 64 + k] = (signed char)a2;
+            // the residue, with the rounding of v * inv (up to 16256 * 2^-23 either way) on top
+            const float th = fabsf(sc - (float)q) + 0.004f;
+            st2 += th * th;
+            sa2 += (float)(a2 * a2);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            st2 += __shfl_xor(st2, o, 64);
+            sa2 += __shfl_xor(sa2, o, 64);
+        }
+        (void)l1;
+        if (lane == 0) {
+            fa8[row] = m * (11.313708498984761f / 16256.0f);   // s sqrt(128) / 16256
+            const float nx = sqrtf(n32[row]);
+            if (nx > 0.0f) {   // (fp32 sums of dp squares: rounded up generously)
+                wr = fmaxf(wr, m * sqrtf(st2) / (16256.0f * nx) * 1.001f);
+                wl = fmaxf(wl, m * sqrtf(sa2) / (16256.0f * nx) * 1.001f);
+            }
+        }
+    }
+    if (lane == 0) {   // non-negative floats order like their bit patterns
+        if (wr > 0.0f) atomicMax(maxima, __float_as_uint(wr));
+        if (wl > 0.0f) atomicMax(maxima + 1, __float_as_uint(wl));
+    }
+    if (__any(bad) && lane == 0) atomicOr(maxima + 2, 1u);
+}
+
+as_status quant_rows_i8(const float* x32, const float* n32, void* x8, float* fa8, int64_t rows, int64_t dp, int64_t dp8, unsigned int* maxima,
+                        hipStream_t st) {
+    if (rows <= 0) return AS_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(quant_i8_kernel, dim3(grid), dim3(256), 0, st, x32, n32, (signed char*)x8, fa8, rows, dp, dp8, maxima);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
 // ------------------------------------------------------------------ LDS through inline asm
 // Each block waits for its own reads before it ends: no register the compiler may copy or reuse holds data in flight.
 __device__ __forceinline__ void lds_frag5(unsigned aa, unsigned ab, f32x4& a, f32x4& b0, f32x4& b1, f32x4& b2, f32x4& b3) {
@@ -87,6 +164,21 @@ __device__ __forceinline__ void lds_read_b128x8(unsigned a0, f32x4 (&v)[8]) {
         : "v"(a0)
         : "memory");
 }
+__device__ __forceinline__ void lds_read_b128x2(unsigned a0, f32x4& v0, f32x4& v1) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0) : "memory");
+}
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned a0) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a0) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_read_b128x4(unsigned a0, f32x4 (&v)[4]) {
+    // one float per row: rows 4h + {0..3} + 8g are 16 contiguous bytes, 32 bytes between groups
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(a0)
+                 : "memory");
+}
 __device__ __forceinline__ void lds_read_b32x4(unsigned a0, float& v0, float& v1, float& v2, float& v3) {
     asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:128\n\tds_read_b32 %2, %4 offset:256\n\tds_read_b32 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
@@ -106,6 +198,7 @@ __device__ __forceinline__ void ring_wait(int n) {
     if (n == NPIECE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n == NPIECE + 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if (n == NPIECE + 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == NPIECE + 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -156,7 +249,13 @@ __device__ __forceinline__ void compact_row_reg(int M, float* bk, int* bi, int c
 
 // ------------------------------------------------------------------ the kernel
 // Block = 8 waves (two per SIMD), tile 256 rows x 128 columns; wave w owns rows [32w, 32w+32) as 1x4 accumulators.
-template <int METRIC, bool COLLECT, bool SYM, int DIAG = 0>
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// I8: the same kernel on the int8 two-digit image (quant_i8_kernel): a slab row is 64 columns (64 bytes of a1, 64 of a2), a
+// k-step 32 columns of v_mfma_i32_32x32x32_i8, the chunk addressing that of heads and tails; two int32 accumulator sets per
+// tile (a1.b1 and the cross terms), turned into the dot by the rows' and columns' scales in the epilogue.
+template <int METRIC, bool COLLECT, bool SYM, int DIAG = 0, bool I8 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_bf16_kernel(KnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Sl = (float*)smem;                     // RING slab buffers: A rows then B rows, 128 B per row
@@ -164,8 +263,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int* s_cur = (int*)(s_ta + BM);
     int* s_drop = s_cur + BM;
     int* s_id = s_drop + BM;                      // collect mode: global item id of every A row
-    float* s_n = (float*)(s_id + BM);             // [SN][2][BN]: the column items' norms and thresholds of the tiles in flight
-    int* s_unit = (int*)(s_n + SN * 2 * BN);
+    float* s_n = (float*)(s_id + BM);             // [SN][3][BN]: the column items' norms, thresholds and (int8 image) scales of the tiles in flight
+    float* s_fa = s_n + SN * 3 * BN;              // int8 image, L2: the rows' scales
+    int* s_unit = (int*)(s_fa + BM);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
@@ -173,12 +273,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* __restrict__ bkey = a.buf_key + (size_t)blockIdx.x * BM * CAP;
     int* __restrict__ bidx = a.buf_idx + (size_t)blockIdx.x * BM * CAP;
     const int units = a.nrb * a.S;
-    const int nslab = (int)(a.dp / BK);
+    const int nslab = a.nslab;
     const float finf = __int_as_float(0x7f800000);
     const int drow = lane >> 3;
     const int csw0 = (lane & 7) ^ ((lane >> 4) & 7);
     const int csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
-    const unsigned lo0 = (unsigned)((drow * a.dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * a.dp + csw1 * 4) * 4);
+    const unsigned lo0 = (unsigned)((drow * a.ld + csw0 * 4) * 4), lo1 = (unsigned)((drow * a.ld + csw1 * 4) * 4);
     // fragment addresses inside a slab buffer: chunk 2 q + h of the lane's row (q = 0, 1: heads of k-step q; q = 2, 3: tails)
     unsigned aoff[4], boff[4];
 #pragma unroll
@@ -190,6 +290,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned ta0 = lds0 + (unsigned)(RING * DSLAB * 4) + (unsigned)((w * 32 + 4 * h) * 8);
     const unsigned cur0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8);
     const unsigned sn0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8 + 3 * BM * 4);
+    const unsigned sfa0 = sn0 + (unsigned)(SN * 3 * BN * 4) + (unsigned)((w * 32 + 4 * h) * 4);
     const bool late = wu >= 4;   // wave-uniform: the second-dispatched half issues its DMA mid-slab
     int xcc = 0;                 // the XCD this block runs on (L2 affinity of the unit lists: speed only)
     if (SYM) {
@@ -198,7 +299,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         xcc = (int)(xr & 7u);
     }
     // vector-memory operations a wave adds to the first slab of a tile: the column items' norms (and thresholds)
-    const int nextra = wu < 2 ? (SYM ? 2 : 1) : 0;
+    const int nextra = wu < 2 ? (SYM ? 2 : 1) + (I8 ? 1 : 0) : 0;
     const float* __restrict__ cnorm = METRIC == AS_METRIC_L2 ? a.n32 : a.inorm32;
     const float* __restrict__ cthr = a.thr_col ? a.thr_col : a.n32;
 
@@ -238,8 +339,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (tid < BM) {
             const int64_t rg = rowbase + tid;
             const bool valid = rg < a.r1;
+            // second component: n_i (L2) or 1 / |x_i| (cosine) -- times the row's scale on the int8 image, where the cosine needs nothing else
+            const float fai = I8 && valid ? a.a_fa[rg] : 1.0f;
+            if (I8) s_fa[tid] = valid ? fai : 0.0f;
             if (COLLECT) {
-                s_ta[tid] = make_float2(valid ? a.a_thr[rg] : -finf, valid ? (METRIC == AS_METRIC_L2 ? a.a_n32[rg] : a.a_inorm32[rg]) : 0.0f);
+                s_ta[tid] = make_float2(valid ? a.a_thr[rg] : -finf, valid ? (METRIC == AS_METRIC_L2 ? a.a_n32[rg] : a.a_inorm32[rg] * fai) : 0.0f);
                 s_id[tid] = valid ? a.a_ids[rg] : -1;
                 s_drop[tid] = 0;
             } else {
@@ -253,12 +357,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         dropped = 1;
                     }
                 }
-                s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.a_inorm32[rg]) : 0.0f);
+                s_ta[tid] = make_float2(valid ? bound : -finf, valid ? (METRIC == AS_METRIC_L2 ? ni : a.a_inorm32[rg] * fai) : 0.0f);
                 s_drop[tid] = dropped;
             }
             s_cur[tid] = 0;
         }
-        const char* pa0 = (const char*)(a.xa + (size_t)(rowbase + wu * 32) * a.dp);
+        const char* pa0 = (const char*)(a.xa + (size_t)(rowbase + wu * 32) * a.ld);
         // prefetch cursor: (tile, slab) of the next slab to issue, RING - 1 slabs ahead of the MFMAs
         int pct = t0, pks = 0, pbuf = 0, inflight = 0;
         bool young_first = false;   // the youngest slab in flight opens a tile (it carries the wave's extra operations)
@@ -268,24 +372,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (pct < t1) {                                                                                                     \
             const int64_t cb_ = ((int64_t)pct * a.tstride + a.tphase) * BN;                                                 \
             const char* sa_ = pa0 + pks * (BK * 4);                                                                         \
-            const char* sb_ = (const char*)(a.x32 + (size_t)(cb_ + wu * 16) * a.dp) + pks * (BK * 4);                       \
+            const char* sb_ = (const char*)(a.x32 + (size_t)(cb_ + wu * 16) * a.ld) + pks * (BK * 4);                       \
             float* dst_ = Sl + pbuf * DSLAB;                                                                                \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa_ + (size_t)(8 * j) * a.dp * 4 + ((j & 1) ? lo1 : lo0)), \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa_ + (size_t)(8 * j) * a.ld * 4 + ((j & 1) ? lo1 : lo0)), \
                                                  (__attribute__((address_space(3))) void*)(dst_ + (wu * 32 + 8 * j) * DROW), 16, 0, 0);          \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb_ + (size_t)(8 * j) * a.dp * 4 + ((j & 1) ? lo1 : lo0)), \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb_ + (size_t)(8 * j) * a.ld * 4 + ((j & 1) ? lo1 : lo0)), \
                                                  (__attribute__((address_space(3))) void*)(dst_ + BM * DROW + (wu * 16 + 8 * j) * DROW), 16, 0, 0); \
             young_first = pks == 0;                                                                                         \
             if (pks == 0 && wu < 2) {                                                                                       \
                 /* always issued, addresses clamped instead of lanes masked: the ring's counts assume the operation */      \
                 const int64_t cg_ = cb_ + wu * 64 + lane;                                                                   \
-                float* sn_ = s_n + (pct & (SN - 1)) * 2 * BN + wu * 64;                                                     \
+                float* sn_ = s_n + (pct & (SN - 1)) * 3 * BN + wu * 64;                                                     \
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cnorm + cg_),              \
                                                  (__attribute__((address_space(3))) void*)sn_, 4, 0, 0);                    \
                 if (SYM)                                                                                                    \
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cthr + (cg_ < a.n ? cg_ : a.n - 1)), \
                                                      (__attribute__((address_space(3))) void*)(sn_ + BN), 4, 0, 0);         \
+                if (I8)                                                                                                     \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.fa + cg_),           \
+                                                     (__attribute__((address_space(3))) void*)(sn_ + 2 * BN), 4, 0, 0);     \
             }                                                                                                               \
             pbuf = pbuf + 1 == RING ? 0 : pbuf + 1;                                                                         \
             if (++pks == nslab) {                                                                                           \
@@ -304,10 +411,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int ct = t0; ct < t1; ++ct) {
             const int64_t colbase = ((int64_t)ct * a.tstride + a.tphase) * BN;
             f32x16 acc[4];
+            i32x16 acc1[4], accx[4];   // int8 image: a1.b1 and the cross terms a1.b2 + a2.b1
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nn][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    if (I8) {
+                        acc1[nn][r] = 0;
+                        accx[nn][r] = 0;
+                    } else {
+                        acc[nn][r] = 0.0f;
+                    }
+                }
             for (int ks = 0; ks < nslab; ++ks) {
                 // the slab has landed once only the younger slab's operations are outstanding (operations retire in
                 // issue order; anything else in flight -- appends -- only makes the wait stricter)
@@ -325,7 +440,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         asm volatile("" : "=v"(fa), "=v"(fb[0]), "=v"(fb[1]), "=v"(fb[2]), "=v"(fb[3]));
                         asm volatile("" : "=v"(ga), "=v"(gb[0]), "=v"(gb[1]), "=v"(gb[2]), "=v"(gb[3]));
                     }
-                    if (!K2_DIAG(1)) {
+                    if (I8 && !K2_DIAG(1)) {
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn)   // a1 . b1
+                            acc1[nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, fa), __builtin_bit_cast(i32x4, fb[nn]), acc1[nn], 0, 0, 0);
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn)   // a1 . b2
+                            accx[nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, fa), __builtin_bit_cast(i32x4, gb[nn]), accx[nn], 0, 0, 0);
+#pragma unroll
+                        for (int nn = 0; nn < 4; ++nn)   // a2 . b1
+                            accx[nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, ga), __builtin_bit_cast(i32x4, fb[nn]), accx[nn], 0, 0, 0);
+                    } else if (!K2_DIAG(1)) {
 #pragma unroll
                         for (int nn = 0; nn < 4; ++nn)   // xh . yh
                             acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb[nn]), acc[nn], 0, 0, 0);
@@ -344,17 +469,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             if (K2_DIAG(4)) {
 #pragma unroll
-                for (int nn = 0; nn < 4; ++nn) asm volatile("" ::"v"(acc[nn]));
+                for (int nn = 0; nn < 4; ++nn) {
+                    if (I8) asm volatile("" ::"v"(acc1[nn]), "v"(accx[nn]));
+                    else asm volatile("" ::"v"(acc[nn]));
+                }
                 continue;
             }
             // ---- epilogue: keys, bound test, append (32 rows per wave).  The tile's norm line was issued with its first
             // slab and waited for with it; a tile of one slab has not met a later wait yet.
-            float nj[4], tj[4] = {finf, finf, finf, finf};
+            float nj[4], tj[4] = {finf, finf, finf, finf}, fj[4] = {1.0f, 1.0f, 1.0f, 1.0f};
             int cj[4];
             {
-                const unsigned sna = sn0 + (unsigned)(((ct & (SN - 1)) * 2 * BN + l31) * 4);
+                const unsigned sna = sn0 + (unsigned)(((ct & (SN - 1)) * 3 * BN + l31) * 4);
                 lds_read_b32x4(sna, nj[0], nj[1], nj[2], nj[3]);
                 if (SYM) lds_read_b32x4(sna + BN * 4, tj[0], tj[1], tj[2], tj[3]);
+                if (I8) lds_read_b32x4(sna + 2 * BN * 4, fj[0], fj[1], fj[2], fj[3]);
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) cj[nn] = (int)(colbase + nn * 32 + l31);
             }
@@ -381,13 +510,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     need &= need - 1;
                 }
             }
-            f32x4 tav[8];   // (bound, norm) of rows 4 h + {0..3} + 8 g: tav[2 g] = rows +0, +1; tav[2 g + 1] = rows +2, +3
-            lds_read_b128x8(ta0, tav);
+            float sj[4];    // per column: what the integer sums are multiplied by besides the row's factor
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) sj[nn] = METRIC == AS_METRIC_L2 ? fj[nn] : nj[nn] * fj[nn];
             const int64_t colg = a.col_goff + colbase, rowg = a.row_goff + rowbase;   // global ids of the tile's corner
             const bool edge = COLLECT || colbase + BN > a.n || (colg < rowg + BM && colg + BN > rowg);
             // symmetric mode: tiles strictly above the row block also serve the column items' rows (the diagonal tiles
             // hold both (i, j) and (j, i) themselves)
             const bool transp = SYM && a.t_cnt && (a.t_all || colbase >= rowbase + BM);
+            f32x4 tg0 = {0, 0, 0, 0}, tg1 = {0, 0, 0, 0}, fg = {1, 1, 1, 1};
             float cb[4];
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn) {
@@ -397,13 +528,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const f32x4 tq = tav[2 * (r >> 2) + ((r & 3) >> 1)];
+                // (bound, norm) of rows 4 h + {0..3} + 8 g, read per group of four registers (g = r >> 2): the accumulators of
+                // the int8 form leave no room to hold all sixteen pairs at once
+                if ((r & 3) == 0) {
+                    lds_read_b128x2(ta0 + (unsigned)(64 * (r >> 2)), tg0, tg1);
+                    if (I8 && METRIC == AS_METRIC_L2) fg = lds_read_b128(sfa0 + (unsigned)(32 * (r >> 2)));
+                }
+                const f32x4 tq = (r & 2) ? tg1 : tg0;
                 const float thr = (r & 1) ? tq[2] : tq[0], ai = (r & 1) ? tq[3] : tq[1];
                 float key[4];
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
-                    const float gg = acc[nn][r];
-                    key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * (ai * nj[nn]));
+                    if (I8) {
+                        // x_i . x_j = s_i s_j (16384 a1.b1 + 128 (a1.b2 + a2.b1)) / 16256^2 = t fa_i fa_j, t = 128 a1.b1 + cross (both sums < 2^24: exact floats)
+                        const float t = fmaf((float)acc1[nn][r], 128.0f, (float)accx[nn][r]);
+                        const float fi = METRIC == AS_METRIC_L2 ? fg[r & 3] : ai;
+                        const float gg = t * (fi * sj[nn]);
+                        key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg);
+                    } else {
+                        const float gg = acc[nn][r];
+                        key[nn] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj[nn]) : 1.0f - fmaxf(0.0f, gg * (ai * nj[nn]));
+                    }
                 }
                 bool any_t = false;
                 if (transp) {
@@ -480,9 +625,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-constexpr size_t K2BF_LDS = sizeof(float) * RING * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + sizeof(float) * SN * 2 * BN + 16;
+constexpr size_t K2BF_LDS = sizeof(float) * RING * DSLAB + sizeof(float2) * BM + sizeof(int) * 3 * BM + sizeof(float) * SN * 3 * BN + sizeof(float) * BM + 16;
 
-as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st) {
+as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st, bool i8) {
+    if (ka.ld <= 0 || ka.nslab <= 0 || (i8 && (!ka.fa || !ka.a_fa))) {
+        set_err("launch_k2_bf16: operand image geometry not set");
+        return AS_EINVAL;
+    }
 #ifdef AS_ABLATION
     if (const char* e = getenv("ARROWSPACE_K2_DIAG")) {   // timing skeletons of the symmetric L2 kernel
         const int dg = atoi(e);
@@ -506,8 +655,13 @@ as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, 
 #endif
 #define AS_K2B(MM, CC, SS)                                                                                                        \
     do {                                                                                                                          \
-        AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<MM, CC, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \
-        hipLaunchKernelGGL((knn_bf16_kernel<MM, CC, SS>), dim3(grid), dim3(512), K2BF_LDS, st, ka);                                \
+        if (i8) {                                                                                                                 \
+            AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<MM, CC, SS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \
+            hipLaunchKernelGGL((knn_bf16_kernel<MM, CC, SS, 0, true>), dim3(grid), dim3(512), K2BF_LDS, st, ka);                   \
+        } else {                                                                                                                  \
+            AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<MM, CC, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \
+            hipLaunchKernelGGL((knn_bf16_kernel<MM, CC, SS>), dim3(grid), dim3(512), K2BF_LDS, st, ka);                            \
+        }                                                                                                                         \
     } while (0)
     if (metric == AS_METRIC_L2) {
         if (collect) AS_K2B(AS_METRIC_L2, true, false);

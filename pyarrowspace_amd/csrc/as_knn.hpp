@@ -67,6 +67,12 @@ struct KnnArgs {
     // side on one XCD they are served by its L2 instead of the fabric (as_build.hip, gang_plan).  Speed only: any block may run any unit.
     const int* xoff = nullptr;
     int* xcur = nullptr;
+    // operand image geometry: ld = floats between consecutive rows of x32 / xa (dp for the bf16 image, dp8 / 2 for the int8
+    // one), nslab = 128-byte slabs per row (dp / 32 or dp8 / 64); int8 image only: the rows' and columns' scales
+    int64_t ld = 0;
+    int nslab = 0;
+    const float* fa = nullptr;     // [np] column items: s_j sqrt(128) / 16256
+    const float* a_fa = nullptr;   // row side
 };
 
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -79,7 +85,11 @@ __device__ __forceinline__ int ld_l2(const int* p) { return __hip_atomic_load(p,
 
 // K2 on the bf16 matrix pipe (as_k2bf.hip).  ka.x32 / ka.xa point at the SPLIT images of the column / row items
 // (as_space::xs: per row and 32-column slab 32 bf16 heads then 32 bf16 tails -- the bytes of the fp32 slab row).
-as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st);
+as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, int grid, hipStream_t st, bool i8 = false);
+// fp32 items -> int8 two-digit image + per-row scales; maxima[0] = max_i s_i |theta_i|_2 / (16256 |x_i|), maxima[1] = max_i s_i
+// |a2_i|_2 / (16256 |x_i|) (float bits, atomicMax: zero them first), maxima[2] != 0: a row with a non-finite value (unusable)
+as_status quant_rows_i8(const float* x32, const float* n32, void* x8, float* fa8, int64_t rows, int64_t dp, int64_t dp8, unsigned int* maxima,
+                        hipStream_t st);
 // fp32 items [rows][dp] -> split image, same shape and stride
 as_status split_rows_bf16(const float* x32, float* xs, int64_t rows, int64_t dp, hipStream_t st);
 // true unless ARROWSPACE_K2_FP32=1 keeps the build on the fp32 matrix pipe (A/B runs, the bit-identity tests)
