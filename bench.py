@@ -29,6 +29,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_F64_PEAK_TF = 78.6    # v_mfma_f64_16x16x4_f64: vendor fp64 matrix peak (half the fp32 rate; not in the guide's table)
 MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (never the 2:1 sparsity figure)
+MFMA_I8_PEAK_TOPS = 5000.0 # v_mfma_i32_32x32x32_i8: the cycles of the bf16 form at twice the K (MI355X_MICROARCH.md, matrix cores table)
 
 
 def launch(n_ranks, argv, child=None):
@@ -549,12 +550,16 @@ def main():
     # (as_k2bf.hip) issues THREE bf16 products per such flop (head x head, head x tail, tail x head): the roofline
     # fraction is issued bf16 flops / 2.5 PFLOP/s; the fp32-equivalent rate is kept beside it.  ARROWSPACE_K2_FP32=1: the
     # fp32 matrix pipe (157.3 TFLOP/s), one product per flop.
-    k2_fp32 = os.environ.get("ARROWSPACE_K2_FP32", "0") not in ("", "0")
+    k2_pipe = aspace.knn_pipe if single else ("fp32" if os.environ.get("ARROWSPACE_K2_FP32", "0") not in ("", "0") else "bf16")
+    k2_fp32 = k2_pipe == "fp32"
     mfma_tf_eq = bstats["mfma_flops"] / max(bstats["knn_mfma_s"], 1e-9) / 1e12
     if feature:
         mfma_tf, mfma_peak, build_kernel, build_dtype = mfma_tf_eq, MFMA_F64_PEAK_TF, "gram_f64_kernel", "f64"
     elif k2_fp32:
         mfma_tf, mfma_peak, build_kernel, build_dtype = mfma_tf_eq, MFMA_F32_PEAK_TF, "knn_mfma_dma8_kernel<%s>" % args.metric, "f32"
+    elif k2_pipe == "int8":
+        # two int8 digits per element, three int8 products per fp32 product: issued int8 ops / 5 POP/s (twice the bf16 rate)
+        mfma_tf, mfma_peak, build_kernel, build_dtype = 3.0 * mfma_tf_eq, MFMA_I8_PEAK_TOPS, "knn_bf16_kernel<%s, I8>" % args.metric, "int8 two-digit image (3 products per fp32 product, exact int32 accumulation)"
     else:
         mfma_tf, mfma_peak, build_kernel, build_dtype = 3.0 * mfma_tf_eq, MFMA_BF16_PEAK_TF, "knn_bf16_kernel<%s>" % args.metric, "bf16 head + tail (3 products per fp32 product)"
 
@@ -639,13 +644,13 @@ def main():
                     "bf16 head + tail (3 x 2*32*N*D flops, error bound in the prefilter's and the proof's coefficients: DESIGN.md 5.5), "
                     "fp16 cosines kept per slot; ARROWSPACE_BATCH_F32_DOTS=1 is the fp32 form"},
         "roofline_build": {"kernel": build_kernel, "bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak,
-                           "unit": "TFLOP/s", "frac": mfma_tf / mfma_peak, "traffic": traffic_mfma,
+                           "unit": "TOP/s" if k2_pipe == "int8" and not feature else "TFLOP/s", "frac": mfma_tf / mfma_peak, "traffic": traffic_mfma,
                            "flops_issued": (1.0 if feature or k2_fp32 else 3.0) * bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"],
                            "fp32_equivalent_tflops": mfma_tf_eq, "fp32_equivalent_flops": bstats["mfma_flops"],
                            "frac_of_fp32_mfma_peak": mfma_tf_eq / MFMA_F32_PEAK_TF, "dtype": build_dtype,
-                           "note": "k-NN kernels of the build (threshold pass + symmetric pass: half the distance block); "
-                                   "on random operands the bf16 kernel is held by the chip's power management, not by its "
-                                   "issue structure (all-zero operands: 1.5 x faster, DESIGN.md 5.2)"},
+                           "pipe": "f64" if feature else k2_pipe,
+                           "note": "k-NN kernels of the build (threshold pass + symmetric pass: half the distance block); the "
+                                   "pipe only prefilters -- graphs are bit-identical on int8, bf16 and fp32 (DESIGN.md 5.2)"},
     }
 
     # ---------------- CPU baseline: the oracle (fp64 C/OpenMP restatement) on this box's host cores

@@ -228,6 +228,10 @@ as_status as_feat_lambdas_global(as_space* sp, as_graph* gr, const double* E_dev
  * through prepare_query_item + search_lambda_aware (src/lib.rs:132-174): its searches are serialised. */
 as_status as_search(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau,
                     int64_t* out_idx, double* out_score, int64_t* out_len, double* out_lambda_q);
+/* matrix pipe the last k-NN pass over this space's rows ran on (as_build, as_knn_rows): 0 fp32 (ARROWSPACE_K2_FP32=1), 1 bf16
+ * head + tail, 2 int8 two-digit image (the default where the items' quantisation error allows it); -1: none yet.  The graphs
+ * are the same bits on every pipe: the pipe only prefilters, the refinement is exact. */
+int32_t as_space_knn_pipe(const as_space* sp);
 /* workspaces the pool of as_search holds at the moment (1 after single-threaded use) */
 int32_t as_search_pool_size(const as_space* sp);
 

@@ -314,6 +314,12 @@ class ArrowSpace:
         return dict(zip(keys, (int(v) for v in out)))
 
     @property
+    def knn_pipe(self) -> str:
+        """Extension: the matrix pipe the build's k-NN block ran on -- "int8" (two-digit image, the default where the items allow
+        it), "bf16" (head + tail), "fp32" (ARROWSPACE_K2_FP32=1) or "none" (feature mode, loaded index)."""
+        return {0: "fp32", 1: "bf16", 2: "int8"}.get(int(_L.as_space_knn_pipe(self._h)), "none")
+
+    @property
     def search_pool_size(self) -> int:
         """Extension: single-query workspaces the library holds for this space -- `search` is re-entrant across host threads
         (ctypes releases the GIL around the call), each concurrent call runs on a workspace and stream of its own."""

@@ -672,6 +672,8 @@ static as_status graph_matches(const as_space* sp, const as_graph* gr, const cha
     return AS_OK;
 }
 
+int32_t as_space_knn_pipe(const as_space* sp) { return sp ? sp->k2_last_pipe : -1; }
+
 int32_t as_search_pool_size(const as_space* sp) {
     if (!sp) return 0;
     std::lock_guard<std::mutex> lk(sp->qmu);

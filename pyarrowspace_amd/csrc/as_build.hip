@@ -1781,6 +1781,7 @@ as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, in
         AS_TRY(k2_items_i8(sp, &usable));
         sp->k2_i8 = usable ? 1 : 0;
     }
+    sp->k2_last_pipe = sp->k2_i8 ? 2 : (k2_bf16_enabled() ? 1 : 0);
     const double coef = err_coef(sp);
     if (!sp->opts.force_exact) {
         KnnCand cand;

@@ -61,6 +61,7 @@ struct as_space {
     mutable double coef8 = 0.0;
     mutable int x8_bad = 0;
     mutable int k2_i8 = 0;
+    mutable int k2_last_pipe = -1;   // matrix pipe of the last k-NN pass on this space: 0 fp32, 1 bf16 head + tail, 2 int8 two digits (as_space_knn_pipe)
     int64_t dp8 = 0;
     double* x64 = nullptr;    // [n][d] or null when the items are exactly fp32-representable
     double* n64 = nullptr;    // [n] squared norms (fp64, from the fp64 items)
