@@ -67,9 +67,19 @@ static as_status k2_items(const as_space* sp, const float** out) {
     return AS_OK;
 }
 
+static as_status k2_items_i8(const as_space* sp, bool* usable);
 // The int8 two-digit image of this space's items and the error coefficient its products carry; made on first use.  False
 // when the image cannot be used: a non-finite item, or a coefficient more than twice the bf16 kernel's (rows dominated by
 // one element: s / |x| near 1) -- the bf16 kernel then.
+as_status space_i8_image(const as_space* sp, bool* present) {
+    static std::mutex mu;   // (searches of several host threads may all be the first to ask)
+    std::lock_guard<std::mutex> lk(mu);
+    bool usable = false;
+    AS_TRY(k2_items_i8(sp, &usable));
+    *present = sp->x8 && !sp->x8_bad;
+    return AS_OK;
+}
+
 static as_status k2_items_i8(const as_space* sp, bool* usable) {
     *usable = false;
     if (!sp->x8 && !sp->x8_bad) {
@@ -104,6 +114,8 @@ static as_status k2_items_i8(const as_space* sp, bool* usable) {
         sp->x8 = x8;
         sp->fa8 = fa8;
         sp->coef8 = err_coef_i8(U, V);
+        sp->u8max = U;
+        sp->v8max = V;
         sp->x8_bad = h[2] ? 1 : 0;
         dbg("k2_items_i8: U = %.3e, V = %.3e -> coefficient %.3e (bf16: %.3e)%s", U, V, sp->coef8, err_coef_dp(sp->dp),
             sp->x8_bad ? ", non-finite items: unusable" : "");

@@ -59,6 +59,7 @@ struct as_space {
     mutable void* x8 = nullptr;
     mutable float* fa8 = nullptr;
     mutable double coef8 = 0.0;
+    mutable double u8max = 0.0, v8max = 0.0;   // max_i s_i |theta_i|_2 / (16256 |x_i|), max_i s_i |a2_i|_2 / (16256 |x_i|)
     mutable int x8_bad = 0;
     mutable int k2_i8 = 0;
     mutable int k2_last_pipe = -1;   // matrix pipe of the last k-NN pass on this space: 0 fp32, 1 bf16 head + tail, 2 int8 two digits (as_space_knn_pipe)
@@ -369,6 +370,9 @@ as_status check_limits(const as_graph_params* resolved, int64_t n, int lambda_mo
 // per-pair fp32 error coefficient: |key32 - key64| <= coef * (n_i + n_j) for L2,
 // <= coef for cosine
 double err_coef(const as_space* sp);
+// the int8 two-digit image of the space's items (x8, fa8, u8max, v8max, coef8), made on first use; *present: it exists and
+// holds no non-finite item (whether its error is acceptable is the caller's call: build pass, scan)
+as_status space_i8_image(const as_space* sp, bool* present);
 
 // build stages (as_build.hip)
 as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld);

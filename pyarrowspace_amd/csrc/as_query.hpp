@@ -135,6 +135,13 @@ struct as_query {
     double* q64 = nullptr;   // [dp] zero padded
     float* q32 = nullptr;    // [dp]
     as::QInfo* info = nullptr;
+    // int8-image scan of the host-prepared single query (as_scan.hip): the query's digit registers (pinned, read by the
+    // kernel in place), its scale, and the error coefficient of THIS query's products (coef_query returns it while i8_scan is set)
+    int* hq8 = nullptr;
+    int* hq8_dev = nullptr;
+    float h_faq = 0.0f;
+    double coef_i8 = 0.0;
+    int i8_scan = 0;
     int pool_slot = 0;       // slot in the space's pool of single-query workspaces (as_search): picks the stream's priority
     float* dots32 = nullptr; // [np]
     float* part32 = nullptr; // batched workspace of rows wider than 768 floats: [K-chunk pass][slots x np] fp32 partial dots (as_scan.hip, gemm_chunks)
@@ -203,6 +210,12 @@ struct PreArgs {
     int* sc_idx = nullptr;   // [waves of the scan][SC_WCAP]: a wave's report -- [0] its number of candidates (-1: more than fit), [1 ..] their rows
     unsigned int* sc_hist = nullptr;   // SC_COPIES cosine histograms
     int sc_dbg = 0;          // measurement only, -DAS_ABLATION builds (ARROWSPACE_SC_DBG): 1 no publication, 2 no histogram read, 4 no candidates
+    // Scan of the int8 two-digit image (scan_dma_kernel<..., I8>: half the bytes of the fp32 items): the rows' scales, the
+    // query's digits in the lanes' register order (per 16-byte chunk of an image row: 16 bytes that multiply into the
+    // 16384-weighted sum, 16 into the 128-weighted one) and the query's scale s_q sqrt(128) / 16256
+    const float* fa8 = nullptr;
+    const int* q8 = nullptr;
+    float faq = 0.0f;
 };
 
 constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats

@@ -601,28 +601,44 @@ __device__ __forceinline__ int sc_bin(float c) {
     const int b = (int)floorf((c + 1.0f) * 32.0f);
     return b < 0 ? 0 : (b > SC_BINS - 1 ? SC_BINS - 1 : b);
 }
-template <int NCH, int NSLOT, bool SC = false>
+// I8: the rows are those of the int8 two-digit image (as_k2bf.hip, quant_i8_kernel: x ~ s (128 a1 + a2) / 16256, per 64-column
+// slab 64 bytes of a1 then 64 of a2) -- HALF the bytes of the fp32 items for this HBM-bound kernel; `dp` is then the image row
+// in floats (dp8 / 2).  A lane's 16-byte chunk is 16 digits a1 or 16 digits a2 of 16 columns; the query's digits q1, q2 of
+// those columns sit in the lane's registers in two roles (pre.q8): qa multiplies into the 16384-weighted sum (q1 for an a1
+// chunk, nothing for an a2 chunk), qb into the 128-weighted one (q2 for an a1 chunk, q1 for an a2 chunk) -- eight
+// v_dot4_i32_i8 per chunk, exact; the dot is (128 HI + XS) fa_row fa_q.  Like every fp32 dot of this path it is a
+// PREFILTER value: what it costs in accuracy is in coef_query (the query's and the items' measured quantisation norms).
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+template <int NCH, int NSLOT, bool SC = false, bool I8 = false>
 __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp,
                                                        int64_t r0, int64_t r1, float* __restrict__ dots, PreArgs pre, int rounds,
                                                        int tail_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RING = NSLOT * NCH * 1024;   // bytes per wave
-    constexpr int WAVE_LDS = RING + 256 + (SC ? 256 + SC_PEND * 8 : 0);   // + the chunk's 64 norms (+ histogram, pending list)
+    constexpr int WAVE_LDS = RING + 256 + (SC ? 256 + SC_PEND * 8 : 0) + (I8 ? 256 : 0);   // + the chunk's 64 norms (+ histogram, pending list) (+ the rows' scales)
     constexpr int K1 = NCH * (NSLOT - 2);      // DMA operations younger than the oldest row of a full ring
+    constexpr int KB = I8 ? 3 : 2;             // operations of a chunk boundary behind its rows: the dots' store, the norm DMA (, the scale DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* myp = smem + wu * WAVE_LDS;
     const unsigned my0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wu * WAVE_LDS;
     const unsigned ax0 = my0 + RING;
     const unsigned hx0 = ax0 + 256, px0 = hx0 + 256;   // SC: histogram landing area, pending list
+    constexpr int FA_OFF = RING + 256 + (SC ? 256 + SC_PEND * 8 : 0);   // I8: the chunk's 64 row scales
     // lanes past the end of a row never receive DMA data: they must read zeros, not stale bits
     for (int i = lane; i < RING / 16; i += 64) *(f32x4*)(myp + i * 16) = f32x4{0, 0, 0, 0};
     f32x4 qv[NCH];
+    i32x4s qa[NCH], qb[NCH];
     bool on[NCH];
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
         on[u] = 4 * (lane + 64 * u) < dp;
-        qv[u] = on[u] ? *(const f32x4*)(q32 + 4 * (lane + 64 * u)) : f32x4{0, 0, 0, 0};
+        if (I8) {
+            qa[u] = on[u] ? *(const i32x4s*)(pre.q8 + 8 * (lane + 64 * u)) : i32x4s{0, 0, 0, 0};
+            qb[u] = on[u] ? *(const i32x4s*)(pre.q8 + 8 * (lane + 64 * u) + 4) : i32x4s{0, 0, 0, 0};
+        } else {
+            qv[u] = on[u] ? *(const f32x4*)(q32 + 4 * (lane + 64 * u)) : f32x4{0, 0, 0, 0};
+        }
     }
     float nq32 = pre.host_q ? pre.nq32 : pre.info->nq32, inq32 = pre.host_q ? pre.inq32 : pre.info->inq32;
     if (pre.host_q && blockIdx.x == 0 && tid == 0) {   // what q_prepare would have filed: read by the kernels behind the scan
@@ -633,7 +649,10 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         pre.infow->tau = 1.0;
     }
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) asm volatile("" : "+v"(qv[u]));   // loads complete here, once (see scan_gemm_kernel)
+    for (int u = 0; u < NCH; ++u) {   // loads complete here, once (see scan_gemm_kernel)
+        if (I8) asm volatile("" : "+v"(qa[u]), "+v"(qb[u]));
+        else asm volatile("" : "+v"(qv[u]));
+    }
     asm volatile("" : "+v"(nq32), "+v"(inq32));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill
     const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
@@ -694,6 +713,9 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         if (cnt <= 0) continue;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),   // padded: readable
                                          (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
+        if (I8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.fa8 + base + lane),
+                                             (__attribute__((address_space(3))) void*)(myp + FA_OFF), 4, 0, 0);
         // SC: the histogram as the other waves have left it (sc1: past this XCD's L2), consumed at the chunk's end -- from
         // the wave's third chunk on: a read issued at the start of the second chunk arrives right behind the burst of
         // publications that ends every wave's first chunk, and queues behind it (in order in front of the row DMAs)
@@ -712,8 +734,8 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             // operations retire in issue order: the oldest row has landed once at most (rows behind it) * NCH
             // (+ 2 for a chunk boundary behind it) operations are outstanding
             if (inflight == NSLOT - 1) {
-                if (marked > 0 && hmark) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + 3) : "memory");
-                else if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + 2) : "memory");
+                if (marked > 0 && hmark) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB + 1) : "memory");
+                else if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -735,17 +757,32 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
                              : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]), "=&v"(xv[NCH > 2 ? 2 : 0]), "=&v"(xv[NCH > 3 ? 3 : 0]) : "v"(a0) : "memory");
             cur = cur + NCH * 1024 == RING ? 0 : cur + NCH * 1024;
             float sacc = 0.0f;
+            if (I8) {
+                int hi = 0, xs = 0;
 #pragma unroll
-            for (int u = 0; u < NCH; ++u)
+                for (int u = 0; u < NCH; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sacc = fmaf(xv[u][e], qv[u][e], sacc);
-            sacc = wave_sum_dpp(sacc);
+                    for (int e = 0; e < 4; ++e) {
+                        hi = __builtin_amdgcn_sdot4(__float_as_int(xv[u][e]), qa[u][e], hi, false);
+                        xs = __builtin_amdgcn_sdot4(__float_as_int(xv[u][e]), qb[u][e], xs, false);
+                    }
+                // (the lanes' partial sums and the wave's totals stay below 2^24: exact in fp32)
+                const float fh = wave_sum_dpp((float)hi), fx = wave_sum_dpp((float)xs);
+                sacc = fmaf(fh, 128.0f, fx);
+            } else {
+#pragma unroll
+                for (int u = 0; u < NCH; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc = fmaf(xv[u][e], qv[u][e], sacc);
+                sacc = wave_sum_dpp(sacc);
+            }
             mydot = lane == r ? sacc : mydot;
         }
         // the norms are older than every row issued inside this chunk; one of those has been consumed once the
         // chunk is at least as long as the ring
         if (cnt < NSLOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float aux = lds_read1(ax0 + lane * 4);
+        if (I8) mydot *= lds_read1(my0 + FA_OFF + lane * 4) * pre.faq;   // x_i . q = (128 HI + XS) fa_i fa_q
         const int64_t row = base + lane;
         if (lane < cnt) {   // cnt >= 1: the store is always issued (the ring's bookkeeping counts it)
             store_dword_issued(dots + row, mydot);
@@ -992,6 +1029,9 @@ int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products) {
 }
 
 double coef_query(const as_query* q, bool exact) {
+    // single query scanned on the int8 two-digit image: |dot - x.q| <= |x||q| (u_q + U + v_q V) + four fp32 roundings of the
+    // scaling -- the query's own measured residue norms with the items' maxima (query_begin forms it per query)
+    if (!exact && q->cap == 1 && q->i8_scan) return q->coef_i8;
     const double u = exact ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
     const int64_t dp = q->sp->dp;
     if (!exact && q->cap > 1) {
@@ -1019,6 +1059,11 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     p.coef = coef_query(q, q->exact != 0);
     p.n = sp->n; p.exclude = exclude; p.enabled = enabled ? 1 : 0;
     p.host_q = q->host_q;
+    if (q->i8_scan && q->cap == 1) {
+        p.fa8 = sp->fa8;
+        p.q8 = q->hq8_dev;
+        p.faq = q->h_faq;
+    }
     if (q->host_q) {
         p.nq = q->h_nq; p.inq = q->h_inq;
         p.nq32 = (float)q->h_nq; p.inq32 = q->h_nq > 0.0 ? (float)(1.0 / sqrt(q->h_nq)) : 0.0f;
@@ -1040,7 +1085,9 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
 }
 
 static constexpr size_t gemm_lds(int nbuf) { return sizeof(float) * ((size_t)4 * nbuf * 1024 + 4 * 3 * 64 * 4 + 4 * 64); }
-static constexpr size_t dma_lds(int nch, int nslot, bool sc = false) { return 4 * ((size_t)nslot * nch * 1024 + 256 + (sc ? 256 + SC_PEND * 8 : 0)); }
+static constexpr size_t dma_lds(int nch, int nslot, bool sc = false, bool i8 = false) {
+    return 4 * ((size_t)nslot * nch * 1024 + 256 + (sc ? 256 + SC_PEND * 8 : 0) + (i8 ? 256 : 0));
+}
 
 // The dynamic-LDS opt-in is a per-device attribute of a kernel: set it for every scan kernel on the device a
 // workspace is created on (query_alloc), not once per process -- a second device would never be opted in.
@@ -1062,6 +1109,14 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_dma_kernel<2, 4>), dma_lds(2, 4));
     AS_ATTR((scan_dma_kernel<3, 5>), dma_lds(3, 5));
     AS_ATTR((scan_dma_kernel<4, 4>), dma_lds(4, 4));
+    AS_ATTR((scan_dma_kernel<1, 8, false, true>), dma_lds(1, 8, false, true));
+    AS_ATTR((scan_dma_kernel<2, 4, false, true>), dma_lds(2, 4, false, true));
+    AS_ATTR((scan_dma_kernel<3, 5, false, true>), dma_lds(3, 5, false, true));
+    AS_ATTR((scan_dma_kernel<4, 4, false, true>), dma_lds(4, 4, false, true));
+    AS_ATTR((scan_dma_kernel<1, 8, true, true>), dma_lds(1, 8, true, true));
+    AS_ATTR((scan_dma_kernel<2, 4, true, true>), dma_lds(2, 4, true, true));
+    AS_ATTR((scan_dma_kernel<3, 5, true, true>), dma_lds(3, 5, true, true));
+    AS_ATTR((scan_dma_kernel<4, 4, true, true>), dma_lds(4, 4, true, true));
     AS_ATTR((scan_dma_kernel<1, 8, true>), dma_lds(1, 8, true));
     AS_ATTR((scan_dma_kernel<2, 4, true>), dma_lds(2, 4, true));
     AS_ATTR((scan_dma_kernel<3, 5, true>), dma_lds(3, 5, true));
@@ -1082,7 +1137,11 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
         hipLaunchKernelGGL(scan_dots_f64_kernel, dim3(grid), dim3(256), 0, st, sp->x32, sp->x64, q->q64, sp->d, sp->dp, q->r0,
                            q->r1, q->dots64, pre);
     } else {
-        const int nch = (int)((sp->dp + 255) / 256);
+        // (single query on the int8 two-digit image: the image's rows are dp8 / 2 floats long -- half the bytes, half the chunks)
+        const bool i8 = q->cap == 1 && q->i8_scan && pre.q8 && pre.fa8 && sp->x8;
+        const int64_t ldrow = i8 ? sp->dp8 / 2 : sp->dp;
+        const float* xrows = i8 ? (const float*)sp->x8 : sp->x32;
+        const int nch = (int)((ldrow + 255) / 256);
         if (q->cap > 1 && q->ss.dots_rs == 4) {
             // batched pass, GEMM-shaped: matrix pipe (bf16 head + tail with the fp16 cosines, else fp32), K split over the 4 waves of a block, 2 blocks per CU
             int64_t chunk = sp->dp;
@@ -1216,7 +1275,13 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int tail_rows = (int)((rem + NW - 1) / NW);
 #define AS_DSCAN(N, S)                                                                                                 \
     do {                                                                                                               \
-        if (pre.sc_enabled)   /* (rows of up to 512 floats: the fused form exists with the ring of 4 only) */               \
+        if (i8 && pre.sc_enabled)                                                                                      \
+            hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), true, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), true, true), st, \
+                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
+        else if (i8)                                                                                                   \
+            hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), false, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), false, true), st, \
+                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
+        else if (pre.sc_enabled)   /* (rows of up to 512 floats: the fused form exists with the ring of 4 only) */          \
             hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), true), st, \
                                sp->x32, q->q32_src, sp->dp, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);          \
         else                                                                                                           \
@@ -1226,7 +1291,8 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             switch (nch) {
                 case 1: AS_DSCAN(1, 8); break;
                 case 2:
-                    if (geom % 10 == 5) AS_DSCAN(2, 5);
+                    if (i8) AS_DSCAN(2, 4);
+                    else if (geom % 10 == 5) AS_DSCAN(2, 5);
                     else if (geom % 10 == 8) AS_DSCAN(2, 8);
                     else AS_DSCAN(2, 4);
                     break;

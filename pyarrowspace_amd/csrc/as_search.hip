@@ -2085,6 +2085,55 @@ static as_status run_score(as_query* q, double tau, int fuse_final) {
     return AS_OK;
 }
 
+// The scan of the int8 two-digit image (as_scan.hip, scan_dma_kernel<..., I8>; the image: as_k2bf.hip, quant_i8_kernel) reads half
+// the bytes of the fp32 items.  The query is quantised the same way -- q ~ s_q (128 q1 + q2) / 16256 -- on the host (D elements),
+// its digits laid out in the lanes' register order: for the 16-byte chunk ci of an image row (slab ci / 8; chunks 0-3 of a slab
+// are a1 of 16 columns each, chunks 4-7 a2) 16 bytes `qa` that multiply into the 16384-weighted sum (q1 of those columns for an
+// a1 chunk, zeros for an a2 chunk) and 16 bytes `qb` for the 128-weighted one (q2 for an a1 chunk, q1 for an a2 chunk).  The
+// dropped q2.a2 and the two quantisation residues are bounded through the measured norms (err_coef_i8 in as_build.hip):
+//   |dot - x.q| <= |x||q| (u_q + 1.001 U + v_q V) + roundings,   u_q = s_q |theta_q|_2 / (16256 |q|),  v_q = s_q |q2|_2 / (16256 |q|).
+// False: no usable image (none yet and it cannot be made, non-finite items, rows too wide for the DMA scan), a query the
+// fp32 scan serves better (zero, non-finite, coefficient beyond 2e-3), or ARROWSPACE_SCAN_FP32=1.
+static bool host_query_digits(as_query* q, int64_t d) {
+    static const bool off = getenv("ARROWSPACE_SCAN_FP32") != nullptr;
+    const as_space* sp = q->sp;
+    if (off || !q->hq8 || sp->opts.force_exact) return false;
+    bool present = false;
+    if (space_i8_image(sp, &present) != AS_OK || !present || sp->dp8 / 2 > 1024) return false;
+    float m = 0.0f;
+    for (int64_t c = 0; c < d; ++c) m = std::max(m, std::fabs(q->hq32[c]));
+    if (!(m > 0.0f) || !(m < 3.0e38f) || !(q->h_nq > 0.0)) return false;
+    const float inv = 16256.0f / m;
+    const int64_t dp8 = sp->dp8;
+    signed char* out = (signed char*)q->hq8;
+    double st2 = 0.0, sa2 = 0.0;
+    for (int64_t c = 0; c < dp8; ++c) {
+        const float v = c < d ? q->hq32[c] : 0.0f;
+        const float sc = v * inv;
+        int qq = (int)std::nearbyint(sc);
+        qq = qq > 16256 ? 16256 : (qq < -16256 ? -16256 : qq);
+        const int q2 = ((qq + 64 + (1 << 20)) & 127) - 64;
+        const int q1 = (qq - q2) >> 7;
+        const double th = std::fabs((double)sc - (double)qq) + 0.004;
+        st2 += th * th;
+        sa2 += (double)(q2 * q2);
+        const int64_t slab = c >> 6, k = c & 63, c4 = k >> 4, j = k & 15;
+        signed char* a1chunk = out + ((slab * 8 + c4) * 32);       // the a1 chunk of these columns: qa = q1, qb = q2
+        signed char* a2chunk = out + ((slab * 8 + 4 + c4) * 32);   // the a2 chunk: qa = 0, qb = q1
+        a1chunk[j] = (signed char)q1;
+        a1chunk[16 + j] = (signed char)q2;
+        a2chunk[j] = 0;
+        a2chunk[16 + j] = (signed char)q1;
+    }
+    const double nq = std::sqrt(q->h_nq);
+    const double uq = (double)m * std::sqrt(st2) / (16256.0 * nq) * 1.001, vq = (double)m * std::sqrt(sa2) / (16256.0 * nq) * 1.001;
+    const double coef = uq + 1.001 * sp->u8max + vq * sp->v8max + 10.0 * 5.9604644775390625e-8;
+    if (!(coef <= 2.0e-3)) return false;
+    q->coef_i8 = coef;
+    q->h_faq = m * (11.313708498984761f / 16256.0f);   // s_q sqrt(128) / 16256
+    return true;
+}
+
 static as_status query_begin(as_query* q, const double* query_host, int64_t src_row, int64_t d, int64_t r0, int64_t r1,
                              double eps, int64_t exclude) {
     const as_space* sp = q->sp;
@@ -2103,6 +2152,7 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     const bool stats = g_search_stats.load(std::memory_order_relaxed) != 0;
     const bool feature = q->gr && q->gr->lambda_mode == AS_LAMBDA_FEATURE;
     q->host_q = 0;
+    q->i8_scan = 0;
     q->q64_src = q->q64;
     q->q32_src = q->q32;
     // Host-prepared query: one query, fp32 LDS-DMA scan (rows up to 1024 floats), item mode.  The host converts the query
@@ -2119,6 +2169,7 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         q->h_nq = host_query_norm(query_host, d);
         q->h_inq = q->h_nq > 0.0 ? 1.0 / sqrt(q->h_nq) : 0.0;
         q->host_q = 1;
+        q->i8_scan = host_query_digits(q, d) ? 1 : 0;
         q->q64_src = q->hq_dev;
         q->q32_src = q->hq32_dev;
         if (!q->info_clean) hipLaunchKernelGGL(reset_info_kernel, dim3(1), dim3(64), 0, st, q->info, q->sc_hist);
@@ -2286,6 +2337,11 @@ static as_status query_alloc(as_query* q) {
         AS_HIP(hipHostMalloc(&q->hq32, sizeof(float) * sp->dp, hipHostMallocMapped | hipHostMallocCoherent));
         memset(q->hq32, 0, sizeof(float) * sp->dp);
         AS_HIP(hipHostGetDevicePointer((void**)&q->hq32_dev, q->hq32, 0));
+        // the query's digit registers for the scan of the int8 image: 32 bytes per 16-byte chunk of an image row
+        const size_t dp8 = (size_t)(sp->dp + 63) / 64 * 64;
+        AS_HIP(hipHostMalloc(&q->hq8, dp8 * 4, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(q->hq8, 0, dp8 * 4);
+        AS_HIP(hipHostGetDevicePointer((void**)&q->hq8_dev, q->hq8, 0));
     }
     AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp * C));
     AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp * C));
@@ -2353,6 +2409,7 @@ void as_query_free(as_query* q) {
     if (q->stream) hipStreamSynchronize(q->stream);
     if (q->hq) hipHostFree(q->hq);
     if (q->hq32) hipHostFree(q->hq32);
+    if (q->hq8) hipHostFree(q->hq8);
     hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32); hipFree(q->part32);
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);
