@@ -542,9 +542,14 @@ def main():
         batch_pass_ms = float(tbm.item()) / (len(QB) / 32) * 1e3
 
     qps = args.steps / dt
+    # the scan reads the int8 two-digit image of the items when it can (2 bytes per element + the rows' norm and scale), else fp32
+    scan_i8 = bool(aspace.last_scan_int8) if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 2048 and not feature
     rows_per_gpu = (n + world - 1) // world
     scan_bytes = rows_per_gpu * (d + 2) * 4.0          # N x D fp32 items + N reciprocal norms read, N fp32 dots written
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
+    d8 = (d + 63) // 64 * 64
+    scan_moved = rows_per_gpu * (2.0 * d8 + 12.0) if scan_i8 else scan_bytes   # bytes the launch moves: image + norms + scales + dots
+    moved = scan_moved / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
     # Build kernel: bstats["mfma_flops"] counts 2 * (pairs computed) * D -- the fp32-equivalent work.  The default kernel
     # (as_k2bf.hip) issues THREE bf16 products per such flop (head x head, head x tail, tail x head): the roofline
@@ -629,9 +634,13 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
                      "traffic_source": traffic_source if traffic_scan is not None else "none (live passes: %s)" % live_note,
                      "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes,
-                     "note": "round 3: this launch also collects the scorer's candidates (fused tail, DESIGN.md 5.4) -- 4-14 us more than "
-                             "round 2's plain scan on the same box, for 3 launches and ~14 us less behind it; ARROWSPACE_NO_FUSED_TAIL=1 "
-                             "runs the plain kernel (tools/scan_ab.sh)"},
+                     "operand": "int8 two-digit image (2 B per element)" if scan_i8 else "fp32 items",
+                     "bytes_moved_per_launch": scan_moved, "achieved_bytes_moved": moved, "frac_bytes_moved": moved / HBM_PEAK_GBS,
+                     "frac_note": "`achieved` and `frac` follow SURVEY 8(d): ALGORITHMIC bytes N (D + 2) 4 over the launch time -- above 1 "
+                                  "when the scan reads the 2-byte image instead of the fp32 items; `frac_bytes_moved` is the physical "
+                                  "HBM rate (what `traffic` measures) against the 8 TB/s peak",
+                     "note": "this launch also collects the scorer's candidates (fused tail, DESIGN.md 5.4); ARROWSPACE_SCAN_FP32=1 scans "
+                             "the fp32 items (round 3's operand), ARROWSPACE_NO_FUSED_TAIL=1 runs the plain kernel"},
         "roofline_query": {"bound": "hbm", "achieved": query_bytes / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "note": "whole query, host-visible latency, per GPU"},

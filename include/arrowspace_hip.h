@@ -232,6 +232,11 @@ as_status as_search(const as_space* sp, const as_graph* gr, const double* query,
  * head + tail, 2 int8 two-digit image (the default where the items' quantisation error allows it); -1: none yet.  The graphs
  * are the same bits on every pipe: the pipe only prefilters, the refinement is exact. */
 int32_t as_space_knn_pipe(const as_space* sp);
+/* 1 when the last single-query scan (of this workspace / of the space's first pooled workspace) read the int8 two-digit image
+ * of the items -- half the bytes of the fp32 matrix -- instead of the fp32 matrix (ARROWSPACE_SCAN_FP32=1, rows wider than 2 048
+ * floats, queries or items the image represents badly).  Either way the scan only prefilters: results are exact. */
+int32_t as_query_scan_int8(const as_query* q);
+int32_t as_last_scan_int8(const as_space* sp);
 /* workspaces the pool of as_search holds at the moment (1 after single-threaded use) */
 int32_t as_search_pool_size(const as_space* sp);
 

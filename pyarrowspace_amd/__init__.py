@@ -320,6 +320,11 @@ class ArrowSpace:
         return {0: "fp32", 1: "bf16", 2: "int8"}.get(int(_L.as_space_knn_pipe(self._h)), "none")
 
     @property
+    def last_scan_int8(self) -> bool:
+        """Extension: the last single-query scan read the int8 two-digit image of the items (half the bytes) rather than fp32."""
+        return bool(_L.as_last_scan_int8(self._h))
+
+    @property
     def search_pool_size(self) -> int:
         """Extension: single-query workspaces the library holds for this space -- `search` is re-entrant across host threads
         (ctypes releases the GIL around the call), each concurrent call runs on a workspace and stream of its own."""

@@ -69,8 +69,8 @@ static as_status k2_items(const as_space* sp, const float** out) {
 
 static as_status k2_items_i8(const as_space* sp, bool* usable);
 // The int8 two-digit image of this space's items and the error coefficient its products carry; made on first use.  False
-// when the image cannot be used: a non-finite item, or a coefficient more than twice the bf16 kernel's (rows dominated by
-// one element: s / |x| near 1) -- the bf16 kernel then.
+// when the image cannot be used: a non-finite item, or a coefficient beyond 1e-3 (rows dominated by one element: s / |x| near
+// 1; clustered unit rows measure 3.6e-4 at any D) -- the bf16 kernel then.
 as_status space_i8_image(const as_space* sp, bool* present) {
     static std::mutex mu;   // (searches of several host threads may all be the first to ask)
     std::lock_guard<std::mutex> lk(mu);
@@ -120,7 +120,9 @@ static as_status k2_items_i8(const as_space* sp, bool* usable) {
         dbg("k2_items_i8: U = %.3e, V = %.3e -> coefficient %.3e (bf16: %.3e)%s", U, V, sp->coef8, err_coef_dp(sp->dp),
             sp->x8_bad ? ", non-finite items: unusable" : "");
     }
-    *usable = sp->x8 && !sp->x8_bad && sp->coef8 <= 2.0 * err_coef_dp(sp->dp) && sp->dp <= 131072;
+    // (the bound that decides is absolute: what matters is e = coef (n_i + n_max) against the gaps between the rows' M-th and
+    // k-th keys -- rows that fail their proof go to the band pass, the result is exact either way)
+    *usable = sp->x8 && !sp->x8_bad && sp->coef8 <= 1.0e-3 && sp->dp <= 131072;
     return AS_OK;
 }
 

@@ -2095,9 +2095,8 @@ static as_status run_score(as_query* q, double tau, int fuse_final) {
 // False: no usable image (none yet and it cannot be made, non-finite items, rows too wide for the DMA scan), a query the
 // fp32 scan serves better (zero, non-finite, coefficient beyond 2e-3), or ARROWSPACE_SCAN_FP32=1.
 static bool host_query_digits(as_query* q, int64_t d) {
-    static const bool off = getenv("ARROWSPACE_SCAN_FP32") != nullptr;
     const as_space* sp = q->sp;
-    if (off || !q->hq8 || sp->opts.force_exact) return false;
+    if (getenv("ARROWSPACE_SCAN_FP32") || !q->hq8 || sp->opts.force_exact) return false;
     bool present = false;
     if (space_i8_image(sp, &present) != AS_OK || !present || sp->dp8 / 2 > 1024) return false;
     float m = 0.0f;
@@ -2676,7 +2675,8 @@ void query_flags(const as_query* q, int* knn_inexact, int* score_inexact) {
     if (q->hout->overflow) *knn_inexact |= 2;
 }
 
-int query_overflow_bits(const as_query* q) { return q->hout->overflow; }   // bit0 k-NN candidates, bit1 scorer's, bit2 the scan's scorer candidates
+int query_overflow_bits(const as_query* q) { return q->hout->overflow; }
+extern "C" int32_t as_query_scan_int8(const as_query* q) { return q ? q->i8_scan : 0; }   // bit0 k-NN candidates, bit1 scorer's, bit2 the scan's scorer candidates
 
 // one full single-GPU search on q's stream: 6 launches, one host wait
 as_status search_once(as_query* q, const double* query, int64_t d, double tau, int mode, int64_t* out_idx, double* out_score,

@@ -129,3 +129,54 @@ def test_search_batch_matches_single_and_oracle(oracle_lib, metric, d):
     far[4, 0] = 40.0                      # one query without neighbours poisons the batch like the reference's assert
     with pytest.raises(asp.PanicException):
         aspace.search_batch(far, gl, 0.62)
+
+
+def test_int8_image_scan_returns_what_the_fp32_scan_returns(oracle_lib):
+    """The single-query scan reads the int8 two-digit image of the items (half the bytes) when the items' and the query's
+    quantisation error allow it; it only prefilters -- k-NN candidates and scorer candidates are re-evaluated exactly and proven
+    against the wider error term -- so hits, scores and lambda_q are those of the fp32 scan (ARROWSPACE_SCAN_FP32=1) and of the
+    oracle: clustered items, three taus, queries near items, an exact item, a scaled item, a query with one dominant component."""
+    import os
+
+    import pyarrowspace_amd as asp
+    n, d, k, topk = 8000, 200, 12, 9
+    X = clustered(n, d, nclust=10, seed=31)
+    gp = {"eps": calibrate_eps(X, k, "l2"), "k": k, "topk": topk, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    assert aspace.knn_pipe == "int8"
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(3)
+    Q = [np.ascontiguousarray(X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d)) for _ in range(24)]
+    Q.append(np.ascontiguousarray(X[77]))
+    Q.append(np.ascontiguousarray(3.5 * X[1234]))
+    spike = np.ascontiguousarray(X[5] * 1e-3)
+    spike[0] = 1.0                      # one dominant component: s_q / |q| ~ 1 -- the query's own residue term is at its largest
+    Q.append(spike)
+    used = []
+    for tau in (0.62, 1.0, 0.0):
+        for q in Q:
+            os.environ.pop("ARROWSPACE_SCAN_FP32", None)
+            try:
+                got = aspace.search(q, gl, tau)
+                used.append(aspace.last_scan_int8)
+            except asp.PanicException:
+                got = None
+            os.environ["ARROWSPACE_SCAN_FP32"] = "1"
+            try:
+                try:
+                    want32 = aspace.search(q, gl, tau)
+                    assert not aspace.last_scan_int8
+                except asp.PanicException:
+                    want32 = None
+            finally:
+                os.environ.pop("ARROWSPACE_SCAN_FP32", None)
+            assert got == want32
+            if got is not None:
+                want, lq = ref.search(q, tau)
+                assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=RTOL)
+    assert all(used) and len(used) >= 70
+    with pytest.raises(asp.PanicException):
+        aspace.search(np.zeros(d), gl, 0.62)
+    assert not aspace.last_scan_int8    # a query without a scale (all zeros) is the fp32 scan's
+    c = aspace.search_counters()
+    assert c["searches_with_rerun"] == 0
