@@ -540,6 +540,7 @@ def main():
             dist.all_reduce(tbm, op=dist.ReduceOp.MAX)
         batched_qps = len(QB) / float(tbm.item())
         batch_pass_ms = float(tbm.item()) / (len(QB) / 32) * 1e3
+    batch_i8 = bool(aspace.last_batch_int8) if single else False
 
     qps = args.steps / dt
     # the scan reads the int8 two-digit image of the items when it can (2 bytes per element + the rows' norm and scale), else fp32
@@ -649,9 +650,15 @@ def main():
             "achieved": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
             "traffic": traffic_batch,
-            "note": "whole 32-query pass, host-visible, per GPU; N*(D+2)*4 bytes per pass; products on the bf16 matrix pipe, every operand as "
-                    "bf16 head + tail (3 x 2*32*N*D flops, error bound in the prefilter's and the proof's coefficients: DESIGN.md 5.5), "
-                    "fp16 cosines kept per slot; ARROWSPACE_BATCH_F32_DOTS=1 is the fp32 form"},
+            "operand": "int8 two-digit images of items and queries (2 B per element)" if batch_i8 else "fp32 items as bf16 head + tail",
+            "frac_bytes_moved": (n * (2.0 * ((d + 63) // 64 * 64) + 8.0 + 64.0) if batch_i8 else query_bytes + n * 64.0) / world
+                                / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "whole 32-query pass, host-visible, per GPU; `achieved` and `frac`: ALGORITHMIC bytes N*(D+2)*4 per pass (SURVEY 8(d)), "
+                    "`frac_bytes_moved`: the bytes the pass moves (operand + norms + 32 fp16 cosines per row) against the peak.  int8 "
+                    "operand: three v_mfma_i32_32x32x32_i8 products per column, exact int32 sums; bf16 operand (the items' or the queries' "
+                    "quantisation error too large, ARROWSPACE_SCAN_FP32=1): three bf16 products.  Either way the pass only prefilters: its "
+                    "error bound sits in the prefilter's and the proof's coefficients (DESIGN.md 5.5).  ARROWSPACE_BATCH_F32_DOTS=1 is the "
+                    "fp32 form"},
         "roofline_build": {"kernel": build_kernel, "bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak,
                            "unit": "TOP/s" if k2_pipe == "int8" and not feature else "TFLOP/s", "frac": mfma_tf / mfma_peak, "traffic": traffic_mfma,
                            "flops_issued": (1.0 if feature or k2_fp32 else 3.0) * bstats["mfma_flops"], "kernel_sec": bstats["knn_mfma_s"],

@@ -237,6 +237,9 @@ int32_t as_space_knn_pipe(const as_space* sp);
  * floats, queries or items the image represents badly).  Either way the scan only prefilters: results are exact. */
 int32_t as_query_scan_int8(const as_query* q);
 int32_t as_last_scan_int8(const as_space* sp);
+/* 1 when the last batched pass of as_search_batch (its first workspace) ran on the int8 images of items and queries
+ * (v_mfma_i32_32x32x32_i8, three products per column) rather than on the bf16 head + tail of the fp32 items. */
+int32_t as_last_batch_int8(const as_space* sp);
 /* workspaces the pool of as_search holds at the moment (1 after single-threaded use) */
 int32_t as_search_pool_size(const as_space* sp);
 

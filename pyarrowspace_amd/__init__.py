@@ -325,6 +325,11 @@ class ArrowSpace:
         return bool(_L.as_last_scan_int8(self._h))
 
     @property
+    def last_batch_int8(self) -> bool:
+        """Extension: the last batched pass of `search_batch` ran on the int8 images of items and queries (int8 matrix pipe)."""
+        return bool(_L.as_last_batch_int8(self._h))
+
+    @property
     def search_pool_size(self) -> int:
         """Extension: single-query workspaces the library holds for this space -- `search` is re-entrant across host threads
         (ctypes releases the GIL around the call), each concurrent call runs on a workspace and stream of its own."""

@@ -674,6 +674,7 @@ static as_status graph_matches(const as_space* sp, const as_graph* gr, const cha
 
 int32_t as_space_knn_pipe(const as_space* sp) { return sp ? sp->k2_last_pipe : -1; }
 int32_t as_last_scan_int8(const as_space* sp) { return sp && sp->qcache ? as_query_scan_int8(sp->qcache) : 0; }
+int32_t as_last_batch_int8(const as_space* sp) { return sp && sp->qcache_b ? as_query_scan_int8(sp->qcache_b) : 0; }
 
 int32_t as_search_pool_size(const as_space* sp) {
     if (!sp) return 0;

@@ -139,6 +139,12 @@ struct as_query {
     // kernel in place), its scale, and the error coefficient of THIS query's products (coef_query returns it while i8_scan is set)
     int* hq8 = nullptr;
     int* hq8_dev = nullptr;
+    // batched workspace: the int8 image of the slots' queries (the items' image layout, [slots][dp8 * 2 bytes]) and their scales,
+    // quantised by the host into pinned staging and copied in front of the scan
+    signed char* hq8img = nullptr;
+    signed char* q8img_dev = nullptr;
+    float* hfaqv = nullptr;
+    float* faqv_dev = nullptr;
     float h_faq = 0.0f;
     double coef_i8 = 0.0;
     int i8_scan = 0;
@@ -216,6 +222,7 @@ struct PreArgs {
     const float* fa8 = nullptr;
     const int* q8 = nullptr;
     float faq = 0.0f;
+    const float* faqv = nullptr;   // batched pass on the int8 images: the slots' scales
 };
 
 constexpr int GEMM_NSW = 6;   // slabs per wave of the batched MFMA scan: rows up to 4 * 6 * 32 floats

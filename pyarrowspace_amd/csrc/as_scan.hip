@@ -293,7 +293,11 @@ __device__ __forceinline__ void split_bf16(const f32x4& a, const f32x4& b, bf16x
 // BF3: the products on the bf16 matrix pipe (16 x the fp32 rate), each operand as head + tail: q.x ~ qh.xh + qh.xl + ql.xh --
 // three v_mfma_f32_32x32x16_bf16 per 16 columns instead of eight v_mfma_f32_32x32x2_f32; bf16 x bf16 is exact in the fp32
 // accumulator, what is dropped (ql.xl and the two remainders) is at most 3 * 2^-16 |q_k x_k| per term (coef_query).
-template <int NBUF, int DIAG, int AUX, bool BF3 = false, int NSW = GEMM_NSW>
+// I8: items and queries as int8 two-digit images (as_k2bf.hip, quant_i8_kernel; the queries' image by the host,
+// host_batch_digits): a slab row is 64 columns (64 bytes of a1, 64 of a2) -- HALF the bytes of the fp32 items --, `dp` the image
+// row in floats, the chunk addressing that of the fp32 slab; three v_mfma_i32_32x32x32_i8 per 32 columns into two int32
+// accumulators (q1.a1 and the cross terms), scaled by the rows' and the slots' factors in the epilogue.
+template <int NBUF, int DIAG, int AUX, bool BF3 = false, int NSW = GEMM_NSW, bool I8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_kernel(
     const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp, int64_t r0, int64_t r1, float* __restrict__ dots,
     int64_t ts, PreArgs pre, int nb, int half_dots, int64_t kbase_, int64_t kcols_, int raw, int npass, int64_t pstride) {
@@ -308,6 +312,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* St = (float*)smem;   // per wave: NBUF slabs x [32 rows][32 floats]; Ex[owner wave][3 senders][64 lanes][4]; Ax[wave][64]
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned ex0 = lds0 + 4 * NBUF * 4096, ax0 = ex0 + 4 * 3 * 64 * 16;
+    const unsigned fx0 = ax0 + 4 * 64 * 4;   // I8: the row block's scales, one 256-byte line per wave
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pz = npass > 1 ? (int)(blockIdx.x % (unsigned)npass) : 0;
@@ -331,6 +338,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float iqv[4];   // 1/|q| of the same queries: the stored value is the cosine (half_dots)
 #pragma unroll
     for (int e = 0; e < 4; ++e) iqv[e] = pre.info[e + 8 * wu + 4 * h].inq32;
+    float fqv[4] = {1.0f, 1.0f, 1.0f, 1.0f};   // I8: the same queries' scales s_q sqrt(128) / 16256
+    if (I8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fqv[e] = pre.faqv[e + 8 * wu + 4 * h];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(fqv[e]));
+    }
     // the loads above complete here, once: otherwise the compiler has to assume they are still pending inside
     // the loop and puts a vmcnt(0) -- which also waits for the whole prefetch ring -- in front of their first use
 #pragma unroll
@@ -396,14 +410,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int full = 0;       // bit e: query e of this lane has overflowed its candidate buffer (see prefilter_f32)
     for (int64_t rb = bx; rb < nrb; rb += gx) {
         f32x16 acc;
+        i32x16 acc1, accx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = 0.0f;
+            if (I8) {
+                acc1[r] = 0;
+                accx[r] = 0;
+            }
+        }
         // the row's norm for the prefilter: issued before this block's slabs, so it is older than every DMA still in
         // flight at the epilogue when the wave has at least NBUF-1 slabs per block
         const int64_t row = r0 + rb * 32 + l31;
         {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + row),   // padded arrays: readable
                                              (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + wu * 64), 4, 0, 0);
+            if (I8)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.fa8 + row),
+                                                 (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + 4 * 64 + wu * 64), 4, 0, 0);
             x0 += 1;
             x1 += 1;
             x2 += 1;
@@ -425,7 +449,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
                     continue;
                 }
-                if (BF3) {
+                if (I8) {
+                    // qf[ks][0..3] = q1 of k-steps 0, 1, q2 of k-steps 0, 1; x0..x3 = a1, a1, a2, a2 likewise
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[ks][0]), __builtin_bit_cast(i32x4, x0), acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[ks][1]), __builtin_bit_cast(i32x4, x1), acc1, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[ks][0]), __builtin_bit_cast(i32x4, x2), accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[ks][1]), __builtin_bit_cast(i32x4, x3), accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[ks][2]), __builtin_bit_cast(i32x4, x0), accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[ks][3]), __builtin_bit_cast(i32x4, x1), accx, 0, 0, 0);
+                } else if (BF3) {
                     // lane (row l31, half h) holds the same 8 + 8 columns of its query and of its item: the order of the
                     // columns inside an instruction is free as long as both operands agree
                     bf16x8 bh0, bl0, bh1, bl1;
@@ -453,6 +485,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // C[i = query][j = row]: register r <-> query (r&3) + 8 (r>>2) + 4 h, lane <-> row l31.  Wave o owns
         // registers [4o, 4o+4) = queries 8o + {0..3} + 4h; the other three waves send it their partials.
         // Raw barriers: __syncthreads() carries a vmcnt(0) fence that would drain the prefetch ring.
+        if (I8) {   // 128 q1.a1 + cross terms: both sums of a wave's quarter of the columns are below 2^24 (exact floats)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf((float)acc1[r], 128.0f, (float)accx[r]);
+        }
         __builtin_amdgcn_s_barrier();   // the previous row block's exchange has been read (its reads were waited for)
         f32x4 mine = {0, 0, 0, 0};
 #pragma unroll
@@ -474,6 +510,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the norms: older than the slabs in flight when those were all issued inside this row block
         wait_vmcnt(myns >= NBUF - 1 ? 4 * inflight : 0);
         const float aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
+        if (I8 && !raw) {   // x . q = (128 q1.a1 + cross) fa_row fa_q
+            const float far = lds_read1(fx0 + (unsigned)((wu * 64 + lane) * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine[e] *= far * fqv[e];
+        }
         if (raw) {   // a K-chunk pass: the partial dots of this chunk, fp32, in the tile layout (gemm_combine_kernel finishes)
             store_x4_issued(dots + (row >> 5) * ts + ((2 * wu + h) * 32 + (row & 31)) * 4, mine);
             x0 += 1;
@@ -970,13 +1011,18 @@ __global__ __launch_bounds__(256) void scan_dots_f64_kernel(const float* __restr
 // scan_gemm_kernel: cosines as fp16 (or the dots as fp32) in the slot buffers and the fused k-NN prefilter.  A thread takes
 // 4 slots of one row (16 contiguous bytes of every partial tile); 32 x N x 4 B per pass read once: 8 % of the item bytes.
 __global__ __launch_bounds__(256) void gemm_combine_kernel(const float* __restrict__ part, int npass, int64_t pstride, int64_t r0, int64_t r1,
-                                                           float* __restrict__ dots, int64_t ts, PreArgs pre, int nb, int half_dots) {
+                                                           float* __restrict__ dots, int64_t ts, PreArgs pre, int nb, int half_dots, int i8) {
     const int64_t tile = blockIdx.x;
     const int quad = threadIdx.x >> 5, r = threadIdx.x & 31;
     const int64_t row = r0 + tile * 32 + r;
     const int64_t off = (row >> 5) * ts + (quad * 32 + (row & 31)) * 4;
     f32x4 mine = *(const f32x4*)(part + off);
     for (int p = 1; p < npass; ++p) mine += *(const f32x4*)(part + (int64_t)p * pstride + off);   // pass order: one summation order per launch geometry
+    if (i8) {   // the passes left unscaled integer sums (int8 images): x . q = t fa_row fa_q
+        const float far = pre.fa8[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[e] *= far * pre.faqv[4 * quad + e];
+    }
     const float aux = pre.metric == AS_METRIC_L2 ? pre.n32[row] : pre.inorm32[row];   // padded arrays: readable past r1
     if (half_dots) {
         const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
@@ -1031,7 +1077,7 @@ int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products) {
 double coef_query(const as_query* q, bool exact) {
     // single query scanned on the int8 two-digit image: |dot - x.q| <= |x||q| (u_q + U + v_q V) + four fp32 roundings of the
     // scaling -- the query's own measured residue norms with the items' maxima (query_begin forms it per query)
-    if (!exact && q->cap == 1 && q->i8_scan) return q->coef_i8;
+    if (!exact && q->i8_scan) return q->coef_i8;   // (batched workspace: the slots' largest residue norms, host_batch_digits)
     const double u = exact ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
     const int64_t dp = q->sp->dp;
     if (!exact && q->cap > 1) {
@@ -1084,7 +1130,7 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     return p;
 }
 
-static constexpr size_t gemm_lds(int nbuf) { return sizeof(float) * ((size_t)4 * nbuf * 1024 + 4 * 3 * 64 * 4 + 4 * 64); }
+static constexpr size_t gemm_lds(int nbuf, bool i8 = false) { return sizeof(float) * ((size_t)4 * nbuf * 1024 + 4 * 3 * 64 * 4 + 4 * 64 + (i8 ? 4 * 64 : 0)); }
 static constexpr size_t dma_lds(int nch, int nslot, bool sc = false, bool i8 = false) {
     return 4 * ((size_t)nslot * nch * 1024 + 256 + (sc ? 256 + SC_PEND * 8 : 0) + (i8 ? 256 : 0));
 }
@@ -1103,6 +1149,8 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_gemm_kernel<4, 0, 0, true>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<4, 0, 2, true>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<4, 0, 2, true, GEMM_NSW_WIDE>), gemm_lds(4));
+    AS_ATTR((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW, true>), gemm_lds(4, true));
+    AS_ATTR((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW_WIDE, true>), gemm_lds(4, true));
     AS_ATTR((scan_dma_kernel<1, 8>), dma_lds(1, 8));
     AS_ATTR((scan_dma_kernel<2, 8>), dma_lds(2, 8));
     AS_ATTR((scan_dma_kernel<2, 5>), dma_lds(2, 5));
@@ -1144,6 +1192,40 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
         const int nch = (int)((ldrow + 255) / 256);
         if (q->cap > 1 && q->ss.dots_rs == 4) {
             // batched pass, GEMM-shaped: matrix pipe (bf16 head + tail with the fp16 cosines, else fp32), K split over the 4 waves of a block, 2 blocks per CU
+            if (q->i8_scan && q->q8img_dev && q->faqv_dev && sp->x8 && q->half_enabled) {
+                // int8 images of items and queries: rows of ld = dp8 / 2 image floats, 768 (6 slabs per wave: 1 536 columns) or
+                // 1 024 (8 slabs: 2 048 columns) of them per launch, K-chunk passes side by side beyond
+                const int64_t ld = sp->dp8 / 2;
+                int64_t ichunk = ld;
+                const int ipass = gemm_chunks(ld, &ichunk, true);
+                if (ipass > 1 && !q->part32) {
+                    set_err("launch_scan: the workspace has no partial buffer for rows of %lld floats", (long long)sp->dp);
+                    return AS_EINVAL;
+                }
+                q->dots_half = 1;
+                const int64_t ipstride = (sp->np + ROW_TILE) * (int64_t)q->cap;
+                const size_t lds = gemm_lds(4, true);
+                const int64_t nrb = (rows + 31) / 32;
+                const int64_t per = std::max<int64_t>(1, std::min<int64_t>(nrb, (2 * q->cus) / ipass));
+                PreArgs p8 = pre;
+                p8.fa8 = sp->fa8;
+                p8.faqv = q->faqv_dev;
+                if (ichunk > 4 * GEMM_NSW * 32)
+                    hipLaunchKernelGGL((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW_WIDE, true>), dim3((unsigned)(per * ipass)), dim3(256), lds, st, (const float*)sp->x8,
+                                       (const float*)q->q8img_dev, ld, q->r0, q->r1, ipass > 1 ? q->part32 : q->dots32, q->ss.dots_ts, p8, q->nb, 1, (int64_t)0,
+                                       ichunk, ipass > 1 ? 1 : 0, ipass, ipstride);
+                else
+                    hipLaunchKernelGGL((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW, true>), dim3((unsigned)(per * ipass)), dim3(256), lds, st, (const float*)sp->x8,
+                                       (const float*)q->q8img_dev, ld, q->r0, q->r1, ipass > 1 ? q->part32 : q->dots32, q->ss.dots_ts, p8, q->nb, 1, (int64_t)0,
+                                       ichunk, ipass > 1 ? 1 : 0, ipass, ipstride);
+                AS_HIP(hipGetLastError());
+                if (ipass > 1) {
+                    hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)nrb), dim3(256), 0, st, (const float*)q->part32, ipass, ipstride, q->r0, q->r1,
+                                       q->dots32, q->ss.dots_ts, p8, q->nb, 1, 1);
+                    AS_HIP(hipGetLastError());
+                }
+                return AS_OK;
+            }
             int64_t chunk = sp->dp;
             q->dots_half = q->half_enabled && q->ss.dots_rs == 4 ? 1 : 0;
             const int npass = gemm_chunks(sp->dp, &chunk, q->dots_half != 0);
@@ -1179,7 +1261,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
                 AS_HIP(hipGetLastError());
                 if (npass > 1) {
                     hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)nrb), dim3(256), 0, st, (const float*)q->part32, npass, pstride, q->r0, q->r1,
-                                       q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);
+                                       q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half, 0);
                     AS_HIP(hipGetLastError());
                 }
                 return AS_OK;
@@ -1196,7 +1278,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
                 }
                 const int64_t nrb = (rows + 31) / 32;
                 hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)nrb), dim3(256), 0, st, (const float*)q->part32, npass, pstride, q->r0, q->r1,
-                                   q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half);
+                                   q->dots32, q->ss.dots_ts, pre, q->nb, q->dots_half, 0);
                 AS_HIP(hipGetLastError());
                 return AS_OK;
             }

@@ -2133,6 +2133,92 @@ static bool host_query_digits(as_query* q, int64_t d) {
     return true;
 }
 
+// The batched pass on the int8 images (as_scan.hip, scan_gemm_kernel<..., I8>): the slots' queries quantised like the items --
+// the items' image layout, one row of dp8 * 2 bytes per slot, so that the kernel's query fragments are the item fragments'
+// counterparts -- with one coefficient for the pass: the largest u_q and v_q of its slots.  Idle slots: zero digits, scale 0.
+// False (the bf16 / fp32 pass serves the batch): no usable image, a slot that is zero or non-finite, a coefficient beyond 2e-3.
+static bool host_batch_digits(as_query* q, const double* query_host, int64_t d) {
+    const as_space* sp = q->sp;
+    if (getenv("ARROWSPACE_SCAN_FP32") || !q->hq8img || !q->half_enabled || q->ss.dots_rs != 4 || q->cap != 32 || sp->opts.force_exact) return false;
+    bool present = false;
+    if (space_i8_image(sp, &present) != AS_OK || !present) return false;
+    const int64_t dp8 = sp->dp8;
+    double umax = 0.0, vmax = 0.0;
+    memset(q->hq8img + (size_t)q->nb * dp8 * 2, 0, (size_t)(q->cap - q->nb) * dp8 * 2);
+    for (int b = 0; b < q->cap; ++b) q->hfaqv[b] = 0.0f;
+    // (loops shaped for the host compiler's vectoriser: 32 slots x 4 096 columns are 131 072 elements in front of every pass)
+    for (int b = 0; b < q->nb; ++b) {
+        const double* src = query_host + (int64_t)b * d;
+        float mm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double nn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t c = 0;
+        for (; c + 8 <= d; c += 8)
+            for (int j = 0; j < 8; ++j) {
+                const float v = (float)src[c + j];
+                const float av = std::fabs(v);
+                mm[j] = av > mm[j] ? av : mm[j];
+                nn[j] += (double)v * (double)v;
+            }
+        for (; c < d; ++c) {
+            const float v = (float)src[c];
+            const float av = std::fabs(v);
+            mm[0] = av > mm[0] ? av : mm[0];
+            nn[0] += (double)v * (double)v;
+        }
+        float m = 0.0f;
+        double nq = 0.0;
+        for (int j = 0; j < 8; ++j) {
+            m = std::max(m, mm[j]);
+            nq += nn[j];   // (a NaN element: nq is NaN and the test below sends the batch to the other pass)
+        }
+        if (!(m > 0.0f) || !(m < 3.0e38f) || !(nq > 0.0) || !(nq < 1.0e300)) return false;
+        const float inv = 16256.0f / m;
+        signed char* out = q->hq8img + (size_t)b * dp8 * 2;
+        double st2 = 0.0, sa2 = 0.0;
+        for (int64_t c0 = 0; c0 < dp8; c0 += 64) {
+            float vb[64];
+            const int64_t nc = std::min<int64_t>(64, d - c0);
+            for (int64_t j = 0; j < 64; ++j) vb[j] = j < nc ? (float)src[c0 + j] : 0.0f;
+            signed char* o1 = out + (c0 >> 6) * 128;
+            signed char* o2 = o1 + 64;
+            float st = 0.0f;
+            int sa = 0;
+            for (int j = 0; j < 64; ++j) {
+                const float sc = vb[j] * inv;
+                const float r = (sc + 12582912.0f) - 12582912.0f;   // round to nearest even: |sc| <= 16256 * (1 + 2^-23)
+                int qq = (int)r;
+                qq = qq > 16256 ? 16256 : (qq < -16256 ? -16256 : qq);
+                const int q2 = ((qq + 64 + (1 << 20)) & 127) - 64;
+                const int q1 = (qq - q2) >> 7;
+                const float th = std::fabs(sc - (float)qq) + 0.004f;
+                st += th * th;
+                sa += q2 * q2;
+                o1[j] = (signed char)q1;
+                o2[j] = (signed char)q2;
+            }
+            st2 += (double)st * 1.00001;   // (64 fp32 additions)
+            sa2 += (double)sa;
+        }
+        const double n2 = std::sqrt(nq);
+        umax = std::max(umax, (double)m * std::sqrt(st2) / (16256.0 * n2) * 1.001);
+        vmax = std::max(vmax, (double)m * std::sqrt(sa2) / (16256.0 * n2) * 1.001);
+        q->hfaqv[b] = m * (11.313708498984761f / 16256.0f);
+    }
+    // the rounding to fp32 of 128 * acc1 + accx, three additions of the waves' quarters, P - 1 of the passes' partials, two
+    // multiplications by the scales, the scales' own roundings (two each)
+    int64_t chunk = 0;
+    const int P = gemm_chunks(dp8 / 2, &chunk, true);
+    const double coef = umax + 1.001 * sp->u8max + vmax * sp->v8max + (double)(12 + P) * 5.9604644775390625e-8;
+    if (!(coef <= 2.0e-3)) return false;
+    q->coef_i8 = coef;
+    if (hipMemcpyAsync(q->q8img_dev, q->hq8img, (size_t)q->cap * dp8 * 2, hipMemcpyHostToDevice, q->stream) != hipSuccess ||
+        hipMemcpyAsync(q->faqv_dev, q->hfaqv, sizeof(float) * q->cap, hipMemcpyHostToDevice, q->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
 static as_status query_begin(as_query* q, const double* query_host, int64_t src_row, int64_t d, int64_t r0, int64_t r1,
                              double eps, int64_t exclude) {
     const as_space* sp = q->sp;
@@ -2187,6 +2273,7 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     } else {
         hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->hq_dev);
     }
+    if (query_host && q->cap > 1 && !q->exact && !feature) q->i8_scan = host_batch_digits(q, query_host, d) ? 1 : 0;
     const int nslots = q->cap > 1 ? q->cap : q->nb;
     // feature mode: lambda_q is a functional of the query alone (SPEC F6/F7) -- no neighbour search, no prefilter, and
     // it is computed by the staging kernel itself
@@ -2348,6 +2435,14 @@ static as_status query_alloc(as_query* q) {
     // (on the query's own stream: it is non-blocking, a memset on the null stream may run LATER than the first search)
     AS_HIP(hipMemsetAsync(q->info, 0, sizeof(QInfo) * C, q->stream));
     AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE) * C));
+    if (C == 32) {   // batched workspace: the slots' int8 image (staging and device copy) and scales
+        const size_t dp8 = (size_t)(sp->dp + 63) / 64 * 64;
+        AS_HIP(hipHostMalloc(&q->hq8img, dp8 * 2 * C, hipHostMallocDefault));
+        memset(q->hq8img, 0, dp8 * 2 * C);
+        AS_HIP(hipHostMalloc(&q->hfaqv, sizeof(float) * C, hipHostMallocDefault));
+        AS_HIP(hipMalloc(&q->q8img_dev, dp8 * 2 * C));
+        AS_HIP(hipMalloc(&q->faqv_dev, sizeof(float) * C));
+    }
     if (C > 1 && C % 4 == 0) {   // batched workspace: the K-chunk passes' partial dots of rows wider than 768 floats
         int64_t chunk = 0;
         const int npass = gemm_chunks(sp->dp, &chunk, false);   // (sized for the fp32 form: the most passes either form takes)
@@ -2409,6 +2504,10 @@ void as_query_free(as_query* q) {
     if (q->hq) hipHostFree(q->hq);
     if (q->hq32) hipHostFree(q->hq32);
     if (q->hq8) hipHostFree(q->hq8);
+    if (q->hq8img) hipHostFree(q->hq8img);
+    if (q->hfaqv) hipHostFree(q->hfaqv);
+    if (q->q8img_dev) hipFree(q->q8img_dev);
+    if (q->faqv_dev) hipFree(q->faqv_dev);
     hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32); hipFree(q->part32);
     if (q->dots64) hipFree(q->dots64);
     hipFree(q->pkey); hipFree(q->pidx); hipFree(q->ckey_k); hipFree(q->cidx_k); hipFree(q->ckey_s); hipFree(q->cidx_s);

@@ -120,6 +120,7 @@ def test_search_batch_matches_single_and_oracle(oracle_lib, metric, d):
     for tau in (0.62, 1.0):
         got = aspace.search_batch(Q, gl, tau)
         assert len(got) == 45
+        assert aspace.last_batch_int8          # clustered rows: the int8 images serve the pass (three i8 products per column)
         for b in range(45):
             want, lq = ref.search(Q[b], tau)
             assert_hits_match(got[b], want, ref.scores(Q[b], tau, lq), rtol=RTOL)
