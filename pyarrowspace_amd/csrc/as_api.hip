@@ -798,20 +798,29 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
         if (s0 != AS_OK) return drain(s0);
     }
     int64_t pass = 0;
+    static const bool timing = getenv("ARROWSPACE_DEBUG") != nullptr;   // host time of the two halves of a pass, per call
+    double t_launch = 0.0, t_collect = 0.0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int64_t i0 = 0; i0 < b; i0 += QUERY_BATCH, ++pass) {
         const int nb = (int)std::min<int64_t>(QUERY_BATCH, b - i0);
         if (batched) {
             as_query* cur = ws[pass & 1];
             as_status s = AS_OK;
+            const double t0 = timing ? now() : 0.0;
             if (piped) {
                 const int64_t i1 = i0 + QUERY_BATCH;
                 if (i1 < b) s = search_batch_launch(ws[(pass + 1) & 1], queries + i1 * d, (int)std::min<int64_t>(QUERY_BATCH, b - i1), d, tau);
             } else {
                 s = search_batch_launch(cur, queries + i0 * d, nb, d, tau);
             }
+            const double t1 = timing ? now() : 0.0;
             if (s == AS_OK)
                 s = search_batch_collect(cur, nb, tau, topk, out_idx + i0 * topk, out_score + i0 * topk, out_len + i0,
                                          out_lambda_q ? out_lambda_q + i0 : nullptr, st_chunk);
+            if (timing) {
+                t_launch += t1 - t0;
+                t_collect += now() - t1;
+            }
             if (s != AS_OK) return drain(s);
         } else {
             for (int t = 0; t < nb; ++t) st_chunk[t] = -1;
@@ -829,6 +838,8 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
             if (out_status) out_status[i] = st_chunk[t];
         }
     }
+    if (timing && batched) dbg("as_search_batch: %lld passes, host time per pass: launch half %.0f us, collect half (with its wait) %.0f us",
+                               (long long)pass, t_launch / std::max<int64_t>(pass, 1), t_collect / std::max<int64_t>(pass, 1));
     return AS_OK;
 }
 

@@ -140,10 +140,8 @@ struct as_query {
     int* hq8 = nullptr;
     int* hq8_dev = nullptr;
     // batched workspace: the int8 image of the slots' queries (the items' image layout, [slots][dp8 * 2 bytes]) and their scales,
-    // quantised by the host into pinned staging and copied in front of the scan
-    signed char* hq8img = nullptr;
+    // quantised on the device behind the staging kernel (q_quant_batch_kernel)
     signed char* q8img_dev = nullptr;
-    float* hfaqv = nullptr;
     float* faqv_dev = nullptr;
     float h_faq = 0.0f;
     double coef_i8 = 0.0;

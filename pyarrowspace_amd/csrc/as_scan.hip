@@ -294,7 +294,7 @@ __device__ __forceinline__ void split_bf16(const f32x4& a, const f32x4& b, bf16x
 // three v_mfma_f32_32x32x16_bf16 per 16 columns instead of eight v_mfma_f32_32x32x2_f32; bf16 x bf16 is exact in the fp32
 // accumulator, what is dropped (ql.xl and the two remainders) is at most 3 * 2^-16 |q_k x_k| per term (coef_query).
 // I8: items and queries as int8 two-digit images (as_k2bf.hip, quant_i8_kernel; the queries' image by the host,
-// host_batch_digits): a slab row is 64 columns (64 bytes of a1, 64 of a2) -- HALF the bytes of the fp32 items --, `dp` the image
+// q_quant_batch_kernel in as_search.hip): a slab row is 64 columns (64 bytes of a1, 64 of a2) -- HALF the bytes of the fp32 items --, `dp` the image
 // row in floats, the chunk addressing that of the fp32 slab; three v_mfma_i32_32x32x32_i8 per 32 columns into two int32
 // accumulators (q1.a1 and the cross terms), scaled by the rows' and the slots' factors in the epilogue.
 template <int NBUF, int DIAG, int AUX, bool BF3 = false, int NSW = GEMM_NSW, bool I8 = false>
@@ -1077,7 +1077,7 @@ int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products) {
 double coef_query(const as_query* q, bool exact) {
     // single query scanned on the int8 two-digit image: |dot - x.q| <= |x||q| (u_q + U + v_q V) + four fp32 roundings of the
     // scaling -- the query's own measured residue norms with the items' maxima (query_begin forms it per query)
-    if (!exact && q->i8_scan) return q->coef_i8;   // (batched workspace: the slots' largest residue norms, host_batch_digits)
+    if (!exact && q->i8_scan) return q->coef_i8;   // (batched workspace: an a-priori bound from the slots' s_q / |q|, host_batch_coef)
     const double u = exact ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
     const int64_t dp = q->sp->dp;
     if (!exact && q->cap > 1) {

@@ -86,6 +86,33 @@ __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int6
     }
 }
 
+// The batched pass on the int8 images: the slots' staged fp32 queries quantised like the items (as_k2bf.hip, quant_i8_kernel) into
+// the items' image layout -- a block per slot; idle slots (zero queries) get zero digits and scale 0.
+__global__ __launch_bounds__(256) void q_quant_batch_kernel(const float* __restrict__ q32, int64_t dp, int64_t dp8, signed char* __restrict__ img,
+                                                            float* __restrict__ faqv) {
+    __shared__ float sh[4];
+    const float* x = q32 + (int64_t)blockIdx.x * dp;
+    float m = 0.0f;
+    for (int64_t c = threadIdx.x; c < dp; c += 256) m = fmaxf(m, fabsf(x[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    const float inv = m > 0.0f ? 16256.0f / m : 0.0f;
+    signed char* dst = img + (int64_t)blockIdx.x * dp8 * 2;
+    for (int64_t c = threadIdx.x; c < dp8; c += 256) {
+        const float v = c < dp ? x[c] : 0.0f;
+        int q = (int)rintf(v * inv);
+        q = q > 16256 ? 16256 : (q < -16256 ? -16256 : q);
+        const int a2 = ((q + 64 + (1 << 20)) & 127) - 64;
+        const int a1 = (q - a2) >> 7;
+        dst[(c >> 6) * 128 + (c & 63)] = (signed char)a1;
+        dst[(c >> 6) * 128 + 64 + (c & 63)] = (signed char)a2;
+    }
+    if (threadIdx.x == 0) faqv[blockIdx.x] = m * (11.313708498984761f / 16256.0f);   // s_q sqrt(128) / 16256
+}
+
 // |q|^2 exactly as q_prepare_kernel forms it (256 strided partial sums, rounded products and sums, then the halving
 // tree): the host-prepared fast path and the staged / batched paths must give a query the same norm, bit for bit.
 // (No fma on either side: std::fma without -mfma is a library call, 6 us for 768 elements.)
@@ -2133,89 +2160,50 @@ static bool host_query_digits(as_query* q, int64_t d) {
     return true;
 }
 
-// The batched pass on the int8 images (as_scan.hip, scan_gemm_kernel<..., I8>): the slots' queries quantised like the items --
-// the items' image layout, one row of dp8 * 2 bytes per slot, so that the kernel's query fragments are the item fragments'
-// counterparts -- with one coefficient for the pass: the largest u_q and v_q of its slots.  Idle slots: zero digits, scale 0.
+// The batched pass on the int8 images (as_scan.hip, scan_gemm_kernel<..., I8>): the slots' queries are quantised like the items
+// by q_quant_batch_kernel, behind the staging kernel.  The host only bounds the error coefficient of the pass A PRIORI, from
+// the slots' largest element s_q and norm |q| (one read of the queries -- 32 x 4 096 elements quantised on the host took
+// 150 us in front of every pass): |theta_c| <= 1/2 + 0.004 and |q2_c| <= 64 over the d columns, so
+//   u_q <= s_q 0.504 sqrt(d) / (16256 |q|),   v_q <= s_q 64 sqrt(d) / (16256 |q|)
+// (1.7 times the measured u_q of a clustered unit query -- 1.1e-4 against 6e-5 at d = 768).
 // False (the bf16 / fp32 pass serves the batch): no usable image, a slot that is zero or non-finite, a coefficient beyond 2e-3.
-static bool host_batch_digits(as_query* q, const double* query_host, int64_t d) {
+static bool host_batch_coef(as_query* q, const double* query_host, int64_t d) {
     const as_space* sp = q->sp;
-    if (getenv("ARROWSPACE_SCAN_FP32") || !q->hq8img || !q->half_enabled || q->ss.dots_rs != 4 || q->cap != 32 || sp->opts.force_exact) return false;
+    if (getenv("ARROWSPACE_SCAN_FP32") || !q->q8img_dev || !q->half_enabled || q->ss.dots_rs != 4 || q->cap != 32 || sp->opts.force_exact) return false;
     bool present = false;
     if (space_i8_image(sp, &present) != AS_OK || !present) return false;
-    const int64_t dp8 = sp->dp8;
-    double umax = 0.0, vmax = 0.0;
-    memset(q->hq8img + (size_t)q->nb * dp8 * 2, 0, (size_t)(q->cap - q->nb) * dp8 * 2);
-    for (int b = 0; b < q->cap; ++b) q->hfaqv[b] = 0.0f;
-    // (loops shaped for the host compiler's vectoriser: 32 slots x 4 096 columns are 131 072 elements in front of every pass)
+    double rmax = 0.0;   // the slots' largest s_q / |q|
     for (int b = 0; b < q->nb; ++b) {
         const double* src = query_host + (int64_t)b * d;
-        float mm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double nn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double mm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int64_t c = 0;
         for (; c + 8 <= d; c += 8)
             for (int j = 0; j < 8; ++j) {
-                const float v = (float)src[c + j];
-                const float av = std::fabs(v);
+                const double v = src[c + j], av = std::fabs(v);
                 mm[j] = av > mm[j] ? av : mm[j];
-                nn[j] += (double)v * (double)v;
+                nn[j] += v * v;
             }
         for (; c < d; ++c) {
-            const float v = (float)src[c];
-            const float av = std::fabs(v);
+            const double v = src[c], av = std::fabs(v);
             mm[0] = av > mm[0] ? av : mm[0];
-            nn[0] += (double)v * (double)v;
+            nn[0] += v * v;
         }
-        float m = 0.0f;
-        double nq = 0.0;
+        double m = 0.0, nq = 0.0;
         for (int j = 0; j < 8; ++j) {
             m = std::max(m, mm[j]);
             nq += nn[j];   // (a NaN element: nq is NaN and the test below sends the batch to the other pass)
         }
-        if (!(m > 0.0f) || !(m < 3.0e38f) || !(nq > 0.0) || !(nq < 1.0e300)) return false;
-        const float inv = 16256.0f / m;
-        signed char* out = q->hq8img + (size_t)b * dp8 * 2;
-        double st2 = 0.0, sa2 = 0.0;
-        for (int64_t c0 = 0; c0 < dp8; c0 += 64) {
-            float vb[64];
-            const int64_t nc = std::min<int64_t>(64, d - c0);
-            for (int64_t j = 0; j < 64; ++j) vb[j] = j < nc ? (float)src[c0 + j] : 0.0f;
-            signed char* o1 = out + (c0 >> 6) * 128;
-            signed char* o2 = o1 + 64;
-            float st = 0.0f;
-            int sa = 0;
-            for (int j = 0; j < 64; ++j) {
-                const float sc = vb[j] * inv;
-                const float r = (sc + 12582912.0f) - 12582912.0f;   // round to nearest even: |sc| <= 16256 * (1 + 2^-23)
-                int qq = (int)r;
-                qq = qq > 16256 ? 16256 : (qq < -16256 ? -16256 : qq);
-                const int q2 = ((qq + 64 + (1 << 20)) & 127) - 64;
-                const int q1 = (qq - q2) >> 7;
-                const float th = std::fabs(sc - (float)qq) + 0.004f;
-                st += th * th;
-                sa += q2 * q2;
-                o1[j] = (signed char)q1;
-                o2[j] = (signed char)q2;
-            }
-            st2 += (double)st * 1.00001;   // (64 fp32 additions)
-            sa2 += (double)sa;
-        }
-        const double n2 = std::sqrt(nq);
-        umax = std::max(umax, (double)m * std::sqrt(st2) / (16256.0 * n2) * 1.001);
-        vmax = std::max(vmax, (double)m * std::sqrt(sa2) / (16256.0 * n2) * 1.001);
-        q->hfaqv[b] = m * (11.313708498984761f / 16256.0f);
+        if (!(m > 1.0e-30) || !(m < 3.0e38) || !(nq > 0.0) || !(nq < 1.0e300)) return false;
+        rmax = std::max(rmax, m / std::sqrt(nq));
     }
-    // the rounding to fp32 of 128 * acc1 + accx, three additions of the waves' quarters, P - 1 of the passes' partials, two
-    // multiplications by the scales, the scales' own roundings (two each)
+    // (1.001: the queries' rounding to fp32 in s_q and |q|) + the rounding to fp32 of 128 * acc1 + accx, three additions of the
+    // waves' quarters, P - 1 of the passes' partials, two multiplications by the scales, the scales' own roundings (two each)
     int64_t chunk = 0;
-    const int P = gemm_chunks(dp8 / 2, &chunk, true);
-    const double coef = umax + 1.001 * sp->u8max + vmax * sp->v8max + (double)(12 + P) * 5.9604644775390625e-8;
+    const int P = gemm_chunks(sp->dp8 / 2, &chunk, true);
+    const double sd = std::sqrt((double)d) / 16256.0 * 1.001;
+    const double coef = rmax * 0.504 * sd + 1.001 * sp->u8max + rmax * 64.0 * sd * sp->v8max + (double)(12 + P) * 5.9604644775390625e-8;
     if (!(coef <= 2.0e-3)) return false;
     q->coef_i8 = coef;
-    if (hipMemcpyAsync(q->q8img_dev, q->hq8img, (size_t)q->cap * dp8 * 2, hipMemcpyHostToDevice, q->stream) != hipSuccess ||
-        hipMemcpyAsync(q->faqv_dev, q->hfaqv, sizeof(float) * q->cap, hipMemcpyHostToDevice, q->stream) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
     return true;
 }
 
@@ -2245,7 +2233,11 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     // memory and files the norms, the kernels behind it read the fp64 query from the pinned buffer: the staging kernel
     // and the idle gap behind it (6 + 5 us in front of every scan) are gone.
     static const bool no_hostq = getenv("ARROWSPACE_NO_HOSTQ") != nullptr;
-    if (query_host && q->cap == 1 && !q->exact && !feature && sp->dp <= 1024 && !(q->scan_variant & 4) && q->hq32 && !no_hostq) {
+    // Rows of 1025 .. 2048 floats: their int8 image is a row of at most 1024 image floats -- the same scan, when the image serves
+    // this query; otherwise the generic path below (and no fused tail: search_once reads q->fused_tail back).
+    const bool narrow = sp->dp <= 1024, wide8 = !narrow && (sp->dp + 63) / 64 * 64 <= 2048;
+    bool host_path = query_host && q->cap == 1 && !q->exact && !feature && (narrow || wide8) && !(q->scan_variant & 4) && q->hq32 && !no_hostq;
+    if (host_path) {
         for (int64_t c = 0; c < d; ++c) {
             const double v = query_host[c];
             q->hq[c] = v;
@@ -2253,8 +2245,12 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         }
         q->h_nq = host_query_norm(query_host, d);
         q->h_inq = q->h_nq > 0.0 ? 1.0 / sqrt(q->h_nq) : 0.0;
-        q->host_q = 1;
         q->i8_scan = host_query_digits(q, d) ? 1 : 0;
+        if (!narrow && !q->i8_scan) host_path = false;
+    }
+    if (!host_path && !narrow) q->fused_tail = 0;
+    if (host_path) {
+        q->host_q = 1;
         q->q64_src = q->hq_dev;
         q->q32_src = q->hq32_dev;
         if (!q->info_clean) hipLaunchKernelGGL(reset_info_kernel, dim3(1), dim3(64), 0, st, q->info, q->sc_hist);
@@ -2273,12 +2269,14 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     } else {
         hipLaunchKernelGGL(q_from_row_kernel, dim3(1), dim3(256), 0, st, sp->x32, sp->x64, sp->d, sp->dp, src_row, q->hq_dev);
     }
-    if (query_host && q->cap > 1 && !q->exact && !feature) q->i8_scan = host_batch_digits(q, query_host, d) ? 1 : 0;
+    if (query_host && q->cap > 1 && !q->exact && !feature) q->i8_scan = host_batch_coef(q, query_host, d) ? 1 : 0;
     const int nslots = q->cap > 1 ? q->cap : q->nb;
     // feature mode: lambda_q is a functional of the query alone (SPEC F6/F7) -- no neighbour search, no prefilter, and
     // it is computed by the staging kernel itself
     if (feature) AS_TRY(feat_query_prepare(q->gr, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, nslots, st));
     else hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, nslots), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
+    if (q->i8_scan && q->cap > 1)
+        hipLaunchKernelGGL(q_quant_batch_kernel, dim3((unsigned)q->cap), dim3(256), 0, st, (const float*)q->q32, sp->dp, sp->dp8, q->q8img_dev, q->faqv_dev);
     if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
     const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !feature && !q->crowded_direct);
     AS_TRY(launch_scan(q, pre));
@@ -2435,11 +2433,8 @@ static as_status query_alloc(as_query* q) {
     // (on the query's own stream: it is non-blocking, a memset on the null stream may run LATER than the first search)
     AS_HIP(hipMemsetAsync(q->info, 0, sizeof(QInfo) * C, q->stream));
     AS_HIP(hipMalloc(&q->dots32, sizeof(float) * (sp->np + ROW_TILE) * C));
-    if (C == 32) {   // batched workspace: the slots' int8 image (staging and device copy) and scales
+    if (C == 32) {   // batched workspace: the slots' int8 image and scales (q_quant_batch_kernel)
         const size_t dp8 = (size_t)(sp->dp + 63) / 64 * 64;
-        AS_HIP(hipHostMalloc(&q->hq8img, dp8 * 2 * C, hipHostMallocDefault));
-        memset(q->hq8img, 0, dp8 * 2 * C);
-        AS_HIP(hipHostMalloc(&q->hfaqv, sizeof(float) * C, hipHostMallocDefault));
         AS_HIP(hipMalloc(&q->q8img_dev, dp8 * 2 * C));
         AS_HIP(hipMalloc(&q->faqv_dev, sizeof(float) * C));
     }
@@ -2504,8 +2499,6 @@ void as_query_free(as_query* q) {
     if (q->hq) hipHostFree(q->hq);
     if (q->hq32) hipHostFree(q->hq32);
     if (q->hq8) hipHostFree(q->hq8);
-    if (q->hq8img) hipHostFree(q->hq8img);
-    if (q->hfaqv) hipHostFree(q->hfaqv);
     if (q->q8img_dev) hipFree(q->q8img_dev);
     if (q->faqv_dev) hipFree(q->faqv_dev);
     hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32); hipFree(q->part32);
@@ -2574,12 +2567,13 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
     // scorer's candidates by its cosine bound, as on one GPU (search_once), and ONE kernel does the step between the two
     // exchanges (staged_score_kernel).
     const bool sc = q->staged_tau >= 0.4 && q->staged_tau <= 1.0 && q->gr->lambda_mode != AS_LAMBDA_FEATURE && !q->robust && !q->exact &&
-                    !q->no_fused && q->cap == 1 && q->sc_widx && q->sp->dp <= 1024 && !(q->scan_variant & 4) && !q->crowded_direct;
+                    !q->no_fused && q->cap == 1 && q->sc_widx && q->sp->dp <= 2048 && !(q->scan_variant & 4) && !q->crowded_direct;
     q->fused_tail = sc ? 1 : 0;
     q->tau_cur = q->staged_tau;
     const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
+    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
     q->fused_tail = 0;
-    q->staged_sc = sc && qb == AS_OK && row_end > row_begin ? 1 : 0;
+    q->staged_sc = sc_ran && qb == AS_OK && row_end > row_begin ? 1 : 0;
     AS_TRY(qb);
     if (q->gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // lambda_q is already there; the k-NN records stay empty
     return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -2794,11 +2788,12 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     // whose candidates overflow the buffer falls back to the threshold chain over the kept dots, and the following 63
     // queries take that chain directly.
     const bool sc_skip = q->sc_crowded > 0 && (q->sc_crowded++ & 63) != 0;
-    const bool fused = !feature && !q->robust && !q->exact && !direct && !q->no_fused && !sc_skip && q->cap == 1 && tau >= 0.4 && tau <= 1.0 &&
-                       q->sp->dp <= 1024 && !(q->scan_variant & 4);
-    q->fused_tail = fused ? 1 : 0;
+    const bool want_fused = !feature && !q->robust && !q->exact && !direct && !q->no_fused && !sc_skip && q->cap == 1 && tau >= 0.4 && tau <= 1.0 &&
+                            q->sp->dp <= 2048 && !(q->scan_variant & 4);
+    q->fused_tail = want_fused ? 1 : 0;
     q->tau_cur = tau;
     const as_status qb = query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1);
+    const bool fused = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
     q->crowded_direct = 0;
     q->fused_tail = 0;
     AS_TRY(qb);
