@@ -109,7 +109,7 @@ def traffic(fetch_csv, write_csv, n, d, out):
         if not fk:
             continue
         k = max(fk, key=lambda name: f[name])   # (the main pass of the build, not its threshold pass)
-        doc[key] = {"fetch_kib": f[k], "write_kib": w.get(k, 0.0), "bytes_per_launch": int((2.0 * f[k] + w.get(k, 0.0)) * 1024)}
+        doc[key] = {"kernel": k, "fetch_kib": f[k], "write_kib": w.get(k, 0.0), "bytes_per_launch": int((2.0 * f[k] + w.get(k, 0.0)) * 1024)}
     if "knn_bf16_kernel" in doc:
         doc["knn_bf16_kernel"]["note"] = ("fabric-side requests of the symmetric main pass (bf16 head + tail kernel); Infinity-Cache hits are "
                                           "counted (MI355X_MICROARCH.md HBM section)")

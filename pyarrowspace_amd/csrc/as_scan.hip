@@ -1159,6 +1159,10 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_dma_kernel<4, 4>), dma_lds(4, 4));
     AS_ATTR((scan_dma_kernel<1, 8, false, true>), dma_lds(1, 8, false, true));
     AS_ATTR((scan_dma_kernel<2, 4, false, true>), dma_lds(2, 4, false, true));
+    AS_ATTR((scan_dma_kernel<2, 6, false, true>), dma_lds(2, 6, false, true));
+    AS_ATTR((scan_dma_kernel<2, 8, false, true>), dma_lds(2, 8, false, true));
+    AS_ATTR((scan_dma_kernel<2, 6, true, true>), dma_lds(2, 6, true, true));
+    AS_ATTR((scan_dma_kernel<2, 8, true, true>), dma_lds(2, 8, true, true));
     AS_ATTR((scan_dma_kernel<3, 5, false, true>), dma_lds(3, 5, false, true));
     AS_ATTR((scan_dma_kernel<4, 4, false, true>), dma_lds(4, 4, false, true));
     AS_ATTR((scan_dma_kernel<1, 8, true, true>), dma_lds(1, 8, true, true));
@@ -1348,21 +1352,30 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             // (ring of 4 two-KiB slots, or of 8 one-KiB slots) -- 400k x 384: 105 -> 99 us, x 256: 78.5 -> 75.7, x 512: 141 -> 137.
             // (measurement: ARROWSPACE_SCAN_GEOM=<blocks per CU><ring slots> for rows up to 512 floats, e.g. 28 = the old form)
             static const int geom = getenv("ARROWSPACE_SCAN_GEOM") ? atoi(getenv("ARROWSPACE_SCAN_GEOM")) : 0;
-            const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : 4, 4)) : 2;   // (<= 4: the wave reports are sized for 16 waves per CU)
+            // The int8 image at 2 chunks per lane (rows of 257 .. 512 image floats = 513 .. 1 024 columns): 2 blocks per CU -- 1M x 768
+            // 0.270 -> 0.255 ms, 200k x 768 57.3 -> 55.8 us, 1M x 512 196 -> 190 us; 1 block 0.357 ms, rings of 6 / 8 slots 0.264 / 0.265 ms
+            // (tools/scan_geom.sh); at 1 chunk per lane 4 blocks stay ahead (400k x 384: 64 us against 84 us with 2).
+            const int bpc_default = i8 && nch == 2 ? 2 : 4;
+            const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : 2;   // (<= 4: the wave reports are sized for 16 waves per CU)
             const int64_t nblk = std::min<int64_t>(want, bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
             q->sc_nw = (int)NW;
             const int rounds = (int)(rows / (NW * 64));
             const int64_t rem = rows - (int64_t)rounds * NW * 64;
             const int tail_rows = (int)((rem + NW - 1) / NW);
+#define AS_DSCAN8(N, S)                                                                                                \
+    do {                                                                                                               \
+        if (pre.sc_enabled)                                                                                            \
+            hipLaunchKernelGGL((scan_dma_kernel<N, S, true, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, S, true, true), st, \
+                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
+        else                                                                                                           \
+            hipLaunchKernelGGL((scan_dma_kernel<N, S, false, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, S, false, true), st, \
+                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
+    } while (0)
 #define AS_DSCAN(N, S)                                                                                                 \
     do {                                                                                                               \
-        if (i8 && pre.sc_enabled)                                                                                      \
-            hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), true, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), true, true), st, \
-                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
-        else if (i8)                                                                                                   \
-            hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), false, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), false, true), st, \
-                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
+        if (i8)                                                                                                        \
+            AS_DSCAN8(N, (N == 2 ? 4 : S));                                                                            \
         else if (pre.sc_enabled)   /* (rows of up to 512 floats: the fused form exists with the ring of 4 only) */          \
             hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), true), st, \
                                sp->x32, q->q32_src, sp->dp, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);          \
@@ -1373,7 +1386,9 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             switch (nch) {
                 case 1: AS_DSCAN(1, 8); break;
                 case 2:
-                    if (i8) AS_DSCAN(2, 4);
+                    if (i8 && geom % 10 == 6) AS_DSCAN8(2, 6);
+                    else if (i8 && geom % 10 == 8) AS_DSCAN8(2, 8);
+                    else if (i8) AS_DSCAN(2, 4);
                     else if (geom % 10 == 5) AS_DSCAN(2, 5);
                     else if (geom % 10 == 8) AS_DSCAN(2, 8);
                     else AS_DSCAN(2, 4);
@@ -1382,6 +1397,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
                 default: AS_DSCAN(4, 4); break;
             }
 #undef AS_DSCAN
+#undef AS_DSCAN8
             AS_HIP(hipGetLastError());
             return AS_OK;
         }
