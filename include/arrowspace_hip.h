@@ -304,13 +304,31 @@ as_status as_query_finish_batch(as_query* q, const as_hit_rec* hits_dev, int32_t
  * (knn_inexact: the k-NN buffer, score_inexact: the scorer's). */
 void as_query_set_exact(as_query* q, int32_t flags);
 as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score_inexact);
+/* ONE exchange per sharded query (tau in [0.4, 1], item-graph lambda; as_query_x1_usable says so, identically on every rank):
+ * as_query_x1_begin scans this rank's rows and finishes what only this rank can finish -- its k exact nearest rows (records)
+ * and the exact cosine and lambda of every row its scan kept as a scorer candidate -- into ONE block of as_query_x1_bytes
+ * bytes at send_dev (device memory of the caller: an all-gather send buffer); the host all-gathers the blocks of the `world`
+ * ranks in rank order; as_query_x1_finish forms lambda_q, scores and ranks every rank's candidates (identically on every rank)
+ * and copies the answer out.  Afterwards as_query_flags as after as_query_finish; as_query_x1_redo != 0: some rank's candidates
+ * did not fit its block (or it had none to offer): run the query again through as_query_scan / _lambda / _score / _finish.
+ * as_query_search_staged takes this pass by itself (ARROWSPACE_STAGED_X1=0: never).
+ * Serves PyArrowSpace::search, /root/reference/src/lib.rs:132-174, on a row-sharded index. */
+int64_t as_query_x1_bytes(const as_query* q, int32_t world);
+int32_t as_query_x1_usable(const as_query* q, double tau);
+as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end, double tau, void* send_dev,
+                            int32_t world);
+as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, double tau, int64_t* out_idx, double* out_score, int64_t* out_len,
+                             double* out_lambda_q);
+int32_t as_query_x1_redo(const as_query* q);
+int64_t as_query_x1_passes(const as_query* q);   /* one-exchange passes this workspace has finished */
 /* The per-query exchange steps issued by the library itself (RCCL on the query's stream; librccl is taken from the
  * process or /opt/rocm/lib by dlopen -- as_comm_available() == 0 on a box without it).  The ranks of an index share one
  * communicator: rank 0 draws an id (as_comm_unique_id: 128 bytes), the host hands it to every rank (any broadcast),
  * every rank calls as_comm_create (collective).  as_query_set_comm binds a single-query workspace to it;
- * as_query_search_staged is then ONE host call per query: scan of this rank's rows, all-gather of the k-NN records,
- * lambda_q, scorer, all-gather of the hit records, merge, and the escalation to the exact paths (every rank with the
- * same query and tau; same results and errors as as_search on one space holding every item).
+ * as_query_search_staged is then ONE host call per query: the one-exchange pass above where it applies, else scan of this
+ * rank's rows, all-gather of the k-NN records, lambda_q, scorer, all-gather of the hit records, merge; and the escalation to
+ * the exact paths (every rank with the same query and tau; same results and errors as as_search on one space holding
+ * every item).
  * Serves PyArrowSpace::search, /root/reference/src/lib.rs:132-174, on a row-sharded index. */
 typedef struct as_comm as_comm;
 int32_t as_comm_available(void);

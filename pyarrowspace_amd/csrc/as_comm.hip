@@ -9,6 +9,7 @@
 // /opt/rocm/lib, by dlopen -- the library keeps working, single-GPU, on a box without it.
 // Reference path this serves: PyArrowSpace::search, /root/reference/src/lib.rs:132-174 (one query per call).
 #include <dlfcn.h>
+#include <chrono>
 #include <unistd.h>
 
 #include <string>
@@ -148,6 +149,13 @@ as_status as_query_set_comm(as_query* q, as_comm* c) {
     q->hits_all = nullptr;
     AS_HIP(hipMalloc(&q->knn_all, sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1) * c->world));
     AS_HIP(hipMalloc(&q->hits_all, sizeof(as_hit_rec) * (q->topk + 1) * c->world));
+    // the one-exchange pass: this rank's block (k-NN records, header, finished scorer candidates) and the gathered blocks
+    if (q->xsend) hipFree(q->xsend);
+    if (q->xall) hipFree(q->xall);
+    q->xsend = q->xall = nullptr;
+    const int64_t xb = as_query_x1_bytes(q, c->world);
+    AS_HIP(hipMalloc(&q->xsend, (size_t)xb));
+    AS_HIP(hipMalloc(&q->xall, (size_t)xb * c->world));
     q->comm = c;
     return AS_OK;
 }
@@ -172,6 +180,61 @@ as_status as_query_search_staged(as_query* q, const double* query_host, int64_t 
     bool sc = !(q->sc_crowded > 0 && (q->sc_crowded++ & 63) != 0);
     for (int pass = 0; pass < 9; ++pass) {
         as_query_set_exact(q, mode);
+        if (sc && mode == 0 && q->xsend && as_query_x1_usable(q, tau)) {
+            // ONE exchange: every rank's k-NN records and finished scorer candidates (exact cosine, lambda) in one all-gather;
+            // lambda_q, the scores and the ranking redundantly on every rank (as_search.hip, staged_x1_kernel).  3 launches
+            // behind the scan and one collective, against 5 and two.
+            const int64_t xb = as_query_x1_bytes(q, c->world);
+            static const bool timing = getenv("ARROWSPACE_DEBUG") != nullptr;   // host time of the pass's three parts, every 100 passes
+            static double t_acc[3] = {0, 0, 0};
+            static int t_n = 0;
+            auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            const double t0 = timing ? now() : 0.0;
+            as_status local = as_query_x1_begin(q, query_host, d, row_begin, row_end, tau, q->xsend, c->world);
+            std::string local_msg = local != AS_OK ? err_slot() : std::string();
+            if (local != AS_OK) (void)hipMemsetAsync(q->xsend, 0xff, (size_t)xb, q->stream);   // a failed rank's block: no records, flag bits all set
+            const double t1 = timing ? now() : 0.0;
+            AS_TRY(nccl_check(r->all_gather(q->xsend, q->xall, (size_t)xb, NCCL_CHAR, c->comm, q->stream), "ncclAllGather (one-exchange block)"));
+            const double t2 = timing ? now() : 0.0;
+            st = as_query_x1_finish(q, q->xall, c->world, tau, out_idx, out_score, out_len, out_lambda_q);
+            if (timing) {
+                t_acc[0] += t1 - t0;
+                t_acc[1] += t2 - t1;
+                t_acc[2] += now() - t2;
+                if (++t_n == 100) {
+                    dbg("one-exchange pass, host us: scan + block kernels enqueued %.1f, all-gather enqueued %.1f, finish kernel + wait %.1f",
+                        t_acc[0] / 100, t_acc[1] / 100, t_acc[2] / 100);
+                    t_acc[0] = t_acc[1] = t_acc[2] = 0.0;
+                    t_n = 0;
+                }
+            }
+            if (local != AS_OK) {
+                set_err("%s", local_msg.c_str());
+                return local;
+            }
+            if (st != AS_OK && st != AS_EZEROLAMBDA) return st;
+            if (q->hout->overflow & 8) {
+                set_err("as_query_search_staged: another rank of the index failed in this pass");
+                return AS_EHIP;
+            }
+            q->sc_crowded = (q->hout->overflow & 4) ? 1 : 0;
+            if ((q->hout->overflow & 4) && debug_enabled()) {
+                int hd[4] = {0, 0, 0, 0};
+                (void)hipMemcpy(hd, q->xall + sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1), sizeof(hd), hipMemcpyDeviceToHost);
+                dbg("one-exchange pass: redo (rank 0's block: %d candidates, flags %d, largest share of a candidate block %d, blocks with an overflowed report %d; merged overflow bits %d)",
+                    hd[0], hd[1], hd[2], hd[3], q->hout->overflow);
+            }
+            if (q->hout->overflow & 4) {   // some rank's candidates did not fit (or it had none to offer): the two-exchange chain
+                sc = false;
+                continue;
+            }
+            int32_t ki = 0, si = 0;
+            as_query_flags(q, &ki, &si);
+            const int overflow = (ki & 2) ? 1 : 0;
+            if (!(ki & 1) && !overflow) return st;
+            mode = (ki & 1) ? (overflow ? 3 : 1) : 4;
+            continue;
+        }
         q->staged_tau = sc && mode == 0 ? tau : -1.0;
         // A failure of THIS rank between the collectives (an allocation of the fp64 escalation, a wait that times out) must
         // not leave the peers blocked in an all-gather it never enters: the pass goes on -- both collectives are issued --,

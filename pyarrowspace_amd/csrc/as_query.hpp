@@ -182,6 +182,9 @@ struct as_query {
     struct as_comm* comm = nullptr;      // as_query_set_comm: the library exchanges this query's records itself (as_comm.hip)
     as_knn_rec* knn_all = nullptr;       // [world][k] gathered k-NN records
     as_hit_rec* hits_all = nullptr;      // [world][topk + 1] gathered hit records
+    char* xsend = nullptr;               // one-exchange pass: this rank's block (as_query_x1_bytes) ...
+    char* xall = nullptr;                // ... and the gathered blocks of all ranks
+    int64_t x1_passes = 0;               // one-exchange passes this workspace has finished
 };
 
 namespace as {

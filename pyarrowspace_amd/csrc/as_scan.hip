@@ -653,7 +653,7 @@ typedef int i32x4s __attribute__((ext_vector_type(4)));
 template <int NCH, int NSLOT, bool SC = false, bool I8 = false>
 __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__ x32, const float* __restrict__ q32, int64_t dp,
                                                        int64_t r0, int64_t r1, float* __restrict__ dots, PreArgs pre, int rounds,
-                                                       int tail_rows) {
+                                                       int tail_rows, int crows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RING = NSLOT * NCH * 1024;   // bytes per wave
     constexpr int WAVE_LDS = RING + 256 + (SC ? 256 + SC_PEND * 8 : 0) + (I8 ? 256 : 0);   // + the chunk's 64 norms (+ histogram, pending list) (+ the rows' scales)
@@ -698,13 +698,14 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill
     const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
     const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
-    const int64_t tail0 = r0 + (int64_t)rounds * NW * 64;
-    // chunk t of this wave: 64 rows for t < rounds, then its share of the remainder
+    const int64_t tail0 = r0 + (int64_t)rounds * NW * crows;
+    // chunk t of this wave: crows rows (64; 32 or 16 when a short scan must still give every wave three chunks -- the scorer's
+    // bound is learned from the chunks before the last, launch_scan) for t < rounds, then its share of the remainder
 #define AS_CHUNK(t, base, cnt)                                                           \
     do {                                                                                 \
         if ((t) < rounds) {                                                              \
-            base = r0 + ((int64_t)(t) * NW + gw) * 64;                                    \
-            cnt = 64;                                                                    \
+            base = r0 + ((int64_t)(t) * NW + gw) * crows;                                 \
+            cnt = crows;                                                                 \
         } else if ((t) == rounds) {                                                      \
             base = tail0 + gw * tail_rows;                                               \
             const int64_t left_ = r1 - base;                                             \
@@ -1360,17 +1361,24 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int64_t nblk = std::min<int64_t>(want, bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
             q->sc_nw = (int)NW;
-            const int rounds = (int)(rows / (NW * 64));
-            const int64_t rem = rows - (int64_t)rounds * NW * 64;
+            // Chunks of 64 rows (a row per lane at the chunk's end).  The scan that also collects the scorer's candidates learns
+            // its cosine bound from the chunks BEFORE a wave's last (scan_dma_kernel, SC): a shard of fewer than 64 rows per
+            // wave (125k rows on 2 048 waves: one chunk each, no bound, every row a candidate -> the fused tail and the
+            // one-exchange pass never applied to an 8-GPU shard of a 1M index) runs chunks of 32 or 16 rows instead: two or
+            // more chunks per wave, the first publishes, the wave's last word reads the bound (as at 200k rows).
+            int crows = 64;
+            if (pre.sc_enabled && rows < NW * 64) crows = rows >= NW * 32 ? 32 : (rows >= NW * 16 ? 16 : 64);
+            const int rounds = (int)(rows / (NW * crows));
+            const int64_t rem = rows - (int64_t)rounds * NW * crows;
             const int tail_rows = (int)((rem + NW - 1) / NW);
 #define AS_DSCAN8(N, S)                                                                                                \
     do {                                                                                                               \
         if (pre.sc_enabled)                                                                                            \
             hipLaunchKernelGGL((scan_dma_kernel<N, S, true, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, S, true, true), st, \
-                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
+                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);             \
         else                                                                                                           \
             hipLaunchKernelGGL((scan_dma_kernel<N, S, false, true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, S, false, true), st, \
-                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);             \
+                               xrows, q->q32_src, ldrow, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);             \
     } while (0)
 #define AS_DSCAN(N, S)                                                                                                 \
     do {                                                                                                               \
@@ -1378,10 +1386,10 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             AS_DSCAN8(N, (N == 2 ? 4 : S));                                                                            \
         else if (pre.sc_enabled)   /* (rows of up to 512 floats: the fused form exists with the ring of 4 only) */          \
             hipLaunchKernelGGL((scan_dma_kernel<N, (N == 2 ? 4 : S), true>), dim3((unsigned)nblk), dim3(256), dma_lds(N, (N == 2 ? 4 : S), true), st, \
-                               sp->x32, q->q32_src, sp->dp, q->r0, q->r1, q->dots32, pre, rounds, tail_rows);          \
+                               sp->x32, q->q32_src, sp->dp, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);          \
         else                                                                                                           \
             hipLaunchKernelGGL((scan_dma_kernel<N, S>), dim3((unsigned)nblk), dim3(256), dma_lds(N, S), st, sp->x32, q->q32_src, sp->dp, \
-                               q->r0, q->r1, q->dots32, pre, rounds, tail_rows);                                       \
+                               q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);                                       \
     } while (0)
             switch (nch) {
                 case 1: AS_DSCAN(1, 8); break;

@@ -1446,6 +1446,12 @@ __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restri
     q_lambda_body(recs_all, m, per, rstride, k, metric, kernel, sigma, p, tau0, info, blockIdx.x);
 }
 
+// the blend of src/lib.rs:166-173 as SPEC S11 has it, from an exact cosine: ONE definition, so that every path that ranks
+// exact scores (single GPU, staged, one-exchange) rounds alike
+__device__ __forceinline__ double blend_score(double tau, double c, double lq, double lj) {
+    return tau * c + (1.0 - tau) / (1.0 + fabs(lq - lj));
+}
+
 __device__ __forceinline__ void publish(HostOut* out, int64_t seq) {
     __threadfence_system();
     out->seq = seq;
@@ -1605,7 +1611,7 @@ __device__ __forceinline__ void score_finish_body(FinishArgs a, double coef_s, c
         const double nj = t < (int)blockDim.x ? pre_n : a.n64[j], lj = t < (int)blockDim.x ? pre_l : a.lam64[j];
         const double den = sqrt(nj * nq);
         const double c = den > 0.0 ? es[t] / den : 0.0;
-        es[t] = tau * c + (1.0 - tau) / (1.0 + fabs(lq - lj));
+        es[t] = blend_score(tau, c, lq, lj);
     }
     __syncthreads();
     AS_STAMP(18);
@@ -1802,6 +1808,245 @@ __global__ __launch_bounds__(1024) void staged_score_kernel(FinishArgs as_, doub
     __syncthreads();
     reset_query_hist(sc_hist, threadIdx.x, blockDim.x);
     score_finish_body<double>(as_, coef_s, work, qx, scan_dots, s_ovf || s_tot > CAND_CAP ? -1 : s_tot);
+}
+
+// ------------------------------------------------------------------ one exchange per sharded query
+// Every rank finishes what only it can finish -- its k exact nearest rows (records) and the EXACT cosine and lambda of every
+// row its scan kept as a scorer candidate -- into one block of bytes; the blocks are all-gathered ONCE; every rank then forms
+// lambda_q from all records, scores all candidates (exact scores: there is nothing left to prove about the list -- that the
+// rows outside it cannot reach the top k is the scan's cosine-bound argument, as on one GPU) and ranks them identically.
+// Block of a rank: [k as_knn_rec][XHead][xcap XCand], padded to a multiple of sizeof(as_knn_rec).
+struct XHead {
+    int count;   // candidates written (may exceed xcap: overflow)
+    int flags;   // bit0 k-NN list not proven, bit2 k-NN buffer overflow, bit3 scorer buffer overflow, bit4 candidates did not fit /
+                 // this rank had none to offer (no fused scan), bit5 this rank failed -- the trailing hit record's bits (score_finish_body)
+    int pad[2];
+};
+struct XCand {
+    int64_t idx;   // global item id
+    double cosv;   // exact fp64 cosine
+    double lam;    // lambda of the item
+};
+constexpr int X1_BLOCKS = 16;        // candidate blocks beside the k-NN block
+constexpr int X1_LOCAL_CAP = 4096;   // candidates one block gathers from its share of the scan's reports
+
+// grid 1 + X1_BLOCKS: block 0 = knn_finish (records into the exchange block), blocks 1.. = the scan waves' reports -> exact
+// cosines.  The two halves do not depend on each other: the k-NN phase (17 us, one block) hides the candidates' evaluation.
+__global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishArgs as_, XHead* head, XCand* cands, int xcap, int preset_flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* qs = (double*)smem;
+    const double* qx = nullptr;
+    if (ak.dp <= Q_LDS_MAX) {
+        for (int64_t c = threadIdx.x; c < ak.dp; c += blockDim.x) qs[c] = ak.q64[c];
+        qx = qs;
+    }
+    char* work = smem + sizeof(double) * Q_LDS_MAX;
+    if (blockIdx.x == 0) {
+        knn_finish_body<float>(ak, work, qx);
+        if (threadIdx.x == 0) {   // (wave 0 ran the whole body: its own stores)
+            const int fl = preset_flags | (ak.info->knn_inexact ? 1 : 0) | ((ak.info->overflow & 1) ? 4 : 0) | ((ak.info->overflow & 2) ? 8 : 0);
+            if (fl) atomicOr(&head->flags, fl);
+        }
+        return;
+    }
+    __shared__ int s_tot, s_ovf, s_base;
+    int* si = (int*)work;                          // X1_LOCAL_CAP rows
+    double* o_sq = (double*)(si + X1_LOCAL_CAP);   // 64 + 64 results of a round
+    double* o_dot = o_sq + 64;
+    if (threadIdx.x == 0) {
+        s_tot = 0;
+        s_ovf = 0;
+    }
+    __syncthreads();
+    // (reports dealt round robin: the waves that end first -- under a bound still loose -- keep the most rows, and they are neighbours)
+    const int nb = (int)gridDim.x - 1, b = (int)blockIdx.x - 1;
+    for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
+        const int* rep = as_.ci + (int64_t)w * SC_WCAP;
+        const int c2 = rep[0];
+        if (c2 < 0) s_ovf = 1;
+        else if (c2 > 0) {
+            const int base = atomicAdd(&s_tot, c2);
+            if (base + c2 <= X1_LOCAL_CAP)
+                for (int e = 0; e < c2; ++e) si[base + e] = rep[1 + e];
+        }
+    }
+    __syncthreads();
+    const int tot = s_tot;
+    if (s_ovf || tot > X1_LOCAL_CAP) {
+        if (threadIdx.x == 0) {
+            atomicOr(&head->flags, 16);
+            atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
+            if (s_ovf) atomicAdd(&head->pad[1], 1);
+        }
+        return;
+    }
+    const double nq = as_.info->nq;
+    for (int base = 0; base < tot; base += 64) {   // (block-uniform)
+        const int m = tot - base < 64 ? tot - base : 64;
+        exact_eval_all(as_.x32, as_.x64, qx ? qx : as_.q64, as_.d, as_.dp, si + base, m, o_sq, o_dot);
+        if (threadIdx.x == 0) s_base = atomicAdd(&head->count, m);   // one ticket per block and round
+        __syncthreads();
+        if ((int)threadIdx.x < m) {
+            const int slot = s_base + (int)threadIdx.x;
+            if (slot < xcap) {
+                const int j = si[base + threadIdx.x];
+                const double den = sqrt(as_.n64[j] * nq);
+                XCand c;
+                c.idx = (int64_t)j + as_.goff;
+                c.cosv = den > 0.0 ? o_dot[threadIdx.x] / den : 0.0;
+                c.lam = as_.lam64[j];
+                cands[slot] = c;
+            } else {
+                atomicOr(&head->flags, 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// After the exchange, on every rank alike: lambda_q (wave 0) while the other waves pull the ranks' candidates into LDS; exact
+// scores; the topk by (score desc, id asc) through a fixed-range histogram prune (a score lies in [-1, 1]) and a rank count;
+// publication.  Clears the per-search state and the scan's histograms behind a clean search.
+__global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __restrict__ all, int world, int64_t xbytes, int64_t krec, int xcap, int64_t k,
+                                                               int metric, int kernel, double sigma, double p, double tau0, double tau, int64_t topk,
+                                                               int64_t ntotal, QInfo* info, HostOut* out, int64_t seq, unsigned int* sc_hist) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sc = (double*)smem;                 // CAND_CAP cosines, then scores
+    double* sl = sc + CAND_CAP;                 // lambdas
+    int* sid = (int*)(sl + CAND_CAP);           // ids
+    double* pk = (double*)(sid + CAND_CAP);     // PRUNE_CAP pruned scores
+    int* pi = (int*)(pk + PRUNE_CAP);
+    __shared__ unsigned int khist[1024];
+    __shared__ int s_tot, s_flags, k_bin, k_cnt;
+    khist[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) {
+        s_tot = 0;
+        s_flags = 0;
+        k_cnt = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        q_lambda_body((const as_knn_rec*)all, krec * world, krec, xbytes / (int64_t)sizeof(as_knn_rec), k, metric, kernel, sigma, p, tau0, info, 0);
+    } else {
+        const int wv = (int)(threadIdx.x >> 6) - 1, nwv = 15, lane = (int)(threadIdx.x & 63);
+        // (a rank per wave; a rank's base in the list by one LDS ticket)
+        for (int r = wv; r < world; r += nwv) {
+            const XHead* h = (const XHead*)(all + (int64_t)r * xbytes + krec * (int64_t)sizeof(as_knn_rec));
+            const XCand* cs = (const XCand*)(h + 1);
+            int cnt = h->count, fl = h->flags;
+            if (cnt < 0 || cnt > xcap) {   // (a block of 0xff bytes is a failed rank's: as_query_search_staged)
+                cnt = 0;
+                fl |= 16;
+            }
+            int base = 0;
+            if (lane == 0) {
+                if (fl) atomicOr(&s_flags, fl);
+                base = atomicAdd(&s_tot, cnt);
+            }
+            base = __shfl(base, 0, 64);
+            if (base + cnt <= CAND_CAP)
+                for (int t = lane; t < cnt; t += 64) {
+                    const XCand c = cs[t];
+                    sc[base + t] = c.cosv;
+                    sl[base + t] = c.lam;
+                    sid[base + t] = (int)c.idx;
+                }
+        }
+    }
+    __syncthreads();
+    reset_query_hist(sc_hist, threadIdx.x, blockDim.x);
+    int flags = s_flags;
+    int total = s_tot;
+    if (total > CAND_CAP) {
+        flags |= 16;
+        total = 0;
+    }
+    const double lq = info->lambda_q;
+    int mybin[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = (int)threadIdx.x + u * (int)blockDim.x;
+        mybin[u] = -1;
+        if (t < total) {
+            double s = blend_score(tau, sc[t], lq, sl[t]);
+            s = s == s ? s : -key_traits<double>::inf();
+            sc[t] = s;
+            const double fb = (1.0 - s) * 512.0;   // descending scores = ascending bins
+            mybin[u] = fb < 0.0 ? 0 : (fb >= 1023.0 ? 1023 : (int)fb);
+            atomicAdd(&khist[mybin[u]], 1u);
+        }
+    }
+    __syncthreads();
+    const int64_t want64 = topk < ntotal ? topk : ntotal;
+    const int nhit = (int)(total < want64 ? total : want64);
+    if (threadIdx.x < 64) {   // 16 bins per lane, inclusive scan over the lanes, the lane whose bins reach nhit finishes
+        unsigned int hh[16], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            hh[j] = khist[16 * threadIdx.x + j];
+            tot += hh[j];
+        }
+        unsigned int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t2 = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += t2;
+        }
+        const unsigned int excl = incl - tot, want_ = (unsigned)nhit;
+        if (threadIdx.x == 0) k_bin = 1023;
+        if (want_ > 0 && excl < want_ && incl >= want_) {
+            unsigned int run = excl;
+            int bsel = 16 * (int)threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                run += hh[j];
+                if (run >= want_) break;
+                bsel += 1;
+            }
+            k_bin = bsel;
+        }
+    }
+    __syncthreads();
+    const int bsel = k_bin;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = (int)threadIdx.x + u * (int)blockDim.x;
+        if (mybin[u] >= 0 && mybin[u] <= bsel) {
+            const int slot = atomicAdd(&k_cnt, 1);
+            if (slot < PRUNE_CAP) {
+                pk[slot] = sc[t];
+                pi[slot] = sid[t];
+            }
+        }
+    }
+    __syncthreads();
+    const int R = k_cnt;
+    if (R > PRUNE_CAP) flags |= 16;   // mass ties in one bin: the two-exchange chain sorts them out
+    else
+        for (int t = threadIdx.x; t < R; t += blockDim.x) {
+            const double myk = -pk[t];
+            const int myi = pi[t];
+            int rank = 0;
+            for (int s2 = 0; s2 < R; ++s2) rank += lex_less<double>(-pk[s2], pi[s2], myk, myi) ? 1 : 0;
+            if (rank < nhit) {
+                out->idx[rank] = myi;
+                out->score[rank] = pk[t];
+            }
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out->len = nhit;
+        out->lambda_q = info->lambda_q;
+        out->status = info->status;
+        out->knn_inexact = (flags & 1) ? 1 : 0;
+        out->score_inexact = 0;
+        out->overflow = ((flags & 4) ? 1 : 0) | ((flags & 8) ? 2 : 0) | ((flags & 16) ? 4 : 0) | ((flags & 32) ? 8 : 0);
+        const int clean = !flags;
+        out->state_reset = clean;
+        if (clean) reset_query_state(info);
+        publish(out, seq);
+    }
 }
 
 // merge m hit records (own or all-gathered) -> final topk, written to pinned host memory
@@ -2509,6 +2754,8 @@ void as_query_free(as_query* q) {
     if (q->sc_hist) hipFree(q->sc_hist);
     if (q->knn_all) hipFree(q->knn_all);
     if (q->hits_all) hipFree(q->hits_all);
+    if (q->xsend) hipFree(q->xsend);
+    if (q->xall) hipFree(q->xall);
     hipFree(q->rsel);
     if (q->own_records) {
         hipFree(q->knn);
@@ -2578,6 +2825,100 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
     if (q->gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // lambda_q is already there; the k-NN records stay empty
     return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
+
+// ---- one exchange per sharded query (staged_x1_kernel / staged_x1_final_kernel above)
+static int x1_cap(int world) { return std::max(512, std::min(CAND_CAP, 8192 / std::max(world, 1))); }
+static size_t x1_lds_a() { return std::max(fused_lds(), sizeof(double) * Q_LDS_MAX + sizeof(int) * X1_LOCAL_CAP + sizeof(double) * 128); }
+static size_t x1_lds_b() { return (2 * sizeof(double) + sizeof(int)) * (size_t)CAND_CAP + (sizeof(double) + sizeof(int)) * (size_t)PRUNE_CAP; }
+
+int64_t as_query_x1_bytes(const as_query* q, int32_t world) {
+    if (!q || world < 1) return 0;
+    const int64_t raw = (int64_t)sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1) + (int64_t)sizeof(XHead) + (int64_t)sizeof(XCand) * x1_cap(world);
+    return (raw + (int64_t)sizeof(as_knn_rec) - 1) / (int64_t)sizeof(as_knn_rec) * (int64_t)sizeof(as_knn_rec);
+}
+
+// 1 when a search with this tau may take the one-exchange pass on this workspace (the same answer on every rank: it depends on
+// the graph's mode, tau and the workspace's kind only); what a RANK cannot offer at run time travels as a flag in its block.
+int32_t as_query_x1_usable(const as_query* q, double tau) {
+    const char* env = getenv("ARROWSPACE_STAGED_X1");   // (per call: an A/B switch)
+    const bool off = env && atoi(env) == 0;
+    return q && q->gr && !off && tau >= 0.4 && tau <= 1.0 && q->gr->lambda_mode != AS_LAMBDA_FEATURE && q->cap == 1 && !q->sp->opts.force_exact &&
+                   (q->sp->opts.search_mode & 3) == 0 ? 1 : 0;
+}
+
+as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end, double tau, void* send_dev,
+                            int32_t world) {
+    if (!q || !query_host || !q->gr || !send_dev || world < 1 || !as_query_x1_usable(q, tau)) {
+        set_err("as_query_x1_begin: null argument, or a search the one-exchange pass does not serve (as_query_x1_usable)");
+        return AS_EINVAL;
+    }
+    if ((int64_t)world * std::max<int64_t>(q->k, 1) > REC_CAP) {
+        set_err("as_query_x1_begin: %d ranks x k = %lld exceed the merge capacity %d", world, (long long)q->k, REC_CAP);
+        return AS_EUNSUPPORTED;
+    }
+    const as_space* sp = q->sp;
+    AS_HIP(hipSetDevice(sp->device));
+    hipStream_t st = q->stream;
+    q->exact = 0;
+    q->robust = 0;
+    q->reuse = 0;
+    const int64_t krec = std::max<int64_t>(q->k, 1);
+    XHead* head = (XHead*)((char*)send_dev + sizeof(as_knn_rec) * krec);
+    XCand* cands = (XCand*)(head + 1);
+    AS_HIP(hipMemsetAsync(head, 0, sizeof(XHead), st));
+    const bool sc = !q->no_fused && q->sc_widx && sp->dp <= 2048 && !(q->scan_variant & 4) && !q->crowded_direct;
+    q->fused_tail = sc ? 1 : 0;
+    q->tau_cur = tau;
+    const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
+    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
+    q->fused_tail = 0;
+    q->staged_sc = 0;
+    AS_TRY(qb);
+    const int64_t rows = row_end - row_begin;
+    const double eps = q->gr->gp.eps;
+    FinishArgs fk = make_finish(q);
+    fk.M = q->Mk; fk.epskey = sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps; fk.coef = coef_query(q, false);
+    fk.recs = (as_knn_rec*)send_dev; fk.fuse = 0; fk.ck = q->ckey_k; fk.ci = q->cidx_k; fk.from_list = 0;
+    FinishArgs fs = make_finish(q);
+    fs.ci = q->sc_widx; fs.sc_nw = sc_ran && rows > 0 ? q->sc_nw : 0;
+    static bool attr_set[64] = {};
+    if (sp->device >= 0 && sp->device < 64 && !attr_set[sp->device]) {
+        AS_HIP(hipFuncSetAttribute((const void*)staged_x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x1_lds_a()));
+        AS_HIP(hipFuncSetAttribute((const void*)staged_x1_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x1_lds_b()));
+        attr_set[sp->device] = true;
+    }
+    // (a rank that could not collect candidates -- no fused scan for this query here -- says so: every rank reads the flag and
+    // the pass is rerun on the two-exchange chain)
+    if (debug_enabled() && (q->x1_passes & 63) == 0)
+        dbg("as_query_x1_begin: sc %d, ran %d, scan waves %d, rows %lld, int8 scan %d, host query %d", (int)sc, (int)sc_ran, q->sc_nw, (long long)rows, q->i8_scan, q->host_q);
+    hipLaunchKernelGGL(staged_x1_kernel, dim3(1 + X1_BLOCKS), dim3(1024), x1_lds_a(), st, fk, fs, head, cands, x1_cap(world),
+                       !sc_ran && rows > 0 ? 16 : 0);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, double tau, int64_t* out_idx, double* out_score, int64_t* out_len,
+                             double* out_lambda_q) {
+    if (!q || !q->gr || !all_dev || world < 1 || !out_idx || !out_score || !out_len) {
+        set_err("as_query_x1_finish: null argument");
+        return AS_EINVAL;
+    }
+    const as_graph* gr = q->gr;
+    const int64_t krec = std::max<int64_t>(q->k, 1);
+    q->seq += 1;
+    hipLaunchKernelGGL(staged_x1_final_kernel, dim3(1), dim3(1024), x1_lds_b(), q->stream, (const char*)all_dev, (int)world, as_query_x1_bytes(q, world),
+                       krec, x1_cap(world), q->k, gr->metric, gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, tau, q->topk,
+                       (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist);
+    AS_HIP(hipGetLastError());
+    if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
+    AS_TRY(wait_published(q));
+    q->info_clean = q->hout->state_reset ? 1 : 0;
+    q->x1_passes += 1;
+    return collect(q, out_idx, out_score, out_len, out_lambda_q);
+}
+
+int32_t as_query_x1_redo(const as_query* q) { return q && (q->hout->overflow & 4) ? 1 : 0; }
+int64_t as_query_x1_passes(const as_query* q) { return q ? q->x1_passes : 0; }
 
 as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {
     if (!q || !q->gr || !recs_dev) {

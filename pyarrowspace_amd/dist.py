@@ -422,6 +422,37 @@ class HipEngine:
         self._q = np.ascontiguousarray(q, dtype=np.float64)
         self._check(self.L.as_query_scan(self.q, self._q.ctypes.data_as(C.c_void_p), self._q.shape[0], r0, r1))
 
+    # ---- one exchange per query (as_query_x1_*): this rank's block -> all-gather -> the same finish on every rank
+    def x1_usable(self, tau):
+        return bool(self.L.as_query_x1_usable(self.q, float(tau)))
+
+    def x1_begin(self, q, tau, r0, r1, world):
+        torch = self.torch
+        if getattr(self, "_x1_world", None) != world:
+            nbytes = int(self.L.as_query_x1_bytes(self.q, int(world)))
+            self.x1_send = torch.zeros((nbytes // 8,), dtype=torch.float64, device=torch.device("cuda", self.op.device))
+            self._x1_world = world
+        self._q = np.ascontiguousarray(q, dtype=np.float64)
+        self._check(self.L.as_query_x1_begin(self.q, self._q.ctypes.data_as(C.c_void_p), self._q.shape[0], r0, r1, float(tau),
+                                             C.c_void_p(self.x1_send.data_ptr()), int(world)))
+        return self.x1_send
+
+    def x1_finish(self, blocks_all, tau, world):
+        """-> (hits, lambda_q, zero_lambda, inexact, overflow, redo); redo: run the query through the two-exchange steps."""
+        ln, lq = C.c_int64(0), C.c_double(0.0)
+        st = self.L.as_query_x1_finish(self.q, C.c_void_p(blocks_all.data_ptr()), int(world), float(tau),
+                                       self._idx.ctypes.data_as(C.c_void_p), self._sc.ctypes.data_as(C.c_void_p), C.byref(ln), C.byref(lq))
+        if st not in (self._lib.AS_OK, self._lib.AS_EZEROLAMBDA):
+            self._check(st)
+        ki, si = C.c_int32(0), C.c_int32(0)
+        self.L.as_query_flags(self.q, C.byref(ki), C.byref(si))
+        hits = [(int(self._idx[t]), float(self._sc[t])) for t in range(ln.value)]
+        return (hits, float(lq.value), st == self._lib.AS_EZEROLAMBDA, bool(ki.value & 1), 1 if ki.value & 2 else 0,
+                bool(self.L.as_query_x1_redo(self.q)))
+
+    def x1_passes(self, library=False):
+        return int(self.L.as_query_x1_passes(self.qs if library else self.q))
+
     def query_lambda(self, knn_all):
         self._check(self.L.as_query_lambda(self.q, C.c_void_p(knn_all.data_ptr()), knn_all.shape[0]))
 
@@ -1075,7 +1106,16 @@ class ShardedIndex:
         ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
         mode = 0
         with ctx:
+            if hasattr(e, "x1_usable") and e.x1_usable(tau):
+                # one exchange: every rank's records and finished candidates in one all-gather, the rest redundantly on every rank
+                nranks = self.world if self._collective() else 1
+                e.set_mode(0)
+                blocks = self._gather_fixed(e.x1_begin(q, tau, *self.scan_rows, nranks), persistent=True)
+                hits, lq, zero, inexact, overflow, redo = e.x1_finish(blocks, tau, nranks)
+                mode = 0 if redo else next_mode(0, inexact, overflow)
             for _ in range(8):
+                if mode is None:
+                    break
                 e.set_mode(mode)
                 e.query_scan(q, *self.scan_rows)
                 knn_all = self._gather_fixed(e.knn_local, persistent=True)

@@ -408,3 +408,41 @@ def test_library_exchange_repairs_a_crowded_neighbourhood(oracle_lib):
         index.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_one_exchange_pass_returns_what_the_two_exchange_chain_returns(oracle_lib, monkeypatch):
+    """tau in [0.4, 1]: the sharded search takes ONE exchange -- every rank's k-NN records and its scorer candidates finished to
+    (id, exact cosine, lambda) in one block, lambda_q / scores / ranking redundantly behind the all-gather (as_query_x1_*).
+    Same hits, bit for bit, as the two-exchange chain (ARROWSPACE_STAGED_X1=0) and as one space; tau below 0.4 keeps the chain."""
+    import torch
+    import pyarrowspace_amd as asp
+    from pyarrowspace_amd.dist import ShardedIndex
+    n, d = 6000, 96
+    X = clustered(n, d, nclust=12, seed=77)
+    gp = {"eps": calibrate_eps(X, 10), "k": 10, "topk": 8, "p": 2.0, "sigma": None}
+    index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(9)
+    Q = [np.ascontiguousarray(X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d)) for _ in range(12)]
+    for tau in (0.62, 1.0, 0.4):
+        for q in Q:
+            before = index.engine.x1_passes()
+            monkeypatch.delenv("ARROWSPACE_STAGED_X1", raising=False)
+            got = index.search(q, tau)
+            assert index.engine.x1_passes() == before + 1
+            monkeypatch.setenv("ARROWSPACE_STAGED_X1", "0")
+            chain = index.search(q, tau)
+            assert index.engine.x1_passes() == before + 1
+            assert got == chain == aspace.search(q, gl, tau)
+            want, lq = ref.search(q, tau)
+            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-9)
+    monkeypatch.delenv("ARROWSPACE_STAGED_X1", raising=False)
+    before = index.engine.x1_passes()
+    assert index.search(Q[0], 0.2) == aspace.search(Q[0], gl, 0.2)
+    assert index.engine.x1_passes() == before
+    far = np.zeros(d)
+    far[0] = 50.0
+    with pytest.raises(PanicException):
+        index.search(far, 0.62)
+    index.close()
