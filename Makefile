@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := pyarrowspace_amd/csrc
-SRCS := $(CSRC)/as_api.hip $(CSRC)/as_build.hip $(CSRC)/as_k2bf.hip $(CSRC)/as_comm.hip $(CSRC)/as_feat.hip $(CSRC)/as_scan.hip $(CSRC)/as_search.hip
+SRCS := $(CSRC)/as_api.hip $(CSRC)/as_build.hip $(CSRC)/as_k2bf.hip $(CSRC)/as_comm.hip $(CSRC)/as_edges.hip $(CSRC)/as_feat.hip $(CSRC)/as_scan.hip $(CSRC)/as_search.hip
 HDRS := $(CSRC)/as_common.hpp $(CSRC)/as_query.hpp $(CSRC)/as_knn.hpp include/arrowspace_hip.h
 OBJS := $(SRCS:.hip=.o)
 LIB := pyarrowspace_amd/libarrowspace_hip.so

@@ -176,6 +176,15 @@ as_status as_graph_from_knn_global(as_space* sp, const as_graph_params* gp, int6
                                    const int32_t* idx_dev, const double* dist_dev, const double* gy_dev,
                                    const int32_t* cnt_dev, const double* n64_global_dev, as_graph** out_graph);
 
+/* Sharded graph stage, in front of the host's variable-count all-to-all: the directed edges i -> j of this rank's k-NN lists
+ * (idx / dist / gy [rows][k], cnt[rows] valid entries per row; device pointers), bucketed by the rank that owns item j
+ * (rank r owns [bounds_host[r], bounds_host[r + 1])): out_ints [E][2] int32 = (j - bounds[owner], row0 + i), out_reals [E][2]
+ * = (dist, gy), buckets in rank order, the lists' (row, slot) order inside a bucket; out_counts_host[r] = entries for rank r.
+ * The output buffers hold rows * k entries.  Count / scan / scatter kernels on `hip_stream`; synchronises it.
+ * Serves ArrowSpaceBuilder::build, /root/reference/src/lib.rs:281-331, on a row-sharded index. */
+as_status as_edges_bucket(const int32_t* idx_dev, const double* dist_dev, const double* gy_dev, const int32_t* cnt_dev, int64_t rows, int64_t k,
+                          int64_t row0, const int64_t* bounds_host, int32_t world, int32_t* out_ints_dev, double* out_reals_dev,
+                          int64_t* out_counts_host, void* hip_stream);
 /* step 3 without replication (SURVEY 8e "Symmetrise + Laplacian": one exchange step).  The space holds the rows
  * [row_offset, row_offset + nitems); idx/dist/gy/cnt are ITS rows' lists (ids global).  in_*: the directed edges
  * (in_col_dev[e] -> row_offset + in_row_dev[e]) of ALL ranks whose target row lives here, this rank's own included

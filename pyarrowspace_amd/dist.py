@@ -22,6 +22,7 @@ tests inject a CPU engine to exercise the sharding logic under the gloo backend.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -340,6 +341,26 @@ class HipEngine:
                                                     C.c_void_p(n64.data_ptr()), C.byref(self.gr)))
 
     # ---- graph stage without replication: this rank's rows of the symmetrised graph
+    def edge_bucket(self, idx, dist, gy, cnt, row0, bounds):
+        """The lists' directed edges bucketed by the owner of their target (as_edges_bucket: count / scan / scatter kernels)
+        -> (ints [E, 2] int32, reals [E, 2] float64, per-rank counts)."""
+        torch = self.torch
+        rows, k = int(idx.shape[0]), int(idx.shape[1])
+        world = len(bounds) - 1
+        idx, dist, gy, cnt = idx.contiguous(), dist.contiguous(), gy.contiguous(), cnt.contiguous()
+        assert idx.dtype == torch.int32 and cnt.dtype == torch.int32 and dist.dtype == torch.float64 and gy.dtype == torch.float64
+        ints = torch.empty((max(rows * k, 1), 2), dtype=torch.int32, device=idx.device)
+        reals = torch.empty((max(rows * k, 1), 2), dtype=torch.float64, device=idx.device)
+        bh = (C.c_int64 * (world + 1))(*[int(b) for b in bounds])
+        counts = (C.c_int64 * world)()
+        self._check(self.L.as_edges_bucket(C.c_void_p(idx.data_ptr()), C.c_void_p(dist.data_ptr()), C.c_void_p(gy.data_ptr()),
+                                           C.c_void_p(cnt.data_ptr()), rows, k, int(row0), C.cast(bh, C.c_void_p), world,
+                                           C.c_void_p(ints.data_ptr()), C.c_void_p(reals.data_ptr()), C.cast(counts, C.c_void_p),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        send = [int(v) for v in counts]
+        total = sum(send)
+        return ints[:total], reals[:total], send
+
     def graph_shard_csr(self, n_global, row_offset, idx, dist, gy, cnt, in_row, in_col, in_dist, in_gy):
         """-> the degrees of this rank's rows (device tensor, a copy)."""
         torch = self.torch
@@ -867,6 +888,17 @@ class ShardedIndex:
         torch, dist = self.torch, self.dist
         rows, k = int(idx.shape[0]), int(idx.shape[1])
         dev = idx.device
+        if idx.is_cuda and hasattr(self.engine, "edge_bucket") and idx.dtype == torch.int32 and cnt.dtype == torch.int32 and self.world <= 64 \
+                and not os.environ.get("ARROWSPACE_TORCH_EDGES"):
+            # count / scan / scatter kernels of the library (as_edges.hip) instead of bucketize + stable argsort + gathers
+            ints, reals, sc = self.engine.edge_bucket(idx, dst, gy, cnt, self.r0, self.bounds)
+            if self._collective():
+                send = torch.tensor(sc, dtype=torch.int64, device=dev)
+                recv = self._all_to_all(send, None, None)
+                rc = [int(v) for v in recv.tolist()]
+                ints = self._all_to_all(ints.contiguous(), rc, sc)
+                reals = self._all_to_all(reals.contiguous(), rc, sc)
+            return (ints[:, 0].contiguous(), ints[:, 1].contiguous(), reals[:, 0].contiguous(), reals[:, 1].contiguous())
         valid = torch.arange(k, device=dev)[None, :] < cnt[:, None].long()
         tgt = idx[valid].long()                                                        # global target item
         src = (torch.arange(rows, device=dev) + self.r0)[:, None].expand(rows, k)[valid]

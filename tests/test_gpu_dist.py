@@ -446,3 +446,38 @@ def test_one_exchange_pass_returns_what_the_two_exchange_chain_returns(oracle_li
     with pytest.raises(PanicException):
         index.search(far, 0.62)
     index.close()
+
+
+@pytest.mark.parametrize("world,rows,k", [(1, 700, 9), (3, 5000, 25), (8, 20000, 12), (64, 3000, 5)])
+def test_edge_bucketing_kernels_match_the_torch_ops(world, rows, k, monkeypatch):
+    """as_edges_bucket (count / scan / scatter kernels in front of the sharded graph stage's all-to-all) against the torch ops
+    it replaces (bucketize, stable argsort, bincount, gathers): same entries in the same order, same counts -- ragged lists,
+    empty rows, targets on every rank, buckets that stay empty."""
+    import torch
+    from pyarrowspace_amd.dist import ShardedIndex, HipEngine
+    rng = np.random.default_rng(world * 1000 + rows)
+    cuts = np.sort(rng.integers(0, 50000, size=world - 1)) if world > 1 else np.zeros(0, dtype=np.int64)
+    if world == 8:
+        cuts[3] = cuts[2]                       # an empty shard: its bucket stays empty
+    bounds = [0] + [int(c) for c in cuts] + [50000]
+    rank = world // 2
+    idx = torch.from_numpy(rng.integers(0, 50000, size=(rows, k)).astype(np.int32)).cuda()
+    cnt = torch.from_numpy(rng.integers(0, k + 1, size=rows).astype(np.int32)).cuda()
+    dst = torch.from_numpy(rng.random((rows, k))).cuda()
+    gy = torch.from_numpy(rng.standard_normal((rows, k))).cuda()
+    index = ShardedIndex()
+    index.torch, index.dist, index.group = torch, None, None
+    index.world, index.rank, index.bounds, index.r0 = world, rank, bounds, bounds[rank]
+    index._collective = lambda: False            # the bucketing alone: what would be handed to the all-to-all
+    index.engine = HipEngine({"eps": 1.0, "k": k, "topk": 3, "p": 2.0, "sigma": None})
+    monkeypatch.setenv("ARROWSPACE_TORCH_EDGES", "1")
+    want = index._exchange_edges(idx, dst, gy, cnt)
+    monkeypatch.delenv("ARROWSPACE_TORCH_EDGES")
+    got = index._exchange_edges(idx, dst, gy, cnt)
+    assert len(got) == 4
+    for g, w in zip(got, want):
+        assert g.dtype == w.dtype and torch.equal(g, w)
+    ints, reals, send = index.engine.edge_bucket(idx, dst, gy, cnt, bounds[rank], bounds)
+    assert sum(send) == int(cnt.sum().item()) and len(send) == world
+    if world == 8:
+        assert send[3] == 0
