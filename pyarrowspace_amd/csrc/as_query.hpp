@@ -185,6 +185,9 @@ struct as_query {
     char* xsend = nullptr;               // one-exchange pass: this rank's block (as_query_x1_bytes) ...
     char* xall = nullptr;                // ... and the gathered blocks of all ranks
     int64_t x1_passes = 0;               // one-exchange passes this workspace has finished
+    void* x1_head = nullptr;             // header of the block the last pass wrote (left zeroed by its finish kernel)
+    int x1_dirty = 1;                    // ... unless that pass never reached its finish
+    char* x1_own = nullptr;              // single space: the block of the fused tail's two-kernel form (search_once)
 };
 
 namespace as {

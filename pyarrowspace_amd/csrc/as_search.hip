@@ -1909,7 +1909,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
 // publication.  Clears the per-search state and the scan's histograms behind a clean search.
 __global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __restrict__ all, int world, int64_t xbytes, int64_t krec, int xcap, int64_t k,
                                                                int metric, int kernel, double sigma, double p, double tau0, double tau, int64_t topk,
-                                                               int64_t ntotal, QInfo* info, HostOut* out, int64_t seq, unsigned int* sc_hist) {
+                                                               int64_t ntotal, QInfo* info, HostOut* out, int64_t seq, unsigned int* sc_hist, XHead* own_head) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = (double*)smem;                 // CAND_CAP cosines, then scores
     double* sl = sc + CAND_CAP;                 // lambdas
@@ -2045,6 +2045,12 @@ __global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __res
         const int clean = !flags;
         out->state_reset = clean;
         if (clean) reset_query_state(info);
+        if (own_head) {   // this rank's block starts the next pass empty (its count and flags are accumulated by atomics)
+            own_head->count = 0;
+            own_head->flags = 0;
+            own_head->pad[0] = 0;
+            own_head->pad[1] = 0;
+        }
         publish(out, seq);
     }
 }
@@ -2756,6 +2762,7 @@ void as_query_free(as_query* q) {
     if (q->hits_all) hipFree(q->hits_all);
     if (q->xsend) hipFree(q->xsend);
     if (q->xall) hipFree(q->xall);
+    if (q->x1_own) hipFree(q->x1_own);
     hipFree(q->rsel);
     if (q->own_records) {
         hipFree(q->knn);
@@ -2846,35 +2853,13 @@ int32_t as_query_x1_usable(const as_query* q, double tau) {
                    (q->sp->opts.search_mode & 3) == 0 ? 1 : 0;
 }
 
-as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end, double tau, void* send_dev,
-                            int32_t world) {
-    if (!q || !query_host || !q->gr || !send_dev || world < 1 || !as_query_x1_usable(q, tau)) {
-        set_err("as_query_x1_begin: null argument, or a search the one-exchange pass does not serve (as_query_x1_usable)");
-        return AS_EINVAL;
-    }
-    if ((int64_t)world * std::max<int64_t>(q->k, 1) > REC_CAP) {
-        set_err("as_query_x1_begin: %d ranks x k = %lld exceed the merge capacity %d", world, (long long)q->k, REC_CAP);
-        return AS_EUNSUPPORTED;
-    }
+// the block kernels behind a scan that has run (query_begin): this workspace's k-NN records and finished candidates into `send_dev`
+static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc_ran) {
     const as_space* sp = q->sp;
-    AS_HIP(hipSetDevice(sp->device));
-    hipStream_t st = q->stream;
-    q->exact = 0;
-    q->robust = 0;
-    q->reuse = 0;
     const int64_t krec = std::max<int64_t>(q->k, 1);
     XHead* head = (XHead*)((char*)send_dev + sizeof(as_knn_rec) * krec);
     XCand* cands = (XCand*)(head + 1);
-    AS_HIP(hipMemsetAsync(head, 0, sizeof(XHead), st));
-    const bool sc = !q->no_fused && q->sc_widx && sp->dp <= 2048 && !(q->scan_variant & 4) && !q->crowded_direct;
-    q->fused_tail = sc ? 1 : 0;
-    q->tau_cur = tau;
-    const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
-    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
-    q->fused_tail = 0;
-    q->staged_sc = 0;
-    AS_TRY(qb);
-    const int64_t rows = row_end - row_begin;
+    const int64_t rows = q->r1 - q->r0;
     const double eps = q->gr->gp.eps;
     FinishArgs fk = make_finish(q);
     fk.M = q->Mk; fk.epskey = sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps; fk.coef = coef_query(q, false);
@@ -2889,12 +2874,53 @@ as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, in
     }
     // (a rank that could not collect candidates -- no fused scan for this query here -- says so: every rank reads the flag and
     // the pass is rerun on the two-exchange chain)
-    if (debug_enabled() && (q->x1_passes & 63) == 0)
-        dbg("as_query_x1_begin: sc %d, ran %d, scan waves %d, rows %lld, int8 scan %d, host query %d", (int)sc, (int)sc_ran, q->sc_nw, (long long)rows, q->i8_scan, q->host_q);
-    hipLaunchKernelGGL(staged_x1_kernel, dim3(1 + X1_BLOCKS), dim3(1024), x1_lds_a(), st, fk, fs, head, cands, x1_cap(world),
+    hipLaunchKernelGGL(staged_x1_kernel, dim3(1 + X1_BLOCKS), dim3(1024), x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
                        !sc_ran && rows > 0 ? 16 : 0);
     AS_HIP(hipGetLastError());
+    q->x1_head = head;
     return AS_OK;
+}
+
+static as_status x1_launch_final(as_query* q, const void* all_dev, int world, double tau) {
+    const as_graph* gr = q->gr;
+    const int64_t krec = std::max<int64_t>(q->k, 1);
+    hipLaunchKernelGGL(staged_x1_final_kernel, dim3(1), dim3(1024), x1_lds_b(), q->stream, (const char*)all_dev, (int)world, as_query_x1_bytes(q, world),
+                       krec, x1_cap(world), q->k, gr->metric, gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, tau, q->topk,
+                       (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist, (XHead*)q->x1_head);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end, double tau, void* send_dev,
+                            int32_t world) {
+    if (!q || !query_host || !q->gr || !send_dev || world < 1 || !as_query_x1_usable(q, tau)) {
+        set_err("as_query_x1_begin: null argument, or a search the one-exchange pass does not serve (as_query_x1_usable)");
+        return AS_EINVAL;
+    }
+    if ((int64_t)world * std::max<int64_t>(q->k, 1) > REC_CAP) {
+        set_err("as_query_x1_begin: %d ranks x k = %lld exceed the merge capacity %d", world, (long long)q->k, REC_CAP);
+        return AS_EUNSUPPORTED;
+    }
+    const as_space* sp = q->sp;
+    AS_HIP(hipSetDevice(sp->device));
+    q->exact = 0;
+    q->robust = 0;
+    q->reuse = 0;
+    // the block's header starts a pass at zero: the finish kernel of the previous pass over the same block left it so
+    // (staged_x1_final_kernel); a first pass, another block or a pass that never reached its finish clears it here
+    void* head = (char*)send_dev + sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1);
+    if (q->x1_dirty || q->x1_head != head) AS_HIP(hipMemsetAsync(head, 0, sizeof(XHead), q->stream));
+    q->x1_dirty = 1;
+    q->x1_head = head;
+    const bool sc = !q->no_fused && q->sc_widx && sp->dp <= 2048 && !(q->scan_variant & 4) && !q->crowded_direct;
+    q->fused_tail = sc ? 1 : 0;
+    q->tau_cur = tau;
+    const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
+    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
+    q->fused_tail = 0;
+    q->staged_sc = 0;
+    AS_TRY(qb);
+    return x1_launch_block(q, send_dev, world, sc_ran);
 }
 
 as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, double tau, int64_t* out_idx, double* out_score, int64_t* out_len,
@@ -2903,15 +2929,11 @@ as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, do
         set_err("as_query_x1_finish: null argument");
         return AS_EINVAL;
     }
-    const as_graph* gr = q->gr;
-    const int64_t krec = std::max<int64_t>(q->k, 1);
     q->seq += 1;
-    hipLaunchKernelGGL(staged_x1_final_kernel, dim3(1), dim3(1024), x1_lds_b(), q->stream, (const char*)all_dev, (int)world, as_query_x1_bytes(q, world),
-                       krec, x1_cap(world), q->k, gr->metric, gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, tau, q->topk,
-                       (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist);
-    AS_HIP(hipGetLastError());
+    AS_TRY(x1_launch_final(q, all_dev, world, tau));
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
     AS_TRY(wait_published(q));
+    q->x1_dirty = 0;
     q->info_clean = q->hout->state_reset ? 1 : 0;
     q->x1_passes += 1;
     return collect(q, out_idx, out_score, out_len, out_lambda_q);
@@ -3138,7 +3160,36 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     q->crowded_direct = 0;
     q->fused_tail = 0;
     AS_TRY(qb);
-    if (fused) {
+    // The fused tail as TWO launches (the one-exchange pass's kernels without an exchange: staged_x1_kernel = the k-NN block beside
+    // 16 blocks that finish the scan's scorer candidates to exact cosines, staged_x1_final_kernel = lambda_q, exact scores, ranking)
+    // instead of the one 1024-thread block that does the phases one after the other (fused_finish_kernel, ARROWSPACE_FUSED_X1=0).
+    // Same box, interleaved (tools/fused_x1_ab.sh): 1M x 768 3 240-3 268 -> 3 340 queries/s, 400k x 384 k = 4 topk = 2 9 560-9 590 ->
+    // 10 950-11 120, 200k x 768 8 620-8 720 -> 8 620-8 660.
+    static const bool fused_x1 = !(getenv("ARROWSPACE_FUSED_X1") && atoi(getenv("ARROWSPACE_FUSED_X1")) == 0);
+    if (fused && fused_x1 && (int64_t)std::max<int64_t>(q->k, 1) <= REC_CAP) {
+        if (!q->x1_own) {
+            AS_HIP(hipMalloc(&q->x1_own, (size_t)as_query_x1_bytes(q, 1)));
+            AS_HIP(hipMemsetAsync(q->x1_own, 0, (size_t)as_query_x1_bytes(q, 1), q->stream));
+        } else if (q->x1_dirty) {
+            AS_HIP(hipMemsetAsync(q->x1_own + sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1), 0, 16, q->stream));   // (behind the scan, in front of the block kernels)
+        }
+        q->x1_dirty = 1;
+        q->seq += 1;
+        AS_TRY(x1_launch_block(q, q->x1_own, 1, true));
+        AS_TRY(x1_launch_final(q, q->x1_own, 1, tau));
+        if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
+        AS_TRY(wait_published(q));
+        q->x1_dirty = 0;
+        q->crowded = (q->hout->overflow & 1) ? 1 : 0;
+        q->sc_crowded = (q->hout->overflow & 4) ? 1 : 0;
+        if ((q->hout->overflow & 4) && !(q->hout->overflow & 1) && !q->hout->knn_inexact) {
+            AS_HIP(hipMemsetAsync(&q->info->sc_cnt, 0, sizeof(int), q->stream));
+            AS_HIP(hipMemsetAsync(&q->info->overflow, 0, sizeof(int), q->stream));
+            q->seq += 1;
+            AS_TRY(run_score(q, tau, 1));
+            AS_TRY(wait_published(q));
+        }
+    } else if (fused) {
         q->seq += 1;
         AS_TRY(run_fused(q, q->gr->gp.eps, tau));
         if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
