@@ -2377,30 +2377,50 @@ static bool host_query_digits(as_query* q, int64_t d) {
     if (getenv("ARROWSPACE_SCAN_FP32") || !q->hq8 || sp->opts.force_exact) return false;
     bool present = false;
     if (space_i8_image(sp, &present) != AS_OK || !present || sp->dp8 / 2 > 1024) return false;
+    // (loops shaped for the host compiler's vectoriser: 768 calls of nearbyint were 4 us in front of every scan)
+    float mm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t c = 0;
+    for (; c + 8 <= d; c += 8)
+        for (int j = 0; j < 8; ++j) {
+            const float av = std::fabs(q->hq32[c + j]);
+            mm[j] = av > mm[j] ? av : mm[j];
+        }
+    for (; c < d; ++c) mm[0] = std::max(mm[0], std::fabs(q->hq32[c]));
     float m = 0.0f;
-    for (int64_t c = 0; c < d; ++c) m = std::max(m, std::fabs(q->hq32[c]));
-    if (!(m > 0.0f) || !(m < 3.0e38f) || !(q->h_nq > 0.0)) return false;
+    for (int j = 0; j < 8; ++j) m = std::max(m, mm[j]);
+    if (!(m > 0.0f) || !(m < 3.0e38f) || !(q->h_nq > 0.0)) return false;   // (a NaN element: h_nq is NaN)
     const float inv = 16256.0f / m;
     const int64_t dp8 = sp->dp8;
     signed char* out = (signed char*)q->hq8;
     double st2 = 0.0, sa2 = 0.0;
-    for (int64_t c = 0; c < dp8; ++c) {
-        const float v = c < d ? q->hq32[c] : 0.0f;
-        const float sc = v * inv;
-        int qq = (int)std::nearbyint(sc);
-        qq = qq > 16256 ? 16256 : (qq < -16256 ? -16256 : qq);
-        const int q2 = ((qq + 64 + (1 << 20)) & 127) - 64;
-        const int q1 = (qq - q2) >> 7;
-        const double th = std::fabs((double)sc - (double)qq) + 0.004;
-        st2 += th * th;
-        sa2 += (double)(q2 * q2);
-        const int64_t slab = c >> 6, k = c & 63, c4 = k >> 4, j = k & 15;
+    for (int64_t c0 = 0; c0 < dp8; c0 += 16) {   // 16 columns = one a1 chunk and one a2 chunk of the image row
+        signed char q1v[16], q2v[16];
+        float tq[16];
+        int sa = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float v = c0 + j < d ? q->hq32[c0 + j] : 0.0f;   // (hq32 is zero beyond d up to dp; dp8 may reach beyond dp)
+            const float sc = v * inv;
+            const float r = (sc + 12582912.0f) - 12582912.0f;   // round to nearest even: |sc| <= 16256 (1 + 2^-23)
+            int qq = (int)r;
+            qq = qq > 16256 ? 16256 : (qq < -16256 ? -16256 : qq);
+            const int q2 = ((qq + 64 + (1 << 20)) & 127) - 64;
+            const int q1 = (qq - q2) >> 7;
+            const float th = std::fabs(sc - (float)qq) + 0.004f;
+            tq[j] = th * th;
+            sa += q2 * q2;
+            q1v[j] = (signed char)q1;
+            q2v[j] = (signed char)q2;
+        }
+        float st = 0.0f;
+        for (int j = 0; j < 16; ++j) st += tq[j];
+        st2 += (double)st * 1.00001;   // (16 fp32 additions)
+        sa2 += (double)sa;
+        const int64_t slab = c0 >> 6, c4 = (c0 & 63) >> 4;
         signed char* a1chunk = out + ((slab * 8 + c4) * 32);       // the a1 chunk of these columns: qa = q1, qb = q2
-        signed char* a2chunk = out + ((slab * 8 + 4 + c4) * 32);   // the a2 chunk: qa = 0, qb = q1
-        a1chunk[j] = (signed char)q1;
-        a1chunk[16 + j] = (signed char)q2;
-        a2chunk[j] = 0;
-        a2chunk[16 + j] = (signed char)q1;
+        signed char* a2chunk = out + ((slab * 8 + 4 + c4) * 32);   // the a2 chunk: qa = 0 (zeroed once, query_create), qb = q1
+        memcpy(a1chunk, q1v, 16);
+        memcpy(a1chunk + 16, q2v, 16);
+        memcpy(a2chunk + 16, q1v, 16);
     }
     const double nq = std::sqrt(q->h_nq);
     const double uq = (double)m * std::sqrt(st2) / (16256.0 * nq) * 1.001, vq = (double)m * std::sqrt(sa2) / (16256.0 * nq) * 1.001;
