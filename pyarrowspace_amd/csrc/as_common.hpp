@@ -59,6 +59,7 @@ struct as_space {
     mutable void* x8 = nullptr;
     mutable float* fa8 = nullptr;
     mutable double coef8 = 0.0;
+    mutable double uq_est = 0.0, vq_est = 0.0;   // batched int8 pass: 1.05 x the queries' measured residue norms of the previous passes (as_search.hip, host_batch_coef)
     mutable double u8max = 0.0, v8max = 0.0;   // max_i s_i |theta_i|_2 / (16256 |x_i|), max_i s_i |a2_i|_2 / (16256 |x_i|)
     mutable int x8_bad = 0;
     mutable int k2_i8 = 0;

@@ -143,6 +143,12 @@ struct as_query {
     // quantised on the device behind the staging kernel (q_quant_batch_kernel)
     signed char* q8img_dev = nullptr;
     float* faqv_dev = nullptr;
+    float* hx8stat = nullptr;            // pinned: the slots' measured (u_q, v_q) of the last int8 batched pass (q_quant_batch_kernel)
+    float* hx8stat_dev = nullptr;
+    double x8_au = 0.0, x8_av = 0.0;     // ... and the values the host assumed when it priced that pass
+    int batch_assume = 0;                // 1: the pass may be priced with the space's estimate (as_search_batch; a sharded pass: 0, a priori), 2: with x8_au / x8_av as they stand
+    int x8_nan = 0;                      // ... a slot's measurement was not a number (non-finite query)
+    int x8_verify = 0;                   // the last pass was: hold the measured values against the assumed ones at collect
     float h_faq = 0.0f;
     double coef_i8 = 0.0;
     int i8_scan = 0;

@@ -89,8 +89,8 @@ __global__ void q_prepare_kernel(const double* __restrict__ qin, int64_t d, int6
 // The batched pass on the int8 images: the slots' staged fp32 queries quantised like the items (as_k2bf.hip, quant_i8_kernel) into
 // the items' image layout -- a block per slot; idle slots (zero queries) get zero digits and scale 0.
 __global__ __launch_bounds__(256) void q_quant_batch_kernel(const float* __restrict__ q32, int64_t dp, int64_t dp8, signed char* __restrict__ img,
-                                                            float* __restrict__ faqv) {
-    __shared__ float sh[4];
+                                                            float* __restrict__ faqv, const QInfo* __restrict__ info, float* __restrict__ stat_host) {
+    __shared__ float sh[4], sh2[2][4];
     const float* x = q32 + (int64_t)blockIdx.x * dp;
     float m = 0.0f;
     for (int64_t c = threadIdx.x; c < dp; c += 256) m = fmaxf(m, fabsf(x[c]));
@@ -101,16 +101,45 @@ __global__ __launch_bounds__(256) void q_quant_batch_kernel(const float* __restr
     m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     const float inv = m > 0.0f ? 16256.0f / m : 0.0f;
     signed char* dst = img + (int64_t)blockIdx.x * dp8 * 2;
+    float st2 = 0.0f, sa2 = 0.0f;
     for (int64_t c = threadIdx.x; c < dp8; c += 256) {
         const float v = c < dp ? x[c] : 0.0f;
-        int q = (int)rintf(v * inv);
+        const float sc = v * inv;
+        int q = (int)rintf(sc);
         q = q > 16256 ? 16256 : (q < -16256 ? -16256 : q);
         const int a2 = ((q + 64 + (1 << 20)) & 127) - 64;
         const int a1 = (q - a2) >> 7;
         dst[(c >> 6) * 128 + (c & 63)] = (signed char)a1;
         dst[(c >> 6) * 128 + 64 + (c & 63)] = (signed char)a2;
+        const float th = fabsf(sc - (float)q) + 0.004f;   // (the residue, with the product's rounding on top: quant_i8_kernel)
+        st2 += th * th;
+        sa2 += (float)(a2 * a2);
     }
-    if (threadIdx.x == 0) faqv[blockIdx.x] = m * (11.313708498984761f / 16256.0f);   // s_q sqrt(128) / 16256
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        st2 += __shfl_xor(st2, o, 64);
+        sa2 += __shfl_xor(sa2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh2[0][threadIdx.x >> 6] = st2;
+        sh2[1][threadIdx.x >> 6] = sa2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        faqv[blockIdx.x] = m * (11.313708498984761f / 16256.0f);   // s_q sqrt(128) / 16256
+        // the slot's measured u_q = s_q |theta|_2 / (16256 |q|) and v_q = s_q |q2|_2 / (16256 |q|), for the host to hold against
+        // the values it ASSUMED when it priced the pass's error (host_batch_coef; pinned memory, a slot per block: plain stores)
+        const double nq = info[blockIdx.x].nq;
+        float u = 0.0f, v = 0.0f;
+        if (m > 0.0f) {
+            const float den = 16256.0f * sqrtf((float)nq);
+            u = m * sqrtf((sh2[0][0] + sh2[0][1]) + (sh2[0][2] + sh2[0][3])) / den * 1.002f;   // (fp32 sums of up to dp8 terms, rounded up generously)
+            v = m * sqrtf((sh2[1][0] + sh2[1][1]) + (sh2[1][2] + sh2[1][3])) / den * 1.002f;
+            if (!(nq > 0.0)) u = v = __int_as_float(0x7fc00000);
+        }
+        stat_host[2 * blockIdx.x] = u;
+        stat_host[2 * blockIdx.x + 1] = v;
+    }
 }
 
 // |q|^2 exactly as q_prepare_kernel forms it (256 strided partial sums, rounded products and sums, then the halving
@@ -2432,50 +2461,83 @@ static bool host_query_digits(as_query* q, int64_t d) {
 }
 
 // The batched pass on the int8 images (as_scan.hip, scan_gemm_kernel<..., I8>): the slots' queries are quantised like the items
-// by q_quant_batch_kernel, behind the staging kernel.  The host only bounds the error coefficient of the pass A PRIORI, from
-// the slots' largest element s_q and norm |q| (one read of the queries -- 32 x 4 096 elements quantised on the host took
-// 150 us in front of every pass): |theta_c| <= 1/2 + 0.004 and |q2_c| <= 64 over the d columns, so
-//   u_q <= s_q 0.504 sqrt(d) / (16256 |q|),   v_q <= s_q 64 sqrt(d) / (16256 |q|)
-// (1.7 times the measured u_q of a clustered unit query -- 1.1e-4 against 6e-5 at d = 768).
-// False (the bf16 / fp32 pass serves the batch): no usable image, a slot that is zero or non-finite, a coefficient beyond 2e-3.
+// by q_quant_batch_kernel, behind the staging kernel -- which also MEASURES every slot's u_q = s_q |theta|_2 / (16256 |q|) and
+// v_q = s_q |q2|_2 / (16256 |q|) into pinned memory.  The host prices the pass's error BEFORE the launch with the values it
+// ASSUMES -- 1.05 times what the previous passes over this space measured (queries of one workload quantise alike); before
+// the first pass an a-priori bound from the slots' s_q / |q|: |theta_c| <= 1/2 + 0.004, |q2_c| <= 64 over the d columns -- and
+// holds the measured values against them when it collects the pass: a pass beyond its assumption is run once more, priced
+// with what was measured (a non-finite query: its slots go to the single-query path like any slot that fails a proof).  (Reading the queries on the host costs 50 us per MB: measuring there put 140 us in
+// front of every pass of 32 x 4 096 elements; the a-priori bound alone is 1.7 times looser -- at topk = 100 most slots then
+// failed the scorer's proof.)
+// False (the bf16 / fp32 pass serves the batch): no usable image, an assumed coefficient beyond 2e-3.
 static bool host_batch_coef(as_query* q, const double* query_host, int64_t d) {
     const as_space* sp = q->sp;
-    if (getenv("ARROWSPACE_SCAN_FP32") || !q->q8img_dev || !q->half_enabled || q->ss.dots_rs != 4 || q->cap != 32 || sp->opts.force_exact) return false;
+    if (getenv("ARROWSPACE_SCAN_FP32") || !q->q8img_dev || !q->hx8stat || !q->half_enabled || q->ss.dots_rs != 4 || q->cap != 32 || sp->opts.force_exact)
+        return false;
     bool present = false;
     if (space_i8_image(sp, &present) != AS_OK || !present) return false;
-    double rmax = 0.0;   // the slots' largest s_q / |q|
-    for (int b = 0; b < q->nb; ++b) {
-        const double* src = query_host + (int64_t)b * d;
-        double mm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int64_t c = 0;
-        for (; c + 8 <= d; c += 8)
-            for (int j = 0; j < 8; ++j) {
-                const double v = src[c + j], av = std::fabs(v);
-                mm[j] = av > mm[j] ? av : mm[j];
-                nn[j] += v * v;
-            }
-        for (; c < d; ++c) {
-            const double v = src[c], av = std::fabs(v);
-            mm[0] = av > mm[0] ? av : mm[0];
-            nn[0] += v * v;
-        }
-        double m = 0.0, nq = 0.0;
-        for (int j = 0; j < 8; ++j) {
-            m = std::max(m, mm[j]);
-            nq += nn[j];   // (a NaN element: nq is NaN and the test below sends the batch to the other pass)
-        }
-        if (!(m > 1.0e-30) || !(m < 3.0e38) || !(nq > 0.0) || !(nq < 1.0e300)) return false;
-        rmax = std::max(rmax, m / std::sqrt(nq));
+    // (a row-sharded index's batched pass -- as_query_scan_batch -- prices a priori always: what a rank measures stays on that
+    // rank, and the ranks must take the same reruns)
+    double au = q->batch_assume ? sp->uq_est : 0.0, av = q->batch_assume ? sp->vq_est : 0.0;
+    if (q->batch_assume == 2) {   // the same queries again, priced with what the device measured on them (search_batch_collect)
+        au = q->x8_au;
+        av = q->x8_av;
     }
-    // (1.001: the queries' rounding to fp32 in s_q and |q|) + the rounding to fp32 of 128 * acc1 + accx, three additions of the
-    // waves' quarters, P - 1 of the passes' partials, two multiplications by the scales, the scales' own roundings (two each)
+    q->x8_verify = au > 0.0 ? 1 : 0;
+    if (!(au > 0.0)) {
+        double rmax = 0.0;   // the slots' largest s_q / |q|
+        for (int b = 0; b < q->nb; ++b) {
+            const double* src = query_host + (int64_t)b * d;
+            double m = 0.0, nq = 0.0;
+            for (int64_t c = 0; c < d; ++c) {
+                const double v = src[c], a = std::fabs(v);
+                m = a > m ? a : m;
+                nq += v * v;
+            }
+            if (!(m > 1.0e-30) || !(m < 3.0e38) || !(nq > 0.0) || !(nq < 1.0e300)) return false;
+            rmax = std::max(rmax, m / std::sqrt(nq));
+        }
+        const double sd = std::sqrt((double)d) / 16256.0 * 1.001;
+        au = rmax * 0.504 * sd;
+        av = rmax * 64.0 * sd;
+    }
+    // the rounding to fp32 of 128 * acc1 + accx, three additions of the waves' quarters, P - 1 of the passes' partials, two
+    // multiplications by the scales, the scales' own roundings (two each)
     int64_t chunk = 0;
     const int P = gemm_chunks(sp->dp8 / 2, &chunk, true);
-    const double sd = std::sqrt((double)d) / 16256.0 * 1.001;
-    const double coef = rmax * 0.504 * sd + 1.001 * sp->u8max + rmax * 64.0 * sd * sp->v8max + (double)(12 + P) * 5.9604644775390625e-8;
+    const double coef = au + 1.001 * sp->u8max + av * sp->v8max + (double)(12 + P) * 5.9604644775390625e-8;
     if (!(coef <= 2.0e-3)) return false;
     q->coef_i8 = coef;
+    q->x8_au = au;
+    q->x8_av = av;
     return true;
+}
+
+// the pass has run: the slots' measured u_q, v_q against the assumed ones; the space's estimate for the next passes
+static bool batch_coef_holds(as_query* q) {
+    const as_space* sp = q->sp;
+    float mu = 0.0f, mv = 0.0f;
+    bool ok = true;
+    for (int b = 0; b < q->cap; ++b) {
+        const float u = q->hx8stat[2 * b], v = q->hx8stat[2 * b + 1];
+        if (!((double)u <= q->x8_au) || !((double)v <= q->x8_av)) ok = false;   // (NaN: a non-finite query)
+        if (u == u && v == v) {
+            mu = std::max(mu, u);
+            mv = std::max(mv, v);
+        }
+    }
+    if (mu > 0.0f) {
+        sp->uq_est = std::max(1.05 * (double)mu, 0.97 * sp->uq_est);
+        sp->vq_est = std::max(1.05 * (double)mv, 0.97 * sp->vq_est);
+    }
+    if (!ok) {   // what a second pass over the same queries is priced with
+        q->x8_au = (double)mu * 1.0005;
+        q->x8_av = (double)mv * 1.0005;
+        q->x8_nan = 0;
+        for (int b = 0; b < q->cap; ++b)
+            if (q->hx8stat[2 * b] != q->hx8stat[2 * b] || q->hx8stat[2 * b + 1] != q->hx8stat[2 * b + 1]) q->x8_nan = 1;
+    }
+    return ok;
 }
 
 static as_status query_begin(as_query* q, const double* query_host, int64_t src_row, int64_t d, int64_t r0, int64_t r1,
@@ -2534,7 +2596,9 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         return AS_OK;
     }
     q->info_clean = 0;
-    if (query_host) {
+    if (query_host == q->hq) {
+        // (the slots' queries are already staged here: a second pass over them, search_batch_collect)
+    } else if (query_host) {
         memcpy(q->hq, query_host, sizeof(double) * d * q->nb);  // pinned + device-mapped: read in place by the kernel
         if (q->cap > q->nb) memset(q->hq + d * q->nb, 0, sizeof(double) * d * (q->cap - q->nb));  // idle slots: zero query
     } else {
@@ -2547,7 +2611,8 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     if (feature) AS_TRY(feat_query_prepare(q->gr, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, nslots, st));
     else hipLaunchKernelGGL(q_prepare_kernel, dim3(1, 1, nslots), dim3(256), 0, st, q->hq_dev, sp->d, sp->dp, q->q64, q->q32, q->info, 1.0);
     if (q->i8_scan && q->cap > 1)
-        hipLaunchKernelGGL(q_quant_batch_kernel, dim3((unsigned)q->cap), dim3(256), 0, st, (const float*)q->q32, sp->dp, sp->dp8, q->q8img_dev, q->faqv_dev);
+        hipLaunchKernelGGL(q_quant_batch_kernel, dim3((unsigned)q->cap), dim3(256), 0, st, (const float*)q->q32, sp->dp, sp->dp8, q->q8img_dev, q->faqv_dev,
+                           (const QInfo*)q->info, q->hx8stat_dev);
     if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
     const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !feature && !q->crowded_direct);
     AS_TRY(launch_scan(q, pre));
@@ -2708,6 +2773,9 @@ static as_status query_alloc(as_query* q) {
         const size_t dp8 = (size_t)(sp->dp + 63) / 64 * 64;
         AS_HIP(hipMalloc(&q->q8img_dev, dp8 * 2 * C));
         AS_HIP(hipMalloc(&q->faqv_dev, sizeof(float) * C));
+        AS_HIP(hipHostMalloc(&q->hx8stat, sizeof(float) * 2 * C, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(q->hx8stat, 0, sizeof(float) * 2 * C);
+        AS_HIP(hipHostGetDevicePointer((void**)&q->hx8stat_dev, q->hx8stat, 0));
     }
     if (C > 1 && C % 4 == 0) {   // batched workspace: the K-chunk passes' partial dots of rows wider than 768 floats
         int64_t chunk = 0;
@@ -2770,6 +2838,7 @@ void as_query_free(as_query* q) {
     if (q->hq) hipHostFree(q->hq);
     if (q->hq32) hipHostFree(q->hq32);
     if (q->hq8) hipHostFree(q->hq8);
+    if (q->hx8stat) hipHostFree(q->hx8stat);
     if (q->q8img_dev) hipFree(q->q8img_dev);
     if (q->faqv_dev) hipFree(q->faqv_dev);
     hipFree(q->q64); hipFree(q->q32); hipFree(q->info); hipFree(q->dots32); hipFree(q->part32);
@@ -3042,6 +3111,7 @@ as_status as_query_scan_batch(as_query* q, const double* queries_host, int32_t n
         return AS_EUNSUPPORTED;
     }
     q->nb = nb;
+    q->batch_assume = 0;
     AS_TRY(query_begin(q, queries_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1));
     if (q->gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;
     q->nb = q->cap;   // idle slots get empty records too: the gathered buffers are read slot by slot
@@ -3268,6 +3338,7 @@ as_status search_batch_launch(as_query* q, const double* queries, int nb, int64_
     q->exact = 0;
     q->robust = 0;
     q->nb = nb;
+    q->batch_assume = 1;
     AS_TRY(query_begin(q, queries, -1, d, 0, q->sp->n, q->gr->gp.eps, -1));
     if (q->gr->lambda_mode != AS_LAMBDA_FEATURE) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
     q->seq += 1;
@@ -3288,10 +3359,26 @@ as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, in
         q->seq += 1;
         AS_TRY(run_score(q, tau, 1));
     }
+    // (int8 pass: its error was priced with ASSUMED residue norms of the queries -- hold the measured ones against them)
+    const bool held = q->i8_scan && q->cap > 1 ? batch_coef_holds(q) : true;   // (always: the space's estimate follows the measurements)
+    bool priced = held || !q->x8_verify;
+    if (!priced && !q->x8_nan && q->batch_assume == 1) {
+        // the assumption did not hold: ONE more pass over the same slots (their queries are still staged in this workspace's
+        // pinned buffer), priced with the measured values -- not 32 single-query searches
+        q->batch_assume = 2;
+        const as_status s2 = query_begin(q, q->hq, -1, q->sp->d, 0, q->sp->n, q->gr->gp.eps, -1);
+        q->batch_assume = 1;
+        AS_TRY(s2);
+        if (q->gr->lambda_mode != AS_LAMBDA_FEATURE) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+        q->seq += 1;
+        AS_TRY(run_score(q, tau, 1));
+        for (int b = 0; b < nb; ++b) AS_TRY(wait_published(q, b));
+        priced = !(q->i8_scan && q->cap > 1) || batch_coef_holds(q) || !q->x8_verify;
+    }
     for (int b = 0; b < nb; ++b) {
         AS_TRY(wait_published(q, b));
         const HostOut* h = q->hout + b;
-        if (h->overflow || h->knn_inexact || h->score_inexact) {
+        if (h->overflow || h->knn_inexact || h->score_inexact || !priced) {
             out_status[b] = -1;
             continue;
         }

@@ -182,3 +182,45 @@ def test_int8_image_scan_returns_what_the_fp32_scan_returns(oracle_lib):
     assert not aspace.last_scan_int8    # a query without a scale (all zeros) is the fp32 scan's
     c = aspace.search_counters()
     assert c["searches_with_rerun"] == 0
+
+
+def test_batched_int8_pass_holds_measured_residues_against_the_assumed_ones(oracle_lib):
+    """The batched int8 pass is priced BEFORE its launch with residue norms of the queries the host assumes (1.25 x what earlier
+    passes measured); the device measures the real ones and the host compares when it collects.  A batch that breaks the
+    assumption -- queries with one dominant component after passes of smooth ones: s_q / |q| near 1 instead of 0.2 -- must still
+    return the oracle's hits (its slots are rerun singly), and so must the smooth batches before and after it."""
+    import pyarrowspace_amd as asp
+    n, d, k, topk = 4000, 256, 10, 8
+    X = clustered(n, d, nclust=10, seed=61)
+    gp = {"eps": calibrate_eps(X, k, "cosine"), "k": k, "topk": topk, "p": 2.0, "sigma": None, "metric": "cosine"}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(5)
+    smooth = np.stack([X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d) for _ in range(40)])
+    spiky = smooth.copy()
+    for b in range(0, 40, 3):
+        spiky[b] = 0.02 * spiky[b]
+        spiky[b, b % d] = 1.0
+
+    def check(Q, tau):
+        got = aspace.search_batch(Q, gl, tau)
+        for b in range(len(Q)):
+            try:
+                want, lq = ref.search(Q[b], tau)
+            except oracle_lib.ZeroLambda:
+                continue
+            assert_hits_match(got[b], want, ref.scores(Q[b], tau, lq), rtol=RTOL)
+
+    for tau in (0.62, 1.0):
+        check(smooth, tau)
+        assert aspace.last_batch_int8
+        try:
+            check(spiky, tau)
+        except asp.PanicException:            # (a spiky query without a neighbour poisons the batch like the reference's assert)
+            for b in range(len(spiky)):
+                try:
+                    want, lq = ref.search(spiky[b], tau)
+                except oracle_lib.ZeroLambda:
+                    continue
+                assert_hits_match(aspace.search(np.ascontiguousarray(spiky[b]), gl, tau), want, ref.scores(spiky[b], tau, lq), rtol=RTOL)
+        check(smooth, tau)
