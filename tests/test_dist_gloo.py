@@ -303,6 +303,116 @@ class OracleEngine:
         pass
 
 
+class OracleEngineX1(OracleEngine):
+    """The one-exchange pass of a sharded query (as_query_x1_begin / _finish, include/arrowspace_hip.h) restated on the oracle:
+    a rank's block = its k-NN records, a header (count, flags) and its scorer candidates as (item id, exact cosine, lambda) --
+    the local rows within W = (1 - tau) / (2 tau) of the rank's topk-th largest cosine, the scan's rule -- so that
+    ShardedIndex.search's one-exchange branch (one all-gather, the same finish on every rank) runs under gloo."""
+    CAP = 64
+
+    def x1_usable(self, tau):
+        return 0.4 <= tau <= 1.0 and not getattr(self, "x1_off", False)
+
+    def x1_begin(self, q, tau, r0, r1, world):
+        import torch
+        self.x1_calls = getattr(self, "x1_calls", 0) + 1
+        self.query_scan(q, r0, r1)
+        blk = np.zeros((self.k * 6 + 2 + self.CAP * 3,))
+        blk[: self.k * 6] = self.knn_local.numpy().reshape(-1)
+        flags, cand = 0, np.zeros((0,), dtype=np.int64)
+        if self.r1 > self.r0:
+            cos = self.o.scores(self.index, self.q, 1.0, 0.0)[self.r0 : self.r1]        # tau = 1: the cosine itself
+            kth = np.sort(cos)[::-1][min(self.topk, len(cos)) - 1]
+            cand = np.nonzero(cos >= kth - (1.0 - tau) / (2.0 * tau) - 1e-12)[0]
+            if len(cand) > self.CAP or getattr(self, "x1_force_redo", False):
+                flags, cand = 16, cand[:0]                                              # did not fit: every rank reruns on the chain
+            c = blk[self.k * 6 + 2 :].reshape(self.CAP, 3)
+            c[: len(cand), 0] = (cand + self.r0).astype(np.int64).view(np.float64)
+            c[: len(cand), 1] = cos[cand]
+            c[: len(cand), 2] = self.index["lambdas"][cand + self.r0]
+        blk[self.k * 6], blk[self.k * 6 + 1] = float(len(cand)), float(flags)
+        self.x1_send = torch.from_numpy(blk)
+        return self.x1_send
+
+    def x1_finish(self, blocks_all, tau, world):
+        r = blocks_all.numpy().reshape(world, -1)
+        self.query_lambda(__import__("torch").from_numpy(np.ascontiguousarray(r[:, : self.k * 6].reshape(-1, 6))))
+        ids, cs, lam, flags = [], [], [], 0
+        for w in range(world):
+            cnt, fl = int(r[w, self.k * 6]), int(r[w, self.k * 6 + 1])
+            flags |= fl
+            c = r[w, self.k * 6 + 2 :].reshape(self.CAP, 3)[:cnt]
+            ids.append(c[:, 0].copy().view(np.int64)); cs.append(c[:, 1]); lam.append(c[:, 2])
+        ids, cs, lam = np.concatenate(ids), np.concatenate(cs), np.concatenate(lam)
+        sc = tau * cs + (1.0 - tau) / (1.0 + np.abs(self.lq - lam))
+        o = np.lexsort((ids, -sc))[: self.topk]
+        hits = [(int(ids[t]), float(sc[t])) for t in o]
+        return hits, self.lq, self.lq == 0.0, False, 0, bool(flags & 16)
+
+
+def _x1_worker(rank, world, port, n, d, cuts, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyarrowspace_amd.dist import ShardedIndex
+        X = clustered(n, d, nclust=6, seed=21)
+        gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+        bounds = sorted([0, n] + list(cuts))
+        shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy())
+        eng = OracleEngineX1(gp)
+        index = ShardedIndex.build(gp, shard, dist, engine=eng)
+        rng = np.random.default_rng(5)
+        res, calls = [], []
+        for i in range(4):
+            q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
+            for tau in (1.0, 0.62, 0.4, 0.2):
+                eng.x1_force_redo = i == 3 and rank == world - 1     # one rank's candidates "do not fit": every rank takes the chain
+                before = getattr(eng, "x1_calls", 0)
+                one = index.search(q, tau)
+                calls.append(getattr(eng, "x1_calls", 0) - before)
+                eng.x1_off = True
+                two = index.search(q, tau)
+                eng.x1_off = False
+                assert one == two, (tau, one, two)
+                res.append((one, index.last_lambda_q))
+        out[rank] = (res, calls)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cuts", [(2, (130,)), (3, (70, 70))])
+def test_one_exchange_search_under_gloo(world, cuts):
+    """ShardedIndex.search's one-exchange branch (tau in [0.4, 1]): one all-gather of the ranks' blocks, the same finish on
+    every rank -- same hits as the two-exchange chain and as one process, an EMPTY shard included; tau = 0.2 keeps the chain;
+    a rank whose candidates do not fit sends every rank to the chain."""
+    import torch.multiprocessing as mp
+    from oracle import oracle_np
+    n, d = 300, 24
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_x1_worker, args=(world, _free_port(), n, d, cuts, out), nprocs=world, join=True)
+    X = clustered(n, d, nclust=6, seed=21)
+    gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_np.build(X, gp)
+    rng = np.random.default_rng(5)
+    want = []
+    for _ in range(4):
+        q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
+        for tau in (1.0, 0.62, 0.4, 0.2):
+            want.append(oracle_np.search(ref, q, tau))
+    for rank in range(world):
+        res, calls = out[rank]
+        assert calls == [1, 1, 1, 0] * 4          # the one-exchange pass ran for tau >= 0.4 only
+        for (hits, lq), (whits, wlq) in zip(res, want):
+            assert [i for i, _ in hits] == [i for i, _ in whits]
+            np.testing.assert_allclose([s for _, s in hits], [s for _, s in whits], rtol=1e-12)
+            assert abs(lq - wlq) <= 1e-12 * abs(wlq)
+        assert out[rank][0] == out[0][0]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
