@@ -120,7 +120,16 @@ int32_t as_knn_list_width(int64_t k);                 /* M; < 0 when k is not su
 int32_t as_record_capacity(int32_t which);            /* 0: k-NN records a query merges (ranks x k); 1: hit records (ranks x (topk + 1)) */
 double as_space_nmax(const as_space* sp);             /* largest squared norm (error bound of a block's dropped candidates) */
 as_status as_space_norms(const as_space* sp, double* out_dev); /* fp64 squared norms of the space's rows, device to device */
-int64_t as_space_row_offset(const as_space* sp);      /* global index of row 0 (set by as_graph_from_knn_global) */
+int64_t as_space_row_offset(const as_space* sp);      /* Ring build: may the block passes (as_knn_block / _pair / _band) run on the int8 two-digit images of the shards?  Every rank
+ * reports what its own rows measure -- out3 = {U, V, 1.0 when its image cannot be used (non-finite rows, ARROWSPACE_K2_NO_I8) else
+ * 0.0} (as_ring_i8_stats makes the image) --, the host all-gathers the three numbers and hands every rank the ring-wide maxima:
+ * as_ring_i8_set(sp, max U, max V, usable = no rank said 1).  usable = 0 or a coefficient 2.001 U + V^2 beyond 1e-3 keeps the
+ * bf16 head + tail form, on every rank alike (as_ring_i8: what was decided).  Graphs are the same bits either way.
+ * Serves ArrowSpaceBuilder::build, /root/reference/src/lib.rs:281-331, on a row-sharded index. */
+as_status as_ring_i8_stats(as_space* sp, double* out3);
+as_status as_ring_i8_set(as_space* sp, double u_max, double v_max, int32_t usable);
+int32_t as_ring_i8(const as_space* sp);
+/* global index of row 0 (set by as_graph_from_knn_global) */
 as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
                        int64_t row_goff, int64_t col_goff, double* p_key_dev, double* p_dist_dev, double* p_gy_dev,
                        int32_t* p_idx_dev, int32_t* p_cnt_dev, float* p_t32_dev);

@@ -321,6 +321,22 @@ as_status as_space_norms(const as_space* sp, double* out_dev) {
 }
 int64_t as_space_row_offset(const as_space* sp) { return sp ? sp->row_offset : 0; }
 
+as_status as_ring_i8_stats(as_space* sp, double* out3) {
+    if (!sp || !out3) {
+        set_err("as_ring_i8_stats: null argument");
+        return AS_EINVAL;
+    }
+    return ring_i8_stats(sp, out3);
+}
+as_status as_ring_i8_set(as_space* sp, double u_max, double v_max, int32_t usable) {
+    if (!sp) {
+        set_err("as_ring_i8_set: null argument");
+        return AS_EINVAL;
+    }
+    return ring_i8_set(sp, u_max, v_max, usable);
+}
+int32_t as_ring_i8(const as_space* sp) { return sp ? sp->ring_i8 : 0; }
+
 as_status as_knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t row_begin, int64_t row_end,
                        int64_t row_goff, int64_t col_goff, double* p_key_dev, double* p_dist_dev, double* p_gy_dev, int32_t* p_idx_dev,
                        int32_t* p_cnt_dev, float* p_t32_dev) {

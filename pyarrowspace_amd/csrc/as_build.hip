@@ -36,7 +36,7 @@ static double err_coef_dp(int64_t dp) {
 // add 8 * 2^-24.  Clustered unit rows at D = 768: 3.6e-4 (bf16 head + tail: 3.2e-4).
 static double err_coef_i8(double U, double V) { return 2.001 * U + V * V + 8.0 * 5.9604644775390625e-8; }
 
-double err_coef(const as_space* sp) { return sp->k2_i8 ? sp->coef8 : err_coef_dp(sp->dp); }
+double err_coef(const as_space* sp) { return sp->ring_i8 ? sp->ring_coef8 : (sp->k2_i8 ? sp->coef8 : err_coef_dp(sp->dp)); }
 
 // The operand of the k-NN kernels for this space's items: the fp32 matrix, or (default) its bf16 head + tail image,
 // made on first use and kept with the space.
@@ -123,6 +123,40 @@ static as_status k2_items_i8(const as_space* sp, bool* usable) {
     // (the bound that decides is absolute: what matters is e = coef (n_i + n_max) against the gaps between the rows' M-th and
     // k-th keys -- rows that fail their proof go to the band pass, the result is exact either way)
     *usable = sp->x8 && !sp->x8_bad && sp->coef8 <= 1.0e-3 && sp->dp <= 131072;
+    return AS_OK;
+}
+
+// The operand of a ring pass (as_knn_block / _pair / _band: this rank's rows against a visiting block): the int8 images of both
+// when the ring agreed on them (as_ring_i8_set: every rank's image usable, the coefficient from the ring-wide maxima of U and
+// V -- a product of a row of one shard with a row of another is off by at most |x||y| (U_a + U_b + U_a U_b + V_a V_b)), else
+// the bf16 head + tail images.  A visiting block's image is made from its raw rows here: the same digits its owner holds.
+struct RingOperand {
+    const float* a = nullptr;
+    const float* b = nullptr;
+    const float* fa = nullptr;   // rows' scales (int8) or null
+    const float* fb = nullptr;
+    int64_t ld = 0;
+    int nslab = 0;
+    bool i8 = false;
+};
+static as_status ring_operand(const as_space* sp, const as_space* cols, RingOperand* o) {
+    if (sp->ring_i8) {
+        bool ua = false, ub = false;
+        AS_TRY(k2_items_i8(sp, &ua));
+        AS_TRY(k2_items_i8(cols, &ub));
+        // (the block's own maxima are at most the ring's: its owner reported them)
+        if (sp->x8 && cols->x8 && !sp->x8_bad && !cols->x8_bad && cols->u8max <= sp->ring_u8 * 1.0000001 && cols->v8max <= sp->ring_v8 * 1.0000001 &&
+            sp->u8max <= sp->ring_u8 * 1.0000001 && sp->v8max <= sp->ring_v8 * 1.0000001) {
+            o->a = (const float*)sp->x8; o->b = (const float*)cols->x8; o->fa = sp->fa8; o->fb = cols->fa8;
+            o->ld = sp->dp8 / 2; o->nslab = (int)(sp->dp8 / 64); o->i8 = true;
+            return AS_OK;
+        }
+        set_err("ring pass: a block's int8 image does not match what the ring agreed on (as_ring_i8_set)");
+        return AS_EINVAL;
+    }
+    AS_TRY(k2_items(sp, &o->a));
+    AS_TRY(k2_items(cols, &o->b));
+    o->ld = sp->dp; o->nslab = (int)(sp->dp / 32);
     return AS_OK;
 }
 
@@ -1561,7 +1595,7 @@ static as_status knn_candidates(const as_space* sp, const as_graph_params* gp, i
     AS_HIP(ccnt.alloc((size_t)rows * S));
     KnnArgs& ka = c.ka;
     const float* items = nullptr;   // fp32 rows, their bf16 head + tail image, or (sp->k2_i8: knn_rows decided) the int8 two-digit image
-    const bool i8 = sp->k2_i8 != 0 && (variant & 48) == 48;
+    const bool i8 = (sp->k2_i8 != 0 || sp->ring_i8 != 0) && (variant & 48) == 48;
     if (i8) items = (const float*)sp->x8;
     else if ((variant & 48) == 48) AS_TRY(k2_items(sp, &items));
     else items = sp->x32;
@@ -2374,6 +2408,41 @@ static as_status block_check(const as_space* sp, const as_space* cols, int64_t r
     return AS_OK;
 }
 
+// Ring build: may the block passes run on the int8 two-digit images?  Every rank reports what its own rows measure
+// (ring_i8_stats: U, V, 1 when the image cannot be used -- non-finite rows --; makes the image), the host all-gathers the
+// three numbers and hands every rank the ring-wide maxima (ring_i8_set; usable = 0, or a coefficient beyond 1e-3: the
+// bf16 head + tail form, on every rank alike).
+as_status ring_i8_stats(as_space* sp, double* out3) {
+    AS_HIP(hipSetDevice(sp->device));
+    out3[0] = out3[1] = 0.0;
+    const bool off = !k2_bf16_enabled() || getenv("ARROWSPACE_K2_NO_I8") != nullptr || sp->opts.force_exact;
+    out3[2] = off ? 1.0 : 0.0;
+    if (off || sp->n == 0) return AS_OK;   // (an empty shard has no say)
+    bool usable = false;
+    AS_TRY(k2_items_i8(sp, &usable));
+    out3[0] = sp->u8max;
+    out3[1] = sp->v8max;
+    out3[2] = sp->x8 && !sp->x8_bad ? 0.0 : 1.0;
+    return AS_OK;
+}
+
+as_status ring_i8_set(as_space* sp, double u_max, double v_max, int32_t usable) {
+    sp->ring_i8 = 0;
+    if (!usable || !(u_max >= 0.0) || !(v_max >= 0.0)) return AS_OK;
+    const double coef = err_coef_i8(u_max, v_max);
+    if (!(coef <= 1.0e-3) || sp->dp > 131072) return AS_OK;
+    if (sp->n > 0 && (!sp->x8 || sp->x8_bad)) {
+        set_err("as_ring_i8_set: this rank has no usable int8 image (as_ring_i8_stats first)");
+        return AS_EINVAL;
+    }
+    sp->ring_u8 = u_max;
+    sp->ring_v8 = v_max;
+    sp->ring_coef8 = coef;
+    sp->ring_i8 = 1;
+    dbg("ring: block passes on the int8 images, U = %.3e, V = %.3e -> coefficient %.3e (bf16: %.3e)", u_max, v_max, coef, err_coef_dp(sp->dp));
+    return AS_OK;
+}
+
 // first pass of one visiting block: fused MFMA kernel + block refinement -> the block's slice of the partial lists
 as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_params* gp, int64_t r0, int64_t r1, int64_t row_goff,
                     int64_t col_goff, int M, double* p_key, double* p_dist, double* p_gy, int32_t* p_idx, int32_t* p_cnt,
@@ -2417,17 +2486,16 @@ as_status knn_block(const as_space* sp, const as_space* cols, const as_graph_par
     AS_HIP(ccnt.alloc((size_t)rows * S));
     const double nmax = std::max(sp->nmax, cols->nmax);
     KnnArgs ka;
-    const float *items_a = nullptr, *items_b = nullptr;
-    AS_TRY(k2_items(sp, &items_a));
-    AS_TRY(k2_items(cols, &items_b));
-    ka.x32 = items_b; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+    RingOperand op;
+    AS_TRY(ring_operand(sp, cols, &op));
+    ka.x32 = op.b; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
     ka.nrb = nrb; ka.S = S; ka.ntile = ntile; ka.M = M; ka.metric = metric;
     ka.epskey = nextafterf((float)epskey, INFINITY); ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(nmax * 1.0000002);
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-    ka.xa = items_a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff + 0; ka.col_goff = col_goff;
+    ka.xa = op.a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff + 0; ka.col_goff = col_goff;
     ka.a_ids = nullptr; ka.a_thr = nullptr;
-    ka.ld = sp->dp; ka.nslab = (int)(sp->dp / 32);
-    AS_TRY(launch_k2(ka, metric, false, false, grid, st));
+    ka.ld = op.ld; ka.nslab = op.nslab; ka.fa = op.fb; ka.a_fa = op.fa;
+    AS_TRY(launch_k2(ka, metric, false, false, grid, st, op.i8));
     BlockRefineArgs ra;
     ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = cols->x32; ra.xb64 = cols->x64; ra.na64 = sp->n64; ra.nb64 = cols->n64;
     ra.d = sp->d; ra.dp = sp->dp; ra.r0 = r0; ra.r1 = r1; ra.col_goff = col_goff; ra.S = S; ra.M = M; ra.metric = metric;
@@ -2536,16 +2604,15 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     AS_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * (size_t)rows * S, st));
     const double nmax = std::max(sp->nmax, cols->nmax);
     KnnArgs ka;
-    const float *items_a = nullptr, *items_b = nullptr;
-    AS_TRY(k2_items(sp, &items_a));
-    AS_TRY(k2_items(cols, &items_b));
-    ka.x32 = items_b; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
+    RingOperand op;
+    AS_TRY(ring_operand(sp, cols, &op));
+    ka.x32 = op.b; ka.n32 = cols->n32; ka.inorm32 = cols->inorm32; ka.n = cols->n; ka.dp = sp->dp; ka.r0 = r0; ka.r1 = r1;
     ka.nrb = nrb; ka.S = S; ka.ntile = ntile_all; ka.M = M; ka.metric = metric;
     ka.epskey = nextafterf((float)epskey, INFINITY); ka.coef = (float)(coef * 1.0000002); ka.nmax = (float)(nmax * 1.0000002);
     ka.buf_key = bkey; ka.buf_idx = bidx; ka.out_key = ckey; ka.out_idx = cidx; ka.out_cnt = ccnt;
-    ka.xa = items_a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff;
+    ka.xa = op.a; ka.a_n32 = sp->n32; ka.a_inorm32 = sp->inorm32; ka.row_goff = row_goff; ka.col_goff = col_goff;
     ka.a_ids = nullptr; ka.a_thr = nullptr;
-    ka.ld = sp->dp; ka.nslab = (int)(sp->dp / 32);
+    ka.ld = op.ld; ka.nslab = op.nslab; ka.fa = op.fb; ka.a_fa = op.fa;
     // the kernel addresses the transposed buffers by the item's number inside the block: bases moved back by the chunk's
     // first item (only items of the chunk's tiles are ever addressed)
     ka.units = d_units; ka.nunits = units; ka.unit_ctr = (int*)tr_cnt + ncc; ka.t_cnt = (int*)tr_cnt - j0;
@@ -2559,7 +2626,7 @@ static as_status pair_chunk(const as_space* sp, const as_space* cols, const as_g
     }
     ka.t_all = 1; ka.thr_col = col_thr;
     ka.thr0 = row_thr;   // the own rows' thresholds (their own-block lists' bounds): what a tighter start rejects lies beyond the row's M-th key
-    AS_TRY(launch_k2(ka, metric, false, true, grid, st));
+    AS_TRY(launch_k2(ka, metric, false, true, grid, st, op.i8));
     // own rows: as in knn_block
     BlockRefineArgs ra;
     ra.xa32 = sp->x32; ra.xa64 = sp->x64; ra.xb32 = cols->x32; ra.xb64 = cols->x64; ra.na64 = sp->n64; ra.nb64 = cols->n64;
@@ -2730,21 +2797,24 @@ as_status knn_block_band(const as_space* sp, const as_space* cols, const as_grap
     AS_HIP(hipMemsetAsync(xa, 0, sizeof(float) * (size_t)(nfp + BM) * sp->dp, st));
     AS_HIP(hipMemsetAsync(over, 0, sizeof(int), st));
     const double nmax = std::max(sp->nmax, cols->nmax);
-    const float *items_a = nullptr, *items_b = nullptr;
-    AS_TRY(k2_items(sp, &items_a));
-    AS_TRY(k2_items(cols, &items_b));
-    hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, items_a, sp->n32, sp->inorm32, sp->n64, sp->dp, r0,
+    RingOperand op;
+    AS_TRY(ring_operand(sp, cols, &op));
+    dev_tmp<float> a_fa;
+    AS_HIP(a_fa.alloc(nfp));
+    AS_HIP(hipMemsetAsync(a_fa, 0, sizeof(float) * nfp, st));
+    // (the rows are gathered from the image the pass runs on: op.ld floats per row -- at most dp, what xa was sized and zeroed for)
+    hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)nf), dim3(192), 0, st, op.a, sp->n32, sp->inorm32, sp->n64, op.ld, r0,
                        (const int*)d_ids, nf, B, metric, coef, nmax, (float*)xa, (float*)a_n32, (float*)a_inorm, (int*)a_ids, (float*)a_thr,
-                       row_goff);
+                       row_goff, op.fa, (float*)a_fa);
     AS_HIP(hipGetLastError());
     KnnArgs kb;
-    kb.x32 = items_b; kb.n32 = cols->n32; kb.inorm32 = cols->inorm32; kb.n = cols->n; kb.dp = sp->dp; kb.r0 = 0; kb.r1 = nf;
+    kb.x32 = op.b; kb.n32 = cols->n32; kb.inorm32 = cols->inorm32; kb.n = cols->n; kb.dp = sp->dp; kb.r0 = 0; kb.r1 = nf;
     kb.nrb = nrb2; kb.S = S2; kb.ntile = ntile; kb.M = CAP; kb.metric = metric;
     kb.epskey = 0; kb.coef = 0; kb.nmax = 0;
     kb.buf_key = bkey; kb.buf_idx = bidx; kb.out_key = c2key; kb.out_idx = c2idx; kb.out_cnt = c2cnt;
     kb.xa = xa; kb.a_n32 = a_n32; kb.a_inorm32 = a_inorm; kb.a_ids = a_ids; kb.a_thr = a_thr; kb.row_goff = 0; kb.col_goff = col_goff;
-    kb.ld = sp->dp; kb.nslab = (int)(sp->dp / 32);
-    AS_TRY(launch_k2(kb, metric, true, false, g2, st));
+    kb.ld = op.ld; kb.nslab = op.nslab; kb.fa = op.fb; kb.a_fa = op.i8 ? (const float*)a_fa : nullptr;
+    AS_TRY(launch_k2(kb, metric, true, false, g2, st, op.i8));
     BlockBandArgs ba;
     ba.xa32 = sp->x32; ba.xa64 = sp->x64; ba.xb32 = cols->x32; ba.xb64 = cols->x64; ba.na64 = sp->n64; ba.nb64 = cols->n64;
     ba.d = sp->d; ba.dp = sp->dp; ba.r0 = r0; ba.col_goff = col_goff; ba.S = S2; ba.CW = CAP; ba.M = M; ba.metric = metric; ba.nf = nf;

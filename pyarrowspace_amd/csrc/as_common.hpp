@@ -59,6 +59,10 @@ struct as_space {
     mutable void* x8 = nullptr;
     mutable float* fa8 = nullptr;
     mutable double coef8 = 0.0;
+    // ring build (one process per GPU): the ranks agreed to run the block passes on the int8 images (as_ring_i8_set); the
+    // coefficient of a product of rows of two shards from the ring-wide maxima of U and V
+    int ring_i8 = 0;
+    double ring_u8 = 0.0, ring_v8 = 0.0, ring_coef8 = 0.0;
     mutable double uq_est = 0.0, vq_est = 0.0;   // batched int8 pass: 1.05 x the queries' measured residue norms of the previous passes (as_search.hip, host_batch_coef)
     mutable double u8max = 0.0, v8max = 0.0;   // max_i s_i |theta_i|_2 / (16256 |x_i|), max_i s_i |a2_i|_2 / (16256 |x_i|)
     mutable int x8_bad = 0;
@@ -371,6 +375,8 @@ as_status check_limits(const as_graph_params* resolved, int64_t n, int lambda_mo
 // per-pair fp32 error coefficient: |key32 - key64| <= coef * (n_i + n_j) for L2,
 // <= coef for cosine
 double err_coef(const as_space* sp);
+as_status ring_i8_stats(as_space* sp, double* out3);
+as_status ring_i8_set(as_space* sp, double u_max, double v_max, int32_t usable);
 // the int8 two-digit image of the space's items (x8, fa8, u8max, v8max, coef8), made on first use; *present: it exists and
 // holds no non-finite item (whether its error is acceptable is the caller's call: build pass, scan)
 as_status space_i8_image(const as_space* sp, bool* present);

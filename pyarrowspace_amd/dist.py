@@ -341,6 +341,16 @@ class HipEngine:
                                                     C.c_void_p(n64.data_ptr()), C.byref(self.gr)))
 
     # ---- graph stage without replication: this rank's rows of the symmetrised graph
+    # ---- ring build on the int8 images: every rank's measurement, then the ring-wide decision (as_ring_i8_stats / _set)
+    def ring_i8_stats(self):
+        out = (C.c_double * 3)()
+        self._check(self.L.as_ring_i8_stats(self.sp, C.cast(out, C.c_void_p)))
+        return [float(out[0]), float(out[1]), float(out[2])]
+
+    def ring_i8_set(self, u_max, v_max, usable):
+        self._check(self.L.as_ring_i8_set(self.sp, float(u_max), float(v_max), 1 if usable else 0))
+        return bool(self.L.as_ring_i8(self.sp))
+
     def edge_bucket(self, idx, dist, gy, cnt, row0, bounds):
         """The lists' directed edges bucketed by the owner of their target (as_edges_bucket: count / scan / scatter kernels)
         -> (ints [E, 2] int32, reals [E, 2] float64, per-rank counts)."""
@@ -526,11 +536,9 @@ class HipEngine:
 
     # ---- persistence: this rank's shard + the graph, one file per rank
     def save(self, path):
-        import os
         self._check(self.L.as_index_save(self.sp, self.gr, os.fsencode(path)))
 
     def load(self, path):
-        import os
         self._check(self.L.as_index_load(os.fsencode(path), C.byref(self.op), C.byref(self.sp), C.byref(self.gr)))
         self.n, self.d = int(self.L.as_nitems(self.sp)), int(self.L.as_nfeatures(self.sp))
         return int(self.L.as_space_row_offset(self.sp)), int(self.L.as_graph_nitems(self.gr))
@@ -647,7 +655,6 @@ class ShardedIndex:
         """A communicator of this index's ranks inside the library (as_comm.hip): search() is then ONE host call per query --
         no Python between the scan, the two all-gathers and the merge.  Needs real RCCL ranks (one GPU per rank);
         ARROWSPACE_PY_COLLECTIVES=1 keeps the torch.distributed path (A/B runs)."""
-        import os
         e = self.engine
         # (what decides here is the same on every rank: the class, the engine type, the group's backend)
         if not (self.library_exchange and self._collective() and hasattr(e, "comm_create")):
@@ -936,6 +943,17 @@ class ShardedIndex:
             nmax = [float(p.item()) for p in parts]
         else:
             nmax = [float(nmax_local.item())]
+        # the block passes on the int8 images of the shards, when every rank's image allows it: each rank's measured maxima
+        # (U, V, unusable) all-gathered, the ring-wide maxima handed back -- the same decision on every rank
+        self.ring_i8 = False
+        if hasattr(e, "ring_i8_stats") and not os.environ.get("ARROWSPACE_RING_NO_I8"):
+            st = torch.tensor(e.ring_i8_stats(), dtype=torch.float64, device=X_shard.device)
+            if ring:
+                sts = [torch.zeros_like(st) for _ in range(world)]
+                dist.all_gather(sts, st, group=self.group)
+                st = torch.stack(sts).max(dim=0).values
+            u8, v8, bad = [float(v) for v in st.tolist()]
+            self.ring_i8 = e.ring_i8_set(u8, v8, bad == 0.0)
 
         def one_round(step_fn):
             cur = 0
@@ -957,7 +975,6 @@ class ShardedIndex:
                     self._exchange_wait(pending)
                 cur ^= 1
 
-        import os
         lap = getattr(self, "_lap", lambda name: None)
         self.ring_symmetric = ring and hasattr(e, "knn_block_pair") and not os.environ.get("ARROWSPACE_RING_FULL")
         if self.ring_symmetric:

@@ -92,6 +92,9 @@ def _worker(rank, world, port, n, d, split, out, replicate=False):
         shard = torch.from_numpy(X[bounds[rank] : bounds[rank + 1]].copy()).cuda()
         index = CpuStaged.build(gp, shard, dist, replicate=replicate)
         assert index.replicated == replicate and getattr(index, "ring_symmetric", False) == (not replicate)
+        # the ring's block passes ran on the shards' int8 images (clustered rows: every rank's image allows it; the ranks
+        # agreed through one all-gather of their measured maxima) -- the lists below are those of the fp64 oracle all the same
+        assert replicate or index.ring_i8
         res = [(index.search(q, tau), index.last_lambda_q) for q, tau in _queries(X, n, d)]
         rng = np.random.default_rng(6)
         Qb = np.stack([X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d) for _ in range(45)])

@@ -102,7 +102,7 @@ def test_blockwise_second_round_settles_duplicate_groups(oracle_lib):
     assert flagged > 0          # the second round did run
 
 
-def _symmetric_ring_lists(X, gp, cuts, dup_round=True):
+def _symmetric_ring_lists(X, gp, cuts, dup_round=True, i8=False):
     """The symmetric ring's first round with every rank in this process: each unordered pair of blocks goes through
     as_knn_block_pair ONCE (the even world's opposite pair split as ShardedIndex._ring_round_symmetric splits it), the
     visiting rows' slice is handed to their engine and folded there; then merge, and the second round for flagged rows
@@ -120,6 +120,9 @@ def _symmetric_ring_lists(X, gp, cuts, dup_round=True):
         e.ring_begin(G)
         eng.append(e)
     nmax = [e.block_nmax(e.own_block()) for e in eng]
+    if i8:   # the ranks' agreement on the int8 images (ShardedIndex._ring_knn: one all-gather of three numbers)
+        st = np.array([e.ring_i8_stats() for e in eng])
+        assert all(e.ring_i8_set(st[:, 0].max(), st[:, 1].max(), st[:, 2].max() == 0.0) for e in eng)
     for r, e in enumerate(eng):
         e.knn_block(e.own_block(), r, cuts[r], cuts[r])
     U = [e.knn_thresholds(max(nmax)) for e in eng]
@@ -165,14 +168,16 @@ def _symmetric_ring_lists(X, gp, cuts, dup_round=True):
     return res, flagged
 
 
+@pytest.mark.parametrize("i8", [False, True], ids=["bf16-ring", "int8-ring"])
 @pytest.mark.parametrize("metric", ["l2", "cosine"])
 @pytest.mark.parametrize("n,d,k,cuts", [(3000, 96, 10, [0, 700, 1900, 3000]), (5000, 768, 25, [0, 2500, 5000]),
                                         (2600, 40, 6, [0, 500, 501, 1700, 2600]), (4100, 64, 12, [0, 300, 1400, 2000, 3300, 4100])])
-def test_symmetric_ring_lists_equal_the_single_space_lists(metric, n, d, k, cuts):
-    """3, 2, 4 and 5 blocks (uneven, one of a single row): whole pairs, the split opposite pair of the even worlds."""
+def test_symmetric_ring_lists_equal_the_single_space_lists(metric, n, d, k, cuts, i8):
+    """3, 2, 4 and 5 blocks (uneven, one of a single row): whole pairs, the split opposite pair of the even worlds; the block
+    passes on the bf16 head + tail images and on the shards' int8 images (the ring-wide coefficient of as_ring_i8_set)."""
     X = clustered(n, d, nclust=max(4, n // 200), seed=n + k)
     gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": 5, "p": 2.0, "sigma": None, "metric": metric}
-    res, _ = _symmetric_ring_lists(X, gp, cuts)
+    res, _ = _symmetric_ring_lists(X, gp, cuts, i8=i8)
     for b in range(len(cuts) - 1):
         lo, hi = cuts[b], cuts[b + 1]
         idx, dist, gy, cnt = res[b]
@@ -183,7 +188,8 @@ def test_symmetric_ring_lists_equal_the_single_space_lists(metric, n, d, k, cuts
         np.testing.assert_array_equal(gy, sgy)
 
 
-def test_symmetric_ring_second_round_settles_duplicate_groups(oracle_lib):
+@pytest.mark.parametrize("i8", [False, True], ids=["bf16-ring", "int8-ring"])
+def test_symmetric_ring_second_round_settles_duplicate_groups(oracle_lib, i8):
     rng = np.random.default_rng(3)
     n, d, k = 2400, 64, 8
     X = clustered(n, d, nclust=12, seed=17)
@@ -193,7 +199,7 @@ def test_symmetric_ring_second_round_settles_duplicate_groups(oracle_lib):
     gp = {"eps": calibrate_eps(clustered(n, d, nclust=12, seed=17), k), "k": k, "topk": 5, "p": 2.0, "sigma": None}
     ref = oracle_lib.OracleIndex(X, gp)
     cuts = [0, 800, 1700, 2400]
-    res, flagged = _symmetric_ring_lists(X, gp, cuts)
+    res, flagged = _symmetric_ring_lists(X, gp, cuts, i8=i8)   # (int8: the band pass gathers the flagged rows from the image)
     assert flagged > 0
     for b in range(3):
         lo, hi = cuts[b], cuts[b + 1]
