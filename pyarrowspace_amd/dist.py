@@ -1252,6 +1252,16 @@ class HostStagedIndex(ShardedIndex):
 
     library_exchange = False      # (gloo ranks sharing a GPU: no RCCL communicator)
 
+    @classmethod
+    def build(cls, graph_params, X_shard, dist=None, *args, **kwargs):
+        # The ranks share ONE card: the library sizes its scratch (the symmetric pass's transposed buffers: 8 KB per item) by
+        # the memory it finds free -- found free by every rank at the same moment.  Each rank plans with its share.
+        if dist is not None and getattr(X_shard, "is_cuda", False) and "ARROWSPACE_SYM_FREE_GB" not in os.environ:
+            import torch
+            free, _ = torch.cuda.mem_get_info(X_shard.device)
+            os.environ["ARROWSPACE_SYM_FREE_GB"] = "%.1f" % (0.8 * free / 1e9 / max(dist.get_world_size(), 1))
+        return super().build(graph_params, X_shard, dist, *args, **kwargs)
+
 
     def _gather_rows(self, t, counts):
         self.torch.cuda.synchronize()
