@@ -544,7 +544,7 @@ def main():
 
     qps = args.steps / dt
     # the scan reads the int8 two-digit image of the items when it can (2 bytes per element + the rows' norm and scale), else fp32
-    scan_i8 = bool(aspace.last_scan_int8) if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 2048 and not feature
+    scan_i8 = bool(aspace.last_scan_int8) if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 4096 and not feature
     rows_per_gpu = (n + world - 1) // world
     scan_bytes = rows_per_gpu * (d + 2) * 4.0          # N x D fp32 items + N reciprocal norms read, N fp32 dots written
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9

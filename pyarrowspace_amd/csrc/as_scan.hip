@@ -794,9 +794,20 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
             if (NCH == 3)
                 asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]), "=&v"(xv[NCH > 2 ? 2 : 0]) : "v"(a0) : "memory");
-            if (NCH == 4)
+            if (NCH >= 4)
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(xv[0]), "=&v"(xv[NCH > 1 ? 1 : 0]), "=&v"(xv[NCH > 2 ? 2 : 0]), "=&v"(xv[NCH > 3 ? 3 : 0]) : "v"(a0) : "memory");
+            // (rows of 1 025 .. 2 048 image floats -- 2 049 .. 4 096 columns of the int8 image: chunks 4 .. 7)
+            if (NCH == 5) asm volatile("ds_read_b128 %0, %1 offset:4096\n\ts_waitcnt lgkmcnt(0)" : "=&v"(xv[NCH > 4 ? 4 : 0]) : "v"(a0) : "memory");
+            if (NCH == 6)
+                asm volatile("ds_read_b128 %0, %2 offset:4096\n\tds_read_b128 %1, %2 offset:5120\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[NCH > 4 ? 4 : 0]), "=&v"(xv[NCH > 5 ? 5 : 0]) : "v"(a0) : "memory");
+            if (NCH == 7)
+                asm volatile("ds_read_b128 %0, %3 offset:4096\n\tds_read_b128 %1, %3 offset:5120\n\tds_read_b128 %2, %3 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[NCH > 4 ? 4 : 0]), "=&v"(xv[NCH > 5 ? 5 : 0]), "=&v"(xv[NCH > 6 ? 6 : 0]) : "v"(a0) : "memory");
+            if (NCH == 8)
+                asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xv[NCH > 4 ? 4 : 0]), "=&v"(xv[NCH > 5 ? 5 : 0]), "=&v"(xv[NCH > 6 ? 6 : 0]), "=&v"(xv[NCH > 7 ? 7 : 0]) : "v"(a0) : "memory");
             cur = cur + NCH * 1024 == RING ? 0 : cur + NCH * 1024;
             float sacc = 0.0f;
             if (I8) {
@@ -1170,6 +1181,14 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_dma_kernel<2, 4, true, true>), dma_lds(2, 4, true, true));
     AS_ATTR((scan_dma_kernel<3, 5, true, true>), dma_lds(3, 5, true, true));
     AS_ATTR((scan_dma_kernel<4, 4, true, true>), dma_lds(4, 4, true, true));
+    AS_ATTR((scan_dma_kernel<5, 3, false, true>), dma_lds(5, 3, false, true));
+    AS_ATTR((scan_dma_kernel<6, 3, false, true>), dma_lds(6, 3, false, true));
+    AS_ATTR((scan_dma_kernel<7, 3, false, true>), dma_lds(7, 3, false, true));
+    AS_ATTR((scan_dma_kernel<8, 3, false, true>), dma_lds(8, 3, false, true));
+    AS_ATTR((scan_dma_kernel<5, 3, true, true>), dma_lds(5, 3, true, true));
+    AS_ATTR((scan_dma_kernel<6, 3, true, true>), dma_lds(6, 3, true, true));
+    AS_ATTR((scan_dma_kernel<7, 3, true, true>), dma_lds(7, 3, true, true));
+    AS_ATTR((scan_dma_kernel<8, 3, true, true>), dma_lds(8, 3, true, true));
     AS_ATTR((scan_dma_kernel<1, 8, true>), dma_lds(1, 8, true));
     AS_ATTR((scan_dma_kernel<2, 4, true>), dma_lds(2, 4, true));
     AS_ATTR((scan_dma_kernel<3, 5, true>), dma_lds(3, 5, true));
@@ -1346,7 +1365,7 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
                                q->r0, q->r1, q->dots32, pre, rev);                                                     \
     } while (0)
         // default for rows up to 1024 floats: the LDS-DMA ring scan (ARROWSPACE_SCAN_VARIANT bit2 = register-staged scan)
-        if (nch <= 4 && !(q->scan_variant & 4)) {
+        if ((nch <= 4 || (i8 && nch <= 8)) && !(q->scan_variant & 4)) {
             const int64_t want = std::max<int64_t>(1, (rows + 63) / 64);                 // blocks that still get >= 16 rows per wave
             // 2 blocks per CU, ring of 5 rows at 768 columns; rings of 4 or 6 rows and 3 blocks per CU measured the same or slower.
             // Short rows (up to 512 floats) pay the same per-row bookkeeping for half the bytes: 4 blocks per CU there
@@ -1357,7 +1376,8 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             // 0.270 -> 0.255 ms, 200k x 768 57.3 -> 55.8 us, 1M x 512 196 -> 190 us; 1 block 0.357 ms, rings of 6 / 8 slots 0.264 / 0.265 ms
             // (tools/scan_geom.sh); at 1 chunk per lane 4 blocks stay ahead (400k x 384: 64 us against 84 us with 2).
             const int bpc_default = i8 && nch == 2 ? 2 : 4;
-            const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : 2;   // (<= 4: the wave reports are sized for 16 waves per CU)
+            // (rows of 2 049 .. 4 096 columns of the image: rings of 3 rows of 5 .. 8 KB per wave -- 2 blocks per CU fit at 5 KB only)
+            const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : (nch <= 5 ? 2 : 1);   // (<= 4: the wave reports are sized for 16 waves per CU)
             const int64_t nblk = std::min<int64_t>(want, bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
             q->sc_nw = (int)NW;
@@ -1402,7 +1422,11 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
                     else AS_DSCAN(2, 4);
                     break;
                 case 3: AS_DSCAN(3, 5); break;
-                default: AS_DSCAN(4, 4); break;
+                case 4: AS_DSCAN(4, 4); break;
+                case 5: AS_DSCAN8(5, 3); break;   // (int8 image only: the dispatch above)
+                case 6: AS_DSCAN8(6, 3); break;
+                case 7: AS_DSCAN8(7, 3); break;
+                default: AS_DSCAN8(8, 3); break;
             }
 #undef AS_DSCAN
 #undef AS_DSCAN8

@@ -916,7 +916,7 @@ __device__ __forceinline__ void merge_partials(const T* pkey, const int* pidx, i
 }
 
 constexpr int PRUNE_CAP = 2048;  // compact list of the radix-pruned candidates
-constexpr int Q_LDS_MAX = 2048;  // widest query (padded floats) the finish kernels keep in LDS
+constexpr int Q_LDS_MAX = 4096;  // widest query (padded floats) the finish kernels keep in LDS (beyond: read from where it is staged)
 
 // rank-select the M smallest (key, idx) of the C buffered candidates into (fk, fi), sorted.
 // Large C (dense neighbourhoods) is first pruned to the candidates at or below the M-th
@@ -2405,7 +2405,7 @@ static bool host_query_digits(as_query* q, int64_t d) {
     const as_space* sp = q->sp;
     if (getenv("ARROWSPACE_SCAN_FP32") || !q->hq8 || sp->opts.force_exact) return false;
     bool present = false;
-    if (space_i8_image(sp, &present) != AS_OK || !present || sp->dp8 / 2 > 1024) return false;
+    if (space_i8_image(sp, &present) != AS_OK || !present || sp->dp8 / 2 > 2048) return false;
     // (loops shaped for the host compiler's vectoriser: 768 calls of nearbyint were 4 us in front of every scan)
     float mm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t c = 0;
@@ -2566,9 +2566,9 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     // memory and files the norms, the kernels behind it read the fp64 query from the pinned buffer: the staging kernel
     // and the idle gap behind it (6 + 5 us in front of every scan) are gone.
     static const bool no_hostq = getenv("ARROWSPACE_NO_HOSTQ") != nullptr;
-    // Rows of 1025 .. 2048 floats: their int8 image is a row of at most 1024 image floats -- the same scan, when the image serves
+    // Rows of 1025 .. 4096 floats: their int8 image is a row of at most 2048 image floats -- the same scan, when the image serves
     // this query; otherwise the generic path below (and no fused tail: search_once reads q->fused_tail back).
-    const bool narrow = sp->dp <= 1024, wide8 = !narrow && (sp->dp + 63) / 64 * 64 <= 2048;
+    const bool narrow = sp->dp <= 1024, wide8 = !narrow && (sp->dp + 63) / 64 * 64 <= 4096;
     bool host_path = query_host && q->cap == 1 && !q->exact && !feature && (narrow || wide8) && !(q->scan_variant & 4) && q->hq32 && !no_hostq;
     if (host_path) {
         for (int64_t c = 0; c < d; ++c) {
@@ -2910,11 +2910,11 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
     // scorer's candidates by its cosine bound, as on one GPU (search_once), and ONE kernel does the step between the two
     // exchanges (staged_score_kernel).
     const bool sc = q->staged_tau >= 0.4 && q->staged_tau <= 1.0 && q->gr->lambda_mode != AS_LAMBDA_FEATURE && !q->robust && !q->exact &&
-                    !q->no_fused && q->cap == 1 && q->sc_widx && q->sp->dp <= 2048 && !(q->scan_variant & 4) && !q->crowded_direct;
+                    !q->no_fused && q->cap == 1 && q->sc_widx && q->sp->dp <= 4096 && !(q->scan_variant & 4) && !q->crowded_direct;
     q->fused_tail = sc ? 1 : 0;
     q->tau_cur = q->staged_tau;
     const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
-    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
+    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->fused_tail = 0;
     q->staged_sc = sc_ran && qb == AS_OK && row_end > row_begin ? 1 : 0;
     AS_TRY(qb);
@@ -3001,11 +3001,11 @@ as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, in
     if (q->x1_dirty || q->x1_head != head) AS_HIP(hipMemsetAsync(head, 0, sizeof(XHead), q->stream));
     q->x1_dirty = 1;
     q->x1_head = head;
-    const bool sc = !q->no_fused && q->sc_widx && sp->dp <= 2048 && !(q->scan_variant & 4) && !q->crowded_direct;
+    const bool sc = !q->no_fused && q->sc_widx && sp->dp <= 4096 && !(q->scan_variant & 4) && !q->crowded_direct;
     q->fused_tail = sc ? 1 : 0;
     q->tau_cur = tau;
     const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
-    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
+    const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->fused_tail = 0;
     q->staged_sc = 0;
     AS_TRY(qb);
@@ -3242,11 +3242,11 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     // queries take that chain directly.
     const bool sc_skip = q->sc_crowded > 0 && (q->sc_crowded++ & 63) != 0;
     const bool want_fused = !feature && !q->robust && !q->exact && !direct && !q->no_fused && !sc_skip && q->cap == 1 && tau >= 0.4 && tau <= 1.0 &&
-                            q->sp->dp <= 2048 && !(q->scan_variant & 4);
+                            q->sp->dp <= 4096 && !(q->scan_variant & 4);
     q->fused_tail = want_fused ? 1 : 0;
     q->tau_cur = tau;
     const as_status qb = query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1);
-    const bool fused = q->fused_tail != 0;   // (rows of 1025 .. 2048 floats: only when the int8 image served the scan)
+    const bool fused = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->crowded_direct = 0;
     q->fused_tail = 0;
     AS_TRY(qb);

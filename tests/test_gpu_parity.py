@@ -125,7 +125,7 @@ def test_search_batch_matches_single_and_oracle(oracle_lib, metric, d):
             want, lq = ref.search(Q[b], tau)
             assert_hits_match(got[b], want, ref.scores(Q[b], tau, lq), rtol=RTOL)
             assert got[b] == aspace.search(np.ascontiguousarray(Q[b]), gl, tau)
-            assert aspace.last_scan_int8 == (d <= 2048)   # rows of up to 2 048 floats: the single-query scan reads the image too
+            assert aspace.last_scan_int8          # rows of up to 4 096 floats: the single-query scan reads the image too
     far = Q.copy()
     far[4] = 0.0
     far[4, 0] = 40.0                      # one query without neighbours poisons the batch like the reference's assert
