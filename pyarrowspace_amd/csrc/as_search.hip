@@ -2695,6 +2695,14 @@ as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query
     q->topk = gr ? std::min<int64_t>(gr->gp.topk, std::max<int64_t>(sp->n, graph_items(gr))) : 1;
     q->Mk = list_width(std::min<int64_t>(q->k, sp->n));
     q->Ms = score_width(q->topk);
+    // (batched workspace, deep lists: the pass's coarse keys -- fp16 cosines, the int8 image's error term -- leave the scorer's
+    // proof little room between the topk-th score and the Ms-th key in a dense cluster: 64 more candidates per slot.  topk = 100
+    // at 1M x 768: 3 % of the slots failed the proof and went to the single-query path, 36 000 queries/s; A/B: ARROWSPACE_BATCH_MS_EXTRA)
+    static const int ms_extra = getenv("ARROWSPACE_BATCH_MS_EXTRA") ? atoi(getenv("ARROWSPACE_BATCH_MS_EXTRA")) : 64;
+    if (cap > 1 && q->topk > 56 && ms_extra > 0) {
+        const int w = score_width(std::min<int64_t>(q->topk + ms_extra, MAX_TOPK));
+        if (w > 0) q->Ms = std::max(q->Ms, w);
+    }
     if (q->Mk < 0 || q->Ms < 0) {
         set_err("k=%lld exceeds the supported maximum of 120, or topk=%lld the maximum of 1024", (long long)q->k, (long long)q->topk);
         delete q;
