@@ -31,4 +31,5 @@ pass write WRITE_SIZE &&
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum &&
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE &&
 pass sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM
+pass mops8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA || echo "(no int8 MFMA op counter under these names on this box)"
 grep -h "n=" $OUT/*.log | head -8
