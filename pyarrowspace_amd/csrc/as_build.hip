@@ -110,6 +110,9 @@ static as_status k2_items_i8(const as_space* sp, bool* usable) {
         float U, V;
         memcpy(&U, &h[0], 4);
         memcpy(&V, &h[1], 4);
+#ifdef AS_ABLATION
+        if (getenv("ARROWSPACE_K2_ZERO")) (void)hipMemset(x8, 0, (size_t)rows_alloc * dp8 * 2);   // clock experiments: all-zero operands
+#endif
         const_cast<as_space*>(sp)->dp8 = dp8;
         sp->x8 = x8;
         sp->fa8 = fa8;
