@@ -607,7 +607,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "SURVEY 8(d) synthetic: np.random.default_rng(42) clustered N=%d x D=%d fp32 (1024 centres, noise 0.5, "
-                               "rows normalised), k=%d topk=%d tau=%.2f eps=%.5f (calibrated: mean degree ~2k), metric=%s kernel=%s "
+                               "rows normalised), k=%d topk=%d tau=%.2f eps=%.5f (calibrated: mean degree ~2k), metric=%s kernel=%s (p=2 is the kernel's "
+                               "exponent, GRAPH_VARIABLES.md:9 -- the distance is L2 or rectified cosine, never a general L_p) "
                                "lambda_mode=%s; queries = items perturbed by default_rng(43) noise (deviation from 8(d): a fresh "
                                "sample of the recipe has no neighbour inside eps); BASELINE.json headline config"
                                % (n, d, args.k, args.topk, args.tau, eps, args.metric, args.kernel, args.lambda_mode),
