@@ -224,3 +224,17 @@ def test_config5_five_ranks_uneven_shards_cosine():
     """BASELINE.json config 5's protocol with as many ranks as the pool allows on one card next to the test runner (5),
     uneven shards, in the mode the reference's parameter sets are written for (rectified-cosine distance, rational weights)."""
     _run(5, 1_200_000, 768, uneven=True, metric="cosine", kernel="rational")
+
+
+def test_config4_full_size_8_8m_by_768_four_ranks():
+    """BASELINE.json config 4 at its FULL size (8.8M x 768 fp32 row-sharded over 4 ranks of 2.2M rows) as a 4-rank job on the one
+    GPU of this box: the ring's block passes on the shards' int8 images, every pair of shards once, slices home, edge
+    all-to-all, sharded graph stage, sharded single + batched search; verification inside the worker (Laplacian identities
+    over all ranks, sampled rows against an fp64 brute force, scores from the definition, single == batched on every rank).
+    About 2.5 minutes; needs most of the card's memory (skipped below 200 GB free)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 200e9:
+        pytest.skip("needs 200 GB of free device memory: %.0f GB free" % (free / 1e9))
+    out = _run(4, 8_800_000, 768, uneven=False, single=False)
+    assert all(out[r]["rows"] == 2_200_000 for r in range(4))
