@@ -1131,7 +1131,9 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
         // finish kernel's keys (a few ulp of fp32 each way)
         p.sc_enabled = 1;
         p.sc_m = q->Ms;
-        p.sc_w = (float)((1.0 - q->tau_cur) / (2.0 * q->tau_cur) + 1.0e-5);
+        // ... and for the scan's own error, twice: a cosine off by at most `coef` (the int8 image: 3e-4 .. 2e-3; fp32: 2e-6) both in
+        // the rows that set the bound and in the row held against it
+        p.sc_w = (float)((1.0 - q->tau_cur) / (2.0 * q->tau_cur) + 2.0 * p.coef * 1.0001 + 1.0e-5);
         p.sc_idx = q->sc_widx;
         p.sc_hist = q->sc_hist;
 #ifdef AS_ABLATION   // measurement switches that return wrong answers exist in `make ABLATION=1` builds only
