@@ -549,7 +549,8 @@ def main():
     scan_bytes = rows_per_gpu * (d + 2) * 4.0          # N x D fp32 items + N reciprocal norms read, N fp32 dots written
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
     d8 = (d + 63) // 64 * 64
-    scan_moved = rows_per_gpu * (2.0 * d8 + 12.0) if scan_i8 else scan_bytes   # bytes the launch moves: image + norms + scales + dots
+    scan_coarse = single and getattr(aspace, "last_scan_operand", "") == "int8-high"   # the image's high digits alone: 1 B per element
+    scan_moved = rows_per_gpu * ((1.0 if scan_coarse else 2.0) * d8 + 12.0) if scan_i8 else scan_bytes   # bytes the launch moves: image + norms + scales + dots
     moved = scan_moved / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
     # Build kernel: bstats["mfma_flops"] counts 2 * (pairs computed) * D -- the fp32-equivalent work.  The default kernel
@@ -636,7 +637,8 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
                      "traffic_source": traffic_source if traffic_scan is not None else "none (live passes: %s)" % live_note,
                      "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes,
-                     "operand": "int8 two-digit image (2 B per element)" if scan_i8 else "fp32 items",
+                     "operand": ("int8 image, high digits alone (1 B per element; every candidate re-evaluated exactly)" if scan_coarse
+                                 else "int8 two-digit image (2 B per element)") if scan_i8 else "fp32 items",
                      "bytes_moved_per_launch": scan_moved, "achieved_bytes_moved": moved, "frac_bytes_moved": moved / HBM_PEAK_GBS,
                      "frac_note": "`achieved` and `frac` follow SURVEY 8(d): ALGORITHMIC bytes N (D + 2) 4 over the launch time -- above 1 "
                                   "when the scan reads the 2-byte image instead of the fp32 items; `frac_bytes_moved` is the physical "

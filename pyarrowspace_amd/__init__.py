@@ -325,6 +325,12 @@ class ArrowSpace:
         return bool(_L.as_last_scan_int8(self._h))
 
     @property
+    def last_scan_operand(self) -> str:
+        """Extension: what the last single-query scan read -- "fp32" items, their "int8" two-digit image, or "int8-high" (the
+        image's high digits alone: the coarse scan, every candidate re-evaluated exactly)."""
+        return {0: "fp32", 1: "int8", 2: "int8-high"}.get(int(_L.as_last_scan_int8(self._h)), "fp32")
+
+    @property
     def last_batch_int8(self) -> bool:
         """Extension: the last batched pass of `search_batch` ran on the int8 images of items and queries (int8 matrix pipe)."""
         return bool(_L.as_last_batch_int8(self._h))

@@ -107,7 +107,7 @@ void as_free_space(as_space* sp) {
     if (sp->qcache_b) as_query_free(sp->qcache_b);
     if (sp->qcache_b2) as_query_free(sp->qcache_b2);
     if (sp->stream) hipStreamSynchronize(sp->stream);
-    hipFree(sp->x32); hipFree(sp->xs); hipFree(sp->x8); hipFree(sp->fa8); hipFree(sp->x64); hipFree(sp->n64); hipFree(sp->n32); hipFree(sp->inorm32);
+    hipFree(sp->x32); hipFree(sp->xs); hipFree(sp->x8); hipFree(sp->x8h); hipFree(sp->fa8); hipFree(sp->x64); hipFree(sp->n64); hipFree(sp->n32); hipFree(sp->inorm32);
     hipFree(sp->lam64); hipFree(sp->lam32);
     if (sp->stream) hipStreamDestroy(sp->stream);
     delete sp;

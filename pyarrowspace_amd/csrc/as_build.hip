@@ -80,6 +80,42 @@ as_status space_i8_image(const as_space* sp, bool* present) {
     return AS_OK;
 }
 
+// The high digits of the int8 image alone, planar: 64 bytes per row and 64-column slab instead of 128 -- the operand of the
+// single query's COARSE scan (as_search.hip, query_begin): x ~ s 128 a1 / 16256, off by at most V |x| (v8max).
+__global__ __launch_bounds__(256) void extract_a1_kernel(const signed char* __restrict__ x8, signed char* __restrict__ x8h, int64_t chunks, int64_t cpr) {
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < chunks; t += (int64_t)gridDim.x * 256) {
+        const int64_t row = t / cpr, c = t - row * cpr;          // c: 16-byte chunk of the planar row; 4 per slab
+        *(i32x4v*)(x8h + t * 16) = *(const i32x4v*)(x8 + (row * cpr * 2 + (c >> 2) * 8 + (c & 3)) * 16);
+    }
+}
+
+as_status space_i8h_image(const as_space* sp, bool* present) {
+    *present = false;
+    bool have = false;
+    AS_TRY(space_i8_image(sp, &have));
+    if (!have) return AS_OK;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!sp->x8h) {
+        const int64_t rows_alloc = sp->np + ROW_TILE, cpr = sp->dp8 / 16;
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)rows_alloc * sp->dp8) != hipSuccess) {
+            (void)hipGetLastError();
+            return AS_OK;   // (no memory for it: the two-digit scan stays)
+        }
+        hipLaunchKernelGGL(extract_a1_kernel, dim3(256 * 8), dim3(256), 0, sp->stream, (const signed char*)sp->x8, (signed char*)p, rows_alloc * cpr, cpr);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sp->stream) != hipSuccess) {
+            (void)hipFree(p);
+            set_err("extract_a1_kernel failed");
+            return AS_EHIP;
+        }
+        sp->x8h = p;
+    }
+    *present = true;
+    return AS_OK;
+}
+
 static as_status k2_items_i8(const as_space* sp, bool* usable) {
     *usable = false;
     if (!sp->x8 && !sp->x8_bad) {

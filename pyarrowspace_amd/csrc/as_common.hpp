@@ -57,6 +57,7 @@ struct as_space {
     // error coefficient its products carry (from max_i s_i / |x_i| and max_i |x_i|_1 / |x_i|); k2_i8: the k-NN pass in
     // flight runs on it (set and cleared by knn_rows: err_coef follows it)
     mutable void* x8 = nullptr;
+    mutable void* x8h = nullptr;   // the HIGH digits alone, planar ([np + 256][dp8] bytes): the single-query scan's coarse operand (space_i8h_image)
     mutable float* fa8 = nullptr;
     mutable double coef8 = 0.0;
     // ring build (one process per GPU): the ranks agreed to run the block passes on the int8 images (as_ring_i8_set); the
@@ -380,6 +381,7 @@ as_status ring_i8_set(as_space* sp, double u_max, double v_max, int32_t usable);
 // the int8 two-digit image of the space's items (x8, fa8, u8max, v8max, coef8), made on first use; *present: it exists and
 // holds no non-finite item (whether its error is acceptable is the caller's call: build pass, scan)
 as_status space_i8_image(const as_space* sp, bool* present);
+as_status space_i8h_image(const as_space* sp, bool* present);
 
 // build stages (as_build.hip)
 as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld);

@@ -152,6 +152,17 @@ struct as_query {
     float h_faq = 0.0f;
     double coef_i8 = 0.0;
     int i8_scan = 0;
+    // COARSE scan (single query, fused tail): the planar high digits of the items alone -- half the image's bytes again -- against
+    // the query's two digits; what it drops (a2 . q, at most V |x||q|) makes every k-NN candidate's exact evaluation necessary
+    // (FinishArgs::exhaustive); a query whose candidates overflow sends the next 63 to the two-digit scan
+    int* hq8h = nullptr;                 // pinned: the query's digit registers in the planar rows' chunk order
+    int* hq8h_dev = nullptr;
+    double coef_i8h = 0.0;               // the coarse scan's coefficient for THIS query (host_query_digits)
+    int coarse = 0;                      // the last scan was the coarse one
+    int coarse_off = 0;                  // > 0: counting the searches that skip it
+    int allow_coarse = 0;                // set by search_once around query_begin: the caller's tail evaluates every k-NN candidate exactly
+    int xknn_dirty = 0;                  // ... its counter may be non-zero (a pass died before its finish kernel)
+    void* xknn = nullptr;                // [CAND_CAP] exact (id, key, distance, gy) of the coarse scan's k-NN candidates (staged_x1_kernel, xk)
     int pool_slot = 0;       // slot in the space's pool of single-query workspaces (as_search): picks the stream's priority
     float* dots32 = nullptr; // [np]
     float* part32 = nullptr; // batched workspace of rows wider than 768 floats: [K-chunk pass][slots x np] fp32 partial dots (as_scan.hip, gemm_chunks)

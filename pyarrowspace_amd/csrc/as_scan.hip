@@ -1119,7 +1119,7 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     p.host_q = q->host_q;
     if (q->i8_scan && q->cap == 1) {
         p.fa8 = sp->fa8;
-        p.q8 = q->hq8_dev;
+        p.q8 = q->coarse ? q->hq8h_dev : q->hq8_dev;
         p.faq = q->h_faq;
     }
     if (q->host_q) {
@@ -1213,8 +1213,9 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
     } else {
         // (single query on the int8 two-digit image: the image's rows are dp8 / 2 floats long -- half the bytes, half the chunks)
         const bool i8 = q->cap == 1 && q->i8_scan && pre.q8 && pre.fa8 && sp->x8;
-        const int64_t ldrow = i8 ? sp->dp8 / 2 : sp->dp;
-        const float* xrows = i8 ? (const float*)sp->x8 : sp->x32;
+        const bool coarse = i8 && q->coarse && sp->x8h;   // (the planar high digits: rows of dp8 bytes)
+        const int64_t ldrow = i8 ? (coarse ? sp->dp8 / 4 : sp->dp8 / 2) : sp->dp;
+        const float* xrows = i8 ? (const float*)(coarse ? sp->x8h : sp->x8) : sp->x32;
         const int nch = (int)((ldrow + 255) / 256);
         if (q->cap > 1 && q->ss.dots_rs == 4) {
             // batched pass, GEMM-shaped: matrix pipe (bf16 head + tail with the fp16 cosines, else fp32), K split over the 4 waves of a block, 2 blocks per CU
@@ -1380,7 +1381,10 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int bpc_default = i8 && nch == 2 ? 2 : 4;
             // (rows of 2 049 .. 4 096 columns of the image: rings of 3 rows of 5 .. 8 KB per wave -- 2 blocks per CU fit at 5 KB only)
             const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : (nch <= 5 ? 2 : 1);   // (<= 4: the wave reports are sized for 16 waves per CU)
-            const int64_t nblk = std::min<int64_t>(want, bpc * (int64_t)q->cus);
+            // (collecting the scorer's candidates: every wave needs a chunk in front of its last to publish from -- at least 32 rows
+            // per wave, two chunks of 16; a 30 000-row index on 1 876 waves had 16 rows per wave, no bound, and every row a candidate)
+            const int64_t want_sc = pre.sc_enabled ? std::max<int64_t>(1, rows / 128) : want;
+            const int64_t nblk = std::min<int64_t>(std::min(want, want_sc), bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
             q->sc_nw = (int)NW;
             // Chunks of 64 rows (a row per lane at the chunk's end).  The scan that also collects the scorer's candidates learns

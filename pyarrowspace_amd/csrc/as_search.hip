@@ -1857,11 +1857,21 @@ struct XCand {
     double lam;    // lambda of the item
 };
 constexpr int X1_BLOCKS = 16;        // candidate blocks beside the k-NN block
+constexpr int X1_BLOCKS_COARSE = 32; // blocks of the coarse scan's tail: scorer candidates AND k-NN candidates by the thousand
 constexpr int X1_LOCAL_CAP = 4096;   // candidates one block gathers from its share of the scan's reports
 
 // grid 1 + X1_BLOCKS: block 0 = knn_finish (records into the exchange block), blocks 1.. = the scan waves' reports -> exact
 // cosines.  The two halves do not depend on each other: the k-NN phase (17 us, one block) hides the candidates' evaluation.
-__global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishArgs as_, XHead* head, XCand* cands, int xcap, int preset_flags) {
+// xk != null (the single space's coarse scan: k-NN candidates by the hundred, every one of them to be evaluated exactly): no
+// k-NN block -- every block takes its share of the k-NN candidate buffer as well and leaves (id, exact key, distance, gy)
+// per candidate in xk, in the buffer's order; the finish kernel ranks them (staged_x1_final_kernel, xk).
+struct XKnn {
+    int idx;   // local row
+    int pad;
+    double key, dist, gy;
+};
+__global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishArgs as_, XHead* head, XCand* cands, int xcap, int preset_flags, XKnn* xk) {
+    int* xk_count = (int*)(xk + CAND_CAP);   // (behind the entries: zero at the start of a pass -- the finish kernel leaves it so)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* qs = (double*)smem;
     const double* qx = nullptr;
@@ -1870,7 +1880,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         qx = qs;
     }
     char* work = smem + sizeof(double) * Q_LDS_MAX;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && !xk) {
         knn_finish_body<float>(ak, work, qx);
         if (threadIdx.x == 0) {   // (wave 0 ran the whole body: its own stores)
             const int fl = preset_flags | (ak.info->knn_inexact ? 1 : 0) | ((ak.info->overflow & 1) ? 4 : 0) | ((ak.info->overflow & 2) ? 8 : 0);
@@ -1888,7 +1898,50 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
     }
     __syncthreads();
     // (reports dealt round robin: the waves that end first -- under a bound still loose -- keep the most rows, and they are neighbours)
-    const int nb = (int)gridDim.x - 1, b = (int)blockIdx.x - 1;
+    const int nb = xk ? (int)gridDim.x : (int)gridDim.x - 1, b = xk ? (int)blockIdx.x : (int)blockIdx.x - 1;
+    if (xk) {
+        // this block's share of the k-NN candidate buffer (entries b, b + nb, ...): exact key, distance and gy of each
+        const int raw = ak.info->knn_cnt;
+        if (raw > CAND_CAP) {
+            if (b == 0 && threadIdx.x == 0) {
+                ak.info->overflow |= 1;
+                atomicOr(&head->flags, 4);
+            }
+        } else {
+            const int mine = raw > b ? (raw - b + nb - 1) / nb : 0;   // <= CAND_CAP / nb + 1
+            for (int t = threadIdx.x; t < mine; t += blockDim.x) si[t] = ak.ci[b + nb * t];
+            __syncthreads();
+            const double nqk = ak.info->nq;
+            for (int base = 0; base < mine; base += 64) {   // (block-uniform)
+                const int m = mine - base < 64 ? mine - base : 64;
+                exact_eval_all(ak.x32, ak.x64, qx ? qx : ak.q64, ak.d, ak.dp, si + base, m, o_sq, o_dot);
+                __syncthreads();
+                if ((int)threadIdx.x < m) {
+                    const int j = si[base + threadIdx.x];
+                    const double sq = o_sq[threadIdx.x], dot = o_dot[threadIdx.x];
+                    XKnn e;
+                    e.idx = j;
+                    e.pad = 0;
+                    if (ak.metric == AS_METRIC_L2) {   // (knn_finish_body's expressions, one for one)
+                        e.key = sq;
+                        e.dist = sqrt(sq);
+                        e.gy = dot;
+                    } else {
+                        const double den = sqrt(nqk * ak.n64[j]);
+                        const double c = den > 0.0 ? dot / den : 0.0;
+                        const double dd = cosine_distance(c);
+                        e.key = dd;
+                        e.dist = dd;
+                        e.gy = c;
+                    }
+                    if (e.key <= ak.epskey) xk[atomicAdd(xk_count, 1)] = e;   // (the few dozen inside eps: the finish kernel ranks them)
+                }
+                __syncthreads();
+            }
+        }
+        if (b == 0 && threadIdx.x == 0 && (preset_flags || (ak.info->overflow & 2))) atomicOr(&head->flags, preset_flags | ((ak.info->overflow & 2) ? 8 : 0));
+        __syncthreads();
+    }
     for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
         const int* rep = as_.ci + (int64_t)w * SC_WCAP;
         const int c2 = rep[0];
@@ -1938,7 +1991,8 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
 // publication.  Clears the per-search state and the scan's histograms behind a clean search.
 __global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __restrict__ all, int world, int64_t xbytes, int64_t krec, int xcap, int64_t k,
                                                                int metric, int kernel, double sigma, double p, double tau0, double tau, int64_t topk,
-                                                               int64_t ntotal, QInfo* info, HostOut* out, int64_t seq, unsigned int* sc_hist, XHead* own_head) {
+                                                               int64_t ntotal, QInfo* info, HostOut* out, int64_t seq, unsigned int* sc_hist, XHead* own_head,
+                                                               const XKnn* __restrict__ xk, FinishArgs ak) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = (double*)smem;                 // CAND_CAP cosines, then scores
     double* sl = sc + CAND_CAP;                 // lambdas
@@ -1954,8 +2008,48 @@ __global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __res
         k_cnt = 0;
     }
     __syncthreads();
+    __shared__ double l_dist[MAX_KLIST], l_gy[MAX_KLIST], l_deg[MAX_KLIST], l_ny[MAX_KLIST];
+    __shared__ int s_npass;
+    if (xk) {
+        // the coarse scan's k-NN candidates, all of them evaluated exactly (staged_x1_kernel, xk): those inside eps, the k nearest
+        // by (key, id) in rank order -- knn_finish_body's selection with nothing left to prove
+        const int raw = info->knn_cnt;
+        int* xk_count = (int*)(xk + CAND_CAP);
+        const int tk = raw <= CAND_CAP ? raw : 0;   // (more than the buffer holds: nothing was evaluated -- the overflow flag sends the host elsewhere)
+        const int P = raw <= CAND_CAP ? *xk_count : 0;   // the candidates inside eps, in no particular order
+        if (threadIdx.x == 0) {
+            s_npass = P;
+            info->knn_total = tk;
+            info->knn_inexact = 0;
+        }
+        {   // ranked by the whole block, in front of everything else (wave 0 alone, beside the candidates' load, took 4 us longer)
+            for (int u = threadIdx.x; u < P; u += blockDim.x) {
+                sl[u] = xk[u].key;
+                sid[u] = xk[u].idx;
+            }
+            __syncthreads();
+            for (int u = threadIdx.x; u < P; u += blockDim.x) {
+                int rank = 0;
+                for (int s2 = 0; s2 < P; ++s2) rank += lex_less<double>(sl[s2], sid[s2], sl[u], sid[u]) ? 1 : 0;
+                if (rank < k && rank < MAX_KLIST) {
+                    const int j = sid[u];
+                    l_dist[rank] = xk[u].dist;
+                    l_gy[rank] = xk[u].gy;
+                    l_deg[rank] = ak.deg ? ak.deg[j + ak.goff] : 0.0;
+                    l_ny[rank] = ak.ny ? ak.ny[j + ak.goff] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < 64) {
-        q_lambda_body((const as_knn_rec*)all, krec * world, krec, xbytes / (int64_t)sizeof(as_knn_rec), k, metric, kernel, sigma, p, tau0, info, 0);
+        if (xk) {
+            if (threadIdx.x == 0) *((int*)(xk + CAND_CAP)) = 0;   // (the next pass's appends start at zero)
+            const int cnt = s_npass < k ? s_npass : (int)k;
+            lambda_from_sorted(cnt < MAX_KLIST ? cnt : MAX_KLIST, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
+        } else {
+            q_lambda_body((const as_knn_rec*)all, krec * world, krec, xbytes / (int64_t)sizeof(as_knn_rec), k, metric, kernel, sigma, p, tau0, info, 0);
+        }
     } else {
         const int wv = (int)(threadIdx.x >> 6) - 1, nwv = 15, lane = (int)(threadIdx.x & 63);
         // (a rank per wave; a rank's base in the list by one LDS ticket)
@@ -2293,6 +2387,7 @@ static as_status run_fused(as_query* q, double eps, double tau) {
     FinishArgs fk = make_finish(q);
     fk.M = q->Mk; fk.epskey = sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps; fk.coef = coef_query(q, false);
     fk.recs = nullptr; fk.fuse = 1; fk.ck = q->ckey_k; fk.ci = q->cidx_k; fk.from_list = 0;   // (records are the staged path's: nobody reads them here)
+    fk.exhaustive = q->coarse;
     FinishArgs fs = make_finish(q);
     fs.tau = tau; fs.M = q->Ms; fs.hits = nullptr; fs.fuse = 1; fs.hout = q->hout_dev; fs.seq = q->seq; fs.auto_reset = 1;
     fs.ck = q->ckey_s; fs.ci = q->sc_widx; fs.from_list = 0; fs.sc_nw = q->sc_nw;
@@ -2450,12 +2545,19 @@ static bool host_query_digits(as_query* q, int64_t d) {
         memcpy(a1chunk, q1v, 16);
         memcpy(a1chunk + 16, q2v, 16);
         memcpy(a2chunk + 16, q1v, 16);
+        if (q->hq8h) {   // the planar rows of the coarse scan: chunk c0 / 16 = these 16 columns' high digits -- qa = q1, qb = q2
+            signed char* hc = (signed char*)q->hq8h + (c0 >> 4) * 32;
+            memcpy(hc, q1v, 16);
+            memcpy(hc + 16, q2v, 16);
+        }
     }
     const double nq = std::sqrt(q->h_nq);
     const double uq = (double)m * std::sqrt(st2) / (16256.0 * nq) * 1.001, vq = (double)m * std::sqrt(sa2) / (16256.0 * nq) * 1.001;
     const double coef = uq + 1.001 * sp->u8max + vq * sp->v8max + 10.0 * 5.9604644775390625e-8;
     if (!(coef <= 2.0e-3)) return false;
     q->coef_i8 = coef;
+    // the coarse scan drops a2 . (128 q1 + q2) as well: at most V |x||q| (1 + u_q)
+    q->coef_i8h = uq + 1.001 * sp->u8max + 1.002 * sp->v8max + 10.0 * 5.9604644775390625e-8;
     q->h_faq = m * (11.313708498984761f / 16256.0f);   // s_q sqrt(128) / 16256
     return true;
 }
@@ -2559,6 +2661,7 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     const bool feature = q->gr && q->gr->lambda_mode == AS_LAMBDA_FEATURE;
     q->host_q = 0;
     q->i8_scan = 0;
+    q->coarse = 0;
     q->q64_src = q->q64;
     q->q32_src = q->q32;
     // Host-prepared query: one query, fp32 LDS-DMA scan (rows up to 1024 floats), item mode.  The host converts the query
@@ -2580,6 +2683,19 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         q->h_inq = q->h_nq > 0.0 ? 1.0 / sqrt(q->h_nq) : 0.0;
         q->i8_scan = host_query_digits(q, d) ? 1 : 0;
         if (!narrow && !q->i8_scan) host_path = false;
+        // Coarse scan: only where everything it collects is re-evaluated exactly (the fused tail: tau >= 0.4, scan-side scorer
+        // candidates) and its error leaves the eps ball recognisable (coefficient up to 4e-2: 1.5e-2 on clustered unit rows)
+        q->coarse = 0;
+        const char* coarse_env = getenv("ARROWSPACE_SCAN_COARSE");   // (per call: an A/B switch)
+        const bool coarse_env_off = coarse_env && atoi(coarse_env) == 0;
+        if (host_path && q->allow_coarse && q->i8_scan && q->fused_tail && q->hq8h && !coarse_env_off && !q->robust && !q->crowded_direct && q->coef_i8h <= 4.0e-2 &&
+            !(q->coarse_off > 0 && (q->coarse_off++ & 63) != 0)) {
+            bool have = false;
+            if (space_i8h_image(sp, &have) == AS_OK && have) {
+                q->coarse = 1;
+                q->coef_i8 = q->coef_i8h;   // (coef_query returns it: prefilter, window and proofs all price the coarse dots)
+            }
+        }
     }
     if (!host_path && !narrow) q->fused_tail = 0;
     if (host_path) {
@@ -2770,6 +2886,9 @@ static as_status query_alloc(as_query* q) {
         AS_HIP(hipHostMalloc(&q->hq8, dp8 * 4, hipHostMallocMapped | hipHostMallocCoherent));
         memset(q->hq8, 0, dp8 * 4);
         AS_HIP(hipHostGetDevicePointer((void**)&q->hq8_dev, q->hq8, 0));
+        AS_HIP(hipHostMalloc(&q->hq8h, dp8 * 2, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(q->hq8h, 0, dp8 * 2);
+        AS_HIP(hipHostGetDevicePointer((void**)&q->hq8h_dev, q->hq8h, 0));
     }
     AS_HIP(hipMalloc(&q->q64, sizeof(double) * sp->dp * C));
     AS_HIP(hipMalloc(&q->q32, sizeof(float) * sp->dp * C));
@@ -2846,6 +2965,7 @@ void as_query_free(as_query* q) {
     if (q->hq) hipHostFree(q->hq);
     if (q->hq32) hipHostFree(q->hq32);
     if (q->hq8) hipHostFree(q->hq8);
+    if (q->hq8h) hipHostFree(q->hq8h);
     if (q->hx8stat) hipHostFree(q->hx8stat);
     if (q->q8img_dev) hipFree(q->q8img_dev);
     if (q->faqv_dev) hipFree(q->faqv_dev);
@@ -2860,6 +2980,7 @@ void as_query_free(as_query* q) {
     if (q->xsend) hipFree(q->xsend);
     if (q->xall) hipFree(q->xall);
     if (q->x1_own) hipFree(q->x1_own);
+    if (q->xknn) hipFree(q->xknn);
     hipFree(q->rsel);
     if (q->own_records) {
         hipFree(q->knn);
@@ -2927,7 +3048,7 @@ as_status as_query_scan(as_query* q, const double* query_host, int64_t d, int64_
     q->staged_sc = sc_ran && qb == AS_OK && row_end > row_begin ? 1 : 0;
     AS_TRY(qb);
     if (q->gr->lambda_mode == AS_LAMBDA_FEATURE) return AS_OK;   // lambda_q is already there; the k-NN records stay empty
-    return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return run_knn(q, q->gr->gp.eps, -1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, q->coarse);
 }
 
 // ---- one exchange per sharded query (staged_x1_kernel / staged_x1_final_kernel above)
@@ -2951,16 +3072,31 @@ int32_t as_query_x1_usable(const as_query* q, double tau) {
 }
 
 // the block kernels behind a scan that has run (query_begin): this workspace's k-NN records and finished candidates into `send_dev`
-static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc_ran) {
+static FinishArgs x1_knn_args(as_query* q, void* send_dev) {
+    const as_space* sp = q->sp;
+    const double eps = q->gr->gp.eps;
+    FinishArgs fk = make_finish(q);
+    fk.M = q->Mk; fk.epskey = sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps; fk.coef = coef_query(q, false);
+    fk.recs = (as_knn_rec*)send_dev; fk.fuse = 0; fk.ck = q->ckey_k; fk.ci = q->cidx_k; fk.from_list = 0;
+    return fk;
+}
+
+// exact_knn: the single space's coarse scan -- no k-NN block, every block evaluates its share of the k-NN candidates into q->xknn
+static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc_ran, bool exact_knn = false) {
     const as_space* sp = q->sp;
     const int64_t krec = std::max<int64_t>(q->k, 1);
     XHead* head = (XHead*)((char*)send_dev + sizeof(as_knn_rec) * krec);
     XCand* cands = (XCand*)(head + 1);
     const int64_t rows = q->r1 - q->r0;
-    const double eps = q->gr->gp.eps;
-    FinishArgs fk = make_finish(q);
-    fk.M = q->Mk; fk.epskey = sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps; fk.coef = coef_query(q, false);
-    fk.recs = (as_knn_rec*)send_dev; fk.fuse = 0; fk.ck = q->ckey_k; fk.ci = q->cidx_k; fk.from_list = 0;
+    FinishArgs fk = x1_knn_args(q, send_dev);
+    fk.exhaustive = q->coarse;   // (the coarse scan's k-NN candidates: every one of them evaluated exactly)
+    if (exact_knn && !q->xknn) {
+        AS_HIP(hipMalloc(&q->xknn, sizeof(XKnn) * CAND_CAP + 16));
+        AS_HIP(hipMemsetAsync((char*)q->xknn + sizeof(XKnn) * CAND_CAP, 0, 16, q->stream));
+    } else if (exact_knn && q->xknn_dirty) {
+        AS_HIP(hipMemsetAsync((char*)q->xknn + sizeof(XKnn) * CAND_CAP, 0, 16, q->stream));   // (a pass that never reached its finish kernel)
+    }
+    if (exact_knn) q->xknn_dirty = 1;
     FinishArgs fs = make_finish(q);
     fs.ci = q->sc_widx; fs.sc_nw = sc_ran && rows > 0 ? q->sc_nw : 0;
     static bool attr_set[64] = {};
@@ -2971,19 +3107,21 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     }
     // (a rank that could not collect candidates -- no fused scan for this query here -- says so: every rank reads the flag and
     // the pass is rerun on the two-exchange chain)
-    hipLaunchKernelGGL(staged_x1_kernel, dim3(1 + X1_BLOCKS), dim3(1024), x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
-                       !sc_ran && rows > 0 ? 16 : 0);
+    hipLaunchKernelGGL(staged_x1_kernel, dim3(exact_knn ? X1_BLOCKS_COARSE : 1 + X1_BLOCKS), dim3(1024), x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
+                       !sc_ran && rows > 0 ? 16 : 0, exact_knn ? (XKnn*)q->xknn : (XKnn*)nullptr);
     AS_HIP(hipGetLastError());
     q->x1_head = head;
     return AS_OK;
 }
 
-static as_status x1_launch_final(as_query* q, const void* all_dev, int world, double tau) {
+static as_status x1_launch_final(as_query* q, const void* all_dev, int world, double tau, bool exact_knn = false) {
     const as_graph* gr = q->gr;
     const int64_t krec = std::max<int64_t>(q->k, 1);
+    const FinishArgs fk = x1_knn_args(q, nullptr);
     hipLaunchKernelGGL(staged_x1_final_kernel, dim3(1), dim3(1024), x1_lds_b(), q->stream, (const char*)all_dev, (int)world, as_query_x1_bytes(q, world),
                        krec, x1_cap(world), q->k, gr->metric, gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, tau, q->topk,
-                       (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist, (XHead*)q->x1_head);
+                       (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist, (XHead*)q->x1_head,
+                       exact_knn ? (const XKnn*)q->xknn : (const XKnn*)nullptr, fk);
     AS_HIP(hipGetLastError());
     return AS_OK;
 }
@@ -3230,7 +3368,7 @@ void query_flags(const as_query* q, int* knn_inexact, int* score_inexact) {
 }
 
 int query_overflow_bits(const as_query* q) { return q->hout->overflow; }
-extern "C" int32_t as_query_scan_int8(const as_query* q) { return q ? q->i8_scan : 0; }   // bit0 k-NN candidates, bit1 scorer's, bit2 the scan's scorer candidates
+extern "C" int32_t as_query_scan_int8(const as_query* q) { return q ? (q->i8_scan ? 1 + q->coarse : 0) : 0; }   // 0 fp32 items, 1 the int8 image, 2 its high digits alone (coarse scan)   // bit0 k-NN candidates, bit1 scorer's, bit2 the scan's scorer candidates
 
 // one full single-GPU search on q's stream: 6 launches, one host wait
 as_status search_once(as_query* q, const double* query, int64_t d, double tau, int mode, int64_t* out_idx, double* out_score,
@@ -3253,7 +3391,10 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
                             q->sp->dp <= 4096 && !(q->scan_variant & 4);
     q->fused_tail = want_fused ? 1 : 0;
     q->tau_cur = tau;
+    static const bool fused_x1_on = !(getenv("ARROWSPACE_FUSED_X1") && atoi(getenv("ARROWSPACE_FUSED_X1")) == 0);
+    q->allow_coarse = want_fused && fused_x1_on ? 1 : 0;   // (the coarse scan needs the two-launch tail: its k-NN candidates are evaluated by all blocks)
     const as_status qb = query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1);
+    q->allow_coarse = 0;
     const bool fused = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->crowded_direct = 0;
     q->fused_tail = 0;
@@ -3273,11 +3414,21 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
         }
         q->x1_dirty = 1;
         q->seq += 1;
-        AS_TRY(x1_launch_block(q, q->x1_own, 1, true));
-        AS_TRY(x1_launch_final(q, q->x1_own, 1, tau));
+        AS_TRY(x1_launch_block(q, q->x1_own, 1, true, q->coarse != 0));
+        AS_TRY(x1_launch_final(q, q->x1_own, 1, tau, q->coarse != 0));
         if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
         AS_TRY(wait_published(q));
         q->x1_dirty = 0;
+        q->xknn_dirty = 0;
+        if (q->coarse && (q->hout->overflow & 5)) {
+            // the coarse scan's candidates did not fit (its wider windows took in too many rows): the same query on the two-digit
+            // image straight away -- the chains behind an overflow would price the coarse dots and fail their proofs
+            dbg("coarse scan: candidates did not fit (overflow bits %d, coefficient %.3e) -> the two-digit scan for this and the next 63 searches",
+                q->hout->overflow, q->coef_i8h);
+            q->coarse_off = 1;
+            q->info_clean = 0;
+            return search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
+        }
         q->crowded = (q->hout->overflow & 1) ? 1 : 0;
         q->sc_crowded = (q->hout->overflow & 4) ? 1 : 0;
         if ((q->hout->overflow & 4) && !(q->hout->overflow & 1) && !q->hout->knn_inexact) {
@@ -3333,6 +3484,11 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
         AS_TRY(wait_published(q));
     }
     q->info_clean = q->hout->state_reset ? 1 : 0;   // the publishing kernel cleared the per-search state behind itself
+    if (q->coarse) {   // a query the coarse scan did not serve cleanly: the next 63 take the two-digit one
+        q->coarse_off = (q->hout->overflow || q->hout->knn_inexact || q->hout->score_inexact) ? 1 : 0;
+        if (q->coarse_off) dbg("coarse scan: overflow bits %d, k-NN %d, scorer %d (coefficient %.3e) -> the two-digit scan for the next 63 searches",
+                               q->hout->overflow, q->hout->knn_inexact, q->hout->score_inexact, q->coef_i8h);
+    }
     return collect(q, out_idx, out_score, out_len, out_lambda_q);
 }
 

@@ -224,3 +224,53 @@ def test_batched_int8_pass_holds_measured_residues_against_the_assumed_ones(orac
                     continue
                 assert_hits_match(aspace.search(np.ascontiguousarray(spiky[b]), gl, tau), want, ref.scores(spiky[b], tau, lq), rtol=RTOL)
         check(smooth, tau)
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_coarse_scan_returns_what_the_two_digit_scan_returns(oracle_lib, metric):
+    """tau >= 0.4 on a single space: the scan reads the HIGH digits of the int8 image alone (1 B per element) -- a prefilter off by
+    up to V |x||q| (1e-2) -- and every k-NN candidate and every scorer candidate it keeps is re-evaluated exactly by the tail's
+    blocks; same hits, bit for bit, as the two-digit scan (ARROWSPACE_SCAN_COARSE=0) and as the oracle; tau below 0.4 keeps the
+    two-digit scan; a query whose coarse candidates do not fit is redone on the two-digit image inside the same call."""
+    import os
+
+    import pyarrowspace_amd as asp
+    n, d, k, topk = 30000, 256, 12, 9
+    X = clustered(n, d, nclust=150, seed=71)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": topk, "p": 2.0, "sigma": None, "metric": metric}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(11)
+    Q = [np.ascontiguousarray(X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d)) for _ in range(20)]
+    Q.append(np.ascontiguousarray(X[123]))
+    ops = []
+    try:
+        for tau in (0.62, 1.0, 0.4, 0.2):
+            for q in Q:
+                os.environ.pop("ARROWSPACE_SCAN_COARSE", None)
+                try:
+                    got = aspace.search(q, gl, tau)
+                except asp.PanicException:                       # (no item inside eps: the reference's assert, on either scan)
+                    got = None
+                ops.append((tau, aspace.last_scan_operand))
+                os.environ["ARROWSPACE_SCAN_COARSE"] = "0"
+                try:
+                    fine = aspace.search(q, gl, tau)
+                except asp.PanicException:
+                    fine = None
+                assert aspace.last_scan_operand == "int8"
+                assert got == fine
+                try:
+                    want, lq = ref.search(q, tau)
+                except oracle_lib.ZeroLambda:
+                    assert got is None
+                    continue
+                assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=RTOL)
+    finally:
+        os.environ.pop("ARROWSPACE_SCAN_COARSE", None)
+    assert all(op == "int8" for tau, op in ops if tau < 0.4)
+    coarse = [op == "int8-high" for tau, op in ops if tau >= 0.4]
+    # (a query whose coarse candidates do not fit -- on an index this small the bound is learnt late -- is redone on the two-digit
+    # image inside the call and reports "int8"; the next 63 searches skip the coarse scan)
+    assert sum(coarse) >= 3, ops
+    assert aspace.search_counters()["searches_with_rerun"] == 0
