@@ -457,10 +457,13 @@ def main():
     # kernel-level timing of the dominant kernel (scan_dots) with HIP events on its own stream,
     # taken over a second pass so the event reads do not perturb the timed region
     asp.enable_search_stats(True)
+    scan_ops = []     # what each of those scans read: the fp32 items, their int8 image, or its high digits alone
     for i in range(min(args.steps, 50)):
         searcher(Q[(args.warmup + i) % len(Q)])
         scan_us.append(aspace.last_search_stats()["scan_us"] if single else index.last_scan_us())
+        scan_ops.append(aspace.last_scan_operand if single else "")
     scan_ms = float(np.mean(scan_us)) * 1e-3
+    scan_operand = max(set(scan_ops), key=scan_ops.count) if scan_ops else ""
 
     # SURVEY 8(d)'s own query recipe (fresh draws around the index's centres), next to the perturbed-item queries of the
     # headline: same protocol (W warmup + K timed), queries whose lambda_q is 0 -- no item within eps, the reference's
@@ -544,12 +547,12 @@ def main():
 
     qps = args.steps / dt
     # the scan reads the int8 two-digit image of the items when it can (2 bytes per element + the rows' norm and scale), else fp32
-    scan_i8 = bool(aspace.last_scan_int8) if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 4096 and not feature
+    scan_i8 = scan_operand in ("int8", "int8-high") if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 4096 and not feature
     rows_per_gpu = (n + world - 1) // world
     scan_bytes = rows_per_gpu * (d + 2) * 4.0          # N x D fp32 items + N reciprocal norms read, N fp32 dots written
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
     d8 = (d + 63) // 64 * 64
-    scan_coarse = single and getattr(aspace, "last_scan_operand", "") == "int8-high"   # the image's high digits alone: 1 B per element
+    scan_coarse = single and scan_operand == "int8-high"   # the image's high digits alone: 1 B per element
     scan_moved = rows_per_gpu * ((1.0 if scan_coarse else 2.0) * d8 + 12.0) if scan_i8 else scan_bytes   # bytes the launch moves: image + norms + scales + dots
     moved = scan_moved / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes

@@ -1393,7 +1393,13 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             // one-exchange pass never applied to an 8-GPU shard of a 1M index) runs chunks of 32 or 16 rows instead: two or
             // more chunks per wave, the first publishes, the wave's last word reads the bound (as at 200k rows).
             int crows = 64;
-            if (pre.sc_enabled && rows < NW * 64) crows = rows >= NW * 32 ? 32 : (rows >= NW * 16 ? 16 : 64);
+            // (the largest chunk that still gives every wave TWO chunks, the remainder's counted: 262 144 rows on 4 096 waves are ONE
+            // chunk of 64 each -- the coarse scan's candidates then never fitted --, two of 32 do; chunks of 16 where 32 would do
+            // learn a poorer bound: the rows that stand out of 16 are fewer)
+            if (pre.sc_enabled) {
+                auto chunks = [&](int c) { return rows / (NW * c) + (rows % (NW * c) ? 1 : 0); };
+                crows = chunks(64) >= 2 ? 64 : (chunks(32) >= 2 ? 32 : (chunks(16) >= 2 ? 16 : 64));
+            }
             const int rounds = (int)(rows / (NW * crows));
             const int64_t rem = rows - (int64_t)rounds * NW * crows;
             const int tail_rows = (int)((rem + NW - 1) / NW);
