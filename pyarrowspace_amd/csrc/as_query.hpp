@@ -160,6 +160,7 @@ struct as_query {
     double coef_i8h = 0.0;               // the coarse scan's coefficient for THIS query (host_query_digits)
     int coarse = 0;                      // the last scan was the coarse one
     int coarse_off = 0;                  // > 0: counting the searches that skip it
+    int coarse_never = 0;                // set around the redo of a query whose coarse candidates did not fit
     int allow_coarse = 0;                // set by search_once around query_begin: the caller's tail evaluates every k-NN candidate exactly
     int xknn_dirty = 0;                  // ... its counter may be non-zero (a pass died before its finish kernel)
     void* xknn = nullptr;                // [CAND_CAP] exact (id, key, distance, gy) of the coarse scan's k-NN candidates (staged_x1_kernel, xk)

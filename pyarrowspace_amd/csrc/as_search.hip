@@ -1862,9 +1862,9 @@ constexpr int X1_LOCAL_CAP = 4096;   // candidates one block gathers from its sh
 
 // grid 1 + X1_BLOCKS: block 0 = knn_finish (records into the exchange block), blocks 1.. = the scan waves' reports -> exact
 // cosines.  The two halves do not depend on each other: the k-NN phase (17 us, one block) hides the candidates' evaluation.
-// xk != null (the single space's coarse scan: k-NN candidates by the hundred, every one of them to be evaluated exactly): no
-// k-NN block -- every block takes its share of the k-NN candidate buffer as well and leaves (id, exact key, distance, gy)
-// per candidate in xk, in the buffer's order; the finish kernel ranks them (staged_x1_final_kernel, xk).
+// xk != null (the coarse scan: k-NN candidates by the hundred, every one of them to be evaluated exactly): no k-NN block --
+// every block takes its share of the k-NN candidate buffer as well and appends (id, exact key, distance, gy) of the candidates
+// inside eps to xk; the last block to finish ranks them and writes the records (below).
 struct XKnn {
     int idx;   // local row
     int pad;
@@ -1954,16 +1954,14 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
     }
     __syncthreads();
     const int tot = s_tot;
-    if (s_ovf || tot > X1_LOCAL_CAP) {
-        if (threadIdx.x == 0) {
-            atomicOr(&head->flags, 16);
-            atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
-            if (s_ovf) atomicAdd(&head->pad[1], 1);
-        }
-        return;
+    const bool sc_fits = !(s_ovf || tot > X1_LOCAL_CAP);
+    if (!sc_fits && threadIdx.x == 0) {
+        atomicOr(&head->flags, 16);
+        atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
+        if (s_ovf) atomicAdd(&head->pad[1], 1);
     }
     const double nq = as_.info->nq;
-    for (int base = 0; base < tot; base += 64) {   // (block-uniform)
+    for (int base = 0; sc_fits && base < tot; base += 64) {   // (block-uniform)
         const int m = tot - base < 64 ? tot - base : 64;
         exact_eval_all(as_.x32, as_.x64, qx ? qx : as_.q64, as_.d, as_.dp, si + base, m, o_sq, o_dot);
         if (threadIdx.x == 0) s_base = atomicAdd(&head->count, m);   // one ticket per block and round
@@ -1984,6 +1982,59 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         }
         __syncthreads();
     }
+    if (!xk) return;
+    // The coarse scan's k-NN records: the LAST block to get here ranks the candidates inside eps that all blocks have appended
+    // (a few dozen) by (key, id) and writes the k nearest as records -- knn_finish_body's selection with nothing left to prove.
+    // (Release / acquire at agent scope around one ticket per block: the blocks sit on different XCDs, each with its own L2.)
+    // One fence per block, by the thread that draws the ticket, behind a barrier (the block's appends happen before it): sixteen
+    // waves fencing in each of 32 blocks -- an L2 write-back each -- made this kernel 38 us instead of 15.
+    __shared__ int s_ticket;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_ticket = atomicAdd(xk_count + 1, 1);
+        if (s_ticket == nb - 1) __threadfence();
+    }
+    __syncthreads();
+    if (s_ticket != nb - 1) return;
+    const int raw = ak.info->knn_cnt;
+    const int P = raw <= CAND_CAP ? __hip_atomic_load(xk_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    double* rk = (double*)work;            // P keys (P <= CAND_CAP: 32 KB + 16 KB of the work area)
+    int* ri = (int*)(rk + CAND_CAP);
+    for (int u = threadIdx.x; u < P; u += blockDim.x) {
+        rk[u] = xk[u].key;
+        ri[u] = xk[u].idx;
+    }
+    if (ak.recs)
+        for (int64_t t = threadIdx.x; t < ak.k; t += blockDim.x) {
+            as_knn_rec r;
+            r.idx = -1;
+            r.key = key_traits<double>::inf();
+            r.dist = 0; r.gy = 0; r.deg = 0; r.ny = 0;
+            ak.recs[t] = r;
+        }
+    __syncthreads();
+    for (int u = threadIdx.x; u < P; u += blockDim.x) {
+        int rank = 0;
+        for (int s2 = 0; s2 < P; ++s2) rank += lex_less<double>(rk[s2], ri[s2], rk[u], ri[u]) ? 1 : 0;
+        if (rank < ak.k && ak.recs) {
+            const int j = ri[u];
+            as_knn_rec r;
+            r.idx = (int64_t)j + ak.goff;
+            r.key = rk[u];
+            r.dist = xk[u].dist;
+            r.gy = xk[u].gy;
+            r.deg = ak.deg ? ak.deg[j + ak.goff] : 0.0;
+            r.ny = ak.ny ? ak.ny[j + ak.goff] : 0.0;
+            ak.recs[rank] = r;
+        }
+    }
+    if (threadIdx.x == 0) {
+        ak.info->knn_total = raw <= CAND_CAP ? raw : CAND_CAP;
+        ak.info->knn_inexact = 0;
+        xk_count[0] = 0;   // (the next pass's appends and tickets start at zero)
+        xk_count[1] = 0;
+    }
 }
 
 // After the exchange, on every rank alike: lambda_q (wave 0) while the other waves pull the ranks' candidates into LDS; exact
@@ -1991,8 +2042,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
 // publication.  Clears the per-search state and the scan's histograms behind a clean search.
 __global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __restrict__ all, int world, int64_t xbytes, int64_t krec, int xcap, int64_t k,
                                                                int metric, int kernel, double sigma, double p, double tau0, double tau, int64_t topk,
-                                                               int64_t ntotal, QInfo* info, HostOut* out, int64_t seq, unsigned int* sc_hist, XHead* own_head,
-                                                               const XKnn* __restrict__ xk, FinishArgs ak) {
+                                                               int64_t ntotal, QInfo* info, HostOut* out, int64_t seq, unsigned int* sc_hist, XHead* own_head) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = (double*)smem;                 // CAND_CAP cosines, then scores
     double* sl = sc + CAND_CAP;                 // lambdas
@@ -2008,48 +2058,8 @@ __global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __res
         k_cnt = 0;
     }
     __syncthreads();
-    __shared__ double l_dist[MAX_KLIST], l_gy[MAX_KLIST], l_deg[MAX_KLIST], l_ny[MAX_KLIST];
-    __shared__ int s_npass;
-    if (xk) {
-        // the coarse scan's k-NN candidates, all of them evaluated exactly (staged_x1_kernel, xk): those inside eps, the k nearest
-        // by (key, id) in rank order -- knn_finish_body's selection with nothing left to prove
-        const int raw = info->knn_cnt;
-        int* xk_count = (int*)(xk + CAND_CAP);
-        const int tk = raw <= CAND_CAP ? raw : 0;   // (more than the buffer holds: nothing was evaluated -- the overflow flag sends the host elsewhere)
-        const int P = raw <= CAND_CAP ? *xk_count : 0;   // the candidates inside eps, in no particular order
-        if (threadIdx.x == 0) {
-            s_npass = P;
-            info->knn_total = tk;
-            info->knn_inexact = 0;
-        }
-        {   // ranked by the whole block, in front of everything else (wave 0 alone, beside the candidates' load, took 4 us longer)
-            for (int u = threadIdx.x; u < P; u += blockDim.x) {
-                sl[u] = xk[u].key;
-                sid[u] = xk[u].idx;
-            }
-            __syncthreads();
-            for (int u = threadIdx.x; u < P; u += blockDim.x) {
-                int rank = 0;
-                for (int s2 = 0; s2 < P; ++s2) rank += lex_less<double>(sl[s2], sid[s2], sl[u], sid[u]) ? 1 : 0;
-                if (rank < k && rank < MAX_KLIST) {
-                    const int j = sid[u];
-                    l_dist[rank] = xk[u].dist;
-                    l_gy[rank] = xk[u].gy;
-                    l_deg[rank] = ak.deg ? ak.deg[j + ak.goff] : 0.0;
-                    l_ny[rank] = ak.ny ? ak.ny[j + ak.goff] : 0.0;
-                }
-            }
-        }
-        __syncthreads();
-    }
     if (threadIdx.x < 64) {
-        if (xk) {
-            if (threadIdx.x == 0) *((int*)(xk + CAND_CAP)) = 0;   // (the next pass's appends start at zero)
-            const int cnt = s_npass < k ? s_npass : (int)k;
-            lambda_from_sorted(cnt < MAX_KLIST ? cnt : MAX_KLIST, l_dist, l_gy, l_deg, l_ny, metric, kernel, sigma, p, tau0, info);
-        } else {
-            q_lambda_body((const as_knn_rec*)all, krec * world, krec, xbytes / (int64_t)sizeof(as_knn_rec), k, metric, kernel, sigma, p, tau0, info, 0);
-        }
+        q_lambda_body((const as_knn_rec*)all, krec * world, krec, xbytes / (int64_t)sizeof(as_knn_rec), k, metric, kernel, sigma, p, tau0, info, 0);
     } else {
         const int wv = (int)(threadIdx.x >> 6) - 1, nwv = 15, lane = (int)(threadIdx.x & 63);
         // (a rank per wave; a rank's base in the list by one LDS ticket)
@@ -2688,8 +2698,9 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         q->coarse = 0;
         const char* coarse_env = getenv("ARROWSPACE_SCAN_COARSE");   // (per call: an A/B switch)
         const bool coarse_env_off = coarse_env && atoi(coarse_env) == 0;
-        if (host_path && q->allow_coarse && q->i8_scan && q->fused_tail && q->hq8h && !coarse_env_off && !q->robust && !q->crowded_direct && q->coef_i8h <= 4.0e-2 &&
-            !(q->coarse_off > 0 && (q->coarse_off++ & 63) != 0)) {
+        const bool coarse_always = coarse_env && atoi(coarse_env) == 2;   // (tests: probe with every search, whatever the last one did)
+        if (host_path && q->allow_coarse && !q->coarse_never && q->i8_scan && q->fused_tail && q->hq8h && !coarse_env_off && !q->robust && !q->crowded_direct && q->coef_i8h <= 4.0e-2 &&
+            (coarse_always || !(q->coarse_off > 0 && (q->coarse_off++ & 63) != 0))) {
             bool have = false;
             if (space_i8h_image(sp, &have) == AS_OK && have) {
                 q->coarse = 1;
@@ -3114,14 +3125,12 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     return AS_OK;
 }
 
-static as_status x1_launch_final(as_query* q, const void* all_dev, int world, double tau, bool exact_knn = false) {
+static as_status x1_launch_final(as_query* q, const void* all_dev, int world, double tau) {
     const as_graph* gr = q->gr;
     const int64_t krec = std::max<int64_t>(q->k, 1);
-    const FinishArgs fk = x1_knn_args(q, nullptr);
     hipLaunchKernelGGL(staged_x1_final_kernel, dim3(1), dim3(1024), x1_lds_b(), q->stream, (const char*)all_dev, (int)world, as_query_x1_bytes(q, world),
                        krec, x1_cap(world), q->k, gr->metric, gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, tau, q->topk,
-                       (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist, (XHead*)q->x1_head,
-                       exact_knn ? (const XKnn*)q->xknn : (const XKnn*)nullptr, fk);
+                       (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist, (XHead*)q->x1_head);
     AS_HIP(hipGetLastError());
     return AS_OK;
 }
@@ -3150,12 +3159,14 @@ as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, in
     const bool sc = !q->no_fused && q->sc_widx && sp->dp <= 4096 && !(q->scan_variant & 4) && !q->crowded_direct;
     q->fused_tail = sc ? 1 : 0;
     q->tau_cur = tau;
+    q->allow_coarse = sc ? 1 : 0;   // (the block kernels evaluate every k-NN candidate of a coarse scan: x1_launch_block, exact_knn)
     const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
+    q->allow_coarse = 0;
     const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->fused_tail = 0;
     q->staged_sc = 0;
     AS_TRY(qb);
-    return x1_launch_block(q, send_dev, world, sc_ran);
+    return x1_launch_block(q, send_dev, world, sc_ran, q->coarse != 0);
 }
 
 as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, double tau, int64_t* out_idx, double* out_score, int64_t* out_len,
@@ -3169,6 +3180,8 @@ as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, do
     if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
     AS_TRY(wait_published(q));
     q->x1_dirty = 0;
+    q->xknn_dirty = 0;
+    if (q->coarse) q->coarse_off = (q->hout->overflow & 5) ? 1 : 0;   // (this rank's next 63 scans: the two-digit image; the pass itself is rerun by every rank alike)
     q->info_clean = q->hout->state_reset ? 1 : 0;
     q->x1_passes += 1;
     return collect(q, out_idx, out_score, out_len, out_lambda_q);
@@ -3415,7 +3428,7 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
         q->x1_dirty = 1;
         q->seq += 1;
         AS_TRY(x1_launch_block(q, q->x1_own, 1, true, q->coarse != 0));
-        AS_TRY(x1_launch_final(q, q->x1_own, 1, tau, q->coarse != 0));
+        AS_TRY(x1_launch_final(q, q->x1_own, 1, tau));
         if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
         AS_TRY(wait_published(q));
         q->x1_dirty = 0;
@@ -3426,8 +3439,11 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
             dbg("coarse scan: candidates did not fit (overflow bits %d, coefficient %.3e) -> the two-digit scan for this and the next 63 searches",
                 q->hout->overflow, q->coef_i8h);
             q->coarse_off = 1;
+            q->coarse_never = 1;   // (for the call below, whatever the switches say: it must not come back here)
             q->info_clean = 0;
-            return search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
+            const as_status redo = search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
+            q->coarse_never = 0;
+            return redo;
         }
         q->crowded = (q->hout->overflow & 1) ? 1 : 0;
         q->sc_crowded = (q->hout->overflow & 4) ? 1 : 0;
