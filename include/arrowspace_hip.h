@@ -338,6 +338,10 @@ as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, in
 as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, double tau, int64_t* out_idx, double* out_score, int64_t* out_len,
                              double* out_lambda_q);
 int32_t as_query_x1_redo(const as_query* q);
+/* A pass that came back with as_query_x1_redo != 0 may be the coarse scan's doing (tau >= 0.4: a rank scans the high digits of
+ * its int8 image alone, with wider candidate windows): as_query_set_coarse(q, 0), run the pass once more (every rank alike),
+ * as_query_set_coarse(q, 1); only if it comes back with redo again take the two-exchange steps. */
+void as_query_set_coarse(as_query* q, int32_t allowed);
 int64_t as_query_x1_passes(const as_query* q);   /* one-exchange passes this workspace has finished */
 /* The per-query exchange steps issued by the library itself (RCCL on the query's stream; librccl is taken from the
  * process or /opt/rocm/lib by dlopen -- as_comm_available() == 0 on a box without it).  The ranks of an index share one

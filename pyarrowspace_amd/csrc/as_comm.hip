@@ -178,7 +178,9 @@ as_status as_query_search_staged(as_query* q, const double* query_host, int64_t 
     // scan-side scorer candidates (as on one GPU): a query whose candidates overflow on some rank is rerun
     // without them -- every rank reads the same merged flag -- and the following 63 queries do not try
     bool sc = !(q->sc_crowded > 0 && (q->sc_crowded++ & 63) != 0);
-    for (int pass = 0; pass < 9; ++pass) {
+    bool x1_fine = false;   // the one-exchange pass has been tried with the coarse scan allowed and some rank's candidates did not fit
+    as_query_set_coarse(q, 1);
+    for (int pass = 0; pass < 10; ++pass) {
         as_query_set_exact(q, mode);
         if (sc && mode == 0 && q->xsend && as_query_x1_usable(q, tau)) {
             // ONE exchange: every rank's k-NN records and finished scorer candidates (exact cosine, lambda) in one all-gather;
@@ -216,6 +218,12 @@ as_status as_query_search_staged(as_query* q, const double* query_host, int64_t 
             if (q->hout->overflow & 8) {
                 set_err("as_query_search_staged: another rank of the index failed in this pass");
                 return AS_EHIP;
+            }
+            if ((q->hout->overflow & 4) && !x1_fine) {
+                // (a coarse scan's wider windows, on whichever rank: once more on the two-digit image -- every rank reads the same flag)
+                x1_fine = true;
+                as_query_set_coarse(q, 0);
+                continue;
             }
             q->sc_crowded = (q->hout->overflow & 4) ? 1 : 0;
             if ((q->hout->overflow & 4) && debug_enabled()) {

@@ -3188,6 +3188,11 @@ as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, do
 }
 
 int32_t as_query_x1_redo(const as_query* q) { return q && (q->hout->overflow & 4) ? 1 : 0; }
+// allowed = 0: the following one-exchange passes of this workspace scan both digits of the image (the retry of a pass whose
+// coarse candidates did not fit, on every rank alike); 1: the default again
+void as_query_set_coarse(as_query* q, int32_t allowed) {
+    if (q) q->coarse_never = allowed ? 0 : 1;
+}
 int64_t as_query_x1_passes(const as_query* q) { return q ? q->x1_passes : 0; }
 
 as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {

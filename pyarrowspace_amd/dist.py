@@ -481,6 +481,9 @@ class HipEngine:
         return (hits, float(lq.value), st == self._lib.AS_EZEROLAMBDA, bool(ki.value & 1), 1 if ki.value & 2 else 0,
                 bool(self.L.as_query_x1_redo(self.q)))
 
+    def x1_set_coarse(self, allowed):
+        self.L.as_query_set_coarse(self.q, 1 if allowed else 0)
+
     def x1_passes(self, library=False):
         return int(self.L.as_query_x1_passes(self.qs if library else self.q))
 
@@ -1161,6 +1164,12 @@ class ShardedIndex:
                 e.set_mode(0)
                 blocks = self._gather_fixed(e.x1_begin(q, tau, *self.scan_rows, nranks), persistent=True)
                 hits, lq, zero, inexact, overflow, redo = e.x1_finish(blocks, tau, nranks)
+                if redo and hasattr(e, "x1_set_coarse"):
+                    # some rank's candidates did not fit -- possibly a coarse scan's wider windows: once more on the two-digit image
+                    e.x1_set_coarse(False)
+                    blocks = self._gather_fixed(e.x1_begin(q, tau, *self.scan_rows, nranks), persistent=True)
+                    hits, lq, zero, inexact, overflow, redo = e.x1_finish(blocks, tau, nranks)
+                    e.x1_set_coarse(True)
                 mode = 0 if redo else next_mode(0, inexact, overflow)
             for _ in range(8):
                 if mode is None:

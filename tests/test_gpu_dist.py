@@ -433,10 +433,11 @@ def test_one_exchange_pass_returns_what_the_two_exchange_chain_returns(oracle_li
             before = index.engine.x1_passes()
             monkeypatch.delenv("ARROWSPACE_STAGED_X1", raising=False)
             got = index.search(q, tau)
-            assert index.engine.x1_passes() == before + 1
+            took = index.engine.x1_passes() - before
+            assert took in (1, 2)     # (2: the coarse scan's candidates did not fit, the pass ran once more on the two-digit image)
             monkeypatch.setenv("ARROWSPACE_STAGED_X1", "0")
             chain = index.search(q, tau)
-            assert index.engine.x1_passes() == before + 1
+            assert index.engine.x1_passes() == before + took
             assert got == chain == aspace.search(q, gl, tau)
             want, lq = ref.search(q, tau)
             assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-9)
