@@ -1,3 +1,6 @@
+"""Probe: which operand each single-query scan read (fp32 / int8 / int8-high) and which search counters moved, on the data of
+tests/test_gpu_parity.py::test_int8_image_scan_returns_what_the_fp32_scan_returns; then the same alternating with
+ARROWSPACE_SCAN_FP32=1 as that test does.  ARROWSPACE_DEBUG=1 shows why a coarse scan was given up."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,3 +1,5 @@
+"""Probe: the coarse scan on a 30 000-row index (the data of test_coarse_scan_returns_what_the_two_digit_scan_returns): operand and
+counters per query; ARROWSPACE_DEBUG=1 prints the overflow bits of a scan whose candidates did not fit."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

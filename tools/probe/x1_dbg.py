@@ -1,3 +1,5 @@
+"""Probe: per query, whether the library-issued one-exchange pass ran (as_query_x1_passes) and whether it asked for a redo --
+one rank, real RCCL.  python tools/probe/x1_dbg.py N"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
