@@ -313,6 +313,12 @@ class OracleEngineX1(OracleEngine):
     def x1_usable(self, tau):
         return 0.4 <= tau <= 1.0 and not getattr(self, "x1_off", False)
 
+    def x1_set_coarse(self, allowed):
+        """as_query_set_coarse: the retry of a pass whose candidates did not fit scans both digits (here: a scripted failure
+        of the 'coarse' first attempt -- x1_coarse_fails -- goes away with it)."""
+        self.x1_coarse_allowed = bool(allowed)
+        self.x1_coarse_log = getattr(self, "x1_coarse_log", []) + [bool(allowed)]
+
     def x1_begin(self, q, tau, r0, r1, world):
         import torch
         self.x1_calls = getattr(self, "x1_calls", 0) + 1
@@ -324,7 +330,8 @@ class OracleEngineX1(OracleEngine):
             cos = self.o.scores(self.index, self.q, 1.0, 0.0)[self.r0 : self.r1]        # tau = 1: the cosine itself
             kth = np.sort(cos)[::-1][min(self.topk, len(cos)) - 1]
             cand = np.nonzero(cos >= kth - (1.0 - tau) / (2.0 * tau) - 1e-12)[0]
-            if len(cand) > self.CAP or getattr(self, "x1_force_redo", False):
+            coarse_fail = getattr(self, "x1_coarse_fails", False) and getattr(self, "x1_coarse_allowed", True)
+            if len(cand) > self.CAP or getattr(self, "x1_force_redo", False) or coarse_fail:
                 flags, cand = 16, cand[:0]                                              # did not fit: every rank reruns on the chain
             c = blk[self.k * 6 + 2 :].reshape(self.CAP, 3)
             c[: len(cand), 0] = (cand + self.r0).astype(np.int64).view(np.float64)
@@ -370,6 +377,7 @@ def _x1_worker(rank, world, port, n, d, cuts, out):
             q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
             for tau in (1.0, 0.62, 0.4, 0.2):
                 eng.x1_force_redo = i == 3 and rank == world - 1     # one rank's candidates "do not fit": every rank takes the chain
+                eng.x1_coarse_fails = i == 2 and rank == 0           # rank 0's "coarse scan" overflows: ONE retry on the fine scan serves it
                 before = getattr(eng, "x1_calls", 0)
                 one = index.search(q, tau)
                 calls.append(getattr(eng, "x1_calls", 0) - before)
@@ -405,7 +413,10 @@ def test_one_exchange_search_under_gloo(world, cuts):
             want.append(oracle_np.search(ref, q, tau))
     for rank in range(world):
         res, calls = out[rank]
-        assert calls == [1, 1, 1, 0] * 4          # the one-exchange pass ran for tau >= 0.4 only
+        # the one-exchange pass ran for tau >= 0.4 only; the query whose first attempt "overflowed" on one rank (i == 2) and the one
+        # whose candidates never fit (i == 3) took a second pass on every rank -- the latter then the two-exchange chain
+        # (tau = 0.4: a window of 0.75 in cosine -- more candidates than the test engine's block holds: a second pass, then the chain)
+        assert calls == [1, 1, 2, 0] * 2 + [2, 2, 2, 0] * 2
         for (hits, lq), (whits, wlq) in zip(res, want):
             assert [i for i, _ in hits] == [i for i, _ in whits]
             np.testing.assert_allclose([s for _, s in hits], [s for _, s in whits], rtol=1e-12)
