@@ -1383,7 +1383,9 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : (nch <= 5 ? 2 : 1);   // (<= 4: the wave reports are sized for 16 waves per CU)
             // (collecting the scorer's candidates: every wave needs a chunk in front of its last to publish from -- at least 32 rows
             // per wave, two chunks of 16; a 30 000-row index on 1 876 waves had 16 rows per wave, no bound, and every row a candidate)
-            const int64_t want_sc = pre.sc_enabled ? std::max<int64_t>(1, rows / 128) : want;
+            // (A/B: 256 rows per block instead of 128 -- 200k x 768 11 700 -> 9 000 queries/s, 100k x 768 13 700 -> 10 900, 65536 x 4096 unchanged)
+            static const int sc_rows_per_block = getenv("ARROWSPACE_SC_ROWS_PER_BLOCK") ? atoi(getenv("ARROWSPACE_SC_ROWS_PER_BLOCK")) : 128;
+            const int64_t want_sc = pre.sc_enabled ? std::max<int64_t>(1, rows / std::max(sc_rows_per_block, 64)) : want;
             const int64_t nblk = std::min<int64_t>(std::min(want, want_sc), bpc * (int64_t)q->cus);
             const int64_t NW = nblk * 4;
             q->sc_nw = (int)NW;
