@@ -254,6 +254,109 @@ def make_queries(X, nq, seed, spread=0.02):
     return Q
 
 
+def make_data_torch(kind, n, d, seed, device):
+    """The unfriendly distributions of the sweep (bench side keys, tools/dist_sweep.py), drawn on the GPU from
+    torch.Generator(seed), rows normalised, fp32:
+      isotropic -- standard normal rows: every pairwise cosine ~ N(0, 1/d), no cluster to stand out of;
+      hier      -- 1 024 centres around 16 super-centres on top of ONE common direction (squared-norm shares 0.45 common,
+                   0.15 super-centre, 0.20 centre, 0.20 noise): background cosine 0.45-0.6 between unrelated rows, 0.8 inside a
+                   cluster -- what sentence embeddings with a large common mean look like;
+      scaled100 -- SURVEY 8(d)'s clustered recipe times 100, unnormalised (/root/reference/tests/test_3_beir.py:19,190)."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    X = torch.empty((n, d), device=device, dtype=torch.float32)
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=g, device=device, dtype=torch.float32)
+
+    if kind == "isotropic":
+        parts = None
+    elif kind == "hier":
+        common = rn(1, d)
+        sup = rn(16, d)
+        cen = rn(1024, d)
+        zs = torch.randint(0, 16, (1024,), generator=g, device=device)
+        parts = (0.45 ** 0.5) * common + (0.15 ** 0.5) * sup[zs] + (0.20 ** 0.5) * cen     # [1024, d]
+    elif kind == "scaled100":
+        parts = rn(1024, d)
+    else:
+        raise ValueError(kind)
+    step = 1 << 17
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        if kind == "isotropic":
+            blk = rn(e - s, d)
+        else:
+            z = torch.randint(0, 1024, (e - s,), generator=g, device=device)
+            blk = parts[z] + (0.20 ** 0.5 if kind == "hier" else 0.5) * rn(e - s, d)
+        blk /= blk.norm(dim=1, keepdim=True)
+        X[s:e] = blk * (100.0 if kind == "scaled100" else 1.0)
+    return X
+
+
+def brute_force_verify(aspace, gl, X, queries, tau, topk, rtol=1e-9):
+    """The library's hits for `queries` against an fp64 brute force on the GPU (torch): cosines of ALL items in fp64,
+    TAUMODE.md:33's score with the library's own lambda_q and lambdas, top-k by (score desc, index asc).  A query counts
+    as a mismatch when its scores differ beyond rtol or its indices differ anywhere outside a run of scores equal to
+    1e-12.  Queries whose lambda_q is zero (the reference's panic, src/lib.rs:156-159) are skipped and counted.
+    Returns {"n", "mismatches", "zero_lambda"}."""
+    import torch
+
+    import pyarrowspace_amd as asp
+
+    dev = X.device
+    got, lqs, keep = [], [], []
+    zero = 0
+    for q in queries:
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        try:
+            hits = aspace.search(q, gl, tau)
+        except asp.PanicException:
+            zero += 1
+            continue
+        got.append(hits)
+        lqs.append(aspace.query_lambda(q, gl))
+        keep.append(q)
+    if not keep:
+        return {"n": 0, "mismatches": 0, "zero_lambda": zero}
+    Qd = torch.from_numpy(np.stack(keep)).to(dev)                       # [nq, d] fp64
+    qn = (Qd * Qd).sum(1).sqrt()
+    lam = torch.from_numpy(aspace.lambdas()).to(dev)
+    lq = torch.tensor(lqs, dtype=torch.float64, device=dev)
+    n = X.shape[0]
+    best_s = torch.full((len(keep), 0), 0.0, dtype=torch.float64, device=dev)
+    best_i = torch.zeros((len(keep), 0), dtype=torch.int64, device=dev)
+    kk = min(topk + 8, n)
+    step = 1 << 17
+    for s in range(0, n, step):
+        Xc = X[s:s + step].double()
+        cos = (Qd @ Xc.T) / (qn[:, None] * (Xc * Xc).sum(1).sqrt()[None, :])
+        sc = tau * cos + (1.0 - tau) / (1.0 + (lq[:, None] - lam[None, s:s + step]).abs())
+        v, i = torch.topk(sc, min(kk, sc.shape[1]), dim=1)
+        best_s = torch.cat([best_s, v], 1)
+        best_i = torch.cat([best_i, i + s], 1)
+        v, o = torch.topk(best_s, min(kk, best_s.shape[1]), dim=1)
+        best_s, best_i = v, torch.gather(best_i, 1, o)
+    best_s, best_i = best_s.cpu().numpy(), best_i.cpu().numpy()
+    bad = 0
+    for t, hits in enumerate(got):
+        # brute-force order: score descending, index ascending inside ties
+        order = np.lexsort((best_i[t], -best_s[t]))
+        ws, wi = best_s[t][order][:len(hits)], best_i[t][order][:len(hits)]
+        gs = np.array([s_ for _, s_ in hits])
+        gi = np.array([i_ for i_, _ in hits])
+        ok = len(hits) == min(topk, n) and np.allclose(gs, ws, rtol=rtol, atol=0.0)
+        if ok and not np.array_equal(gi, wi):
+            for a in np.nonzero(gi != wi)[0]:
+                # a swapped pair inside a run of equal scores is two summation orders, not a wrong answer
+                if not (abs(ws[a] - gs[a]) <= 1e-12 * abs(ws[a]) and gi[a] in best_i[t][np.abs(best_s[t] - ws[a]) <= 1e-12 * abs(ws[a])]):
+                    ok = False
+        bad += 0 if ok else 1
+    return {"n": len(got), "mismatches": bad, "zero_lambda": zero}
+
+
 def calibrate_eps(X, k, metric="l2", target=2.0, sample=512, seed=5):
     """eps with mean degree before the k-cap ~ target*k; L2 distance or the rectified-cosine
     distance of GRAPH_VARIABLES.md:7."""
@@ -292,6 +395,65 @@ def calibrate_feature_eps(X, k, metric="cosine", target=2.0):
     return float(torch.quantile(off[: 1 << 24], min(1.0, target * k / max(d - 1, 1))).item())
 
 
+def run_distribution(kind, n, d, args, device):
+    """One unfriendly distribution at the headline shape: build, W + K single-query searches (perturbed items), the
+    fallback counters by cause, the scan's operand, and a brute-force check of 32 of the timed queries."""
+    import torch
+
+    import pyarrowspace_amd as asp
+
+    X = make_data_torch(kind, n, d, 4242, device)
+    if kind == "scaled100":
+        # /root/reference/tests/test_3_beir.py:19,190,194-200: unnormalised x100 rows, eps = 10 -- a rectified-cosine distance
+        # never exceeds 1, so EVERY item is inside eps: the neighbourhood is the k nearest, the candidate buffers overflow
+        metric, kernel, eps = "cosine", "rational", 10.0
+    else:
+        metric, kernel = args.metric, args.kernel
+        eps = calibrate_eps(X, args.k, metric)
+    gp = {"eps": eps, "k": args.k, "topk": args.topk, "p": 2.0, "sigma": None, "metric": metric, "kernel": kernel}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    aspace, gl = asp.ArrowSpaceBuilder.build_from_device(gp, X.data_ptr(), "float32", n, d, d)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    nq = max(args.steps + args.warmup, 64)
+    Q = make_queries(X, nq, 43)
+    zero = 0
+
+    def go(q):
+        try:
+            aspace.search(q, gl, args.tau)
+            return 0
+        except asp.PanicException:
+            return 1
+
+    for i in range(args.warmup):
+        go(Q[i % nq])
+    c0 = aspace.search_counters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        zero += go(Q[(args.warmup + i) % nq])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = aspace.search_counters()
+    asp.enable_search_stats(True)
+    us, ops = [], []
+    for i in range(min(args.steps, 20)):
+        go(Q[(args.warmup + i) % nq])
+        us.append(aspace.last_search_stats()["scan_us"])
+        ops.append(aspace.last_scan_operand)
+    asp.enable_search_stats(False)
+    ver = brute_force_verify(aspace, gl, X, [Q[(args.warmup + i) % nq] for i in range(min(32, args.steps))], args.tau, min(args.topk, n))
+    out = {"value": args.steps / dt, "unit": "queries/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+           "zero_lambda": zero, "eps": eps, "metric": metric, "kernel": kernel, "index_build_sec": build_s,
+           "fallbacks": {k: c1[k] - c0[k] for k in c1}, "scan_us": float(np.mean(us)), "scan_operands": {o: ops.count(o) for o in set(ops)},
+           "verified": ver}
+    del aspace, gl, X
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +479,8 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/traffic.json (when it is of this workload) instead of two rocprofv3 --pmc passes run now")
     ap.add_argument("--no-threaded", action="store_true", help="skip the 2- and 4-host-thread search runs (kernel-trace profiles: their overlapping kernels stretch each other)")
+    ap.add_argument("--no-distributions", action="store_true", help="skip the unfriendly-distribution side keys (isotropic, hierarchical, x100-scaled rows): three more index builds")
+    ap.add_argument("--verify-queries", type=int, default=64, help="timed queries (and as many in-distribution ones) re-issued after the timed loops and held against an fp64 brute force on the GPU")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the short child pass live_traffic() profiles
     args = ap.parse_args()
 
@@ -399,6 +563,7 @@ def main():
 
     # ---------------- index build (timed once, inputs resident in HBM)
     single = world == 1 and not force_dist
+    Xh32 = None
     if single:
         barrier()
         t0 = time.perf_counter()
@@ -412,6 +577,7 @@ def main():
 
         b = asdist.shard_bounds(n, world)
         shard = X[b[rank]:b[rank + 1]].clone()      # this rank's rows; the rest arrives by RCCL all-gather
+        Xh32 = X.cpu() if rank == 0 and not args.no_cpu_baseline else None   # (rank 0's CPU baseline scans all N items on the host)
         del X
         torch.cuda.empty_cache()
         barrier()
@@ -520,7 +686,7 @@ def main():
                 th.join()
             dth = time.perf_counter() - t0
             threaded[str(nthr)] = {"value": nthr * per / dth, "unit": "queries/s", "host_threads": nthr, "queries": nthr * per,
-                                   "frac": n * (d + 2) * 4.0 * nthr * per / dth / 1e9 / HBM_PEAK_GBS, "errors": errs[:2]}
+                                   "algorithmic_speedup": n * (d + 2) * 4.0 * nthr * per / dth / 1e9 / HBM_PEAK_GBS, "errors": errs[:2]}
         threaded["pool_size"] = aspace.search_pool_size
 
     # extension, reported next to the headline, never as it: batched search, 32 query
@@ -545,6 +711,28 @@ def main():
         batch_pass_ms = float(tbm.item()) / (len(QB) / 32) * 1e3
     batch_i8 = bool(aspace.last_batch_int8) if single else False
 
+    # ---------------- parity statement about the workload just timed: the first `verify_queries` TIMED queries and as many
+    # in-distribution ones, re-issued and held against an fp64 brute force over all items on the GPU (indices and scores)
+    verified = None
+    if single and not args.traffic_probe and args.verify_queries > 0:
+        nv = min(args.verify_queries, args.steps)
+        v1 = brute_force_verify(aspace, gl, X, [Q[(args.warmup + i) % len(Q)] for i in range(nv)], args.tau, min(args.topk, n))
+        v2 = brute_force_verify(aspace, gl, X, [Qin[(args.warmup + i) % len(Qin)] for i in range(nv)], args.tau, min(args.topk, n))
+        verified = {"n": v1["n"] + v2["n"], "mismatches": v1["mismatches"] + v2["mismatches"],
+                    "timed_queries": v1, "in_distribution_queries": v2,
+                    "how": "re-issued after the timed loops; torch fp64 cosines of all N items, TAUMODE.md:33 with the library's lambda_q and "
+                           "lambdas, top-k by (score desc, index asc); indices equal and scores within 1e-9 relative"}
+
+    # ---------------- unfriendly distributions (side keys, never the headline): same N x D, k, topk, tau; queries = perturbed items
+    distributions = None
+    if single and not args.traffic_probe and not args.no_distributions and not feature:
+        distributions = {}
+        for kind in ("isotropic", "hier", "scaled100"):
+            try:
+                distributions[kind] = run_distribution(kind, n, d, args, device)
+            except Exception as e:      # noqa: BLE001 -- a side key must not cost the headline line
+                distributions[kind] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     qps = args.steps / dt
     # the scan reads the int8 two-digit image of the items when it can (2 bytes per element + the rows' norm and scale), else fp32
     scan_i8 = scan_operand in ("int8", "int8-high") if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 4096 and not feature
@@ -554,8 +742,12 @@ def main():
     d8 = (d + 63) // 64 * 64
     scan_coarse = single and scan_operand == "int8-high"   # the image's high digits alone: 1 B per element
     scan_moved = rows_per_gpu * ((1.0 if scan_coarse else 2.0) * d8 + 12.0) if scan_i8 else scan_bytes   # bytes the launch moves: image + norms + scales + dots
+    if threaded:
+        for key in ("2", "4"):
+            threaded[key]["frac"] = scan_moved * threaded[key]["value"] / 1e9 / HBM_PEAK_GBS
     moved = scan_moved / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
+    batch_moved = (n * (2.0 * d8 + 8.0 + 64.0) if batch_i8 else query_bytes + n * 64.0) / world   # a 32-query pass: operand + norms + scales + 32 fp16 cosines per row
     # Build kernel: bstats["mfma_flops"] counts 2 * (pairs computed) * D -- the fp32-equivalent work.  The default kernel
     # (as_k2bf.hip) issues THREE bf16 products per such flop (head x head, head x tail, tail x head): the roofline
     # fraction is issued bf16 flops / 2.5 PFLOP/s; the fp32-equivalent rate is kept beside it.  ARROWSPACE_K2_FP32=1: the
@@ -608,7 +800,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": ("int8 prefilter (items' image) + fp64 exact re-evaluation of every candidate; items fp32 in HBM, API fp64" if scan_i8
+                  else "f32 prefilter + fp64 exact re-evaluation"),
         "data": "synthetic",
         "config": {"workload": "SURVEY 8(d) synthetic: np.random.default_rng(42) clustered N=%d x D=%d fp32 (1024 centres, noise 0.5, "
                                "rows normalised), k=%d topk=%d tau=%.2f eps=%.5f (calibrated: mean degree ~2k), metric=%s kernel=%s (p=2 is the kernel's "
@@ -620,9 +813,12 @@ def main():
                    "parallelism": "row-shard x%d" % world + (" (ranks share %d GPU(s): exchange steps staged through host memory, a "
                                                               "rehearsal of the N-rank job, not a scaling measurement)" % shared_gpu if shared_gpu else "")},
         "parity": PARITY,
+        "verified": verified,
+        "distributions": distributions,
         "in_distribution_queries": {"value": (args.steps - zero_in) / dt_in if dt_in > 0 else None, "unit": "queries/s",
                                     "ms_per_step": dt_in / args.steps * 1e3, "steps": args.steps, "zero_lambda_skipped": zero_in,
-                                    "frac": query_bytes / world / (dt_in / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                    "frac": scan_moved / (dt_in / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                    "algorithmic_speedup": query_bytes / world / (dt_in / args.steps) / 1e9 / HBM_PEAK_GBS,
                                     "workload": "SURVEY 8(d) query recipe: the index's 1024 centres, labels and noise 0.5 from "
                                                 "np.random.default_rng(43), rows normalised"},
         "index_build_sec": build_s,
@@ -636,31 +832,33 @@ def main():
         "build_stages_sec": {k: bstats[k] for k in ("ingest_s", "knn_mfma_s", "refine_s", "fallback_s", "graph_s")},
         "build_fallback_rows": bstats["fallback_rows"],
         "build_band_rows": bstats["band_rows"],
-        "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_scan,
+        # `achieved`, `frac`: the bytes one launch MOVES (operand image + norms + scales read, dots written; `traffic` is the
+        # PMC measurement of the same) over the launch's duration, against the 8 TB/s peak -- a roofline fraction, <= 1.
+        # SURVEY 8(d)'s ALGORITHMIC bytes N (D + 2) 4 (an fp32 scan of the items) over the same time is kept beside it as
+        # `algorithmic_speedup`: how many fp32-scan rooflines the launch is worth (above 1 when it reads the 1- or 2-byte image).
+        "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": moved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": moved / HBM_PEAK_GBS, "traffic": traffic_scan,
+                     "frac_from_traffic": None if traffic_scan is None else traffic_scan / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic_source": traffic_source if traffic_scan is not None else "none (live passes: %s)" % live_note,
-                     "avg_launch_ms": scan_ms, "bytes_per_launch": scan_bytes,
+                     "avg_launch_ms": scan_ms, "bytes_per_launch": scan_moved,
                      "operand": ("int8 image, high digits alone (1 B per element; every candidate re-evaluated exactly)" if scan_coarse
                                  else "int8 two-digit image (2 B per element)") if scan_i8 else "fp32 items",
-                     "bytes_moved_per_launch": scan_moved, "achieved_bytes_moved": moved, "frac_bytes_moved": moved / HBM_PEAK_GBS,
-                     "frac_note": "`achieved` and `frac` follow SURVEY 8(d): ALGORITHMIC bytes N (D + 2) 4 over the launch time -- above 1 "
-                                  "when the scan reads the 2-byte image instead of the fp32 items; `frac_bytes_moved` is the physical "
-                                  "HBM rate (what `traffic` measures) against the 8 TB/s peak",
+                     "algorithmic_bytes_per_launch": scan_bytes, "algorithmic_gbs": achieved, "algorithmic_speedup": achieved / HBM_PEAK_GBS,
                      "note": "this launch also collects the scorer's candidates (fused tail, DESIGN.md 5.4); ARROWSPACE_SCAN_FP32=1 scans "
                              "the fp32 items (round 3's operand), ARROWSPACE_NO_FUSED_TAIL=1 runs the plain kernel"},
-        "roofline_query": {"bound": "hbm", "achieved": query_bytes / world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                           "note": "whole query, host-visible latency, per GPU"},
+        "roofline_query": {"bound": "hbm", "achieved": scan_moved / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": scan_moved / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                           "algorithmic_speedup": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                           "note": "whole query, host-visible latency, per GPU: the scan's bytes moved over ms_per_step"},
         "roofline_batch": None if batch_pass_ms is None else {
             "kernel": "scan_gemm_kernel + per-slot selection", "bound": "hbm", "queries_per_pass": 32,
-            "achieved": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
-            "traffic": traffic_batch,
+            "achieved": batch_moved / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": batch_moved / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
+            "bytes_per_pass": batch_moved, "traffic": traffic_batch,
             "operand": "int8 two-digit images of items and queries (2 B per element)" if batch_i8 else "fp32 items as bf16 head + tail",
-            "frac_bytes_moved": (n * (2.0 * ((d + 63) // 64 * 64) + 8.0 + 64.0) if batch_i8 else query_bytes + n * 64.0) / world
-                                / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "whole 32-query pass, host-visible, per GPU; `achieved` and `frac`: ALGORITHMIC bytes N*(D+2)*4 per pass (SURVEY 8(d)), "
-                    "`frac_bytes_moved`: the bytes the pass moves (operand + norms + 32 fp16 cosines per row) against the peak.  int8 "
+            "algorithmic_speedup": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "whole 32-query pass, host-visible, per GPU; `frac`: the bytes the pass moves (operand + norms + 32 fp16 cosines per "
+                    "row) against the peak; `algorithmic_speedup`: SURVEY 8(d)'s N*(D+2)*4 per pass over the same time.  int8 "
                     "operand: three v_mfma_i32_32x32x32_i8 products per column, exact int32 sums; bf16 operand (the items' or the queries' "
                     "quantisation error too large, ARROWSPACE_SCAN_FP32=1): three bf16 products.  Either way the pass only prefilters: its "
                     "error bound sits in the prefilter's and the proof's coefficients (DESIGN.md 5.5).  ARROWSPACE_BATCH_F32_DOTS=1 is the "
@@ -675,27 +873,43 @@ def main():
                                    "pipe only prefilters -- graphs are bit-identical on int8, bf16 and fp32 (DESIGN.md 5.2)"},
     }
 
-    # ---------------- CPU baseline: the oracle (fp64 C/OpenMP restatement) on this box's host cores
-    if rank == 0 and single and not args.no_cpu_baseline:
+    # ---------------- CPU baseline: the oracle (fp64 C/OpenMP restatement) on this box's host cores, rank 0 (at any N)
+    lam_all = deg_all = None
+    if not single and not args.no_cpu_baseline and not feature:
+        lam_all = index.lambdas()        # (collectives: every rank takes part, rank 0 uses the result)
+        deg_all = index.degrees()
+    if rank == 0 and not args.no_cpu_baseline and (single or (Xh32 is not None and lam_all is not None)):
         from oracle import oracle_c
 
         cores = oracle_c.threads()
-        Xh = X.double().cpu().numpy()
+        Xh = X.double().cpu().numpy() if single else Xh32.double().numpy()
         nq = args.cpu_queries
         if feature:
             # feature mode: the CPU build is N-linear (Gram + per-item energies) -- timed on the whole index
             t0 = time.perf_counter()
             ref = oracle_c.OracleIndex(Xh, gp)
             cpu_build = [{"value": time.perf_counter() - t0, "unit": "s", "n": n, "sample": "full feature-mode build (fp64 Gram + energies)"}]
-        else:
+        elif single:
             ref = oracle_c.OracleSearchOnly(Xh, gp, gl.degrees(), aspace.lambdas(), gl.tau0)
             cpu_build = None
+        else:
+            ref = oracle_c.OracleSearchOnly(Xh, gp, deg_all, lam_all, index.engine.tau0())
+            cpu_build = None
         ref.search(Q[0], args.tau, fused=True)
+        cpu_hits = []
         t0 = time.perf_counter()
         for i in range(nq):
-            ref.search(Q[(args.warmup + i) % len(Q)], args.tau, fused=True)
+            cpu_hits.append(ref.search(Q[(args.warmup + i) % len(Q)], args.tau, fused=True))
         cpu_dt = time.perf_counter() - t0
         del ref
+        # the checker's answers to those queries, held against the GPU path's (indices rank-exact, scores to 1e-9): free here
+        agree = None
+        if single:
+            agree = 0
+            for i, (want, _) in enumerate(cpu_hits):
+                got = searcher(Q[(args.warmup + i) % len(Q)])
+                agree += int([a for a, _ in got] == [a for a, _ in want]
+                             and np.allclose([b for _, b in got], [b for _, b in want], rtol=1e-9, atol=0.0))
         if cpu_build is None:
             # all-pairs fp64 build: N^2 work, timed at the sizes SURVEY 8(d) names, never extrapolated into `value`
             cpu_build, per_pair = [], None
@@ -714,12 +928,16 @@ def main():
             "sample": "%d single queries over the full N=%d x D=%d fp64 items; one fused pass per query (neighbour search and "
                       "cosines from the same read of the items, scorer over the kept cosines), OpenMP static over items, items "
                       "first-touched by the threads that scan them; %.2f GB/s effective" % (nq, n, d, n * d * 8.0 * nq / cpu_dt / 1e9),
+            "gpu_agrees_on_those_queries": None if agree is None else "%d/%d" % (agree, nq),
             "index_build": cpu_build,
         }
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if verified is not None and verified["mismatches"]:
+        print("bench.py: %d of %d verified queries differ from the fp64 brute force" % (verified["mismatches"], verified["n"]), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -333,6 +333,11 @@ as_status as_query_flags(const as_query* q, int32_t* knn_inexact, int32_t* score
  * Serves PyArrowSpace::search, /root/reference/src/lib.rs:132-174, on a row-sharded index. */
 int64_t as_query_x1_bytes(const as_query* q, int32_t world);
 int32_t as_query_x1_usable(const as_query* q, double tau);
+/* The pass's switch is a property of the workspace: read from ARROWSPACE_STAGED_X1 when the workspace is made
+ * (as_query_x1_enabled), set for good by as_query_set_x1 -- the host of a row-sharded index agrees on it over its ranks (one
+ * all-reduce, MIN) when it opens the query: every rank must issue the same collectives for every query that follows. */
+int32_t as_query_x1_enabled(const as_query* q);
+void as_query_set_x1(as_query* q, int32_t enabled);
 as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end, double tau, void* send_dev,
                             int32_t world);
 as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, double tau, int64_t* out_idx, double* out_score, int64_t* out_len,

@@ -50,7 +50,7 @@ SYMBOLS = [
     "as_get_item", "as_lambdas", "as_nnodes", "as_get_graph_params", "as_graph_nnz", "as_graph_csr",
     "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_last_search_stats", "as_search_counters", "as_enable_search_stats", "as_index_save", "as_index_load", "as_free_space",
     "as_free_graph", "as_set_debug", "as_last_error", "as_device_count", "as_version",
-    "as_comm_available", "as_comm_unique_id", "as_comm_create", "as_comm_free", "as_query_set_comm", "as_query_search_staged", "as_query_x1_bytes", "as_query_x1_usable", "as_query_x1_begin", "as_query_x1_finish", "as_query_x1_redo", "as_query_set_coarse", "as_query_x1_passes", "as_edges_bucket", "as_ring_i8_stats", "as_ring_i8_set", "as_ring_i8",
+    "as_comm_available", "as_comm_unique_id", "as_comm_create", "as_comm_free", "as_query_set_comm", "as_query_search_staged", "as_query_x1_bytes", "as_query_x1_usable", "as_query_x1_enabled", "as_query_set_x1", "as_query_x1_begin", "as_query_x1_finish", "as_query_x1_redo", "as_query_set_coarse", "as_query_x1_passes", "as_edges_bucket", "as_ring_i8_stats", "as_ring_i8_set", "as_ring_i8",
 ]
 
 _lib = None
@@ -163,6 +163,8 @@ def load():
         "as_query_set_comm": (i32, [vp, vp]),
         "as_query_x1_bytes": (i64, [vp, i32]),
         "as_query_x1_usable": (i32, [vp, C.c_double]),
+        "as_query_x1_enabled": (i32, [vp]),
+        "as_query_set_x1": (None, [vp, i32]),
         "as_query_x1_begin": (i32, [vp, vp, i64, i64, i64, C.c_double, vp, i32]),
         "as_query_x1_finish": (i32, [vp, vp, i32, C.c_double, vp, vp, C.POINTER(i64), C.POINTER(C.c_double)]),
         "as_query_x1_redo": (i32, [vp]),

@@ -607,7 +607,9 @@ static as_status pool_acquire(const as_space* sp, const as_graph* gr, int* slot,
     for (;;) {
         bool any = false, busy = false;
         for (int i = 0; i < as_space::QPOOL; ++i) {
-            any = any || sp->qpool[i] != nullptr;
+            // (a slot reserved while its workspace is being made -- outside the lock -- belongs to qcache_gr like a finished one: a
+            // caller with another graph handle must wait for it, not reserve a slot of its own beside it)
+            any = any || sp->qpool[i] != nullptr || sp->qbusy[i];
             busy = busy || sp->qbusy[i];
         }
         if (any && sp->qcache_gr != gr) {

@@ -34,7 +34,9 @@ static double err_coef_dp(int64_t dp) {
 // (the rows' ACTUAL residue and low-digit norms, measured by the quantisation kernel).  Doubled in the key and against
 // n_i + n_j >= 2 |x_i||x_j| the bracket IS the coefficient; the epilogue's fp32 scaling (four roundings) and the rounded norms
 // add 8 * 2^-24.  Clustered unit rows at D = 768: 3.6e-4 (bf16 head + tail: 3.2e-4).
-static double err_coef_i8(double U, double V) { return 2.001 * U + V * V + 8.0 * 5.9604644775390625e-8; }
+// (12 fp32 roundings: the two integer sums' conversions -- exact below 2^24, i.e. up to D = 1 040 columns (127^2 D), one rounding each
+// beyond --, their fused combination, the product of the two scales, the scaling, the scales' own two roundings each, two of slack)
+static double err_coef_i8(double U, double V) { return 2.001 * U + V * V + 12.0 * 5.9604644775390625e-8; }
 
 double err_coef(const as_space* sp) { return sp->ring_i8 ? sp->ring_coef8 : (sp->k2_i8 ? sp->coef8 : err_coef_dp(sp->dp)); }
 
@@ -72,10 +74,26 @@ static as_status k2_items_i8(const as_space* sp, bool* usable);
 // when the image cannot be used: a non-finite item, or a coefficient beyond 1e-3 (rows dominated by one element: s / |x| near
 // 1; clustered unit rows measure 3.6e-4 at any D) -- the bf16 kernel then.
 as_status space_i8_image(const as_space* sp, bool* present) {
-    static std::mutex mu;   // (searches of several host threads may all be the first to ask)
-    std::lock_guard<std::mutex> lk(mu);
+    // every single-query and batched search asks: once the image (or the decision against it) stands, no lock is taken --
+    // one process-wide mutex here serialised the re-entrant pool's threads and all spaces on each other
+    if (sp->x8_ready.load(std::memory_order_acquire)) {
+        *present = sp->x8 && !sp->x8_bad;
+        return AS_OK;
+    }
+    std::lock_guard<std::mutex> lk(sp->imu);   // (searches of several host threads may all be the first to ask)
     bool usable = false;
-    AS_TRY(k2_items_i8(sp, &usable));
+    const as_status s = k2_items_i8(sp, &usable);
+    if (s == AS_ENOMEM) {
+        // no memory for the image: remembered -- every later search would otherwise retry a multi-GB hipMalloc under the lock
+        // before it falls back to the fp32 items
+        (void)hipGetLastError();
+        sp->x8_bad = 2;
+        sp->x8_ready.store(1, std::memory_order_release);
+        *present = false;
+        return AS_OK;
+    }
+    AS_TRY(s);
+    sp->x8_ready.store(1, std::memory_order_release);
     *present = sp->x8 && !sp->x8_bad;
     return AS_OK;
 }
@@ -95,14 +113,20 @@ as_status space_i8h_image(const as_space* sp, bool* present) {
     bool have = false;
     AS_TRY(space_i8_image(sp, &have));
     if (!have) return AS_OK;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
+    const int rdy = sp->x8h_ready.load(std::memory_order_acquire);
+    if (rdy) {
+        *present = rdy == 1;
+        return AS_OK;
+    }
+    std::lock_guard<std::mutex> lk(sp->imu);
+    if (sp->x8h_ready.load(std::memory_order_relaxed) == 2) return AS_OK;
     if (!sp->x8h) {
         const int64_t rows_alloc = sp->np + ROW_TILE, cpr = sp->dp8 / 16;
         void* p = nullptr;
         if (hipMalloc(&p, (size_t)rows_alloc * sp->dp8) != hipSuccess) {
             (void)hipGetLastError();
-            return AS_OK;   // (no memory for it: the two-digit scan stays)
+            sp->x8h_ready.store(2, std::memory_order_release);
+            return AS_OK;   // (no memory for it: the two-digit scan stays -- and the allocation is not tried again per query)
         }
         hipLaunchKernelGGL(extract_a1_kernel, dim3(256 * 8), dim3(256), 0, sp->stream, (const signed char*)sp->x8, (signed char*)p, rows_alloc * cpr, cpr);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sp->stream) != hipSuccess) {
@@ -112,6 +136,7 @@ as_status space_i8h_image(const as_space* sp, bool* present) {
         }
         sp->x8h = p;
     }
+    sp->x8h_ready.store(1, std::memory_order_release);
     *present = true;
     return AS_OK;
 }
@@ -156,6 +181,7 @@ static as_status k2_items_i8(const as_space* sp, bool* usable) {
         sp->u8max = U;
         sp->v8max = V;
         sp->x8_bad = h[2] ? 1 : 0;
+        sp->x8_ready.store(1, std::memory_order_release);   // (space_i8_image's readers: everything above is published)
         dbg("k2_items_i8: U = %.3e, V = %.3e -> coefficient %.3e (bf16: %.3e)%s", U, V, sp->coef8, err_coef_dp(sp->dp),
             sp->x8_bad ? ", non-finite items: unusable" : "");
     }
@@ -2458,7 +2484,13 @@ as_status ring_i8_stats(as_space* sp, double* out3) {
     out3[2] = off ? 1.0 : 0.0;
     if (off || sp->n == 0) return AS_OK;   // (an empty shard has no say)
     bool usable = false;
-    AS_TRY(k2_items_i8(sp, &usable));
+    const as_status s = k2_items_i8(sp, &usable);
+    if (s == AS_ENOMEM) {   // no room for this rank's image: "unusable" is an answer the ring can act on (bf16 passes on every rank), an error is not
+        (void)hipGetLastError();
+        out3[2] = 1.0;
+        return AS_OK;
+    }
+    AS_TRY(s);
     out3[0] = sp->u8max;
     out3[1] = sp->v8max;
     out3[2] = sp->x8 && !sp->x8_bad ? 0.0 : 1.0;

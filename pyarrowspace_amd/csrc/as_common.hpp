@@ -1,5 +1,6 @@
 // Shared host/device definitions for the gfx950 hot path (not part of the C ABI).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -66,7 +67,11 @@ struct as_space {
     double ring_u8 = 0.0, ring_v8 = 0.0, ring_coef8 = 0.0;
     mutable double uq_est = 0.0, vq_est = 0.0;   // batched int8 pass: 1.05 x the queries' measured residue norms of the previous passes (as_search.hip, host_batch_coef)
     mutable double u8max = 0.0, v8max = 0.0;   // max_i s_i |theta_i|_2 / (16256 |x_i|), max_i s_i |a2_i|_2 / (16256 |x_i|)
-    mutable int x8_bad = 0;
+    mutable int x8_bad = 0;           // 1: non-finite items (the image exists but cannot be used), 2: no memory for the image (not retried)
+    // image state for readers that do not take imu: 0 nothing decided, 1 x8 / fa8 / coef8 published (or x8_bad set): read-only from now on
+    mutable std::atomic<int> x8_ready{0};
+    mutable std::atomic<int> x8h_ready{0};   // ... the planar high digits: 1 x8h published, 2 not available (no memory)
+    mutable std::mutex imu;           // makes the images (first use), per space
     mutable int k2_i8 = 0;
     mutable int k2_last_pipe = -1;   // matrix pipe of the last k-NN pass on this space: 0 fp32, 1 bf16 head + tail, 2 int8 two digits (as_space_knn_pipe)
     int64_t dp8 = 0;

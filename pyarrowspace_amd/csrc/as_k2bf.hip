@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
                     if (I8) {
-                        // x_i . x_j = s_i s_j (16384 a1.b1 + 128 (a1.b2 + a2.b1)) / 16256^2 = t fa_i fa_j, t = 128 a1.b1 + cross (both sums < 2^24: exact floats)
+                        // x_i . x_j = s_i s_j (16384 a1.b1 + 128 (a1.b2 + a2.b1)) / 16256^2 = t fa_i fa_j, t = 128 a1.b1 + cross (both sums < 2^24 -- exact floats -- up to 1 040 columns; one rounding each beyond: charged in err_coef_i8)
                         const float t = fmaf((float)acc1[nn][r], 128.0f, (float)accx[nn][r]);
                         const float fi = METRIC == AS_METRIC_L2 ? fg[r & 3] : ai;
                         const float gg = t * (fi * sj[nn]);

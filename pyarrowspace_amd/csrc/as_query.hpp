@@ -202,6 +202,7 @@ struct as_query {
     as_hit_rec* hits_all = nullptr;      // [world][topk + 1] gathered hit records
     char* xsend = nullptr;               // one-exchange pass: this rank's block (as_query_x1_bytes) ...
     char* xall = nullptr;                // ... and the gathered blocks of all ranks
+    int x1_off = 0;                      // the one-exchange pass is switched off for this workspace (ARROWSPACE_STAGED_X1=0 when it was made; as_query_set_x1)
     int64_t x1_passes = 0;               // one-exchange passes this workspace has finished
     void* x1_head = nullptr;             // header of the block the last pass wrote (left zeroed by its finish kernel)
     int x1_dirty = 1;                    // ... unless that pass never reached its finish

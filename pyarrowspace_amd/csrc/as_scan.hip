@@ -819,7 +819,8 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
                         hi = __builtin_amdgcn_sdot4(__float_as_int(xv[u][e]), qa[u][e], hi, false);
                         xs = __builtin_amdgcn_sdot4(__float_as_int(xv[u][e]), qb[u][e], xs, false);
                     }
-                // (the lanes' partial sums and the wave's totals stay below 2^24: exact in fp32)
+                // (the lanes' partial sums stay below 2^24; the wave's totals too up to 1 040 columns -- 127^2 D --, beyond that each of the
+                // six additions of a wave sum may round: host_query_digits charges 12 more roundings for rows wider than 1 024 columns)
                 const float fh = wave_sum_dpp((float)hi), fx = wave_sum_dpp((float)xs);
                 sacc = fmaf(fh, 128.0f, fx);
             } else {

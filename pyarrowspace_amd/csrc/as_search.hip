@@ -2563,11 +2563,14 @@ static bool host_query_digits(as_query* q, int64_t d) {
     }
     const double nq = std::sqrt(q->h_nq);
     const double uq = (double)m * std::sqrt(st2) / (16256.0 * nq) * 1.001, vq = (double)m * std::sqrt(sa2) / (16256.0 * nq) * 1.001;
-    const double coef = uq + 1.001 * sp->u8max + vq * sp->v8max + 10.0 * 5.9604644775390625e-8;
+    // (fp32 roundings behind the exact integer sums: ten for the scaling -- and, for rows wider than 1 024 columns, whose wave
+    // totals pass 2^24, six more for each of the two wave sums' additions)
+    const double rnd = (sp->dp8 > 1024 ? 22.0 : 10.0) * 5.9604644775390625e-8;
+    const double coef = uq + 1.001 * sp->u8max + vq * sp->v8max + rnd;
     if (!(coef <= 2.0e-3)) return false;
     q->coef_i8 = coef;
     // the coarse scan drops a2 . (128 q1 + q2) as well: at most V |x||q| (1 + u_q)
-    q->coef_i8h = uq + 1.001 * sp->u8max + 1.002 * sp->v8max + 10.0 * 5.9604644775390625e-8;
+    q->coef_i8h = uq + 1.001 * sp->u8max + 1.002 * sp->v8max + rnd;
     q->h_faq = m * (11.313708498984761f / 16256.0f);   // s_q sqrt(128) / 16256
     return true;
 }
@@ -2848,6 +2851,7 @@ static as_status query_alloc(as_query* q) {
     const as_space* sp = q->sp;
     const size_t C = (size_t)q->cap;
     q->nwaves = 4096;
+    if (const char* ev = getenv("ARROWSPACE_STAGED_X1")) q->x1_off = atoi(ev) == 0 ? 1 : 0;
     if (const char* ev = getenv("ARROWSPACE_SCAN_VARIANT")) q->scan_variant = atoi(ev) & 7;
     if (const char* ev = getenv("ARROWSPACE_GEMM_VARIANT")) q->gemm_variant = atoi(ev);
     q->half_enabled = getenv("ARROWSPACE_BATCH_F32_DOTS") ? 0 : 1;
@@ -3076,8 +3080,9 @@ int64_t as_query_x1_bytes(const as_query* q, int32_t world) {
 // 1 when a search with this tau may take the one-exchange pass on this workspace (the same answer on every rank: it depends on
 // the graph's mode, tau and the workspace's kind only); what a RANK cannot offer at run time travels as a flag in its block.
 int32_t as_query_x1_usable(const as_query* q, double tau) {
-    const char* env = getenv("ARROWSPACE_STAGED_X1");   // (per call: an A/B switch)
-    const bool off = env && atoi(env) == 0;
+    // (the A/B switch ARROWSPACE_STAGED_X1 is read ONCE, when the workspace is made -- x1_off -- and a row-sharded index agrees on
+    // it over its ranks, as_query_set_x1: ranks that decided per call from their own environment issued different collectives)
+    const bool off = q && q->x1_off;
     return q && q->gr && !off && tau >= 0.4 && tau <= 1.0 && q->gr->lambda_mode != AS_LAMBDA_FEATURE && q->cap == 1 && !q->sp->opts.force_exact &&
                    (q->sp->opts.search_mode & 3) == 0 ? 1 : 0;
 }
@@ -3190,6 +3195,10 @@ as_status as_query_x1_finish(as_query* q, const void* all_dev, int32_t world, do
 int32_t as_query_x1_redo(const as_query* q) { return q && (q->hout->overflow & 4) ? 1 : 0; }
 // allowed = 0: the following one-exchange passes of this workspace scan both digits of the image (the retry of a pass whose
 // coarse candidates did not fit, on every rank alike); 1: the default again
+int32_t as_query_x1_enabled(const as_query* q) { return q && !q->x1_off ? 1 : 0; }
+void as_query_set_x1(as_query* q, int32_t enabled) {
+    if (q) q->x1_off = enabled ? 0 : 1;
+}
 void as_query_set_coarse(as_query* q, int32_t allowed) {
     if (q) q->coarse_never = allowed ? 0 : 1;
 }

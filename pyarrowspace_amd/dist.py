@@ -435,6 +435,7 @@ class HipEngine:
         self.qs = C.c_void_p()
         self._check(self.L.as_query_create(self.sp, self.gr, C.byref(self.qs)))
         self._check(self.L.as_query_set_comm(self.qs, self.comm))
+        self.L.as_query_set_x1(self.qs, self.L.as_query_x1_enabled(self.q))   # (what the ranks agreed on for self.q)
         self._sidx = np.empty(max(self.topk, 1), dtype=np.int64)
         self._ssc = np.empty(max(self.topk, 1), dtype=np.float64)
 
@@ -456,6 +457,16 @@ class HipEngine:
     # ---- one exchange per query (as_query_x1_*): this rank's block -> all-gather -> the same finish on every rank
     def x1_usable(self, tau):
         return bool(self.L.as_query_x1_usable(self.q, float(tau)))
+
+    def x1_enabled(self):
+        """This rank's own switch of the one-exchange pass (ARROWSPACE_STAGED_X1 when the workspace was made)."""
+        return bool(self.L.as_query_x1_enabled(self.q))
+
+    def x1_set_enabled(self, enabled):
+        """The switch the ranks agreed on, for every query workspace of this engine."""
+        self.L.as_query_set_x1(self.q, 1 if enabled else 0)
+        if getattr(self, "qs", None):
+            self.L.as_query_set_x1(self.qs, 1 if enabled else 0)
 
     def x1_begin(self, q, tau, r0, r1, world):
         torch = self.torch
@@ -659,6 +670,7 @@ class ShardedIndex:
         no Python between the scan, the two all-gathers and the merge.  Needs real RCCL ranks (one GPU per rank);
         ARROWSPACE_PY_COLLECTIVES=1 keeps the torch.distributed path (A/B runs)."""
         e = self.engine
+        self._agree_query_switches()
         # (what decides here is the same on every rank: the class, the engine type, the group's backend)
         if not (self.library_exchange and self._collective() and hasattr(e, "comm_create")):
             return
@@ -690,6 +702,20 @@ class ShardedIndex:
         ok.fill_(made)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
         self._lib_comm = int(ok.item()) == 1     # all ranks or none: the two paths issue different collectives
+
+    def _agree_query_switches(self):
+        """What a rank's ENVIRONMENT may switch about the query path -- the one-exchange pass, ARROWSPACE_STAGED_X1 -- decides
+        which collectives a search issues (one all-gather of blocks, or two of records): agreed once over the ranks when
+        the query is opened (MIN: any rank that has it off switches it off for all), never read per call and per rank."""
+        e = self.engine
+        if not (hasattr(e, "x1_enabled") and hasattr(e, "x1_set_enabled")):
+            return
+        mine = 1.0 if e.x1_enabled() else 0.0
+        if self._collective():
+            torch = self.torch
+            t = torch.tensor([mine], dtype=torch.float64, device=e.knn_local.device)
+            mine = float(self._gather_fixed(t).min().item())
+        e.x1_set_enabled(mine > 0.0)
 
     # ---- collectives
     def _collective(self):
@@ -949,8 +975,15 @@ class ShardedIndex:
         # the block passes on the int8 images of the shards, when every rank's image allows it: each rank's measured maxima
         # (U, V, unusable) all-gathered, the ring-wide maxima handed back -- the same decision on every rank
         self.ring_i8 = False
-        if hasattr(e, "ring_i8_stats") and not os.environ.get("ARROWSPACE_RING_NO_I8"):
-            st = torch.tensor(e.ring_i8_stats(), dtype=torch.float64, device=X_shard.device)
+        if hasattr(e, "ring_i8_stats"):
+            # (every rank enters the all-gather below whatever its own environment or image says: a rank that may not or cannot
+            # use its image -- ARROWSPACE_RING_NO_I8 set on it, no memory for the image -- reports "unusable", and all ranks
+            # fall back to the bf16 passes alike; a rank that skipped the collective would leave the others waiting in it)
+            try:
+                mine = [0.0, 0.0, 1.0] if os.environ.get("ARROWSPACE_RING_NO_I8") else list(e.ring_i8_stats())
+            except (RuntimeError, MemoryError, ValueError):
+                mine = [0.0, 0.0, 1.0]
+            st = torch.tensor(mine, dtype=torch.float64, device=X_shard.device)
             if ring:
                 sts = [torch.zeros_like(st) for _ in range(world)]
                 dist.all_gather(sts, st, group=self.group)
@@ -1167,9 +1200,11 @@ class ShardedIndex:
                 if redo and hasattr(e, "x1_set_coarse"):
                     # some rank's candidates did not fit -- possibly a coarse scan's wider windows: once more on the two-digit image
                     e.x1_set_coarse(False)
-                    blocks = self._gather_fixed(e.x1_begin(q, tau, *self.scan_rows, nranks), persistent=True)
-                    hits, lq, zero, inexact, overflow, redo = e.x1_finish(blocks, tau, nranks)
-                    e.x1_set_coarse(True)
+                    try:
+                        blocks = self._gather_fixed(e.x1_begin(q, tau, *self.scan_rows, nranks), persistent=True)
+                        hits, lq, zero, inexact, overflow, redo = e.x1_finish(blocks, tau, nranks)
+                    finally:   # (an error in between must not leave the coarse scan switched off on this rank for good)
+                        e.x1_set_coarse(True)
                 mode = 0 if redo else next_mode(0, inexact, overflow)
             for _ in range(8):
                 if mode is None:
@@ -1241,6 +1276,16 @@ class ShardedIndex:
         t = torch.from_numpy(np.ascontiguousarray(lam[: self.counts[self.rank]])).to(dev)
         return self._gather_rows(t, self.counts).cpu().numpy()
 
+    def degrees(self):
+        """Weighted degrees of ALL items, in item order (a collective on a row-sharded graph: every rank holds its rows')."""
+        deg = self.engine.degrees()
+        if self.replicated or not self._collective() or len(deg) == self.n:
+            return deg
+        torch = self.torch
+        dev = self.engine.knn_local.device
+        t = torch.from_numpy(np.ascontiguousarray(deg[: self.counts[self.rank]])).to(dev)
+        return self._gather_rows(t, self.counts).cpu().numpy()
+
     def last_scan_us(self):
         return self.engine.scan_us(self.engine.qs if self._lib_comm else None)
 
@@ -1265,11 +1310,19 @@ class HostStagedIndex(ShardedIndex):
     def build(cls, graph_params, X_shard, dist=None, *args, **kwargs):
         # The ranks share ONE card: the library sizes its scratch (the symmetric pass's transposed buffers: 8 KB per item) by
         # the memory it finds free -- found free by every rank at the same moment.  Each rank plans with its share.
-        if dist is not None and getattr(X_shard, "is_cuda", False) and "ARROWSPACE_SYM_FREE_GB" not in os.environ:
+        # (set around THIS build only: a later build in the process measures again -- the card is fuller by then -- and a plain
+        # ShardedIndex / ArrowSpace build is not handed a share meant for ranks that shared a card)
+        group = kwargs.get("group", args[0] if args else None)
+        mine = dist is not None and getattr(X_shard, "is_cuda", False) and "ARROWSPACE_SYM_FREE_GB" not in os.environ
+        if mine:
             import torch
             free, _ = torch.cuda.mem_get_info(X_shard.device)
-            os.environ["ARROWSPACE_SYM_FREE_GB"] = "%.1f" % (0.8 * free / 1e9 / max(dist.get_world_size(), 1))
-        return super().build(graph_params, X_shard, dist, *args, **kwargs)
+            os.environ["ARROWSPACE_SYM_FREE_GB"] = "%.1f" % (0.8 * free / 1e9 / max(dist.get_world_size(group), 1))
+        try:
+            return super().build(graph_params, X_shard, dist, *args, **kwargs)
+        finally:
+            if mine:
+                os.environ.pop("ARROWSPACE_SYM_FREE_GB", None)
 
 
     def _gather_rows(self, t, counts):

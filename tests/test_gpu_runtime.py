@@ -89,3 +89,46 @@ def test_search_is_reentrant_across_host_threads(oracle_lib):
         assert_hits_match(single[i], want, ref.scores(q, taus[i % 3], lq), rtol=RTOL)
         for t in range(4):
             assert results[t][i] == single[i], (t, i)
+
+
+def test_two_graph_handles_on_one_space_from_two_threads():
+    """The pool's workspaces carry ONE graph handle's k / topk layout: threads that search the same space against two
+    different handles at once must each get their handle's layout (a slot reserved while its workspace is being made
+    counts as that handle's: pool_acquire) -- every result equals the single-threaded one, lengths follow the handle's topk."""
+    import threading
+
+    import numpy as np
+
+    import pyarrowspace_amd as asp
+    from conftest import calibrate_eps, clustered
+    n, d = 5000, 64
+    X = clustered(n, d, nclust=10, seed=31)
+    eps = calibrate_eps(X, 8, "l2")
+    gp1 = {"eps": eps, "k": 8, "topk": 5, "p": 2.0, "sigma": None}
+    gp2 = {"eps": eps, "k": 12, "topk": 40, "p": 2.0, "sigma": None}
+    aspace, gl1 = asp.ArrowSpaceBuilder.build(gp1, X)
+    _other, gl2 = asp.ArrowSpaceBuilder.build(gp2, X)
+    rng = np.random.default_rng(9)
+    Q = [np.ascontiguousarray(X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d)) for _ in range(40)]
+    want1 = [aspace.search(q, gl1, 0.62) for q in Q]
+    want2 = [aspace.search(q, gl2, 0.62) for q in Q]
+    assert all(len(h) == 5 for h in want1) and all(len(h) == 40 for h in want2)
+    errors = []
+
+    def worker(gl, want):
+        try:
+            for _ in range(3):
+                for q, w in zip(Q, want):
+                    got = aspace.search(q, gl, 0.62)
+                    if got != w:
+                        errors.append((len(got), len(w)))
+        except BaseException as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(gl1, want1)), threading.Thread(target=worker, args=(gl2, want2)),
+           threading.Thread(target=worker, args=(gl1, want1)), threading.Thread(target=worker, args=(gl2, want2))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:4]
