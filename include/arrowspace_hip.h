@@ -407,6 +407,10 @@ as_status as_query_stats(const as_query* q, double* out, int32_t n);
 /* HIP-event timing of searches is off by default (the events cost a few microseconds per
  * query); enable it before the searches whose stats are read */
 void as_enable_search_stats(int32_t enabled);
+/* Measurement knob, no reference counterpart: launch parameters the library otherwise picks itself.  "tile_geom" = <blocks per
+ * CU><two digits: ring KiB per wave> of the single query's tile scan (e.g. 406, 308, 216; ARROWSPACE_TILE_GEOM at load).
+ * Returns 0, or 1 for an unknown key.  Results never depend on it. */
+int32_t as_set_tuning(const char* key, int32_t value);
 /* same, for the workspace as_search keeps inside the space (last as_search call) */
 as_status as_last_search_stats(const as_space* sp, double* out, int32_t n);
 /* single-query searches on this space since it was made: out[0] searches, [1] zero-lambda results (src/lib.rs:156-159),

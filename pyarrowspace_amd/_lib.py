@@ -48,7 +48,7 @@ SYMBOLS = [
     "as_query_finish", "as_query_create_batch", "as_query_slots", "as_query_scan_batch", "as_query_lambda_batch",
     "as_query_score_batch", "as_query_finish_batch", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
     "as_get_item", "as_lambdas", "as_nnodes", "as_get_graph_params", "as_graph_nnz", "as_graph_csr",
-    "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_last_search_stats", "as_search_counters", "as_enable_search_stats", "as_index_save", "as_index_load", "as_free_space",
+    "as_graph_degrees", "as_graph_tau0", "as_lambdas_dev", "as_build_stats", "as_query_stats", "as_last_search_stats", "as_search_counters", "as_enable_search_stats", "as_set_tuning", "as_index_save", "as_index_load", "as_free_space",
     "as_free_graph", "as_set_debug", "as_last_error", "as_device_count", "as_version",
     "as_comm_available", "as_comm_unique_id", "as_comm_create", "as_comm_free", "as_query_set_comm", "as_query_search_staged", "as_query_x1_bytes", "as_query_x1_usable", "as_query_x1_enabled", "as_query_set_x1", "as_query_x1_begin", "as_query_x1_finish", "as_query_x1_redo", "as_query_set_coarse", "as_query_x1_passes", "as_edges_bucket", "as_ring_i8_stats", "as_ring_i8_set", "as_ring_i8",
 ]
@@ -194,6 +194,7 @@ def load():
         "as_last_search_stats": (i32, [vp, vp, i32]),
         "as_search_counters": (i32, [vp, vp, i32]),
         "as_enable_search_stats": (None, [i32]),
+        "as_set_tuning": (i32, [C.c_char_p, i32]),
         "as_index_save": (i32, [vp, vp, C.c_char_p]),
         "as_index_load": (i32, [C.c_char_p, pop, pvp, pvp]),
         "as_free_space": (None, [vp]),

@@ -98,12 +98,15 @@ as_status space_i8_image(const as_space* sp, bool* present) {
     return AS_OK;
 }
 
-// The high digits of the int8 image alone, planar: 64 bytes per row and 64-column slab instead of 128 -- the operand of the
-// single query's COARSE scan (as_search.hip, query_begin): x ~ s 128 a1 / 16256, off by at most V |x| (v8max).
+// The high digits of the int8 image alone, in TILES: per 64 consecutive rows and 16-column chunk c one KiB holding row r's sixteen
+// digits at byte 16 r ([tile][chunk][64 rows][16 bytes]; half the image's bytes) -- the operand of the single query's COARSE
+// scan (as_scan.hip, scan_tile_kernel; as_search.hip, query_begin): x ~ s 128 a1 / 16256, off by at most V |x| (v8max).  One
+// LDS-DMA of a scanning wave brings chunk c of 64 rows: lane r gets row r, and a row's dot never leaves its lane.
 __global__ __launch_bounds__(256) void extract_a1_kernel(const signed char* __restrict__ x8, signed char* __restrict__ x8h, int64_t chunks, int64_t cpr) {
     typedef int i32x4v __attribute__((ext_vector_type(4)));
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < chunks; t += (int64_t)gridDim.x * 256) {
-        const int64_t row = t / cpr, c = t - row * cpr;          // c: 16-byte chunk of the planar row; 4 per slab
+        const int64_t tile = t / (cpr * 64), rem = t - tile * (cpr * 64);
+        const int64_t c = rem >> 6, row = tile * 64 + (rem & 63);   // c: 16-column chunk; 4 per slab of the two-digit image
         *(i32x4v*)(x8h + t * 16) = *(const i32x4v*)(x8 + (row * cpr * 2 + (c >> 2) * 8 + (c & 3)) * 16);
     }
 }

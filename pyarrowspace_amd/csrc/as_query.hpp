@@ -254,6 +254,7 @@ double coef_query(const as_query* q, bool exact);
 int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products);
 PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
 as_status launch_scan(as_query* q, const PreArgs& pre);
+void set_tile_geom(int v);
 as_status set_scan_attrs();   // per-device dynamic-LDS opt-in of the scan kernels
 
 }  // namespace as

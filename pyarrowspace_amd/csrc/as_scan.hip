@@ -642,6 +642,131 @@ __device__ __forceinline__ int sc_bin(float c) {
     const int b = (int)floorf((c + 1.0f) * 32.0f);
     return b < 0 ? 0 : (b > SC_BINS - 1 ? SC_BINS - 1 : b);
 }
+// ---- what a scanning wave does at the end of a chunk of up to 64 rows (lane r holds the dot of the chunk's row r), shared by the
+// row-ring scan (scan_dma_kernel) and the tile scan (scan_tile_kernel): the dots' store, the k-NN prefilter and -- SC -- the
+// scorer's candidates: publication into the cosine histogram, the bound read back, the wave's pending list.
+struct ScanWave {
+    int full = 0;                // the k-NN candidate buffer has overflowed (this lane has seen it)
+    int npend = 0;               // SC: entries of the wave's pending list
+    float thr_last = -3.0e38f;   // SC: the threshold of the last chunk that read the histogram
+    bool thr_known = false;
+    int jb_last = -1;
+    int sc_over = 0;             // SC: the list overflowed (the wave reports -1 candidates: the host takes the threshold chain)
+};
+template <bool SC>
+__device__ __forceinline__ void scan_chunk_end(const PreArgs& pre, ScanWave& w, float* __restrict__ dots, int t, int rounds, int64_t gw, int lane,
+                                               int64_t base, int cnt, float mydot, float aux, bool hread, unsigned hx0, unsigned px0,
+                                               float nq32, float inq32) {
+    const int64_t row = base + lane;
+    if (lane < cnt) {   // cnt >= 1: the store is always issued (the ring's bookkeeping counts it)
+        store_dword_issued(dots + row, mydot);
+        prefilter_f32(pre, row, mydot, aux, nq32, inq32, w.full);
+    }
+    if (SC) {
+        int jb = w.jb_last;
+        if (hread) {   // (between reads the wave keeps the bound of its last one)
+            w.thr_last = sc_bound(lds_read1u(hx0 + lane * 4), pre.sc_m, lane, jb) - pre.sc_w;
+            w.jb_last = jb;
+            w.thr_known = true;
+        }
+        const float thr = w.thr_last;
+        const bool valid = lane < cnt && row < pre.n;
+        const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
+        const float c = mydot * inr * inq32;
+        // Publish the chunk's best rows: the bins within two of the chunk's maximum that lie above the bound's -- but
+        // only rows that stand out of their own chunk (more than 4 standard deviations above its mean), or every
+        // 16th chunk unconditionally.  Any subset of the rows bounds B from below; the rule keeps the atomics few:
+        // a posted atomic is cheap for its wave, but every wave's next histogram read (past the L2, in order in front
+        // of its row DMAs) queues behind the atomics in flight on that line -- 2 048 chunks publishing at once made
+        // the whole launch 35 % slower.  A query's near neighbours are outliers of their chunks; smooth cosine
+        // distributions are covered by the unconditional chunks.
+        const bool fin = valid && c == c;           // (a NaN cosine neither publishes nor bounds)
+        const int mybin = fin ? sc_bin(c) : -1;
+        // (only a row above the bound's bin can raise the bound: once it stands, the chunk statistics below -- 18
+        // cross-lane operations -- are skipped for almost every chunk)
+        if (__ballot(mybin > jb) && (t < rounds || rounds >= 2) && !AS_SC_DBG(1)) {
+            float cm = fin ? c : -2.0f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+            const float nv = (float)__popcll(__ballot(fin));
+            const float mean = wave_sum_dpp(fin ? c : 0.0f) / fmaxf(nv, 1.0f);
+            const float var = fmaxf(wave_sum_dpp(fin ? (c - mean) * (c - mean) : 0.0f) / fmaxf(nv, 1.0f), 0.0f);
+            const bool every = (((int)gw + t) & 31) == 0;
+            const int bfloor = every ? -1 : sc_bin(mean + 4.0f * sqrtf(var));
+            const int bmax = cm > -2.0f ? sc_bin(cm) : -1;
+            int nb3[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) nb3[u] = __popcll(__ballot(mybin == bmax - u && bmax - u >= 0));
+            // lane = copy * 3 + u: bin bmax - u of histogram copy `copy`.  (A wave of one or two chunks does not publish
+            // its last one: nobody is left to read it but the waves' final reads, which would queue behind it.)
+            const int u = lane % 3, copy = lane / 3;
+            const int b = bmax - u;
+            const int nb_ = u == 0 ? nb3[0] : (u == 1 ? nb3[1] : nb3[2]);
+            if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0) atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
+        }
+        // candidates: c >= thr -- a NaN cosine (a poisoned row) never qualifies, as under the plain chain's `key <= thr`
+        const bool pass = valid && c >= thr && !AS_SC_DBG(4);
+        const unsigned long long pm = __ballot(pass);
+        const int np = __popcll(pm);
+        if (w.npend + np > SC_PEND) {
+            // re-test the list against the bound known now (rows kept before a bound existed); flush what is left
+            int keep = 0;
+            for (int e0 = 0; e0 < w.npend; e0 += 64) {
+                float ce = 0.0f;
+                int re = 0;
+                if (e0 + lane < w.npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
+                const bool kp = e0 + lane < w.npend && ce >= thr;
+                const unsigned long long km = __ballot(kp);
+                // in place: the entries written are at or before the entries read by this or an earlier trip
+                if (kp) lds_write2(px0 + (unsigned)(keep + __popcll(km & ((1ull << lane) - 1))) * 8, ce, re);
+                AS_LDS_FENCE();
+                keep += __popcll(km);
+            }
+            w.npend = keep;
+            if (w.npend + np > SC_PEND) {   // more than the list holds even under the current bound: this query is not for the fused tail
+                w.sc_over = 1;
+                w.npend = 0;
+            }
+        }
+        if (pass) lds_write2(px0 + (unsigned)(w.npend + __popcll(pm & ((1ull << lane) - 1))) * 8, c, (int)row);
+        AS_LDS_FENCE();
+        w.npend += np;
+    }
+}
+// the wave's last word (SC): its surviving candidates into its own region of the report buffer
+template <bool SC>
+__device__ __forceinline__ void scan_wave_report(const PreArgs& pre, ScanWave& w, int64_t gw, int lane, unsigned px0) {
+    if (SC) {
+        // The wave's last word: the histogram as it stands now, the list re-tested against it, the survivors into the
+        // wave's OWN region of the candidate buffer (SC_WCAP words: the count, then the rows -- one 16-byte load tells the
+        // finish kernel the count and the first three) -- plain stores: a returning atomic per wave on one counter, all
+        // waves ending together, cost the launch 20 us.
+        int keep = 0;
+        int* region = pre.sc_idx + gw * SC_WCAP;   // [0] = number of candidates (-1: more than the region holds), [1 ..] = their rows
+        if (w.npend > 0 && !w.sc_over) {
+            // (a wave of three or more chunks has read the histogram with its last chunks: that threshold will do -- a
+            // fresh read past the L2 at every wave's end is two microseconds of every launch's tail)
+            float thr = w.thr_last;
+            if (!w.thr_known) {
+                int jb;
+                const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+            }
+            for (int e0 = 0; e0 < w.npend; e0 += 64) {
+                float ce = 0.0f;
+                int re = 0;
+                if (e0 + lane < w.npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
+                const bool kp = e0 + lane < w.npend && ce >= thr;
+                const unsigned long long km = __ballot(kp);
+                const int pos = keep + __popcll(km & ((1ull << lane) - 1));
+                if (kp && pos < SC_WCAP - 1) region[1 + pos] = re;
+                keep += __popcll(km);
+            }
+        }
+        if (lane == 0) region[0] = w.sc_over || keep > SC_WCAP - 1 ? -1 : keep;
+    }
+}
+
 // I8: the rows are those of the int8 two-digit image (as_k2bf.hip, quant_i8_kernel: x ~ s (128 a1 + a2) / 16256, per 64-column
 // slab 64 bytes of a1 then 64 of a2) -- HALF the bytes of the fp32 items for this HBM-bound kernel; `dp` is then the image row
 // in floats (dp8 / 2).  A lane's 16-byte chunk is 16 digits a1 or 16 digits a2 of 16 columns; the query's digits q1, q2 of
@@ -741,13 +866,8 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
     for (int i = 0; i < NSLOT - 1; ++i) AS_ISSUE_ROW();
     unsigned cur = 0;    // byte offset of the oldest row in the ring
     int marked = 0;      // rows in flight that have a chunk boundary's store + norm DMA behind them in the queue
-    int full = 0;
     bool first = true;
-    int npend = 0;       // SC: entries of the wave's pending list
-    float thr_last = -3.0e38f;   // SC: the threshold of the last chunk that read the histogram
-    bool thr_known = false;
-    int jb_last = -1;
-    int sc_over = 0;     // SC: the list overflowed (the wave reports -1 candidates: the host takes the threshold chain)
+    ScanWave w;
     for (int t = 0; t <= rounds; ++t) {
         int64_t base;
         int cnt;
@@ -837,113 +957,178 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         if (cnt < NSLOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float aux = lds_read1(ax0 + lane * 4);
         if (I8) mydot *= lds_read1(my0 + FA_OFF + lane * 4) * pre.faq;   // x_i . q = (128 HI + XS) fa_i fa_q
-        const int64_t row = base + lane;
-        if (lane < cnt) {   // cnt >= 1: the store is always issued (the ring's bookkeeping counts it)
-            store_dword_issued(dots + row, mydot);
-            prefilter_f32(pre, row, mydot, aux, nq32, inq32, full);
-        }
-        if (SC) {
-            int jb = jb_last;
-            if (hread) {   // (between reads the wave keeps the bound of its last one)
-                thr_last = sc_bound(lds_read1u(hx0 + lane * 4), pre.sc_m, lane, jb) - pre.sc_w;
-                jb_last = jb;
-                thr_known = true;
-            }
-            const float thr = thr_last;
-            const bool valid = lane < cnt && row < pre.n;
-            const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
-            const float c = mydot * inr * inq32;
-            // Publish the chunk's best rows: the bins within two of the chunk's maximum that lie above the bound's -- but
-            // only rows that stand out of their own chunk (more than 4 standard deviations above its mean), or every
-            // 16th chunk unconditionally.  Any subset of the rows bounds B from below; the rule keeps the atomics few:
-            // a posted atomic is cheap for its wave, but every wave's next histogram read (past the L2, in order in front
-            // of its row DMAs) queues behind the atomics in flight on that line -- 2 048 chunks publishing at once made
-            // the whole launch 35 % slower.  A query's near neighbours are outliers of their chunks; smooth cosine
-            // distributions are covered by the unconditional chunks.
-            const bool fin = valid && c == c;           // (a NaN cosine neither publishes nor bounds)
-            const int mybin = fin ? sc_bin(c) : -1;
-            // (only a row above the bound's bin can raise the bound: once it stands, the chunk statistics below -- 18
-            // cross-lane operations -- are skipped for almost every chunk)
-            if (__ballot(mybin > jb) && (t < rounds || rounds >= 2) && !AS_SC_DBG(1)) {
-                float cm = fin ? c : -2.0f;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
-                const float nv = (float)__popcll(__ballot(fin));
-                const float mean = wave_sum_dpp(fin ? c : 0.0f) / fmaxf(nv, 1.0f);
-                const float var = fmaxf(wave_sum_dpp(fin ? (c - mean) * (c - mean) : 0.0f) / fmaxf(nv, 1.0f), 0.0f);
-                const bool every = (((int)gw + t) & 31) == 0;
-                const int bfloor = every ? -1 : sc_bin(mean + 4.0f * sqrtf(var));
-                const int bmax = cm > -2.0f ? sc_bin(cm) : -1;
-                int nb3[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u) nb3[u] = __popcll(__ballot(mybin == bmax - u && bmax - u >= 0));
-                // lane = copy * 3 + u: bin bmax - u of histogram copy `copy`.  (A wave of one or two chunks does not publish
-                // its last one: nobody is left to read it but the waves' final reads, which would queue behind it.)
-                const int u = lane % 3, copy = lane / 3;
-                const int b = bmax - u;
-                const int nb_ = u == 0 ? nb3[0] : (u == 1 ? nb3[1] : nb3[2]);
-                if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0) atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
-            }
-            // candidates: c >= thr -- a NaN cosine (a poisoned row) never qualifies, as under the plain chain's `key <= thr`
-            const bool pass = valid && c >= thr && !AS_SC_DBG(4);
-            const unsigned long long pm = __ballot(pass);
-            const int np = __popcll(pm);
-            if (npend + np > SC_PEND) {
-                // re-test the list against the bound known now (rows kept before a bound existed); flush what is left
-                int keep = 0;
-                for (int e0 = 0; e0 < npend; e0 += 64) {
-                    float ce = 0.0f;
-                    int re = 0;
-                    if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
-                    const bool kp = e0 + lane < npend && ce >= thr;
-                    const unsigned long long km = __ballot(kp);
-                    // in place: the entries written are at or before the entries read by this or an earlier trip
-                    if (kp) lds_write2(px0 + (unsigned)(keep + __popcll(km & ((1ull << lane) - 1))) * 8, ce, re);
-                    AS_LDS_FENCE();
-                    keep += __popcll(km);
-                }
-                npend = keep;
-                if (npend + np > SC_PEND) {   // more than the list holds even under the current bound: this query is not for the fused tail
-                    sc_over = 1;
-                    npend = 0;
-                }
-            }
-            if (pass) lds_write2(px0 + (unsigned)(npend + __popcll(pm & ((1ull << lane) - 1))) * 8, c, (int)row);
-            AS_LDS_FENCE();
-            npend += np;
-        }
+        scan_chunk_end<SC>(pre, w, dots, t, rounds, gw, lane, base, cnt, mydot, aux, hread, hx0, px0, nq32, inq32);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (SC) {
-        // The wave's last word: the histogram as it stands now, the list re-tested against it, the survivors into the
-        // wave's OWN region of the candidate buffer (SC_WCAP words: the count, then the rows -- one 16-byte load tells the
-        // finish kernel the count and the first three) -- plain stores: a returning atomic per wave on one counter, all
-        // waves ending together, cost the launch 20 us.
-        int keep = 0;
-        int* region = pre.sc_idx + gw * SC_WCAP;   // [0] = number of candidates (-1: more than the region holds), [1 ..] = their rows
-        if (npend > 0 && !sc_over) {
-            // (a wave of three or more chunks has read the histogram with its last chunks: that threshold will do -- a
-            // fresh read past the L2 at every wave's end is two microseconds of every launch's tail)
-            float thr = thr_last;
-            if (!thr_known) {
-                int jb;
-                const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+    scan_wave_report<SC>(pre, w, gw, lane, px0);
+#undef AS_ISSUE_ROW
+#undef AS_CHUNK
+}
+
+// Tile scan -- the single query's COARSE scan.  The items' high digits lie in TILES: per 64 consecutive rows and
+// 16-column chunk c ONE KiB -- row r's sixteen digits at byte 16 r ([tile][chunk][64 rows][16 B]; space_i8h_image).  A wave takes
+// a chunk of up to 64 consecutive rows as before, but one LDS-DMA now brings chunk c of ALL its rows: lane r receives row r's
+// digits, multiplies them with the query's digits of those 16 columns -- the same for every lane: read from LDS by broadcast --
+// and keeps row r's two integer sums in its own registers for the whole chunk.  No cross-lane reduction (the row-ring kernel
+// pays two 64-lane DPP sums and a readlane per 768-byte row, with 48 of 64 lanes busy), every DMA a full KiB whatever the row
+// width, a quarter of the instructions per byte: per KiB one counted wait, one DMA, three LDS reads, eight v_dot4_i32_i8.
+// Chunks need not be aligned with tiles (the remainder's even split, short shards' chunks of 32 / 16 rows): the lanes' source
+// addresses are computed per row.  The ring holds NSLOT KiB per wave, NSLOT - 2 in flight; items are issued and consumed in
+// pairs (the row width in 16-column chunks is a multiple of 4).  Chunk schedule, chunk end (dots, k-NN prefilter, scorer
+// candidates) and the wave's report are those of scan_dma_kernel.
+template <int NSLOT, bool SC>
+__global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __restrict__ xt, int C, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                        PreArgs pre, int rounds, int tail_rows, int crows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int U = 2;                          // items (KiB) per step
+    constexpr int RING = NSLOT * 1024;            // bytes per wave
+    constexpr int WAVE_LDS = RING + 256 + 256 + (SC ? 256 + SC_PEND * 8 : 0);   // + the chunk's 64 norms, 64 scales (+ histogram, pending list)
+    constexpr int K1 = NSLOT - 2 * U;             // DMA operations younger than the oldest pair of a full ring
+    constexpr int KB = 3;                         // operations of a chunk boundary: the dots' store, the norm DMA, the scale DMA
+    static_assert(NSLOT % U == 0 && NSLOT >= 2 * U, "ring of whole steps");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* myp = smem + wu * WAVE_LDS;
+    const unsigned s0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned my0 = s0 + wu * WAVE_LDS;
+    const unsigned ax0 = my0 + RING, fx0 = ax0 + 256, hx0 = fx0 + 256, px0 = hx0 + 256;
+    const unsigned qx0 = s0 + 4 * WAVE_LDS;       // the query's digits, shared by the block: per chunk 16 bytes q1, 16 bytes q2
+    {
+        int* qd = (int*)(smem + 4 * WAVE_LDS);
+        for (int i = tid; i < C * 8; i += 256) qd[i] = pre.q8[i];
+    }
+    float nq32 = pre.host_q ? pre.nq32 : pre.info->nq32, inq32 = pre.host_q ? pre.inq32 : pre.info->inq32;
+    if (pre.host_q && blockIdx.x == 0 && tid == 0) {   // what q_prepare would have filed: read by the kernels behind the scan
+        pre.infow->nq = pre.nq;
+        pre.infow->inq = pre.inq;
+        pre.infow->nq32 = pre.nq32;
+        pre.infow->inq32 = pre.inq32;
+        pre.infow->tau = 1.0;
+    }
+    asm volatile("" : "+v"(nq32), "+v"(inq32));
+    __syncthreads();   // (the only block barrier: the query's digits are in LDS; from here on every LDS access is inline asm)
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
+    const int64_t tail0 = r0 + (int64_t)rounds * NW * crows;
+#define AS_CHUNK(t, base, cnt)                                                           \
+    do {                                                                                 \
+        if ((t) < rounds) {                                                              \
+            base = r0 + ((int64_t)(t) * NW + gw) * crows;                                 \
+            cnt = crows;                                                                 \
+        } else if ((t) == rounds) {                                                      \
+            base = tail0 + gw * tail_rows;                                               \
+            const int64_t left_ = r1 - base;                                             \
+            cnt = (int)(left_ < 0 ? 0 : (left_ < tail_rows ? left_ : tail_rows));        \
+        } else {                                                                         \
+            base = r1;                                                                   \
+            cnt = 0;                                                                     \
+        }                                                                                \
+    } while (0)
+    // prefetch cursor: chunk pt, column chunk pcol; the lanes' byte offsets from the chunk's first tile
+    int pt = 0, pcol = 0, pcnt = 0, pslot = 0, inflight = 0;
+    int64_t pbase = 0;
+    unsigned pvoff = 0;
+    const signed char* pub = xt;
+    const size_t tile_bytes = (size_t)C * 1024;
+#define AS_TILE_ENTER()                                                                                                  \
+    do {                                                                                                                 \
+        if (pcnt > 0) {                                                                                                  \
+            const int rl_ = lane < pcnt ? lane : pcnt - 1;   /* lanes past the chunk's end fetch its last row again */     \
+            const int tl_ = (int)(pbase & 63) + rl_;                                                                     \
+            pvoff = (unsigned)(tl_ >> 6) * (unsigned)tile_bytes + (unsigned)(tl_ & 63) * 16u;                            \
+            pub = xt + (size_t)(pbase >> 6) * tile_bytes;                                                                \
+        }                                                                                                                \
+    } while (0)
+#define AS_TILE_ISSUE()                                                                                                  \
+    do {                                                                                                                 \
+        if (pcnt > 0) {                                                                                                  \
+            _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                                                             \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pub + pvoff + u_ * 1024), \
+                                                 (__attribute__((address_space(3))) void*)(myp + (pslot + u_) * 1024), 16, 0, 2); \
+            pub += U * 1024;                                                                                             \
+            pslot = pslot + U == NSLOT ? 0 : pslot + U;                                                                  \
+            inflight += U;                                                                                               \
+            pcol += U;                                                                                                   \
+            if (pcol == C) {                                                                                             \
+                pcol = 0;                                                                                                \
+                ++pt;                                                                                                    \
+                AS_CHUNK(pt, pbase, pcnt);                                                                               \
+                AS_TILE_ENTER();                                                                                         \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
+    AS_CHUNK(0, pbase, pcnt);
+    AS_TILE_ENTER();
+#pragma unroll
+    for (int i = 0; i < NSLOT / U - 1; ++i) AS_TILE_ISSUE();
+    unsigned cur = 0;    // byte offset of the oldest pair in the ring
+    int marked = 0;      // items in flight that have a chunk boundary's store + norm + scale DMA behind them in the queue
+    bool first = true;
+    ScanWave w;
+    for (int t = 0; t <= rounds; ++t) {
+        int64_t base;
+        int cnt;
+        AS_CHUNK(t, base, cnt);
+        if (cnt <= 0) continue;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),   // padded: readable
+                                         (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.fa8 + base + lane),
+                                         (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 0);
+        // SC: the histogram as the other waves have left it, consumed at the chunk's end (chunks 2, 3, 5, 9, 17, ...: scan_dma_kernel)
+        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0) && !AS_SC_DBG(2);
+        if (hread)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
+                                             (__attribute__((address_space(3))) void*)(myp + RING + 512), 4, 0, 16);
+        marked = first ? 0 : inflight;   // the first chunk has no store in front of its boundary DMAs: assume nothing
+        const bool hmark = hread;
+        first = false;
+        int hi0 = 0, xs0 = 0, hi1 = 0, xs1 = 0;
+        unsigned qa = qx0;
+        for (int c = 0; c < C; c += U) {
+            // operations retire in issue order: the oldest pair has landed once at most NSLOT - 2 U younger items (+ a chunk
+            // boundary's operations behind it) are outstanding
+            if (inflight == NSLOT - U) {
+                if (marked > 0 && hmark) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB + 1) : "memory");
+                else if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            for (int e0 = 0; e0 < npend; e0 += 64) {
-                float ce = 0.0f;
-                int re = 0;
-                if (e0 + lane < npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
-                const bool kp = e0 + lane < npend && ce >= thr;
-                const unsigned long long km = __ballot(kp);
-                const int pos = keep + __popcll(km & ((1ull << lane) - 1));
-                if (kp && pos < SC_WCAP - 1) region[1 + pos] = re;
-                keep += __popcll(km);
+            marked = marked > U ? marked - U : 0;
+            inflight -= U;
+            AS_TILE_ISSUE();   // into the slots consumed one step ago
+            i32x4s xv0, xv1, qa0, qb0, qa1, qb1;
+            const unsigned a0 = my0 + cur + lane * 16;
+            asm volatile(
+                "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
+                "ds_read_b128 %4, %7 offset:32\n\tds_read_b128 %5, %7 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(xv0), "=&v"(xv1), "=&v"(qa0), "=&v"(qb0), "=&v"(qa1), "=&v"(qb1)
+                : "v"(a0), "v"(qa)
+                : "memory");
+            cur = cur + U * 1024 == RING ? 0 : cur + U * 1024;
+            qa += U * 32;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi0 = __builtin_amdgcn_sdot4(xv0[e], qa0[e], hi0, false);
+                xs0 = __builtin_amdgcn_sdot4(xv0[e], qb0[e], xs0, false);
+                hi1 = __builtin_amdgcn_sdot4(xv1[e], qa1[e], hi1, false);
+                xs1 = __builtin_amdgcn_sdot4(xv1[e], qb1[e], xs1, false);
             }
         }
-        if (lane == 0) region[0] = sc_over || keep > SC_WCAP - 1 ? -1 : keep;
+        // the boundary DMAs are older than every item issued inside this chunk; one of those has been consumed once the chunk
+        // has more items than the ring keeps in flight
+        if (C <= NSLOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float aux = lds_read1(ax0 + lane * 4);
+        // x_i . q = (128 HI + XS) fa_i fa_q: the integer is exact, its conversion the one rounding the row-ring kernel's fused
+        // multiply-add makes
+        const long long tot = (long long)(hi0 + hi1) * 128 + (long long)(xs0 + xs1);
+        const float mydot = (float)tot * (lds_read1(fx0 + lane * 4) * pre.faq);
+        scan_chunk_end<SC>(pre, w, dots, t, rounds, gw, lane, base, cnt, mydot, aux, hread, hx0, px0, nq32, inq32);
     }
-#undef AS_ISSUE_ROW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    scan_wave_report<SC>(pre, w, gw, lane, px0);
+#undef AS_TILE_ISSUE
+#undef AS_TILE_ENTER
 #undef AS_CHUNK
 }
 
@@ -1150,6 +1335,14 @@ static constexpr size_t dma_lds(int nch, int nslot, bool sc = false, bool i8 = f
     return 4 * ((size_t)nslot * nch * 1024 + 256 + (sc ? 256 + SC_PEND * 8 : 0) + (i8 ? 256 : 0));
 }
 
+// launch geometry of the tile scan, <blocks per CU><two digits: ring KiB per wave>; ARROWSPACE_TILE_GEOM at load, as_set_tuning("tile_geom", v) later
+static std::atomic<int> g_tile_geom{getenv("ARROWSPACE_TILE_GEOM") ? atoi(getenv("ARROWSPACE_TILE_GEOM")) : 406};
+void set_tile_geom(int v) { g_tile_geom.store(v, std::memory_order_relaxed); }
+
+static constexpr size_t tile_lds(int nslot, bool sc, int64_t chunks) {
+    return 4 * ((size_t)nslot * 1024 + 512 + (sc ? 256 + SC_PEND * 8 : 0)) + (size_t)chunks * 32;
+}
+
 // The dynamic-LDS opt-in is a per-device attribute of a kernel: set it for every scan kernel on the device a
 // workspace is created on (query_alloc), not once per process -- a second device would never be opted in.
 as_status set_scan_attrs() {
@@ -1166,6 +1359,11 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_gemm_kernel<4, 0, 2, true, GEMM_NSW_WIDE>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW, true>), gemm_lds(4, true));
     AS_ATTR((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW_WIDE, true>), gemm_lds(4, true));
+    AS_ATTR((scan_tile_kernel<6, true>), tile_lds(6, true, 256));
+    AS_ATTR((scan_tile_kernel<8, true>), tile_lds(8, true, 256));
+    AS_ATTR((scan_tile_kernel<12, true>), tile_lds(12, true, 256));
+    AS_ATTR((scan_tile_kernel<16, true>), tile_lds(16, true, 256));
+    AS_ATTR((scan_tile_kernel<8, false>), tile_lds(8, false, 256));
     AS_ATTR((scan_dma_kernel<1, 8>), dma_lds(1, 8));
     AS_ATTR((scan_dma_kernel<2, 8>), dma_lds(2, 8));
     AS_ATTR((scan_dma_kernel<2, 5>), dma_lds(2, 5));
@@ -1381,7 +1579,12 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             // (tools/scan_geom.sh); at 1 chunk per lane 4 blocks stay ahead (400k x 384: 64 us against 84 us with 2).
             const int bpc_default = i8 && nch == 2 ? 2 : 4;
             // (rows of 2 049 .. 4 096 columns of the image: rings of 3 rows of 5 .. 8 KB per wave -- 2 blocks per CU fit at 5 KB only)
-            const int bpc = nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : (nch <= 5 ? 2 : 1);   // (<= 4: the wave reports are sized for 16 waves per CU)
+            // The coarse scan reads TILES (scan_tile_kernel): its geometry is <blocks per CU><ring KiB per wave> -- 4 x 6 by default;
+            // measurement: ARROWSPACE_TILE_GEOM=<blocks per CU><two digits of ring slots>, e.g. 308, 216)
+            const int tgeom = g_tile_geom.load(std::memory_order_relaxed);
+            const int tslots = tgeom % 100 >= 16 ? 16 : (tgeom % 100 >= 12 ? 12 : (tgeom % 100 >= 8 ? 8 : 6));
+            const int bpc = coarse ? std::max(1, std::min(tgeom / 100, 4))
+                                   : (nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : (nch <= 5 ? 2 : 1));   // (<= 4: the wave reports are sized for 16 waves per CU)
             // (collecting the scorer's candidates: every wave needs a chunk in front of its last to publish from -- at least 32 rows
             // per wave, two chunks of 16; a 30 000-row index on 1 876 waves had 16 rows per wave, no bound, and every row a candidate)
             // (A/B: 256 rows per block instead of 128 -- 200k x 768 11 700 -> 9 000 queries/s, 100k x 768 13 700 -> 10 900, 65536 x 4096 unchanged)
@@ -1406,6 +1609,28 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             const int rounds = (int)(rows / (NW * crows));
             const int64_t rem = rows - (int64_t)rounds * NW * crows;
             const int tail_rows = (int)((rem + NW - 1) / NW);
+            if (coarse) {
+                const int C = (int)(sp->dp8 / 16);
+                const signed char* xt = (const signed char*)sp->x8h;
+#define AS_TSCAN(S)                                                                                                    \
+    do {                                                                                                               \
+        if (pre.sc_enabled)                                                                                            \
+            hipLaunchKernelGGL((scan_tile_kernel<S, true>), dim3((unsigned)nblk), dim3(256), tile_lds(S, true, C), st, xt, C, q->r0, q->r1, \
+                               q->dots32, pre, rounds, tail_rows, crows);                                              \
+        else                                                                                                           \
+            hipLaunchKernelGGL((scan_tile_kernel<8, false>), dim3((unsigned)nblk), dim3(256), tile_lds(8, false, C), st, xt, C, q->r0, q->r1, \
+                               q->dots32, pre, rounds, tail_rows, crows);                                              \
+    } while (0)
+                switch (tslots) {
+                    case 16: AS_TSCAN(16); break;
+                    case 12: AS_TSCAN(12); break;
+                    case 8: AS_TSCAN(8); break;
+                    default: AS_TSCAN(6); break;
+                }
+#undef AS_TSCAN
+                AS_HIP(hipGetLastError());
+                return AS_OK;
+            }
 #define AS_DSCAN8(N, S)                                                                                                \
     do {                                                                                                               \
         if (pre.sc_enabled)                                                                                            \

@@ -2795,6 +2795,14 @@ extern "C" {
 
 void as_enable_search_stats(int32_t enabled) { g_search_stats.store(enabled ? 1 : 0, std::memory_order_relaxed); }
 
+int32_t as_set_tuning(const char* key, int32_t value) {
+    if (key && !strcmp(key, "tile_geom")) {
+        set_tile_geom(value);
+        return 0;
+    }
+    return 1;
+}
+
 #ifdef AS_STAMPS
 // diagnostic build only (not declared in the public header): the raw stamps of the last finish kernels
 int as_debug_stamps(unsigned long long* out) {
