@@ -229,6 +229,12 @@ struct PreArgs {
     int host_q = 0;
     float nq32 = 0.0f, inq32 = 0.0f;
     double nq = 0.0, inq = 0.0;
+    // ... and the scan copies the fp64 query from the host's pinned buffer into device memory on its way (the first qdp / 256
+    // blocks, one element per thread, in flight with the loads every block starts with): the kernels behind the scan read it
+    // from HBM / L2 -- 6 KB per BLOCK over PCIe put a floor of 4 us under a tail of 32 blocks and ruled out a wider one
+    const double* q64_host = nullptr;
+    double* q64_dev = nullptr;
+    int qdp = 0;
     // Fused tail: the scan also collects the scorer's candidates, before lambda_q is known.  The lambda term of the
     // score lies in [(1 - tau) / 2, (1 - tau)] for lambdas in [0, 1], so a row whose cosine is more than
     // W = (1 - tau) / (2 tau) below the M-th largest cosine cannot be among the M best scores whatever lambda_q turns

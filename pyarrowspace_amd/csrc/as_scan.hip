@@ -814,6 +814,8 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         pre.infow->inq32 = pre.inq32;
         pre.infow->tau = 1.0;
     }
+    if (pre.host_q && pre.q64_dev)   // the fp64 query for the kernels behind the scan: pinned host memory -> device (PreArgs)
+        for (int g = (int)blockIdx.x * 256 + tid; g < pre.qdp; g += (int)gridDim.x * 256) pre.q64_dev[g] = pre.q64_host[g];
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {   // loads complete here, once (see scan_gemm_kernel)
         if (I8) asm volatile("" : "+v"(qa[u]), "+v"(qb[u]));
@@ -976,16 +978,16 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
 // addresses are computed per row.  The ring holds NSLOT KiB per wave, NSLOT - 2 in flight; items are issued and consumed in
 // pairs (the row width in 16-column chunks is a multiple of 4).  Chunk schedule, chunk end (dots, k-NN prefilter, scorer
 // candidates) and the wave's report are those of scan_dma_kernel.
-template <int NSLOT, bool SC>
+template <int NSLOT, bool SC, int U = 2>
 __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __restrict__ xt, int C, int64_t r0, int64_t r1, float* __restrict__ dots,
                                                         PreArgs pre, int rounds, int tail_rows, int crows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int U = 2;                          // items (KiB) per step
+    // U: items (KiB) per step
     constexpr int RING = NSLOT * 1024;            // bytes per wave
     constexpr int WAVE_LDS = RING + 256 + 256 + (SC ? 256 + SC_PEND * 8 : 0);   // + the chunk's 64 norms, 64 scales (+ histogram, pending list)
     constexpr int K1 = NSLOT - 2 * U;             // DMA operations younger than the oldest pair of a full ring
     constexpr int KB = 3;                         // operations of a chunk boundary: the dots' store, the norm DMA, the scale DMA
-    static_assert(NSLOT % U == 0 && NSLOT >= 2 * U, "ring of whole steps");
+    static_assert((U == 2 || U == 4) && NSLOT % U == 0 && NSLOT >= 2 * U, "ring of whole steps");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* myp = smem + wu * WAVE_LDS;
@@ -993,20 +995,6 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
     const unsigned my0 = s0 + wu * WAVE_LDS;
     const unsigned ax0 = my0 + RING, fx0 = ax0 + 256, hx0 = fx0 + 256, px0 = hx0 + 256;
     const unsigned qx0 = s0 + 4 * WAVE_LDS;       // the query's digits, shared by the block: per chunk 16 bytes q1, 16 bytes q2
-    {
-        int* qd = (int*)(smem + 4 * WAVE_LDS);
-        for (int i = tid; i < C * 8; i += 256) qd[i] = pre.q8[i];
-    }
-    float nq32 = pre.host_q ? pre.nq32 : pre.info->nq32, inq32 = pre.host_q ? pre.inq32 : pre.info->inq32;
-    if (pre.host_q && blockIdx.x == 0 && tid == 0) {   // what q_prepare would have filed: read by the kernels behind the scan
-        pre.infow->nq = pre.nq;
-        pre.infow->inq = pre.inq;
-        pre.infow->nq32 = pre.nq32;
-        pre.infow->inq32 = pre.inq32;
-        pre.infow->tau = 1.0;
-    }
-    asm volatile("" : "+v"(nq32), "+v"(inq32));
-    __syncthreads();   // (the only block barrier: the query's digits are in LDS; from here on every LDS access is inline asm)
     const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
     const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
     const int64_t tail0 = r0 + (int64_t)rounds * NW * crows;
@@ -1061,6 +1049,24 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
     AS_TILE_ENTER();
 #pragma unroll
     for (int i = 0; i < NSLOT / U - 1; ++i) AS_TILE_ISSUE();
+    // (behind the ring's first fill: the query's digits come from the host's pinned memory -- a PCIe round trip every block
+    // would otherwise take before its first DMA)
+    {
+        int* qd = (int*)(smem + 4 * WAVE_LDS);
+        for (int i = tid; i < C * 8; i += 256) qd[i] = pre.q8[i];
+    }
+    float nq32 = pre.host_q ? pre.nq32 : pre.info->nq32, inq32 = pre.host_q ? pre.inq32 : pre.info->inq32;
+    if (pre.host_q && blockIdx.x == 0 && tid == 0) {   // what q_prepare would have filed: read by the kernels behind the scan
+        pre.infow->nq = pre.nq;
+        pre.infow->inq = pre.inq;
+        pre.infow->nq32 = pre.nq32;
+        pre.infow->inq32 = pre.inq32;
+        pre.infow->tau = 1.0;
+    }
+    if (pre.host_q && pre.q64_dev)   // the fp64 query for the kernels behind the scan: pinned host memory -> device (PreArgs)
+        for (int g = (int)blockIdx.x * 256 + tid; g < pre.qdp; g += (int)gridDim.x * 256) pre.q64_dev[g] = pre.q64_host[g];
+    asm volatile("" : "+v"(nq32), "+v"(inq32));
+    __syncthreads();   // (the only block barrier: the query's digits are in LDS; from here on every LDS access is inline asm)
     unsigned cur = 0;    // byte offset of the oldest pair in the ring
     int marked = 0;      // items in flight that have a chunk boundary's store + norm + scale DMA behind them in the queue
     bool first = true;
@@ -1097,23 +1103,39 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
             marked = marked > U ? marked - U : 0;
             inflight -= U;
             AS_TILE_ISSUE();   // into the slots consumed one step ago
-            i32x4s xv0, xv1, qa0, qb0, qa1, qb1;
+            i32x4s xv[U], qa_[U], qb_[U];
             const unsigned a0 = my0 + cur + lane * 16;
-            asm volatile(
-                "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
-                "ds_read_b128 %4, %7 offset:32\n\tds_read_b128 %5, %7 offset:48\n\ts_waitcnt lgkmcnt(0)"
-                : "=&v"(xv0), "=&v"(xv1), "=&v"(qa0), "=&v"(qb0), "=&v"(qa1), "=&v"(qb1)
-                : "v"(a0), "v"(qa)
-                : "memory");
+            if (U == 2)
+                asm volatile(
+                    "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
+                    "ds_read_b128 %4, %7 offset:32\n\tds_read_b128 %5, %7 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                    : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(qa_[0]), "=&v"(qb_[0]), "=&v"(qa_[1]), "=&v"(qb_[1])
+                    : "v"(a0), "v"(qa)
+                    : "memory");
+            if (U == 4)
+                asm volatile(
+                    "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:1024\n\tds_read_b128 %2, %12 offset:2048\n\tds_read_b128 %3, %12 offset:3072\n\t"
+                    "ds_read_b128 %4, %13\n\tds_read_b128 %5, %13 offset:16\n\tds_read_b128 %6, %13 offset:32\n\tds_read_b128 %7, %13 offset:48\n\t"
+                    "ds_read_b128 %8, %13 offset:64\n\tds_read_b128 %9, %13 offset:80\n\tds_read_b128 %10, %13 offset:96\n\tds_read_b128 %11, %13 offset:112\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[U > 2 ? 2 : 0]), "=&v"(xv[U > 3 ? 3 : 0]), "=&v"(qa_[0]), "=&v"(qb_[0]), "=&v"(qa_[1]), "=&v"(qb_[1]),
+                      "=&v"(qa_[U > 2 ? 2 : 0]), "=&v"(qb_[U > 2 ? 2 : 0]), "=&v"(qa_[U > 3 ? 3 : 0]), "=&v"(qb_[U > 3 ? 3 : 0])
+                    : "v"(a0), "v"(qa)
+                    : "memory");
             cur = cur + U * 1024 == RING ? 0 : cur + U * 1024;
             qa += U * 32;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi0 = __builtin_amdgcn_sdot4(xv0[e], qa0[e], hi0, false);
-                xs0 = __builtin_amdgcn_sdot4(xv0[e], qb0[e], xs0, false);
-                hi1 = __builtin_amdgcn_sdot4(xv1[e], qa1[e], hi1, false);
-                xs1 = __builtin_amdgcn_sdot4(xv1[e], qb1[e], xs1, false);
-            }
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u & 1) {
+                        hi1 = __builtin_amdgcn_sdot4(xv[u][e], qa_[u][e], hi1, false);
+                        xs1 = __builtin_amdgcn_sdot4(xv[u][e], qb_[u][e], xs1, false);
+                    } else {
+                        hi0 = __builtin_amdgcn_sdot4(xv[u][e], qa_[u][e], hi0, false);
+                        xs0 = __builtin_amdgcn_sdot4(xv[u][e], qb_[u][e], xs0, false);
+                    }
+                }
         }
         // the boundary DMAs are older than every item issued inside this chunk; one of those has been consumed once the chunk
         // has more items than the ring keeps in flight
@@ -1311,6 +1333,7 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     if (q->host_q) {
         p.nq = q->h_nq; p.inq = q->h_inq;
         p.nq32 = (float)q->h_nq; p.inq32 = q->h_nq > 0.0 ? (float)(1.0 / sqrt(q->h_nq)) : 0.0f;
+        p.q64_host = q->hq_dev; p.q64_dev = q->q64; p.qdp = (int)sp->dp;
     }
     if (q->fused_tail && enabled) {
         // window of the cosine bound + slack for the fp32 cosine of the scan against the fp64-over-fp32-dot cosine of the
@@ -1336,7 +1359,7 @@ static constexpr size_t dma_lds(int nch, int nslot, bool sc = false, bool i8 = f
 }
 
 // launch geometry of the tile scan, <blocks per CU><two digits: ring KiB per wave>; ARROWSPACE_TILE_GEOM at load, as_set_tuning("tile_geom", v) later
-static std::atomic<int> g_tile_geom{getenv("ARROWSPACE_TILE_GEOM") ? atoi(getenv("ARROWSPACE_TILE_GEOM")) : 406};
+static std::atomic<int> g_tile_geom{getenv("ARROWSPACE_TILE_GEOM") ? atoi(getenv("ARROWSPACE_TILE_GEOM")) : 208};
 void set_tile_geom(int v) { g_tile_geom.store(v, std::memory_order_relaxed); }
 
 static constexpr size_t tile_lds(int nslot, bool sc, int64_t chunks) {
@@ -1364,6 +1387,9 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_tile_kernel<12, true>), tile_lds(12, true, 256));
     AS_ATTR((scan_tile_kernel<16, true>), tile_lds(16, true, 256));
     AS_ATTR((scan_tile_kernel<8, false>), tile_lds(8, false, 256));
+    AS_ATTR((scan_tile_kernel<8, true, 4>), tile_lds(8, true, 256));
+    AS_ATTR((scan_tile_kernel<12, true, 4>), tile_lds(12, true, 256));
+    AS_ATTR((scan_tile_kernel<16, true, 4>), tile_lds(16, true, 256));
     AS_ATTR((scan_dma_kernel<1, 8>), dma_lds(1, 8));
     AS_ATTR((scan_dma_kernel<2, 8>), dma_lds(2, 8));
     AS_ATTR((scan_dma_kernel<2, 5>), dma_lds(2, 5));
@@ -1583,7 +1609,8 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             // measurement: ARROWSPACE_TILE_GEOM=<blocks per CU><two digits of ring slots>, e.g. 308, 216)
             const int tgeom = g_tile_geom.load(std::memory_order_relaxed);
             const int tslots = tgeom % 100 >= 16 ? 16 : (tgeom % 100 >= 12 ? 12 : (tgeom % 100 >= 8 ? 8 : 6));
-            const int bpc = coarse ? std::max(1, std::min(tgeom / 100, 4))
+            const int tstep = tgeom / 1000 == 4 && tslots >= 8 ? 4 : 2;   // (thousands digit 4: four KiB per step instead of two)
+            const int bpc = coarse ? std::max(1, std::min((tgeom / 100) % 10, 4))
                                    : (nch <= 2 ? std::max(1, std::min(geom ? geom / 10 : bpc_default, 4)) : (nch <= 5 ? 2 : 1));   // (<= 4: the wave reports are sized for 16 waves per CU)
             // (collecting the scorer's candidates: every wave needs a chunk in front of its last to publish from -- at least 32 rows
             // per wave, two chunks of 16; a 30 000-row index on 1 876 waves had 16 rows per wave, no bound, and every row a candidate)
@@ -1621,6 +1648,11 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             hipLaunchKernelGGL((scan_tile_kernel<8, false>), dim3((unsigned)nblk), dim3(256), tile_lds(8, false, C), st, xt, C, q->r0, q->r1, \
                                q->dots32, pre, rounds, tail_rows, crows);                                              \
     } while (0)
+                if (tstep == 4 && pre.sc_enabled) {
+                    if (tslots == 16) hipLaunchKernelGGL((scan_tile_kernel<16, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(16, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);
+                    else if (tslots == 12) hipLaunchKernelGGL((scan_tile_kernel<12, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(12, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);
+                    else hipLaunchKernelGGL((scan_tile_kernel<8, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(8, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);
+                } else
                 switch (tslots) {
                     case 16: AS_TSCAN(16); break;
                     case 12: AS_TSCAN(12); break;

@@ -1857,7 +1857,7 @@ struct XCand {
     double lam;    // lambda of the item
 };
 constexpr int X1_BLOCKS = 16;        // candidate blocks beside the k-NN block
-constexpr int X1_BLOCKS_COARSE = 32; // blocks of the coarse scan's tail: scorer candidates AND k-NN candidates by the thousand
+constexpr int X1_BLOCKS_COARSE = 128; // blocks of the coarse scan's tail: scorer candidates AND k-NN candidates by the thousand, one round of 64 rows per block
 constexpr int X1_LOCAL_CAP = 4096;   // candidates one block gathers from its share of the scan's reports
 
 // grid 1 + X1_BLOCKS: block 0 = knn_finish (records into the exchange block), blocks 1.. = the scan waves' reports -> exact
@@ -1900,25 +1900,57 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
     // (reports dealt round robin: the waves that end first -- under a bound still loose -- keep the most rows, and they are neighbours)
     const int nb = xk ? (int)gridDim.x : (int)gridDim.x - 1, b = xk ? (int)blockIdx.x : (int)blockIdx.x - 1;
     if (xk) {
-        // this block's share of the k-NN candidate buffer (entries b, b + nb, ...): exact key, distance and gy of each
+        // The coarse scan's tail: ONE list per block -- its share of the k-NN candidate buffer (entries b, b + nb, ...) in front,
+        // its share of the scan waves' scorer reports behind -- evaluated exactly in rounds of 64 rows (one round at 1M x 768 on
+        // 128 blocks: 10 + 9 rows), each row then filed by its kind.  (Before: the two shares in rounds of their own on 32 blocks,
+        // three serial rounds per block.)
         const int raw = ak.info->knn_cnt;
+        int mine = 0;
         if (raw > CAND_CAP) {
             if (b == 0 && threadIdx.x == 0) {
                 ak.info->overflow |= 1;
                 atomicOr(&head->flags, 4);
             }
         } else {
-            const int mine = raw > b ? (raw - b + nb - 1) / nb : 0;   // <= CAND_CAP / nb + 1
+            mine = raw > b ? (raw - b + nb - 1) / nb : 0;   // <= CAND_CAP / nb + 1
             for (int t = threadIdx.x; t < mine; t += blockDim.x) si[t] = ak.ci[b + nb * t];
+        }
+        if (b == 0 && threadIdx.x == 0 && (preset_flags || (ak.info->overflow & 2))) atomicOr(&head->flags, preset_flags | ((ak.info->overflow & 2) ? 8 : 0));
+        const int room = X1_LOCAL_CAP - mine;
+        for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
+            const int* rep = as_.ci + (int64_t)w * SC_WCAP;
+            const int c2 = rep[0];
+            if (c2 < 0) s_ovf = 1;
+            else if (c2 > 0) {
+                const int base = atomicAdd(&s_tot, c2);
+                if (base + c2 <= room)
+                    for (int e = 0; e < c2; ++e) si[mine + base + e] = rep[1 + e];
+            }
+        }
+        __syncthreads();
+        int tot = s_tot;
+        if (s_ovf || tot > room) {
+            if (threadIdx.x == 0) {
+                atomicOr(&head->flags, 16);
+                atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
+                if (s_ovf) atomicAdd(&head->pad[1], 1);
+            }
+            tot = 0;
+        }
+        const double nqk = ak.info->nq;
+        const int total = mine + tot;
+        for (int base = 0; base < total; base += 64) {   // (block-uniform)
+            const int m = total - base < 64 ? total - base : 64;
+            exact_eval_all(ak.x32, ak.x64, qx ? qx : ak.q64, ak.d, ak.dp, si + base, m, o_sq, o_dot);
+            const int sc_lo = base > mine ? base : mine;          // first scorer entry of this round
+            const int m_sc = base + m - sc_lo;
+            if (threadIdx.x == 0 && m_sc > 0) s_base = atomicAdd(&head->count, m_sc);   // one ticket per block and round
             __syncthreads();
-            const double nqk = ak.info->nq;
-            for (int base = 0; base < mine; base += 64) {   // (block-uniform)
-                const int m = mine - base < 64 ? mine - base : 64;
-                exact_eval_all(ak.x32, ak.x64, qx ? qx : ak.q64, ak.d, ak.dp, si + base, m, o_sq, o_dot);
-                __syncthreads();
-                if ((int)threadIdx.x < m) {
-                    const int j = si[base + threadIdx.x];
-                    const double sq = o_sq[threadIdx.x], dot = o_dot[threadIdx.x];
+            if ((int)threadIdx.x < m) {
+                const int e_ = base + (int)threadIdx.x;
+                const int j = si[e_];
+                const double sq = o_sq[threadIdx.x], dot = o_dot[threadIdx.x];
+                if (e_ < mine) {
                     XKnn e;
                     e.idx = j;
                     e.pad = 0;
@@ -1934,55 +1966,67 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
                         e.dist = dd;
                         e.gy = c;
                     }
-                    if (e.key <= ak.epskey) xk[atomicAdd(xk_count, 1)] = e;   // (the few dozen inside eps: the finish kernel ranks them)
+                    if (e.key <= ak.epskey) xk[atomicAdd(xk_count, 1)] = e;   // (the few dozen inside eps: the last block ranks them)
+                } else {
+                    const int slot = s_base + (e_ - sc_lo);
+                    if (slot < xcap) {
+                        const double den = sqrt(as_.n64[j] * nqk);
+                        XCand c;
+                        c.idx = (int64_t)j + as_.goff;
+                        c.cosv = den > 0.0 ? dot / den : 0.0;
+                        c.lam = as_.lam64[j];
+                        cands[slot] = c;
+                    } else {
+                        atomicOr(&head->flags, 16);
+                    }
                 }
-                __syncthreads();
             }
-        }
-        if (b == 0 && threadIdx.x == 0 && (preset_flags || (ak.info->overflow & 2))) atomicOr(&head->flags, preset_flags | ((ak.info->overflow & 2) ? 8 : 0));
-        __syncthreads();
-    }
-    for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
-        const int* rep = as_.ci + (int64_t)w * SC_WCAP;
-        const int c2 = rep[0];
-        if (c2 < 0) s_ovf = 1;
-        else if (c2 > 0) {
-            const int base = atomicAdd(&s_tot, c2);
-            if (base + c2 <= X1_LOCAL_CAP)
-                for (int e = 0; e < c2; ++e) si[base + e] = rep[1 + e];
+            __syncthreads();
         }
     }
-    __syncthreads();
-    const int tot = s_tot;
-    const bool sc_fits = !(s_ovf || tot > X1_LOCAL_CAP);
-    if (!sc_fits && threadIdx.x == 0) {
-        atomicOr(&head->flags, 16);
-        atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
-        if (s_ovf) atomicAdd(&head->pad[1], 1);
-    }
-    const double nq = as_.info->nq;
-    for (int base = 0; sc_fits && base < tot; base += 64) {   // (block-uniform)
-        const int m = tot - base < 64 ? tot - base : 64;
-        exact_eval_all(as_.x32, as_.x64, qx ? qx : as_.q64, as_.d, as_.dp, si + base, m, o_sq, o_dot);
-        if (threadIdx.x == 0) s_base = atomicAdd(&head->count, m);   // one ticket per block and round
-        __syncthreads();
-        if ((int)threadIdx.x < m) {
-            const int slot = s_base + (int)threadIdx.x;
-            if (slot < xcap) {
-                const int j = si[base + threadIdx.x];
-                const double den = sqrt(as_.n64[j] * nq);
-                XCand c;
-                c.idx = (int64_t)j + as_.goff;
-                c.cosv = den > 0.0 ? o_dot[threadIdx.x] / den : 0.0;
-                c.lam = as_.lam64[j];
-                cands[slot] = c;
-            } else {
-                atomicOr(&head->flags, 16);
+    if (!xk) {
+        for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
+            const int* rep = as_.ci + (int64_t)w * SC_WCAP;
+            const int c2 = rep[0];
+            if (c2 < 0) s_ovf = 1;
+            else if (c2 > 0) {
+                const int base = atomicAdd(&s_tot, c2);
+                if (base + c2 <= X1_LOCAL_CAP)
+                    for (int e = 0; e < c2; ++e) si[base + e] = rep[1 + e];
             }
         }
         __syncthreads();
+        const int tot = s_tot;
+        const bool sc_fits = !(s_ovf || tot > X1_LOCAL_CAP);
+        if (!sc_fits && threadIdx.x == 0) {
+            atomicOr(&head->flags, 16);
+            atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
+            if (s_ovf) atomicAdd(&head->pad[1], 1);
+        }
+        const double nq = as_.info->nq;
+        for (int base = 0; sc_fits && base < tot; base += 64) {   // (block-uniform)
+            const int m = tot - base < 64 ? tot - base : 64;
+            exact_eval_all(as_.x32, as_.x64, qx ? qx : as_.q64, as_.d, as_.dp, si + base, m, o_sq, o_dot);
+            if (threadIdx.x == 0) s_base = atomicAdd(&head->count, m);   // one ticket per block and round
+            __syncthreads();
+            if ((int)threadIdx.x < m) {
+                const int slot = s_base + (int)threadIdx.x;
+                if (slot < xcap) {
+                    const int j = si[base + threadIdx.x];
+                    const double den = sqrt(as_.n64[j] * nq);
+                    XCand c;
+                    c.idx = (int64_t)j + as_.goff;
+                    c.cosv = den > 0.0 ? o_dot[threadIdx.x] / den : 0.0;
+                    c.lam = as_.lam64[j];
+                    cands[slot] = c;
+                } else {
+                    atomicOr(&head->flags, 16);
+                }
+            }
+            __syncthreads();
+        }
+        return;
     }
-    if (!xk) return;
     // The coarse scan's k-NN records: the LAST block to get here ranks the candidates inside eps that all blocks have appended
     // (a few dozen) by (key, id) and writes the k nearest as records -- knn_finish_body's selection with nothing left to prove.
     // (Release / acquire at agent scope around one ticket per block: the blocks sit on different XCDs, each with its own L2.)
@@ -2714,7 +2758,8 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
     if (!host_path && !narrow) q->fused_tail = 0;
     if (host_path) {
         q->host_q = 1;
-        q->q64_src = q->hq_dev;
+        // (device memory: the scan copies the fp64 query there on its way, PreArgs::q64_dev -- an empty row range launches no scan)
+        q->q64_src = r1 > r0 ? q->q64 : q->hq_dev;
         q->q32_src = q->hq32_dev;
         if (!q->info_clean) hipLaunchKernelGGL(reset_info_kernel, dim3(1), dim3(64), 0, st, q->info, q->sc_hist);
         q->info_clean = 0;

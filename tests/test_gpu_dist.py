@@ -416,7 +416,8 @@ def test_library_exchange_repairs_a_crowded_neighbourhood(oracle_lib):
 def test_one_exchange_pass_returns_what_the_two_exchange_chain_returns(oracle_lib, monkeypatch):
     """tau in [0.4, 1]: the sharded search takes ONE exchange -- every rank's k-NN records and its scorer candidates finished to
     (id, exact cosine, lambda) in one block, lambda_q / scores / ranking redundantly behind the all-gather (as_query_x1_*).
-    Same hits, bit for bit, as the two-exchange chain (ARROWSPACE_STAGED_X1=0) and as one space; tau below 0.4 keeps the chain."""
+    Same hits, bit for bit, as the two-exchange chain (the workspaces' switch off: as_query_set_x1 -- ARROWSPACE_STAGED_X1=0 when
+    they are made; a row-sharded index agrees on it over its ranks, never per call) and as one space; tau below 0.4 keeps the chain."""
     import torch
     import pyarrowspace_amd as asp
     from pyarrowspace_amd.dist import ShardedIndex
@@ -431,17 +432,17 @@ def test_one_exchange_pass_returns_what_the_two_exchange_chain_returns(oracle_li
     for tau in (0.62, 1.0, 0.4):
         for q in Q:
             before = index.engine.x1_passes()
-            monkeypatch.delenv("ARROWSPACE_STAGED_X1", raising=False)
+            index.engine.x1_set_enabled(True)
             got = index.search(q, tau)
             took = index.engine.x1_passes() - before
             assert took in (1, 2)     # (2: the coarse scan's candidates did not fit, the pass ran once more on the two-digit image)
-            monkeypatch.setenv("ARROWSPACE_STAGED_X1", "0")
+            index.engine.x1_set_enabled(False)
             chain = index.search(q, tau)
             assert index.engine.x1_passes() == before + took
             assert got == chain == aspace.search(q, gl, tau)
             want, lq = ref.search(q, tau)
             assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-9)
-    monkeypatch.delenv("ARROWSPACE_STAGED_X1", raising=False)
+    index.engine.x1_set_enabled(True)
     before = index.engine.x1_passes()
     assert index.search(Q[0], 0.2) == aspace.search(Q[0], gl, 0.2)
     assert index.engine.x1_passes() == before

@@ -1,5 +1,5 @@
 """One rank, real RCCL, the exchanges issued by the library (as_query_search_staged): host-visible latency of a sharded query
-with the one-exchange pass (default) and with the two-exchange chain (ARROWSPACE_STAGED_X1=0), next to the fused single-space
+with the one-exchange pass (default) and with the two-exchange chain (the workspaces' switch off: as_query_set_x1), next to the fused single-space
 as_search on the same items.  python tools/x1_overhead.py [N] [D]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,13 +42,13 @@ def run(fn, label):
 for tau in (0.62,):
     for rnd in range(2):
         f = run(lambda q: aspace.search(q, gl, tau), "fused single space, tau=%.2f" % tau)
-        os.environ.pop("ARROWSPACE_STAGED_X1", None)
+        index.engine.x1_set_enabled(True)
         p0 = index.engine.x1_passes(library=True)
         a = run(lambda q: index.search(q, tau), "one rank RCCL, ONE exchange, tau=%.2f" % tau)
         assert index.engine.x1_passes(library=True) > p0
-        os.environ["ARROWSPACE_STAGED_X1"] = "0"
+        index.engine.x1_set_enabled(False)
         b = run(lambda q: index.search(q, tau), "one rank RCCL, two exchanges, tau=%.2f" % tau)
-        os.environ.pop("ARROWSPACE_STAGED_X1", None)
+        index.engine.x1_set_enabled(True)
         print("  -> over fused: one exchange %+.1f us, two exchanges %+.1f us" % (a - f, b - f))
 same = all(index.search(q, 0.62) == aspace.search(q, gl, 0.62) for q in Q[340:380] if True)
 print("hits equal to the single space's:", same)
