@@ -774,6 +774,8 @@ def main():
     k2_fp32_env = os.environ.get("ARROWSPACE_K2_FP32", "0") not in ("", "0")
     # rows up to 1024 floats take the LDS-DMA ring scan, wider rows the register-staged one
     scan_kernel = "scan_dma_kernel" if d <= 1024 and os.environ.get("ARROWSPACE_SCAN_VARIANT", "0") in ("", "0") else "scan_dots_f32_kernel"
+    if scan_coarse:
+        scan_kernel = "scan_tile_kernel"   # (the coarse operand lies in tiles of 64 rows x 16 columns: as_scan.hip)
     if live:
         traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), (live.get("knn_mfma_kernel") if k2_fp32_env else live.get("knn_bf16_kernel")), live.get("scan_gemm_kernel")
         traffic_source = live_note

@@ -61,7 +61,7 @@ def timeline(d, out):
     chains, cur = [], None
     for st, en, name, gz in rows:
         opens = name.startswith("as::q_prepare_kernel") or (
-            name.startswith("as::scan_dma_kernel") and not (cur and len(cur) == 1 and cur[0][2].startswith("as::q_prepare_kernel")))
+            (name.startswith("as::scan_dma_kernel") or name.startswith("as::scan_tile_kernel")) and not (cur and len(cur) == 1 and cur[0][2].startswith("as::q_prepare_kernel")))
         if opens:
             if cur:
                 chains.append(cur)
@@ -70,19 +70,20 @@ def timeline(d, out):
             cur.append((st, en, name, gz))
     if cur:
         chains.append(cur)
-    single = [c for c in chains if all(g == 1 for _, _, _, g in c) and any("scan_d" in n for _, _, n, _ in c)]
+    single = [c for c in chains if all(g == 1 for _, _, _, g in c) and any("scan_d" in n or "scan_t" in n for _, _, n, _ in c)]
     from collections import Counter
     shape = Counter(tuple(n for _, _, n, _ in c) for c in single).most_common(1)[0][0]
     sel = [c for c in single if tuple(n for _, _, n, _ in c) == shape]
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["position", "kernel", "avg_us", "avg_gap_before_us", "queries"])
+        w.writerow(["position", "kernel", "avg_us", "avg_gap_before_us", "queries", "p10_us", "p50_us", "p90_us"])
         tot = 0.0
         for i, name in enumerate(shape):
             dur = sum(c[i][1] - c[i][0] for c in sel) / len(sel) / 1e3
             gap = sum((c[i][0] - c[i - 1][1]) for c in sel) / len(sel) / 1e3 if i else 0.0
             tot += dur + gap
-            w.writerow([i, name, "%.2f" % dur, "%.2f" % gap, len(sel)])
+            ds = sorted((c[i][1] - c[i][0]) / 1e3 for c in sel)
+            w.writerow([i, name, "%.2f" % dur, "%.2f" % gap, len(sel)] + ["%.2f" % ds[int(f_ * (len(ds) - 1))] for f_ in (0.1, 0.5, 0.9)])
         inter = [b[0][0] - a[-1][1] for a, b in zip(sel, sel[1:]) if 0 < b[0][0] - a[-1][1] < 5e6]
         span = sum(c[-1][1] - c[0][0] for c in sel) / len(sel) / 1e3
         w.writerow(["", "device span of one query (first start -> last end)", "%.2f" % span, "", len(sel)])
@@ -102,7 +103,7 @@ def traffic(fetch_csv, write_csv, n, d, out):
     doc = {"_comment": traffic.__doc__.strip().replace("\n    ", " ") + "  Separate --pmc passes (profiles/*_pmc_*.csv). "
                        "Valid only for the workload named in 'workload'.",
            "workload": {"n": int(n), "d": int(d)}}
-    for key, prefix in (("scan_dma_kernel", "as::scan_dma_kernel"), ("scan_dots_f32_kernel", "as::scan_dots_f32_kernel"),
+    for key, prefix in (("scan_tile_kernel", "as::scan_tile_kernel"), ("scan_dma_kernel", "as::scan_dma_kernel"), ("scan_dots_f32_kernel", "as::scan_dots_f32_kernel"),
                         ("scan_gemm_kernel", "as::scan_gemm_kernel"), ("knn_mfma_kernel", "as::knn_mfma"),
                         ("knn_bf16_kernel", "as::knn_bf16_kernel")):
         fk = [k for k in f if k.startswith(prefix)]

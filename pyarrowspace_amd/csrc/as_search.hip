@@ -2043,11 +2043,35 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
     if (s_ticket != nb - 1) return;
     const int raw = ak.info->knn_cnt;
     const int P = raw <= CAND_CAP ? __hip_atomic_load(xk_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    double* rk = (double*)work;            // P keys (P <= CAND_CAP: 32 KB + 16 KB of the work area)
+    double* rk = (double*)work;            // P keys (P <= CAND_CAP: 32 KB + 16 KB + 16 KB of the work area)
     int* ri = (int*)(rk + CAND_CAP);
-    for (int u = threadIdx.x; u < P; u += blockDim.x) {
-        rk[u] = xk[u].key;
-        ri[u] = xk[u].idx;
+    int* sel = ri + CAND_CAP;              // entries that may be among the k nearest
+    __shared__ unsigned int khist[1024];
+    __shared__ unsigned long long s_kmin, s_kmax;
+    __shared__ int s_kbin, s_nsel;
+    khist[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) {
+        s_kmin = ~0ull;
+        s_kmax = 0ull;
+        s_kbin = 1023;
+        s_nsel = 0;
+    }
+    __syncthreads();
+    {
+        // (keys are >= 0 -- squared distances, rectified-cosine distances --: their bit patterns order like the values)
+        unsigned long long lmin = ~0ull, lmax = 0ull;
+        for (int u = threadIdx.x; u < P; u += blockDim.x) {
+            const double kk = xk[u].key;
+            rk[u] = kk;
+            ri[u] = xk[u].idx;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(kk);
+            lmin = bits < lmin ? bits : lmin;
+            lmax = bits > lmax ? bits : lmax;
+        }
+        if (lmax >= lmin) {
+            atomicMin(&s_kmin, lmin);
+            atomicMax(&s_kmax, lmax);
+        }
     }
     if (ak.recs)
         for (int64_t t = threadIdx.x; t < ak.k; t += blockDim.x) {
@@ -2058,19 +2082,72 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
             ak.recs[t] = r;
         }
     __syncthreads();
-    for (int u = threadIdx.x; u < P; u += blockDim.x) {
-        int rank = 0;
-        for (int s2 = 0; s2 < P; ++s2) rank += lex_less<double>(rk[s2], ri[s2], rk[u], ri[u]) ? 1 : 0;
-        if (rank < ak.k && ak.recs) {
-            const int j = ri[u];
-            as_knn_rec r;
-            r.idx = (int64_t)j + ak.goff;
-            r.key = rk[u];
-            r.dist = xk[u].dist;
-            r.gy = xk[u].gy;
-            r.deg = ak.deg ? ak.deg[j + ak.goff] : 0.0;
-            r.ny = ak.ny ? ak.ny[j + ak.goff] : 0.0;
-            ak.recs[rank] = r;
+    // The k nearest of P entries: a dense neighbourhood puts hundreds of rows inside eps (a query at the heart of a cluster: a
+    // thousand), and ranking every entry against every other in ONE block was this kernel's long tail (P = 500: +20 us, P = 1000:
+    // +80 us; a tenth of the queries at 1M x 768).  A 1024-bin histogram over [min key, max key] finds the bin that holds the k-th
+    // key; only the entries up to that bin are ranked (entries of later bins have larger keys), one WAVE per entry, the P
+    // comparisons of an entry spread over its lanes.
+    const double kmin = __longlong_as_double((long long)s_kmin), kmax = __longlong_as_double((long long)s_kmax);
+    const double kscale = P > 0 && kmax > kmin ? 1023.0 / (kmax - kmin) : 0.0;
+    auto kbin_of = [&](double kk) {
+        const double fb = (kk - kmin) * kscale;
+        return fb >= 1023.0 ? 1023 : (fb > 0.0 ? (int)fb : 0);   // (monotone in the key: a larger bin means a larger key)
+    };
+    for (int u = threadIdx.x; u < P; u += blockDim.x) atomicAdd(&khist[kbin_of(rk[u])], 1u);
+    __syncthreads();
+    const int want_k = (int)(ak.k < (int64_t)P ? ak.k : (int64_t)P);
+    if (threadIdx.x < 64) {   // 16 bins per lane, inclusive scan over the lanes, the lane whose bins reach k finishes
+        unsigned int hh[16], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            hh[j] = khist[16 * threadIdx.x + j];
+            tot += hh[j];
+        }
+        unsigned int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t2 = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += t2;
+        }
+        const unsigned int excl = incl - tot, want_ = (unsigned)want_k;
+        if (want_ > 0 && excl < want_ && incl >= want_) {
+            unsigned int run = excl;
+            int bsel = 16 * (int)threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                run += hh[j];
+                if (run >= want_) break;
+                bsel += 1;
+            }
+            s_kbin = bsel;
+        }
+    }
+    __syncthreads();
+    const int kbin = s_kbin;
+    for (int u = threadIdx.x; u < P; u += blockDim.x)
+        if (kbin_of(rk[u]) <= kbin) sel[atomicAdd(&s_nsel, 1)] = u;
+    __syncthreads();
+    const int nsel = s_nsel;
+    {
+        const int wv = (int)(threadIdx.x >> 6), nwv = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63);
+        for (int c = wv; c < nsel; c += nwv) {   // (wave-uniform)
+            const int u = sel[c];
+            const double myk = rk[u];
+            const int myi = ri[u];
+            int cnt = 0;
+            for (int s2 = lane; s2 < P; s2 += 64) cnt += lex_less<double>(rk[s2], ri[s2], myk, myi) ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if (lane == 0 && cnt < ak.k && ak.recs) {
+                as_knn_rec r;
+                r.idx = (int64_t)myi + ak.goff;
+                r.key = myk;
+                r.dist = xk[u].dist;
+                r.gy = xk[u].gy;
+                r.deg = ak.deg ? ak.deg[myi + ak.goff] : 0.0;
+                r.ny = ak.ny ? ak.ny[myi + ak.goff] : 0.0;
+                ak.recs[cnt] = r;
+            }
         }
     }
     if (threadIdx.x == 0) {
