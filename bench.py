@@ -479,6 +479,7 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/traffic.json (when it is of this workload) instead of two rocprofv3 --pmc passes run now")
     ap.add_argument("--no-threaded", action="store_true", help="skip the 2- and 4-host-thread search runs (kernel-trace profiles: their overlapping kernels stretch each other)")
+    ap.add_argument("--no-host-build", action="store_true", help="skip the timing of the reference's own call: build(graph_params, float64 ndarray in HOST memory)")
     ap.add_argument("--no-distributions", action="store_true", help="skip the unfriendly-distribution side keys (isotropic, hierarchical, x100-scaled rows): three more index builds")
     ap.add_argument("--verify-queries", type=int, default=64, help="timed queries (and as many in-distribution ones) re-issued after the timed loops and held against an fp64 brute force on the GPU")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the short child pass live_traffic() profiles
@@ -733,6 +734,39 @@ def main():
             except Exception as e:      # noqa: BLE001 -- a side key must not cost the headline line
                 distributions[kind] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---------------- the reference's own build call: build(graph_params, items: float64 ndarray in HOST memory)
+    # (/root/reference/src/lib.rs:271-277) -- the rows stream through two pinned chunks into the ingest kernel (as_build).
+    # Beside it: the H2D rate of this box (one pinned 1 GiB copy) and what the device-resident build plus that copy would take.
+    build_from_host = None
+    if single and not args.traffic_probe and not args.no_host_build:
+        try:
+            Xh64 = X.cpu().numpy().astype(np.float64)
+            pin = torch.empty(1 << 28, dtype=torch.float32).pin_memory()
+            dbuf = torch.empty(1 << 28, dtype=torch.float32, device=device)
+            dbuf.copy_(pin, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dbuf.copy_(pin, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d = pin.numel() * 4 / (time.perf_counter() - t0) / 1e9
+            del pin, dbuf
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            a2, g2 = asp.ArrowSpaceBuilder.build(gp, Xh64)
+            torch.cuda.synchronize()
+            hb = time.perf_counter() - t0
+            same = bool(np.array_equal(a2.lambdas(), aspace.lambdas())) and g2.tau0 == gl.tau0
+            st2 = g2.build_stats()
+            build_from_host = {"value": hb, "unit": "s", "host_bytes": n * d * 8.0, "h2d_gbs_pinned_measured": h2d, "ingest_sec": st2["ingest_s"],
+                               "device_build_plus_copy_sec": build_s + n * d * 8.0 / (h2d * 1e9),
+                               "same_lambdas_as_device_build": same,
+                               "how": "ArrowSpaceBuilder.build(graph_params, X.astype(float64)) from pageable host memory; two pinned chunks "
+                                      "of 64 MB, host threads packing one chunk under the copy of the other and the ingest kernel of the one before"}
+            del a2, g2, Xh64
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001 -- a side key must not cost the headline line
+            build_from_host = {"error": "%s: %s" % (type(e).__name__, e)}
+
     qps = args.steps / dt
     # the scan reads the int8 two-digit image of the items when it can (2 bytes per element + the rows' norm and scale), else fp32
     scan_i8 = scan_operand in ("int8", "int8-high") if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 4096 and not feature
@@ -824,6 +858,8 @@ def main():
                                     "workload": "SURVEY 8(d) query recipe: the index's 1024 centres, labels and noise 0.5 from "
                                                 "np.random.default_rng(43), rows normalised"},
         "index_build_sec": build_s,
+        "index_build_from_host_sec": None if not build_from_host or "value" not in build_from_host else build_from_host["value"],
+        "index_build_from_host": build_from_host,
         "priming_queries": primed,
         "batched_queries_per_sec": batched_qps,
         "threaded_queries_per_sec": threaded,

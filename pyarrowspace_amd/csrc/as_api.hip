@@ -122,30 +122,14 @@ void as_free_graph(as_graph* gr) {
     delete gr;
 }
 
-as_status as_space_create_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_opts* opts,
-                              as_space** out_space) {
-    if (!out_space) {
-        set_err("as_space_create_dev: null output");
-        return AS_EINVAL;
-    }
-    *out_space = nullptr;
-    if (!items_dev || n <= 0 || d <= 0) {
-        set_err("items must be non-empty 2D array");  // src/helpers.rs:27-29
-        return AS_EINVAL;
-    }
-    if (ld < d || (dtype != AS_DTYPE_F32 && dtype != AS_DTYPE_F64)) {
-        set_err("as_space_create_dev: bad leading dimension or dtype");
-        return AS_EINVAL;
-    }
+// a space without items yet: validated options, device, private stream
+static as_status space_new(int64_t n, int64_t d, const as_opts* opts, as_space** out) {
     if (n >= (int64_t)1 << 31) {
         set_err("as_space_create_dev: n=%lld does not fit 32-bit item indices on one device", (long long)n);
         return AS_EUNSUPPORTED;
     }
     int dev = 0;
     AS_TRY(pick_device(opts, &dev));
-    // the items come from the caller's own stream(s), which a raw pointer does not name: everything queued on the
-    // device has to be finished before the ingest (on the space's private non-blocking stream) reads them
-    AS_HIP(hipDeviceSynchronize());
     as_space* sp = new as_space();
     sp->device = dev;
     sp->n = n;
@@ -171,6 +155,34 @@ as_status as_space_create_dev(const void* items_dev, int32_t dtype, int64_t n, i
     if (e != hipSuccess) {
         set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
         delete sp;
+        return AS_EHIP;
+    }
+    *out = sp;
+    return AS_OK;
+}
+
+as_status as_space_create_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_opts* opts,
+                              as_space** out_space) {
+    if (!out_space) {
+        set_err("as_space_create_dev: null output");
+        return AS_EINVAL;
+    }
+    *out_space = nullptr;
+    if (!items_dev || n <= 0 || d <= 0) {
+        set_err("items must be non-empty 2D array");  // src/helpers.rs:27-29
+        return AS_EINVAL;
+    }
+    if (ld < d || (dtype != AS_DTYPE_F32 && dtype != AS_DTYPE_F64)) {
+        set_err("as_space_create_dev: bad leading dimension or dtype");
+        return AS_EINVAL;
+    }
+    as_space* sp = nullptr;
+    AS_TRY(space_new(n, d, opts, &sp));
+    // the items come from the caller's own stream(s), which a raw pointer does not name: everything queued on the
+    // device has to be finished before the ingest (on the space's private non-blocking stream) reads them
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_err("as_space_create_dev: %s", hipGetErrorString(hipGetLastError()));
+        as_free_space(sp);
         return AS_EHIP;
     }
     as_status s = ingest(sp, items_dev, dtype, ld);
@@ -480,21 +492,9 @@ as_status as_knn_block_exact(const as_space* sp, const as_space* cols, const as_
     return s;
 }
 
-as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_graph_params* gp,
-                       const as_opts* opts, as_space** out_space, as_graph** out_graph) {
-    if (!out_space || !out_graph) {
-        set_err("as_build: null output");
-        return AS_EINVAL;
-    }
-    *out_space = nullptr;
-    *out_graph = nullptr;
-    as_graph_params r;
-    AS_TRY(resolve_params(gp, &r));
-    if (n > 0) AS_TRY(check_limits(&r, n, opts ? opts->lambda_mode : 0));
-    const double t0 = now_s();
-    as_space* sp = nullptr;
-    AS_TRY(as_space_create_dev(items_dev, dtype, n, d, ld, opts, &sp));
-    const double t1 = now_s();
+// graph + Laplacian + lambdas over a space whose items are in place (t0: the call's start, t1: the end of the ingest)
+static as_status build_from_space(as_space* sp, const as_graph_params& r, double t0, double t1, as_space** out_space, as_graph** out_graph) {
+    const int64_t n = sp->n, d = sp->d;
     int32_t *idx = nullptr, *cnt = nullptr;
     double *key = nullptr, *dist = nullptr, *gy = nullptr;
     as_graph* gr = new as_graph();
@@ -545,6 +545,26 @@ as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t 
     return AS_OK;
 }
 
+as_status as_build_dev(const void* items_dev, int32_t dtype, int64_t n, int64_t d, int64_t ld, const as_graph_params* gp,
+                       const as_opts* opts, as_space** out_space, as_graph** out_graph) {
+    if (!out_space || !out_graph) {
+        set_err("as_build: null output");
+        return AS_EINVAL;
+    }
+    *out_space = nullptr;
+    *out_graph = nullptr;
+    as_graph_params r;
+    AS_TRY(resolve_params(gp, &r));
+    if (n > 0) AS_TRY(check_limits(&r, n, opts ? opts->lambda_mode : 0));
+    const double t0 = now_s();
+    as_space* sp = nullptr;
+    AS_TRY(as_space_create_dev(items_dev, dtype, n, d, ld, opts, &sp));
+    return build_from_space(sp, r, t0, now_s(), out_space, out_graph);
+}
+
+// The reference's own call: float64 items in HOST memory, any numpy strides (/root/reference/src/lib.rs:271-277,
+// src/helpers.rs:24-46 -- `as_array()` accepts them).  The rows stream to the device through two pinned chunks, the ingest
+// kernel converting one chunk under the copy of the next (ingest_host): no device copy of the whole fp64 matrix.
 as_status as_build(const double* items, int64_t n, int64_t d, int64_t row_stride, int64_t col_stride, const as_graph_params* gp,
                    const as_opts* opts, as_space** out_space, as_graph** out_graph) {
     if (!out_space || !out_graph) {
@@ -560,32 +580,16 @@ as_status as_build(const double* items, int64_t n, int64_t d, int64_t row_stride
     as_graph_params r;
     AS_TRY(resolve_params(gp, &r));
     AS_TRY(check_limits(&r, n, opts ? opts->lambda_mode : 0));   // before the upload
-    int dev = 0;
-    AS_TRY(pick_device(opts, &dev));
     dbg("items shape: (%lld, %lld)", (long long)n, (long long)d);  // src/helpers.rs:31
-    double* staging = nullptr;
-    AS_HIP(hipMalloc(&staging, sizeof(double) * n * d));
-    hipError_t e = hipSuccess;
-    if (col_stride == 1 && row_stride >= d) {
-        e = hipMemcpy2D(staging, sizeof(double) * d, items, sizeof(double) * row_stride, sizeof(double) * d, n, hipMemcpyHostToDevice);
-    } else {
-        // arbitrary numpy strides (src/helpers.rs:25 `as_array()` accepts them): repack on the host
-        std::vector<double> tmp((size_t)n * d);
-        for (int64_t i = 0; i < n; ++i)
-            for (int64_t c = 0; c < d; ++c) tmp[(size_t)i * d + c] = items[i * row_stride + c * col_stride];
-        e = hipMemcpy(staging, tmp.data(), sizeof(double) * n * d, hipMemcpyHostToDevice);
+    const double t0 = now_s();
+    as_space* sp = nullptr;
+    AS_TRY(space_new(n, d, opts, &sp));
+    const as_status s = ingest_host(sp, items, row_stride, col_stride);
+    if (s != AS_OK) {
+        as_free_space(sp);
+        return s;
     }
-    if (e != hipSuccess) {
-        set_err("upload of items failed: %s", hipGetErrorString(e));
-        hipFree(staging);
-        return AS_EHIP;
-    }
-    as_opts o{};
-    if (opts) o = *opts;
-    o.device = dev;
-    as_status s = as_build_dev(staging, AS_DTYPE_F64, n, d, d, &r, &o, out_space, out_graph);
-    hipFree(staging);
-    return s;
+    return build_from_space(sp, r, t0, now_s(), out_space, out_graph);
 }
 
 // ---------------------------------------------------------------- search

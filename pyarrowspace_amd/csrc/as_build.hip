@@ -4,6 +4,7 @@
 // (`builder.build(rows)`); SPEC = DESIGN.md section 2.
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "as_knn.hpp"
@@ -278,7 +279,17 @@ __global__ void copy_f64_kernel(const T* __restrict__ src, int64_t ld, int64_t n
     dst[i] = (double)src[(i / d) * ld + (i % d)];
 }
 
-as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
+// The ingest in three steps, so that a host-resident input can stream through it chunk by chunk (ingest_host):
+// ingest_begin allocates the space's arrays and the flag words, ingest_rows runs the kernel over a range of rows,
+// ingest_end reads the flags back and decides about exact mode; ingest_keep_f64 says whether the fp64 items must be kept.
+struct IngestState {
+    int* flags = nullptr;
+    unsigned long long *nmax_bits = nullptr, *nmin_bits = nullptr;
+    int cus = 256;
+    bool range_unsafe = false;
+};
+
+static as_status ingest_begin(as_space* sp, IngestState* st) {
     const int64_t n = sp->n, d = sp->d;
     sp->np = (n + ROW_TILE - 1) / ROW_TILE * ROW_TILE;
     sp->dp = (d + COL_PAD - 1) / COL_PAD * COL_PAD;
@@ -295,47 +306,67 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
     AS_HIP(hipMemsetAsync(sp->inorm32, 0, sizeof(float) * rows_alloc, sp->stream));
     AS_HIP(hipMemsetAsync(sp->lam64, 0, sizeof(double) * n, sp->stream));
     AS_HIP(hipMemsetAsync(sp->lam32, 0, sizeof(float) * rows_alloc, sp->stream));
-    int* flags = nullptr;
-    AS_HIP(hipMalloc(&flags, 24));
+    AS_HIP(hipMalloc(&st->flags, 24));
     int hinit[6] = {1, 0, 0, 0, -1, 0x7fefffff};   // lossless, pad, nmax bits = 0, nmin bits = DBL_MAX
-    AS_HIP(hipMemcpyAsync(flags, hinit, 24, hipMemcpyHostToDevice, sp->stream));
-    unsigned long long* nmax_bits = (unsigned long long*)(flags + 2);
-    unsigned long long* nmin_bits = (unsigned long long*)(flags + 4);
+    AS_HIP(hipMemcpyAsync(st->flags, hinit, 24, hipMemcpyHostToDevice, sp->stream));
+    st->nmax_bits = (unsigned long long*)(st->flags + 2);
+    st->nmin_bits = (unsigned long long*)(st->flags + 4);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) st->cus = prop.multiProcessorCount;
+    return AS_OK;
+}
+
+// rows [row0, row0 + rows) of the space from `src` (device memory: row 0 of src is item row0, leading dimension ld)
+static as_status ingest_rows(as_space* sp, const IngestState* st, const void* src, int dtype, int64_t ld, int64_t row0, int64_t rows, hipStream_t stream) {
     const int wpb = 4;
-    int ing_cus = 256;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, sp->device) == hipSuccess) ing_cus = prop.multiProcessorCount;
-    }
-    const unsigned grid = (unsigned)std::min<int64_t>((n + wpb - 1) / wpb, (int64_t)ing_cus * 8);   // 32 waves per CU
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + wpb - 1) / wpb, (int64_t)st->cus * 8);   // 32 waves per CU
+    float* x32 = sp->x32 + (size_t)row0 * sp->dp;
     if (dtype == AS_DTYPE_F64)
-        hipLaunchKernelGGL(ingest_kernel<double>, dim3(grid), dim3(64 * wpb), 0, sp->stream, (const double*)items_dev, ld,
-                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits, nmin_bits);
+        hipLaunchKernelGGL(ingest_kernel<double>, dim3(grid), dim3(64 * wpb), 0, stream, (const double*)src, ld, rows, sp->d, sp->dp, x32,
+                           sp->n64 + row0, sp->n32 + row0, sp->inorm32 + row0, st->flags, st->nmax_bits, st->nmin_bits);
     else
-        hipLaunchKernelGGL(ingest_kernel<float>, dim3(grid), dim3(64 * wpb), 0, sp->stream, (const float*)items_dev, ld,
-                           n, d, sp->dp, sp->x32, sp->n64, sp->n32, sp->inorm32, flags, nmax_bits, nmin_bits);
+        hipLaunchKernelGGL(ingest_kernel<float>, dim3(grid), dim3(64 * wpb), 0, stream, (const float*)src, ld, rows, sp->d, sp->dp, x32,
+                           sp->n64 + row0, sp->n32 + row0, sp->inorm32 + row0, st->flags, st->nmax_bits, st->nmin_bits);
     AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+static as_status ingest_end(as_space* sp, IngestState* st) {
     int hout[6];
-    AS_HIP(hipMemcpyAsync(hout, flags, 24, hipMemcpyDeviceToHost, sp->stream));
+    AS_HIP(hipMemcpyAsync(hout, st->flags, 24, hipMemcpyDeviceToHost, sp->stream));
     AS_HIP(hipStreamSynchronize(sp->stream));
     sp->lossless = hout[0];
     unsigned long long nb;
     memcpy(&nb, &hout[2], 8);
     long long nbs = (long long)nb;
     memcpy(&sp->nmax, &nbs, 8);
-    AS_HIP(hipFree(flags));
+    AS_HIP(hipFree(st->flags));
+    st->flags = nullptr;
     double nmin;
     memcpy(&nmin, &hout[4], 8);
     // The fp32 prefilters need every squared norm (and sums of two) inside the normal fp32 range: items scaled
     // by 1e20 overflow them, by 1e-22 flush them to zero, and a prefilter that sees inf/0 keys silently drops
     // true neighbours.  Outside a generous safe band the whole index runs in fp64 end to end (slow, exact).
     const double hi = 0x1p+120, lo = 0x1p-100;
-    const bool range_unsafe = (sp->nmax < 1.0e308 && sp->nmax > hi) || (nmin < lo);
-    if (range_unsafe && !sp->opts.force_exact) {
+    st->range_unsafe = (sp->nmax < 1.0e308 && sp->nmax > hi) || (nmin < lo);
+    if (st->range_unsafe && !sp->opts.force_exact) {
         sp->opts.force_exact = 1;
         dbg("ingest: squared norms span [%.3g, %.3g], outside the fp32-safe range: fp64 end to end", nmin, sp->nmax);
     }
-    const bool keep = (dtype == AS_DTYPE_F64 && !sp->lossless) || sp->opts.keep_f64 == AS_KEEP_F64_ALWAYS || range_unsafe;
+    return AS_OK;
+}
+
+static bool ingest_keep_f64(const as_space* sp, const IngestState* st, int dtype) {
+    return (dtype == AS_DTYPE_F64 && !sp->lossless) || sp->opts.keep_f64 == AS_KEEP_F64_ALWAYS || st->range_unsafe;
+}
+
+as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
+    const int64_t n = sp->n, d = sp->d;
+    IngestState st;
+    AS_TRY(ingest_begin(sp, &st));
+    AS_TRY(ingest_rows(sp, &st, items_dev, dtype, ld, 0, n, sp->stream));
+    AS_TRY(ingest_end(sp, &st));
+    const bool keep = ingest_keep_f64(sp, &st, dtype);
     if (keep) {
         AS_HIP(hipMalloc(&sp->x64, sizeof(double) * n * d));
         const int64_t tot = n * d;
@@ -349,6 +380,119 @@ as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld) {
     }
     dbg("ingest: n=%lld d=%lld np=%lld dp=%lld lossless_f32=%d keep_f64=%d nmax=%.6g", (long long)n, (long long)d,
         (long long)sp->np, (long long)sp->dp, sp->lossless, (int)keep, sp->nmax);
+    return AS_OK;
+}
+
+// The reference's own call -- build(graph_params, items: float64 ndarray in HOST memory, any strides;
+// /root/reference/src/lib.rs:271-277, src/helpers.rs:24-46) -- without a device copy of the whole fp64 matrix: the rows stream
+// through TWO pinned chunks of about 64 MB and two device chunks of the same size; host threads pack chunk i + 1 (a memcpy per
+// row, or an element gather for a non-unit column stride) while the copy engine moves chunk i and the ingest kernel converts
+// chunk i - 1 -- host packing, PCIe and the kernel overlap, peak extra device memory 128 MB.  (Before: one hipMalloc of
+// N D 8 bytes -- 6.1 GB at 1M x 768, 54 GB at 8.8M -- and one synchronous pageable copy in front of the ingest.)  Items that do
+// not round-trip through fp32 are kept in fp64 as before: a second streaming pass straight into x64.
+as_status ingest_host(as_space* sp, const double* items, int64_t row_stride, int64_t col_stride) {
+    const int64_t n = sp->n, d = sp->d;
+    IngestState st;
+    AS_TRY(ingest_begin(sp, &st));
+    const int64_t chunk_mb = getenv("ARROWSPACE_INGEST_CHUNK_MB") ? std::max(1, atoi(getenv("ARROWSPACE_INGEST_CHUNK_MB"))) : 64;   // (per build: tests stream small inputs in many chunks)
+    const int64_t crows = std::max<int64_t>(1, std::min<int64_t>(n, (chunk_mb << 20) / (int64_t)(sizeof(double) * d)));
+    const size_t cbytes = sizeof(double) * (size_t)crows * d;
+    double* hbuf[2] = {nullptr, nullptr};
+    double* dbuf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    as_status rs = AS_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            if (hbuf[i]) (void)hipHostFree(hbuf[i]);
+            if (dbuf[i]) (void)hipFree(dbuf[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+    };
+    for (int i = 0; i < 2 && rs == AS_OK; ++i) {
+        if (hipHostMalloc(&hbuf[i], cbytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&dbuf[i], cbytes) != hipSuccess ||
+            hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) {
+            set_err("ingest_host: no memory for the staging chunks (%lld MB each)", (long long)(cbytes >> 20));
+            rs = AS_ENOMEM;
+        }
+    }
+    if (rs != AS_OK) {
+        (void)hipGetLastError();
+        cleanup();
+        return rs;
+    }
+    static const int nthreads = [] {
+        const char* e = getenv("ARROWSPACE_INGEST_THREADS");
+        const int v = e ? atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, std::min(v, 64));
+    }();
+    // rows [r0, r0 + rows) of the caller's array into a dense [rows][d] chunk, split over host threads
+    auto pack = [&](double* dst, int64_t r0, int64_t rows) {
+        auto part = [&](int64_t a, int64_t b) {
+            if (col_stride == 1) {
+                for (int64_t i = a; i < b; ++i) memcpy(dst + (size_t)(i - r0) * d, items + (r0 + (i - r0)) * row_stride, sizeof(double) * d);
+            } else {
+                for (int64_t i = a; i < b; ++i) {
+                    const double* src = items + i * row_stride;
+                    double* o = dst + (size_t)(i - r0) * d;
+                    for (int64_t c = 0; c < d; ++c) o[c] = src[c * col_stride];
+                }
+            }
+        };
+        const int nt = (int)std::min<int64_t>(nthreads, std::max<int64_t>(1, rows / 256));
+        if (nt <= 1) {
+            part(r0, r0 + rows);
+            return;
+        }
+        std::vector<std::thread> th;
+        const int64_t per = (rows + nt - 1) / nt;
+        for (int t = 1; t < nt; ++t) th.emplace_back(part, r0 + std::min<int64_t>(rows, t * per), r0 + std::min<int64_t>(rows, (t + 1) * per));
+        part(r0, r0 + std::min<int64_t>(rows, per));
+        for (auto& t : th) t.join();
+    };
+    // pass 0: every chunk through the ingest kernel; pass 1 (only when the fp64 items must be kept): every chunk into x64
+    for (int pass = 0; pass < 2 && rs == AS_OK; ++pass) {
+        if (pass == 1) {
+            if ((rs = ingest_end(sp, &st)) != AS_OK) break;
+            if (!ingest_keep_f64(sp, &st, AS_DTYPE_F64)) break;
+            if (hipMalloc(&sp->x64, sizeof(double) * n * d) != hipSuccess) {
+                (void)hipGetLastError();
+                set_err("ingest_host: no memory to keep the fp64 items");
+                rs = AS_ENOMEM;
+                break;
+            }
+        }
+        int64_t ci = 0;
+        for (int64_t r0 = 0; r0 < n && rs == AS_OK; r0 += crows, ++ci) {
+            const int b = (int)(ci & 1);
+            const int64_t rows = std::min<int64_t>(crows, n - r0);
+            if (ci >= 2 && hipEventSynchronize(done[b]) != hipSuccess) {   // the pinned chunk's previous copy (and the kernel behind it) has finished
+                set_err("ingest_host: %s", hipGetErrorString(hipGetLastError()));
+                rs = AS_EHIP;
+                break;
+            }
+            pack(hbuf[b], r0, rows);
+            double* dst = pass == 0 ? dbuf[b] : sp->x64 + (size_t)r0 * d;
+            if (hipMemcpyAsync(dst, hbuf[b], sizeof(double) * (size_t)rows * d, hipMemcpyHostToDevice, sp->stream) != hipSuccess) {
+                set_err("upload of items failed: %s", hipGetErrorString(hipGetLastError()));
+                rs = AS_EHIP;
+                break;
+            }
+            if (pass == 0) rs = ingest_rows(sp, &st, dbuf[b], AS_DTYPE_F64, d, r0, rows, sp->stream);
+            if (rs == AS_OK && hipEventRecord(done[b], sp->stream) != hipSuccess) {
+                set_err("ingest_host: %s", hipGetErrorString(hipGetLastError()));
+                rs = AS_EHIP;
+            }
+        }
+        if (rs == AS_OK && hipStreamSynchronize(sp->stream) != hipSuccess) {
+            set_err("ingest_host: %s", hipGetErrorString(hipGetLastError()));
+            rs = AS_EHIP;
+        }
+    }
+    if (st.flags) (void)hipFree(st.flags);   // (an error before ingest_end)
+    cleanup();
+    if (rs != AS_OK) return rs;
+    dbg("ingest (host, chunks of %lld rows, %d pack threads): n=%lld d=%lld np=%lld dp=%lld lossless_f32=%d keep_f64=%d nmax=%.6g",
+        (long long)crows, nthreads, (long long)n, (long long)d, (long long)sp->np, (long long)sp->dp, sp->lossless, (int)(sp->x64 != nullptr), sp->nmax);
     return AS_OK;
 }
 

@@ -390,6 +390,7 @@ as_status space_i8h_image(const as_space* sp, bool* present);
 
 // build stages (as_build.hip)
 as_status ingest(as_space* sp, const void* items_dev, int dtype, int64_t ld);
+as_status ingest_host(as_space* sp, const double* items, int64_t row_stride, int64_t col_stride);
 as_status knn_rows(const as_space* sp, const as_graph_params* gp, int64_t r0, int64_t r1, int32_t* out_idx,
                    double* out_key, double* out_dist, double* out_gy, int32_t* out_cnt, double* stats);
 as_status graph_from_knn(as_space* sp, const as_graph_params* gp, const int32_t* idx, const double* dist,

@@ -395,3 +395,46 @@ def test_batched_pass_bf16_products_and_fp32_products_agree(metric, kernel):
                     os.environ["ARROWSPACE_BATCH_F32_DOTS"] = old
         assert got["bf16"] == got["fp32"]
         assert all(len(h) == topk for h in got["bf16"][0.62])
+
+
+def test_host_build_streams_chunks_and_matches_the_device_build(monkeypatch):
+    """The reference's own call -- build(graph_params, float64 ndarray in host memory, any strides; src/lib.rs:271-277,
+    src/helpers.rs:24-46) -- streams the rows through two pinned chunks (as_build -> ingest_host).  With 1 MB chunks a
+    20 000 x 96 input takes 15 chunks: same lambdas, Laplacian and items, bit for bit, as the device-resident build of the same
+    values; a column-strided view and a row-strided slice of a wider array give the same index; items that do not round-trip
+    through fp32 come back from get_item exactly (the second streaming pass into x64)."""
+    import torch
+
+    import pyarrowspace_amd as asp
+    from conftest import calibrate_eps, clustered
+    monkeypatch.setenv("ARROWSPACE_INGEST_CHUNK_MB", "1")
+    n, d = 20000, 96
+    X32 = clustered(n, d, nclust=20, seed=41).astype(np.float32)
+    X = X32.astype(np.float64)                         # lossless in fp32, as embeddings cast up are
+    gp = {"eps": calibrate_eps(X, 8, "l2"), "k": 8, "topk": 5, "p": 2.0, "sigma": None}
+    Xd = torch.from_numpy(X32).cuda()
+    a0, g0 = asp.ArrowSpaceBuilder.build_from_device(gp, Xd.data_ptr(), "float32", n, d, d)
+    a1, g1 = asp.ArrowSpaceBuilder.build(gp, X)
+    assert np.array_equal(a1.lambdas(), a0.lambdas()) and g1.tau0 == g0.tau0
+    for x, y in zip(g1.to_csr(), g0.to_csr()):
+        assert np.array_equal(x, y)
+    for i in (0, 10921, 10922, n - 1):                 # (chunk boundaries of 1 MB / (96 * 8 B) = 1365 rows and the ends)
+        assert np.array_equal(a1.get_item(i)[0], X[i])
+    wide = np.zeros((n, 2 * d + 3))
+    wide[:, 1:2 * d:2] = X                             # element strides (2 d + 3, 2)
+    a2, g2 = asp.ArrowSpaceBuilder.build(gp, wide[:, 1:2 * d:2])
+    assert np.array_equal(a2.lambdas(), a0.lambdas())
+    wide2 = np.zeros((n, d + 7))
+    wide2[:, 3:3 + d] = X                              # unit column stride, row stride d + 7
+    a3, g3 = asp.ArrowSpaceBuilder.build(gp, wide2[:, 3:3 + d])
+    assert np.array_equal(a3.lambdas(), a0.lambdas())
+    q = np.ascontiguousarray(X[77] * 1.001)
+    assert a1.search(q, g1, 0.62) == a0.search(q, g0, 0.62) == a2.search(q, g2, 0.62) == a3.search(q, g3, 0.62)
+    # fp64 items that fp32 cannot hold: kept in fp64 by the second streaming pass
+    Y = X + 1e-11 * np.arange(d)[None, :]
+    a4, g4 = asp.ArrowSpaceBuilder.build(gp, Y)
+    for i in (0, 1364, 1365, 12345, n - 1):
+        assert np.array_equal(a4.get_item(i)[0], Y[i])
+    Yd = torch.from_numpy(Y).cuda()
+    a5, g5 = asp.ArrowSpaceBuilder.build_from_device(gp, Yd.data_ptr(), "float64", n, d, d)
+    assert np.array_equal(a4.lambdas(), a5.lambdas())
