@@ -628,7 +628,7 @@ def main():
     for i in range(min(args.steps, 50)):
         searcher(Q[(args.warmup + i) % len(Q)])
         scan_us.append(aspace.last_search_stats()["scan_us"] if single else index.last_scan_us())
-        scan_ops.append(aspace.last_scan_operand if single else "")
+        scan_ops.append(aspace.last_scan_operand if single else index.last_scan_operand())
     scan_ms = float(np.mean(scan_us)) * 1e-3
     scan_operand = max(set(scan_ops), key=scan_ops.count) if scan_ops else ""
 
@@ -769,16 +769,29 @@ def main():
 
     qps = args.steps / dt
     # the scan reads the int8 two-digit image of the items when it can (2 bytes per element + the rows' norm and scale), else fp32
-    scan_i8 = scan_operand in ("int8", "int8-high") if single else os.environ.get("ARROWSPACE_SCAN_FP32") is None and d <= 4096 and not feature
+    scan_i8 = scan_operand in ("int8", "int8-high")
     rows_per_gpu = (n + world - 1) // world
     scan_bytes = rows_per_gpu * (d + 2) * 4.0          # N x D fp32 items + N reciprocal norms read, N fp32 dots written
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
     d8 = (d + 63) // 64 * 64
-    scan_coarse = single and scan_operand == "int8-high"   # the image's high digits alone: 1 B per element
+    scan_coarse = scan_operand == "int8-high"   # the image's high digits alone: 1 B per element
     scan_moved = rows_per_gpu * ((1.0 if scan_coarse else 2.0) * d8 + 12.0) if scan_i8 else scan_bytes   # bytes the launch moves: image + norms + scales + dots
     if threaded:
         for key in ("2", "4"):
             threaded[key]["frac"] = scan_moved * threaded[key]["value"] / 1e9 / HBM_PEAK_GBS
+    # N > 1: every rank's own scan (its rows, its launch time, its operand) next to rank 0's, and the ranks the collective
+    # layer really connected (an all-reduce of ones: RCCL over xGMI, or gloo when the ranks of a rehearsal share a card)
+    ranks_seen, per_rank = world if dist is None else None, None
+    if dist is not None:
+        ones = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        my_rows = (index.scan_rows[1] - index.scan_rows[0]) if not single else n
+        my_moved = my_rows * ((1.0 if scan_coarse else 2.0) * d8 + 12.0) if scan_i8 else my_rows * (d + 2) * 4.0
+        mine = {"rank": rank, "rows": int(my_rows), "avg_launch_ms": scan_ms, "operand": scan_operand, "bytes_per_launch": my_moved,
+                "achieved": my_moved / (scan_ms * 1e-3) / 1e9, "frac": my_moved / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     moved = scan_moved / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
     batch_moved = (n * (2.0 * d8 + 8.0 + 64.0) if batch_i8 else query_bytes + n * 64.0) / world   # a 32-query pass: operand + norms + scales + 32 fp16 cosines per row
@@ -830,6 +843,7 @@ def main():
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -884,6 +898,7 @@ def main():
                      "algorithmic_bytes_per_launch": scan_bytes, "algorithmic_gbs": achieved, "algorithmic_speedup": achieved / HBM_PEAK_GBS,
                      "note": "this launch also collects the scorer's candidates (fused tail, DESIGN.md 5.4); ARROWSPACE_SCAN_FP32=1 scans "
                              "the fp32 items (round 3's operand), ARROWSPACE_NO_FUSED_TAIL=1 runs the plain kernel"},
+        "roofline_per_rank": per_rank,
         "roofline_query": {"bound": "hbm", "achieved": scan_moved / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": scan_moved / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "algorithmic_speedup": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

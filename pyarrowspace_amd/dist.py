@@ -1289,6 +1289,12 @@ class ShardedIndex:
     def last_scan_us(self):
         return self.engine.scan_us(self.engine.qs if self._lib_comm else None)
 
+    def last_scan_operand(self):
+        """What this rank's last single-query scan read: "fp32" items, their "int8" two-digit image or "int8-high" (coarse)."""
+        e = self.engine
+        q = e.qs if self._lib_comm else e.q
+        return {0: "fp32", 1: "int8", 2: "int8-high"}.get(int(e.L.as_query_scan_int8(q)), "fp32")
+
     def build_stats(self):
         return getattr(self.engine, "stats", lambda: {})()
 

@@ -238,3 +238,31 @@ def test_config4_full_size_8_8m_by_768_four_ranks():
         pytest.skip("needs 200 GB of free device memory: %.0f GB free" % (free / 1e9))
     out = _run(4, 8_800_000, 768, uneven=False, single=False)
     assert all(out[r]["rows"] == 2_200_000 for r in range(4))
+
+
+def test_bench_line_of_a_two_rank_job():
+    """`python bench.py --gpus 2` as the driver starts it (no launcher: bench.py spawns its ranks; on this one-GPU box they
+    share the card and the exchange steps go through host memory): ONE JSON line from rank 0 with the N > 1 contract --
+    n_gpus, ranks_seen (an all-reduce of ones over the ranks' collective layer), `roofline` a physical fraction with its
+    per-rank breakdown, `cpu_baseline` on rank 0 (the oracle over ALL items, the lambdas and degrees gathered from the ranks)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, ARROWSPACE_BENCH_NDEV="1", ARROWSPACE_BENCH_LAUNCH_TIMEOUT="500")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "120000", "--d", "128", "--k", "10", "--topk", "5",
+                        "--steps", "30", "--warmup", "5", "--cpu-queries", "4", "--cpu-build-n", "2000"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    pr = out["roofline_per_rank"]
+    assert [e["rank"] for e in pr] == [0, 1] and sum(e["rows"] for e in pr) == 120000 and all(0 < e["frac"] <= 1.0 for e in pr)
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "4 single queries over the full N=120000" in cb["sample"]
+    assert out["index_build_sec"] > 0 and out["batched_queries_per_sec"] > 0
