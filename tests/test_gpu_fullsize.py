@@ -183,3 +183,44 @@ def test_feature_mode_at_headline_size():
     check_search(X, aspace, gl, lam, TAU, TOPK, sample[:3])
     stats = gl.build_stats()
     assert stats["total_s"] < 2.0          # N-linear: no all-pairs work in this mode
+
+
+def test_coarse_scan_against_the_oracle_at_headline_size(big):
+    """The headline's own path -- the coarse scan over the tiles of the int8 image's high digits, the merged exact tail -- held
+    against the ORACLE (C restatement, fp64 over all 1M items) on 216 queries: tau in {0.4, 0.62, 1.0}, half of them perturbed
+    items (the bench's timed queries), half fresh draws around the index's centres (SURVEY 8(d)'s query recipe; the ones with no
+    item inside eps must raise the zero-lambda panic on both sides).  Indices rank-exact, scores and lambda_q to 1e-9."""
+    import torch
+
+    import pyarrowspace_amd as asp
+    from conftest import assert_hits_match
+    from oracle import oracle_c
+    X, aspace, gl, gp = big["X"], big["aspace"], big["gl"], big["gp"]
+    ref = oracle_c.OracleSearchOnly(X.double().cpu().numpy(), gp, big["deg"], big["lam"], gl.tau0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    C = torch.randn((1024, D), generator=g, device="cuda", dtype=torch.float32).double().cpu().numpy()   # gpu_clustered's centres
+    rng = np.random.default_rng(77)
+    per = 36
+    operands, zero = set(), 0
+    for tau in (0.4, 0.62, 1.0):
+        rows = rng.integers(0, N, per)
+        Qp = X[torch.from_numpy(rows).cuda()].double().cpu().numpy() + 0.02 * rng.standard_normal((per, D)) / np.sqrt(D)
+        Qi = C[rng.integers(0, 1024, per)] + 0.5 * rng.standard_normal((per, D))
+        for q in np.concatenate([Qp, Qi]):
+            q = np.ascontiguousarray(q / np.linalg.norm(q))
+            try:
+                want, lq = ref.search(q, tau, fused=True)
+            except oracle_c.ZeroLambda:
+                zero += 1
+                with pytest.raises(asp.PanicException):
+                    aspace.search(q, gl, tau)
+                continue
+            got = aspace.search(q, gl, tau)
+            operands.add(aspace.last_scan_operand)
+            assert_hits_match(got, want, ref.scores(q, tau, lq), rtol=1e-9)
+            assert abs(aspace.query_lambda(q, gl) - lq) <= 1e-9 * abs(lq)
+    assert "int8-high" in operands                      # the coarse scan did serve these queries
+    assert zero < per * 3                                # (some in-distribution draws have no neighbour inside eps; not all)
+    c = aspace.search_counters()
+    assert c["searches_with_rerun"] <= 0.05 * c["searches"]
