@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_F64_PEAK_TF = 78.6    # v_mfma_f64_16x16x4_f64: vendor fp64 matrix peak (half the fp32 rate; not in the guide's table)
 MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (never the 2:1 sparsity figure)
-MFMA_I8_PEAK_TOPS = 5000.0 # v_mfma_i32_32x32x32_i8: the cycles of the bf16 form at twice the K (MI355X_MICROARCH.md, matrix cores table)
+MFMA_I8_PEAK_TOPS = 5000.0 # v_mfma_i32_32x32x32_i8 / _16x16x64_i8: the cycles of the bf16 form of the same M x N at twice the K (MI355X_MICROARCH.md, matrix cores table)
 
 
 def launch(n_ranks, argv, child=None):
@@ -808,7 +808,10 @@ def main():
         mfma_tf, mfma_peak, build_kernel, build_dtype = mfma_tf_eq, MFMA_F32_PEAK_TF, "knn_mfma_dma8_kernel<%s>" % args.metric, "f32"
     elif k2_pipe == "int8":
         # two int8 digits per element, three int8 products per fp32 product: issued int8 ops / 5 POP/s (twice the bf16 rate)
-        mfma_tf, mfma_peak, build_kernel, build_dtype = 3.0 * mfma_tf_eq, MFMA_I8_PEAK_TOPS, "knn_bf16_kernel<%s, I8>" % args.metric, "int8 two-digit image (3 products per fp32 product, exact int32 accumulation)"
+        s16 = os.environ.get("ARROWSPACE_K2_MFMA16", "1") not in ("0",)
+        mfma_tf, mfma_peak, build_kernel, build_dtype = (3.0 * mfma_tf_eq, MFMA_I8_PEAK_TOPS, "knn_bf16_kernel<%s, I8%s>" % (args.metric, ", S16" if s16 else ""),
+                                                         "int8 two-digit image (3 products per fp32 product, exact int32 accumulation) on %s"
+                                                         % ("v_mfma_i32_16x16x64_i8" if s16 else "v_mfma_i32_32x32x32_i8"))
     else:
         mfma_tf, mfma_peak, build_kernel, build_dtype = 3.0 * mfma_tf_eq, MFMA_BF16_PEAK_TF, "knn_bf16_kernel<%s>" % args.metric, "bf16 head + tail (3 products per fp32 product)"
 

@@ -144,6 +144,7 @@ as_status quant_rows_i8(const float* x32, const float* n32, void* x8, float* fa8
     return AS_OK;
 }
 
+typedef int i32x4k __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------ LDS through inline asm
 // Each block waits for its own reads before it ends: no register the compiler may copy or reuse holds data in flight.
 __device__ __forceinline__ void lds_frag5(unsigned aa, unsigned ab, f32x4& a, f32x4& b0, f32x4& b1, f32x4& b2, f32x4& b3) {
@@ -184,6 +185,33 @@ __device__ __forceinline__ void lds_read_b32x4(unsigned a0, float& v0, float& v1
                  : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
                  : "v"(a0)
                  : "memory");
+}
+// S16 form: eight values of a column line, one per 16-column group (64 bytes apart)
+__device__ __forceinline__ void lds_read_b32x8(unsigned a0, float (&v)[8]) {
+    asm volatile(
+        "ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\tds_read_b32 %3, %8 offset:192\n\t"
+        "ds_read_b32 %4, %8 offset:256\n\tds_read_b32 %5, %8 offset:320\n\tds_read_b32 %6, %8 offset:384\n\tds_read_b32 %7, %8 offset:448\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(a0)
+        : "memory");
+}
+// S16 form: the A fragments of a slab -- both 16-row groups, high and low digits
+__device__ __forceinline__ void lds_frag_a16(unsigned a00, unsigned a10, unsigned a01, unsigned a11, i32x4k& x00, i32x4k& x10, i32x4k& x01, i32x4k& x11) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x00), "=&v"(x10), "=&v"(x01), "=&v"(x11)
+                 : "v"(a00), "v"(a10), "v"(a01), "v"(a11)
+                 : "memory");
+}
+// ... and the B fragments of four consecutive 16-column groups (2 KiB apart), high digits from b1, low digits from b2
+__device__ __forceinline__ void lds_frag_b16(unsigned b1, unsigned b2, i32x4k (&h)[4], i32x4k (&l)[4]) {
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:2048\n\tds_read_b128 %2, %8 offset:4096\n\tds_read_b128 %3, %8 offset:6144\n\t"
+        "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:2048\n\tds_read_b128 %6, %9 offset:4096\n\tds_read_b128 %7, %9 offset:6144\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+        : "v"(b1), "v"(b2)
+        : "memory");
 }
 __device__ __forceinline__ int lds_read_i32(unsigned a) {
     int v;
@@ -255,8 +283,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // I8: the same kernel on the int8 two-digit image (quant_i8_kernel): a slab row is 64 columns (64 bytes of a1, 64 of a2), a
 // k-step 32 columns of v_mfma_i32_32x32x32_i8, the chunk addressing that of heads and tails; two int32 accumulator sets per
 // tile (a1.b1 and the cross terms), turned into the dot by the rows' and columns' scales in the epilogue.
-template <int METRIC, bool COLLECT, bool SYM, int DIAG = 0, bool I8 = false>
+// S16 (int8 image only): the products on v_mfma_i32_16x16x64_i8 -- a wave's 32 x 128 tile as 2 x 8 accumulators of 16 x 16, one
+// k-step of 64 columns per slab; the same LDS image, the same bytes read per product, the same cycles per product -- but the
+// chip holds a higher clock under this shape on random data (MI355X_MICROARCH.md, DVFS give-back item 7; a bare loop of it
+// delivered 1.21 x the 32x32x32 loop's rate: tools/probe/mfma_rate_probe.hip).  Lane l of the wave supplies row (l % 16) and
+// columns 16 (l / 16) .. + 15 of a fragment; result register i of accumulator (rg, cg) is row 16 rg + 4 (l / 16) + i, column
+// 16 cg + l % 16 (tools/probe/mfma16_layout.hip).  The epilogue appends in ascending column order as the 32x32 form does: the
+// candidate buffers, and everything behind them, are the same bit for bit.
+template <int METRIC, bool COLLECT, bool SYM, int DIAG = 0, bool I8 = false, bool S16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_bf16_kernel(KnnArgs a) {
+    static_assert(!S16 || I8, "the 16x16x64 shape is the int8 image's");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Sl = (float*)smem;                     // RING slab buffers: A rows then B rows, 128 B per row
     float2* s_ta = (float2*)(Sl + RING * DSLAB);  // per row: (running bound, n_i or 1/|x_i|)
@@ -287,10 +323,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         aoff[q] = lds0 + (unsigned)((w * 32 + l31) * DROW * 4) + sw;
         boff[q] = lds0 + (unsigned)((BM + l31) * DROW * 4) + sw;
     }
+    // S16: row (lane % 16) of a 16-row group, chunk (lane / 16) of its high digits (+ 4: low digits)
+    const int l15 = lane & 15, g4 = lane >> 4;
+    unsigned a16[2][2], b16[2];
+#pragma unroll
+    for (int dg = 0; dg < 2; ++dg) {
+        const unsigned sw = (unsigned)(((g4 + 4 * dg) ^ ((l15 >> 1) & 7)) << 4);
+        a16[0][dg] = lds0 + (unsigned)((w * 32 + l15) * DROW * 4) + sw;
+        a16[1][dg] = lds0 + (unsigned)((w * 32 + 16 + l15) * DROW * 4) + sw;
+        b16[dg] = lds0 + (unsigned)((BM + l15) * DROW * 4) + sw;
+    }
+    const unsigned ta16 = lds0 + (unsigned)(RING * DSLAB * 4) + (unsigned)((w * 32 + 4 * g4) * 8);
     const unsigned ta0 = lds0 + (unsigned)(RING * DSLAB * 4) + (unsigned)((w * 32 + 4 * h) * 8);
     const unsigned cur0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8);
     const unsigned sn0 = lds0 + (unsigned)(RING * DSLAB * 4 + BM * 8 + 3 * BM * 4);
     const unsigned sfa0 = sn0 + (unsigned)(SN * 3 * BN * 4) + (unsigned)((w * 32 + 4 * h) * 4);
+    const unsigned sfa16 = sn0 + (unsigned)(SN * 3 * BN * 4) + (unsigned)((w * 32 + 4 * g4) * 4);
     const bool late = wu >= 4;   // wave-uniform: the second-dispatched half issues its DMA mid-slab
     int xcc = 0;                 // the XCD this block runs on (L2 affinity of the unit lists: speed only)
     if (SYM) {
@@ -412,11 +460,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int64_t colbase = ((int64_t)ct * a.tstride + a.tphase) * BN;
             f32x16 acc[4];
             i32x16 acc1[4], accx[4];   // int8 image: a1.b1 and the cross terms a1.b2 + a2.b1
+            i32x4k c1[2][8], cx[2][8];   // ... as 16 x 16 accumulators (S16): [16-row group][16-column group]
+            if (S16) {
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int cg = 0; cg < 8; ++cg) {
+                        c1[rg][cg] = i32x4k{0, 0, 0, 0};
+                        cx[rg][cg] = i32x4k{0, 0, 0, 0};
+                    }
+            }
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (I8) {
+                    if (S16) {
+                    } else if (I8) {
                         acc1[nn][r] = 0;
                         accx[nn][r] = 0;
                     } else {
@@ -430,6 +489,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (!K2_DIAG(16)) __builtin_amdgcn_s_barrier();   // everybody's pieces are in, everybody is done with the buffer issued into next
                 --inflight;
                 if (!late && !K2_DIAG(2)) K2_ISSUE();
+                if (S16) {
+                    // one k-step of 64 columns: 4 A fragments, then the 16-column groups in two batches of four
+                    i32x4k fa1[2], fa2[2], hb[4], lb[4];
+                    lds_frag_a16(a16[0][0] + cbuf, a16[1][0] + cbuf, a16[0][1] + cbuf, a16[1][1] + cbuf, fa1[0], fa1[1], fa2[0], fa2[1]);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        lds_frag_b16(b16[0] + cbuf + (unsigned)(hf * 8192), b16[1] + cbuf + (unsigned)(hf * 8192), hb, lb);
+                        if (!K2_DIAG(1)) {
+#pragma unroll
+                            for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)   // a1 . b1
+                                    c1[rg][4 * hf + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa1[rg], hb[j], c1[rg][4 * hf + j], 0, 0, 0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)   // a1 . b2
+                                    cx[rg][4 * hf + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa1[rg], lb[j], cx[rg][4 * hf + j], 0, 0, 0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)   // a2 . b1
+                                    cx[rg][4 * hf + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa2[rg], hb[j], cx[rg][4 * hf + j], 0, 0, 0);
+                            }
+                        }
+                        if (hf == 0 && late && !K2_DIAG(2)) K2_ISSUE();
+                    }
+                    cbuf = cbuf + DSLAB * 4 == RING * DSLAB * 4 ? 0 : cbuf + DSLAB * 4;
+                    continue;
+                }
                 f32x4 fa, fb[4], ga, gb[4];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -468,10 +553,133 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 cbuf = cbuf + DSLAB * 4 == RING * DSLAB * 4 ? 0 : cbuf + DSLAB * 4;
             }
             if (K2_DIAG(4)) {
+                if (S16) {
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                        for (int cg = 0; cg < 8; ++cg) asm volatile("" ::"v"(c1[rg][cg]), "v"(cx[rg][cg]));
+                }
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
+                    if (S16) continue;
                     if (I8) asm volatile("" ::"v"(acc1[nn]), "v"(accx[nn]));
                     else asm volatile("" ::"v"(acc[nn]));
+                }
+                continue;
+            }
+            if (S16) {
+                // ---- epilogue of the 16 x 16 accumulators: a lane holds 8 columns (16 cg + lane % 16) of rows 16 rg + 4 (lane / 16) + i;
+                // sixteen lanes share a row.  Keys, bound test, transposed appends and appends as below, column order kept.
+                float nj8[8], tj8[8], fj8[8], sj8[8], cb8[8];
+                int cj8[8];
+                {
+                    const unsigned sna = sn0 + (unsigned)(((ct & (SN - 1)) * 3 * BN + l15) * 4);
+                    lds_read_b32x8(sna, nj8);
+                    if (SYM) lds_read_b32x8(sna + BN * 4, tj8);
+                    lds_read_b32x8(sna + 2 * BN * 4, fj8);
+#pragma unroll
+                    for (int cg = 0; cg < 8; ++cg) {
+                        cj8[cg] = (int)(colbase + cg * 16 + l15);
+                        if (!SYM) tj8[cg] = finf;
+                    }
+                }
+                {
+                    const int mycnt = lds_read_i32(cur0 + (unsigned)((w * 32 + l31) * 4));
+                    unsigned long long need = __ballot(lane < 32 && mycnt > CAP - BN);
+                    if (COLLECT) {
+                        if (need) {
+                            const int rl = w * 32 + l31;
+                            if (lane < 32 && s_cur[rl] > CAP - BN) {
+                                s_ta[rl].x = -finf;
+                                s_drop[rl] = 2;
+                            }
+                            AS_LDS_FENCE();
+                        }
+                        need = 0;
+                    }
+                    while (need) {
+                        const int r = __ffsll((long long)need) - 1;
+                        const unsigned rr = w * 32 + r;
+                        compact_row_reg(a.M, bkey + rr * CAP, bidx + rr * CAP, s_cur[rr], &s_ta[rr].x, s_cur + rr, s_drop + rr,
+                                        SYM && a.thr_pub ? a.thr_pub + (rowbase + rr) : nullptr);
+                        need &= need - 1;
+                    }
+                }
+                const int64_t colg = a.col_goff + colbase, rowg = a.row_goff + rowbase;
+                const bool edge = COLLECT || colbase + BN > a.n || (colg < rowg + BM && colg + BN > rowg);
+                const bool transp = SYM && a.t_cnt && (a.t_all || colbase >= rowbase + BM);
+#pragma unroll
+                for (int cg = 0; cg < 8; ++cg) {
+                    sj8[cg] = METRIC == AS_METRIC_L2 ? fj8[cg] : nj8[cg] * fj8[cg];
+                    cb8[cg] = !transp || cj8[cg] >= (int)a.n ? -finf : (METRIC == AS_METRIC_L2 ? a.epskey + a.coef * (nj8[cg] + a.nmax) : a.epskey + a.coef);
+                    if (transp && a.thr_col && cj8[cg] < (int)a.n) cb8[cg] = fminf(cb8[cg], tj8[cg]);
+                }
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    // (bound, norm) of rows 16 rg + 4 (lane / 16) + {0..3}: 32 contiguous bytes; their scales: 16
+                    f32x4 tg0, tg1, fg = {1, 1, 1, 1};
+                    lds_read_b128x2(ta16 + (unsigned)(128 * rg), tg0, tg1);
+                    if (METRIC == AS_METRIC_L2) fg = lds_read_b128(sfa16 + (unsigned)(64 * rg));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rl = w * 32 + rg * 16 + 4 * g4 + i;
+                        const f32x4 tq = (i & 2) ? tg1 : tg0;
+                        const float thr = (i & 1) ? tq[2] : tq[0], ai = (i & 1) ? tq[3] : tq[1];
+                        const float fi = METRIC == AS_METRIC_L2 ? fg[i] : ai;
+                        float key[8];
+#pragma unroll
+                        for (int cg = 0; cg < 8; ++cg) {
+                            const float t = fmaf((float)c1[rg][cg][i], 128.0f, (float)cx[rg][cg][i]);
+                            const float gg = t * (fi * sj8[cg]);
+                            key[cg] = METRIC == AS_METRIC_L2 ? fmaf(-2.0f, gg, ai + nj8[cg]) : 1.0f - fmaxf(0.0f, gg);
+                        }
+                        const bool rowok = rowbase + rl < a.r1;
+                        bool any_t = false;
+                        if (transp) {
+#pragma unroll
+                            for (int cg = 0; cg < 8; ++cg) any_t = any_t || (rowok && key[cg] <= cb8[cg]);
+                        }
+                        if (transp && __ballot(any_t)) {
+                            const int rg_ = (int)(rowg + rl);
+#pragma unroll
+                            for (int cg = 0; cg < 8; ++cg)
+                                if (rowok && key[cg] <= cb8[cg]) {
+                                    const int slot = atomicAdd(a.t_cnt + cj8[cg], 1);
+                                    if (slot < a.t_cap) {
+                                        a.t_key[(size_t)cj8[cg] * a.t_cap + slot] = key[cg];
+                                        a.t_idx[(size_t)cj8[cg] * a.t_cap + slot] = rg_;
+                                    }
+                                }
+                        }
+                        if (edge) {
+                            const float excl = COLLECT ? __int_as_float(0x7fc00000) : finf;
+                            const int rg_ = COLLECT ? s_id[rl] : (int)(rowg + rl);
+#pragma unroll
+                            for (int cg = 0; cg < 8; ++cg)
+                                if (cj8[cg] >= (int)a.n || cj8[cg] + (int)a.col_goff == rg_) key[cg] = excl;
+                        }
+                        float kmin = key[0];
+#pragma unroll
+                        for (int cg = 1; cg < 8; ++cg) kmin = fminf(kmin, key[cg]);
+                        if (__ballot(kmin <= thr)) {
+#pragma unroll
+                            for (int cg = 0; cg < 8; ++cg) {
+                                const bool p = key[cg] <= thr;
+                                const unsigned long long mk = __ballot(p);
+                                if (!mk) continue;
+                                const unsigned gm = (unsigned)(mk >> (16 * g4)) & 0xffffu;   // this row's sixteen lanes
+                                const int base = s_cur[rl];
+                                if (p) {
+                                    const unsigned slot = (unsigned)rl * CAP + base + __popc(gm & ((1u << l15) - 1u));
+                                    bkey[slot] = key[cg];
+                                    bidx[slot] = cj8[cg] + (int)a.col_goff;
+                                }
+                                AS_CBAR();
+                                s_cur[rl] = base + __popc(gm);
+                                AS_CBAR();
+                            }
+                        }
+                    }
                 }
                 continue;
             }
@@ -653,9 +861,14 @@ as_status launch_k2_bf16(const KnnArgs& ka, int metric, bool collect, bool sym, 
         }
     }
 #endif
+    // (A/B: ARROWSPACE_K2_MFMA16=0 keeps the 32x32x32 shape on the int8 image)
+    static const bool s16 = !(getenv("ARROWSPACE_K2_MFMA16") && atoi(getenv("ARROWSPACE_K2_MFMA16")) == 0);
 #define AS_K2B(MM, CC, SS)                                                                                                        \
     do {                                                                                                                          \
-        if (i8) {                                                                                                                 \
+        if (i8 && s16) {                                                                                                          \
+            AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<MM, CC, SS, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \
+            hipLaunchKernelGGL((knn_bf16_kernel<MM, CC, SS, 0, true, true>), dim3(grid), dim3(512), K2BF_LDS, st, ka);             \
+        } else if (i8) {                                                                                                          \
             AS_HIP(hipFuncSetAttribute((const void*)knn_bf16_kernel<MM, CC, SS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2BF_LDS)); \
             hipLaunchKernelGGL((knn_bf16_kernel<MM, CC, SS, 0, true>), dim3(grid), dim3(512), K2BF_LDS, st, ka);                   \
         } else {                                                                                                                  \

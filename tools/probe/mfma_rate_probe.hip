@@ -1,6 +1,8 @@
 // Sustained matrix-pipe rate on RANDOM operands (the chip lowers its clock under load: MI355X_MICROARCH.md, DVFS give-back):
 // v_mfma_f32_32x32x16_bf16 against v_mfma_i32_32x32x32_i8, operands in registers, 2 waves per SIMD, 4 accumulators per wave.
-// usage: mfma_rate_probe            prints TMAC/s of both and their ratio
+// KIND 2: v_mfma_i32_16x16x64_i8 on the same 32 x 128 output tile per wave (2 x 8 accumulators of 16 x 16), the same products per
+// iteration -- the guide's DVFS item 7 measured the 16x16 bf16 shape at 1.12-1.15 x the 32x32 one on random data.
+// usage: mfma_rate_probe            prints TMAC/s of each and the ratios
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +23,25 @@ __global__ __launch_bounds__(512) void k(const f32x4* __restrict__ src, float* o
     }
     f32x16 accf[4] = {};
     i32x16 acci[4] = {};
+    if (KIND == 2) {
+        i32x4 b8[8], acc16[2][8] = {};
+        for (int i = 0; i < 8; ++i) b8[i] = __builtin_bit_cast(i32x4, src[(t * 16 + 8 + i) & 0xfffff]);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 8; ++v)
+                        acc16[rg][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a[rg * 2 + u]), b8[v], acc16[rg][v], 0, 0, 0);
+        }
+        float s2 = 0;
+        for (int rg = 0; rg < 2; ++rg)
+            for (int v = 0; v < 8; ++v)
+                for (int r = 0; r < 4; ++r) s2 += (float)acc16[rg][v][r];
+        out[t] = s2;
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -50,19 +71,20 @@ int main() {
     hipMemcpy(d, h.data(), n * 16, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    double rate[2];
-    for (int kind = 0; kind < 2; ++kind) {
+    double rate[3];
+    for (int kind = 0; kind < 3; ++kind) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
             if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, d, o, iters);
-            else hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, d, o, iters);
+            else if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, d, o, iters);
+            else hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, d, o, iters);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            const double macs = 256.0 * 8 * iters * 16.0 * 32 * 32 * (kind == 0 ? 16 : 32);
+            const double macs = 256.0 * 8 * iters * 16.0 * 32 * 32 * (kind == 0 ? 16 : 32);   // (kind 2: 32 instructions of 16 x 16 x 64 = the same products)
             rate[kind] = macs / (ms * 1e-3) / 1e12;
-            printf("%s: %.1f ms, %.1f TMAC/s (%.1f TOP/s)\n", kind == 0 ? "bf16 32x32x16" : "i8   32x32x32", ms, rate[kind], 2 * rate[kind]);
+            printf("%s: %.1f ms, %.1f TMAC/s (%.1f TOP/s)\n", kind == 0 ? "bf16 32x32x16" : (kind == 1 ? "i8   32x32x32" : "i8   16x16x64"), ms, rate[kind], 2 * rate[kind]);
         }
     }
-    printf("ratio i8 / bf16 = %.2f\n", rate[1] / rate[0]);
+    printf("ratio i8 / bf16 = %.2f, i8 16x16x64 / 32x32x32 = %.3f\n", rate[1] / rate[0], rate[2] / rate[1]);
     return 0;
 }
