@@ -689,6 +689,21 @@ def main():
             threaded[str(nthr)] = {"value": nthr * per / dth, "unit": "queries/s", "host_threads": nthr, "queries": nthr * per,
                                    "algorithmic_speedup": n * (d + 2) * 4.0 * nthr * per / dth / 1e9 / HBM_PEAK_GBS, "errors": errs[:2]}
         threaded["pool_size"] = aspace.search_pool_size
+        threaded["gang_scans_by_members"] = aspace.gang_counters()   # scans that served 1 / 2 / 3 / 4 callers at once
+        threaded["note"] = ("\"2\", \"4\": Python threads (the interpreter lock serialises what the threads do between two calls, a wake-up of tens of "
+                            "microseconds each); native_*: the same closed loops from native threads against the C ABI (tools/probe/thread_driver.cpp). "
+                            "Callers that arrive together share ONE pass over the items (gang scans, DESIGN.md 5.4)")
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import thread_bench
+
+            per = max(args.steps, 64)
+            for nthr in (1, 2, 4):
+                rate, errs, gangs = thread_bench.native_rate(aspace, gl, Q[args.warmup:], args.tau, nthr, per)
+                threaded["native_%d" % nthr] = {"value": rate, "unit": "queries/s", "host_threads": nthr, "queries": nthr * per, "errors": errs,
+                                                "scans_by_members": gangs}
+        except Exception as e:      # noqa: BLE001 -- a side key must not cost the headline line
+            threaded["native_error"] = "%s: %s" % (type(e).__name__, e)
 
     # extension, reported next to the headline, never as it: batched search, 32 query
     # slots per pass over the items (GEMM-shaped scan on fp32 MFMA)
@@ -777,8 +792,9 @@ def main():
     scan_coarse = scan_operand == "int8-high"   # the image's high digits alone: 1 B per element
     scan_moved = rows_per_gpu * ((1.0 if scan_coarse else 2.0) * d8 + 12.0) if scan_i8 else scan_bytes   # bytes the launch moves: image + norms + scales + dots
     if threaded:
-        for key in ("2", "4"):
-            threaded[key]["frac"] = scan_moved * threaded[key]["value"] / 1e9 / HBM_PEAK_GBS
+        for key in ("2", "4", "native_1", "native_2", "native_4"):
+            if key in threaded:
+                threaded[key]["frac"] = scan_moved * threaded[key]["value"] / 1e9 / HBM_PEAK_GBS
     # N > 1: every rank's own scan (its rows, its launch time, its operand) next to rank 0's, and the ranks the collective
     # layer really connected (an all-reduce of ones: RCCL over xGMI, or gloo when the ranks of a rehearsal share a card)
     ranks_seen, per_rank = world if dist is None else None, None

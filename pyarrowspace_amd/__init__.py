@@ -341,6 +341,15 @@ class ArrowSpace:
         (ctypes releases the GIL around the call), each concurrent call runs on a workspace and stream of its own."""
         return int(_L.as_search_pool_size(self._h))
 
+    def gang_counters(self) -> list:
+        """Extension: scans shared by concurrent `search` callers -- [launched with 1 member, 2, 3, 4] (gang scans: host threads whose
+        searches arrive together are served by one pass over the items)."""
+        out = np.zeros(4, dtype=np.int64)
+        st = _L.as_gang_counters(self._h, out.ctypes.data_as(C.c_void_p), 4)
+        if st:
+            _raise(st)
+        return [int(v) for v in out]
+
     def save(self, gl: GraphLaplacian, path: str) -> None:
         """Extension: write the built index (items, lambdas, graph) to one file."""
         st = _L.as_index_save(self._h, gl._h, os.fsencode(path))

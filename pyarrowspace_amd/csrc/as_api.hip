@@ -672,11 +672,21 @@ static as_status search_single(const as_space* sp, const as_graph* gr, as_query*
 static as_status search_pooled(const as_space* sp, const as_graph* gr, const double* query, int64_t d, double tau, int64_t* out_idx,
                                double* out_score, int64_t* out_len, double* out_lambda_q) {
     AS_HIP(hipSetDevice(sp->device));
+    // (what gang_launch goes by: callers inside as_search on this space right now, and whether two or more were seen lately)
+    const int act = sp->active_callers.fetch_add(1, std::memory_order_relaxed) + 1;
+    // (gang_width: the most callers seen at once over the last 64 searches or so -- restarted from the current count every 64th)
+    if ((sp->gang_tick.fetch_add(1, std::memory_order_relaxed) & 63) == 0 || act > sp->gang_width.load(std::memory_order_relaxed))
+        sp->gang_width.store(act, std::memory_order_relaxed);
+    if (act >= 2) sp->gang_hint.store(64, std::memory_order_relaxed);
+    else if (sp->gang_hint.load(std::memory_order_relaxed) > 0) sp->gang_hint.fetch_sub(1, std::memory_order_relaxed);
     int slot = -1;
     as_query* q = nullptr;
-    AS_TRY(pool_acquire(sp, gr, &slot, &q));
-    const as_status s = search_single(sp, gr, q, query, d, tau, out_idx, out_score, out_len, out_lambda_q);
-    pool_release(sp, slot);
+    as_status s = pool_acquire(sp, gr, &slot, &q);
+    if (s == AS_OK) {
+        s = search_single(sp, gr, q, query, d, tau, out_idx, out_score, out_len, out_lambda_q);
+        pool_release(sp, slot);
+    }
+    sp->active_callers.fetch_sub(1, std::memory_order_relaxed);
     return s;
 }
 
@@ -697,6 +707,16 @@ static as_status graph_matches(const as_space* sp, const as_graph* gr, const cha
 int32_t as_space_knn_pipe(const as_space* sp) { return sp ? sp->k2_last_pipe : -1; }
 int32_t as_last_scan_int8(const as_space* sp) { return sp && sp->qcache ? as_query_scan_int8(sp->qcache) : 0; }
 int32_t as_last_batch_int8(const as_space* sp) { return sp && sp->qcache_b ? as_query_scan_int8(sp->qcache_b) : 0; }
+
+as_status as_gang_counters(const as_space* sp, int64_t* out, int32_t n) {
+    if (!sp || !out) {
+        set_err("as_gang_counters: null argument");
+        return AS_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(sp->gmu);
+    for (int i = 0; i < n && i < 4; ++i) out[i] = sp->gang_scans[i + 1];
+    return AS_OK;
+}
 
 int32_t as_search_pool_size(const as_space* sp) {
     if (!sp) return 0;

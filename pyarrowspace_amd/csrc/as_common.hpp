@@ -1,5 +1,6 @@
 // Shared host/device definitions for the gfx950 hot path (not part of the C ABI).
 #pragma once
+#include <memory>
 #include <atomic>
 #include <hip/hip_runtime.h>
 
@@ -100,6 +101,22 @@ struct as_space {
     mutable as_query* qcache_b2 = nullptr;    // its twin: passes alternate, one scans while the other finishes
     mutable const as_graph* qcache_b_gr = nullptr;
     mutable std::mutex qmu;
+    // Gang scans (as_search.hip, gang_launch): single queries of host threads that arrive together share ONE pass over the tiles
+    // of the coarse image.  active_callers: threads inside as_search on this space right now; gang_hint > 0: two or more were seen
+    // within the last 64 searches (a lone thread never lingers); gang_width: the most seen at once lately; gang_open: the gang
+    // that is gathering members (under gmu).
+    mutable std::mutex gmu;
+    mutable std::atomic<int> active_callers{0};
+    mutable std::atomic<int> gang_hint{0};
+    mutable std::atomic<int> gang_width{1};
+    mutable std::atomic<unsigned> gang_tick{0};
+    mutable std::shared_ptr<struct as_gang> gang_open;
+    // one shared scan at a time, in the order the gangs were opened: the ticket of the next gang to open / to launch, and the event
+    // behind the scan launched last (a workspace's gang_ev)
+    mutable int64_t gang_seq_next = 0;                 // under gmu
+    mutable std::atomic<int64_t> gang_seq_launched{0};
+    mutable std::atomic<hipEvent_t> last_scan_ev{nullptr};
+    mutable int64_t gang_scans[5] = {0, 0, 0, 0, 0};   // scans launched with 1 .. 4 members (index = members; under gmu)
     // as_search_counters: [0] searches, [1] zero-lambda results, [2] reruns because the k-NN a-posteriori check failed,
     // [3] reruns because a candidate buffer overflowed, [4] reruns because the scorer's check failed, [5] searches that
     // took at least one rerun (under qmu)

@@ -96,8 +96,20 @@ struct HostOut {
 };
 
 struct RSel;
+struct PreArgs;
 
 }  // namespace as
+
+// a gang: the workspaces whose coarse scans run as ONE launch (as_search.hip, gang_launch)
+struct as_gang {
+    as_query* m[4] = {nullptr, nullptr, nullptr, nullptr};
+    as::PreArgs* pre = nullptr;      // [4], owned
+    std::atomic<int> n{0};           // members so far (the leader is member 0)
+    std::atomic<int> state{0};       // 0 gathering, 1 launched (the leader's gang_ev is recorded), 2 the launch failed
+    hipEvent_t ev = nullptr;         // the leader's event
+    int64_t seq = 0;                 // the gang's place in the space's order of shared scans
+    ~as_gang();
+};
 
 struct as_query {
     const as_space* sp = nullptr;
@@ -165,6 +177,8 @@ struct as_query {
     int xknn_dirty = 0;                  // ... its counter may be non-zero (a pass died before its finish kernel)
     void* xknn = nullptr;                // [CAND_CAP] exact (id, key, distance, gy) of the coarse scan's k-NN candidates (staged_x1_kernel, xk)
     int pool_slot = 0;       // slot in the space's pool of single-query workspaces (as_search): picks the stream's priority
+    int gang_ok = 0;         // set by search_once around query_begin: this scan may be shared with other callers' (gang_launch)
+    hipEvent_t gang_ev = nullptr;   // recorded behind a gang's scan on its leader's stream: the followers' tails wait for it
     float* dots32 = nullptr; // [np]
     float* part32 = nullptr; // batched workspace of rows wider than 768 floats: [K-chunk pass][slots x np] fp32 partial dots (as_scan.hip, gemm_chunks)
     double* dots64 = nullptr;
@@ -260,6 +274,7 @@ double coef_query(const as_query* q, bool exact);
 int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products);
 PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
 as_status launch_scan(as_query* q, const PreArgs& pre);
+as_status launch_scan_gang(as_query* const* m, const PreArgs* pre, int n, hipStream_t st);
 void set_tile_geom(int v);
 as_status set_scan_attrs();   // per-device dynamic-LDS opt-in of the scan kernels
 

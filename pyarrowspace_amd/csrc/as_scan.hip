@@ -608,6 +608,8 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // nothing behind.  A dropped row has score < tau (B - W) + (1 - tau) <= the score of each of the >= M kept rows with
 // cosine >= B: the M best scores are all in the buffer, and the finish kernel's a-posteriori proof applies unchanged.
 constexpr int SC_PEND = 128;   // per-wave list of pending candidates (cosine, row)
+constexpr int TILE_PEND = 256;  // ... of the tile scan (scan_chunk_end), GANG_PEND: per query of a gang scan
+constexpr int GANG_PEND = 192;
 constexpr int SC_BINS = 64;
 __device__ __forceinline__ void lds_write2(unsigned addr, float a, int b) {   // 8-byte aligned
     const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)(unsigned)b << 32);
@@ -652,8 +654,14 @@ struct ScanWave {
     bool thr_known = false;
     int jb_last = -1;
     int sc_over = 0;             // SC: the list overflowed (the wave reports -1 candidates: the host takes the threshold chain)
+    float floor = -3.0e38f;      // SC: the largest cosine the wave let go of while it had no bound tight enough (scan_chunk_end)
 };
-template <bool SC>
+// PEND: entries of the wave's pending list.  Until the wave knows a bound (its third chunk at the earliest: the histogram must hold
+// M rows) every row is kept: 128 entries last exactly to that third chunk -- enough when all waves of the launch run side by
+// side, not when the launch shares the chip (another query's tail kernels on half the CUs when it starts: the waves that run
+// ahead find too few rows published and report an overflow).  The tile kernels keep 256 / 192 entries and read the histogram at
+// every chunk until they have a bound.
+template <bool SC, int PEND = SC_PEND>
 __device__ __forceinline__ void scan_chunk_end(const PreArgs& pre, ScanWave& w, float* __restrict__ dots, int t, int rounds, int64_t gw, int lane,
                                                int64_t base, int cnt, float mydot, float aux, bool hread, unsigned hx0, unsigned px0,
                                                float nq32, float inq32) {
@@ -705,10 +713,10 @@ __device__ __forceinline__ void scan_chunk_end(const PreArgs& pre, ScanWave& w, 
             if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0) atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
         }
         // candidates: c >= thr -- a NaN cosine (a poisoned row) never qualifies, as under the plain chain's `key <= thr`
-        const bool pass = valid && c >= thr && !AS_SC_DBG(4);
-        const unsigned long long pm = __ballot(pass);
-        const int np = __popcll(pm);
-        if (w.npend + np > SC_PEND) {
+        bool pass = valid && c >= thr && !AS_SC_DBG(4);
+        unsigned long long pm = __ballot(pass);
+        int np = __popcll(pm);
+        if (w.npend + np > PEND) {
             // re-test the list against the bound known now (rows kept before a bound existed); flush what is left
             int keep = 0;
             for (int e0 = 0; e0 < w.npend; e0 += 64) {
@@ -723,7 +731,55 @@ __device__ __forceinline__ void scan_chunk_end(const PreArgs& pre, ScanWave& w, 
                 keep += __popcll(km);
             }
             w.npend = keep;
-            if (w.npend + np > SC_PEND) {   // more than the list holds even under the current bound: this query is not for the fused tail
+            if (w.npend + np > PEND && (PEND + 63) / 64 <= 4) {
+                // More than the list holds under the bound the wave knows -- none at all, when the launch shares the chip and the
+                // waves that run ahead find too few rows published.  The wave then keeps the PEND rows of the LARGEST cosines (list
+                // and this chunk's together) and remembers the largest cosine it let go (w.floor): lossless as long as the bound
+                // the wave ends with lies above it (scan_wave_report says "overflow" otherwise).  The cut is found by bisection
+                // over the order-preserving bit patterns of the cosines, entries in registers (up to four per lane); a rare path.
+                auto okey = [](float f) -> unsigned { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+                unsigned ek[4];
+                int er[4];
+                float ec[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = lane + 64 * u;
+                    ec[u] = 0.0f;
+                    er[u] = 0;
+                    if (e < w.npend) lds_read2(px0 + (unsigned)e * 8, ec[u], er[u]);
+                    ek[u] = e < w.npend ? okey(ec[u]) : 0xffffffffu;   // (absent entries sort above everything: never counted)
+                }
+                const unsigned nk = pass ? okey(c) : 0xffffffffu;
+                const int excess = w.npend + np - PEND;
+                // smallest cut with at least `excess` entries at or below it
+                unsigned lo = 0u, hi = 0xfffffffeu;
+                while (lo < hi) {   // (wave-uniform: 32 trips)
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    int cntl = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cntl += __popcll(__ballot(ek[u] <= mid));
+                    cntl += __popcll(__ballot(nk <= mid));
+                    if (cntl >= excess) hi = mid;
+                    else lo = mid + 1u;
+                }
+                const unsigned cut = lo;
+                const unsigned cb_ = (cut & 0x80000000u) ? (cut & 0x7fffffffu) : ~cut;   // back to the float it came from
+                w.floor = fmaxf(w.floor, __uint_as_float(cb_));
+                int keep2 = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {   // (in place: written positions are at or before the positions read by this or an earlier trip)
+                    const bool kp = ek[u] != 0xffffffffu && ek[u] > cut;
+                    const unsigned long long km = __ballot(kp);
+                    if (kp) lds_write2(px0 + (unsigned)(keep2 + __popcll(km & ((1ull << lane) - 1))) * 8, ec[u], er[u]);
+                    AS_LDS_FENCE();
+                    keep2 += __popcll(km);
+                }
+                w.npend = keep2;
+                pass = pass && nk > cut;
+                pm = __ballot(pass);
+                np = __popcll(pm);
+            }
+            if (w.npend + np > PEND) {   // (a list of more than 256 entries: no selection) this query is not for the fused tail
                 w.sc_over = 1;
                 w.npend = 0;
             }
@@ -752,6 +808,7 @@ __device__ __forceinline__ void scan_wave_report(const PreArgs& pre, ScanWave& w
                 const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
             }
+            if (!(thr > w.floor)) w.sc_over = 1;   // (rows the wave let go of might pass the bound it ends with)
             for (int e0 = 0; e0 < w.npend; e0 += 64) {
                 float ce = 0.0f;
                 int re = 0;
@@ -762,6 +819,15 @@ __device__ __forceinline__ void scan_wave_report(const PreArgs& pre, ScanWave& w
                 if (kp && pos < SC_WCAP - 1) region[1 + pos] = re;
                 keep += __popcll(km);
             }
+        } else if (w.npend == 0 && !w.sc_over && w.floor > -3.0e38f) {
+            // (nothing pending, but rows were let go of: the same question against the bound the wave knows)
+            float thr = w.thr_last;
+            if (!w.thr_known) {
+                int jb;
+                const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
+            }
+            if (!(thr > w.floor)) w.sc_over = 1;
         }
         if (lane == 0) region[0] = w.sc_over || keep > SC_WCAP - 1 ? -1 : keep;
     }
@@ -886,7 +952,10 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(const float* __restrict__
         // ... and then ever more rarely (chunks 2, 3, 5, 9, 17, ...): the read comes back later than a row's DMA and every
         // operation behind it retires behind it -- six reads per wave cost the 1M x 768 scan 8 us, and the bound hardly
         // moves once the first quarter of the rows has been seen
-        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0) && !AS_SC_DBG(2);
+        // (... and at every chunk for as long as the wave has no bound at all: a scan that shares the chip with another kernel has only
+        // part of its waves resident at first, and the waves that run ahead found an empty histogram at their third chunk, kept
+        // every row and reported an overflow -- "candidates did not fit" on every workspace of a 4-thread run)
+        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0 || w.jb_last < 0) && !AS_SC_DBG(2);
         if (hread)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
                                              (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 16);
@@ -984,7 +1053,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // U: items (KiB) per step
     constexpr int RING = NSLOT * 1024;            // bytes per wave
-    constexpr int WAVE_LDS = RING + 256 + 256 + (SC ? 256 + SC_PEND * 8 : 0);   // + the chunk's 64 norms, 64 scales (+ histogram, pending list)
+    constexpr int WAVE_LDS = RING + 256 + 256 + (SC ? 256 + TILE_PEND * 8 : 0);   // + the chunk's 64 norms, 64 scales (+ histogram, pending list)
     constexpr int K1 = NSLOT - 2 * U;             // DMA operations younger than the oldest pair of a full ring
     constexpr int KB = 3;                         // operations of a chunk boundary: the dots' store, the norm DMA, the scale DMA
     static_assert((U == 2 || U == 4) && NSLOT % U == 0 && NSLOT >= 2 * U, "ring of whole steps");
@@ -1081,7 +1150,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.fa8 + base + lane),
                                          (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 0);
         // SC: the histogram as the other waves have left it, consumed at the chunk's end (chunks 2, 3, 5, 9, 17, ...: scan_dma_kernel)
-        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0) && !AS_SC_DBG(2);
+        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0 || w.jb_last < 0) && !AS_SC_DBG(2);
         if (hread)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
                                              (__attribute__((address_space(3))) void*)(myp + RING + 512), 4, 0, 16);
@@ -1145,10 +1214,211 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
         // multiply-add makes
         const long long tot = (long long)(hi0 + hi1) * 128 + (long long)(xs0 + xs1);
         const float mydot = (float)tot * (lds_read1(fx0 + lane * 4) * pre.faq);
-        scan_chunk_end<SC>(pre, w, dots, t, rounds, gw, lane, base, cnt, mydot, aux, hread, hx0, px0, nq32, inq32);
+        scan_chunk_end<SC, TILE_PEND>(pre, w, dots, t, rounds, gw, lane, base, cnt, mydot, aux, hread, hx0, px0, nq32, inq32);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     scan_wave_report<SC>(pre, w, gw, lane, px0);
+#undef AS_TILE_ISSUE
+#undef AS_TILE_ENTER
+#undef AS_CHUNK
+}
+
+// Gang scan: ONE pass over the tiles for up to FOUR single queries of concurrent host threads (as_search is re-entrant: callers
+// that arrive together share the read of the image instead of competing for HBM with a scan each; as_search.hip, gang_join).
+// The products move to the matrix pipe, which the single-query kernel leaves idle: one v_mfma_i32_16x16x64_i8 per KiB and digit.
+// A DMA'd KiB is chunk c of 64 rows, lane l holding row l -- as the MFMA's A operand that reads "rows 0..15, four k-chunks", the
+// k-chunk g = l / 16 being row group g.  The B operand's 16 columns are SLOTS (query qq, row group g') = 4 qq + g': slot (qq, g')
+// carries query qq's digits of chunk c in k-chunk g' and zeros elsewhere, so D[r][4 qq + g'] = row (16 g' + r) . q_qq -- 64 rows x 4
+// queries per instruction.  A lane's B fragment is either its query's 16 digits or zeros: lanes of the second kind read a zero
+// line of LDS (their address does not move), no select in the loop.  Per KiB: one counted wait, one DMA, three LDS reads, two
+// MFMAs -- whatever the number of queries.  At the chunk's end the accumulators (result register i of lane l: row 16 (l % 4) +
+// 4 (l / 16) + i of query (l % 16) / 4) pass through LDS into "lane r holds row r", query by query, and every query runs the
+// chunk end of the single-query kernels on its own buffers.  Bit-identical dots: the integer sums are exact.
+struct GangArgs {
+    PreArgs p[4];
+    float* dots[4];
+};
+typedef int i32x4g __attribute__((ext_vector_type(4)));
+template <int NSLOT, int NQ>
+__global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* __restrict__ xt, int C, int64_t r0, int64_t r1, GangArgs ga, int rounds,
+                                                             int tail_rows, int crows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int U = 2;
+    constexpr int RING = NSLOT * 1024;
+    constexpr int QAREA = 256 + GANG_PEND * 8;                     // per query and wave: histogram landing area, pending list
+    constexpr int TR = NQ * 64 * 4 * 2;                            // per wave: the accumulators on their way to "lane r = row r" (HI and XS)
+    constexpr int WAVE_LDS = RING + 512 + NQ * QAREA + TR;
+    constexpr int K1 = NSLOT - 2 * U;
+    constexpr int KB = NQ + 2;                                     // a chunk boundary: NQ dot stores, the norm DMA, the scale DMA
+    static_assert(NSLOT % U == 0 && NSLOT >= 2 * U && NQ >= 2 && NQ <= 4, "ring of whole steps, two to four queries");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* myp = smem + wu * WAVE_LDS;
+    const unsigned s0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned my0 = s0 + wu * WAVE_LDS;
+    const unsigned ax0 = my0 + RING, fx0 = ax0 + 256, qa0 = fx0 + 256, tr0 = qa0 + NQ * QAREA;
+    // block: the queries' digits (per query C x 32 bytes: 16 of q1, 16 of q2 per chunk), then one zero line of 32 bytes
+    const int QS = C * 32;
+    const unsigned qx0 = s0 + 4 * WAVE_LDS, zx0 = qx0 + NQ * QS;
+    const signed char* pub = xt;
+    int pt = 0, pcol = 0, pcnt = 0, pslot = 0, inflight = 0;
+    int64_t pbase = 0;
+    unsigned pvoff = 0;
+    const size_t tile_bytes = (size_t)C * 1024;
+    const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
+    const int64_t tail0 = r0 + (int64_t)rounds * NW * crows;
+#define AS_CHUNK(t, base, cnt)                                                           \
+    do {                                                                                 \
+        if ((t) < rounds) {                                                              \
+            base = r0 + ((int64_t)(t) * NW + gw) * crows;                                 \
+            cnt = crows;                                                                 \
+        } else if ((t) == rounds) {                                                      \
+            base = tail0 + gw * tail_rows;                                               \
+            const int64_t left_ = r1 - base;                                             \
+            cnt = (int)(left_ < 0 ? 0 : (left_ < tail_rows ? left_ : tail_rows));        \
+        } else {                                                                         \
+            base = r1;                                                                   \
+            cnt = 0;                                                                     \
+        }                                                                                \
+    } while (0)
+#define AS_TILE_ENTER()                                                                                                  \
+    do {                                                                                                                 \
+        if (pcnt > 0) {                                                                                                  \
+            const int rl_ = lane < pcnt ? lane : pcnt - 1;                                                               \
+            const int tl_ = (int)(pbase & 63) + rl_;                                                                     \
+            pvoff = (unsigned)(tl_ >> 6) * (unsigned)tile_bytes + (unsigned)(tl_ & 63) * 16u;                            \
+            pub = xt + (size_t)(pbase >> 6) * tile_bytes;                                                                \
+        }                                                                                                                \
+    } while (0)
+#define AS_TILE_ISSUE()                                                                                                  \
+    do {                                                                                                                 \
+        if (pcnt > 0) {                                                                                                  \
+            _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                                                             \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pub + pvoff + u_ * 1024), \
+                                                 (__attribute__((address_space(3))) void*)(myp + (pslot + u_) * 1024), 16, 0, 2); \
+            pub += U * 1024;                                                                                             \
+            pslot = pslot + U == NSLOT ? 0 : pslot + U;                                                                  \
+            inflight += U;                                                                                               \
+            pcol += U;                                                                                                   \
+            if (pcol == C) {                                                                                             \
+                pcol = 0;                                                                                                \
+                ++pt;                                                                                                    \
+                AS_CHUNK(pt, pbase, pcnt);                                                                               \
+                AS_TILE_ENTER();                                                                                         \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
+    AS_CHUNK(0, pbase, pcnt);
+    AS_TILE_ENTER();
+#pragma unroll
+    for (int i = 0; i < NSLOT / U - 1; ++i) AS_TILE_ISSUE();
+    {
+        int* qd = (int*)(smem + 4 * WAVE_LDS);
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq)
+            for (int i = tid; i < C * 8; i += 256) qd[qq * C * 8 + i] = ga.p[qq].q8[i];
+        if (tid < 8) qd[NQ * C * 8 + tid] = 0;
+    }
+    float nq32[NQ], inq32[NQ];
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        const PreArgs& pre = ga.p[qq];
+        nq32[qq] = pre.nq32;
+        inq32[qq] = pre.inq32;
+        if (blockIdx.x == 0 && tid == 0) {   // (every member's query is host-prepared: what q_prepare would have filed)
+            pre.infow->nq = pre.nq;
+            pre.infow->inq = pre.inq;
+            pre.infow->nq32 = pre.nq32;
+            pre.infow->inq32 = pre.inq32;
+            pre.infow->tau = 1.0;
+        }
+        if (pre.q64_dev)
+            for (int g = (int)blockIdx.x * 256 + tid; g < pre.qdp; g += (int)gridDim.x * 256) pre.q64_dev[g] = pre.q64_host[g];
+    }
+    __syncthreads();
+    const float* __restrict__ auxv = ga.p[0].metric == AS_METRIC_L2 ? ga.p[0].n32 : ga.p[0].inorm32;
+    // this lane's B fragment: slot lane % 16 = (query qq, row group g'); its k-chunk is lane / 16: digits where g' == lane / 16
+    const int myq = (lane & 15) >> 2;
+    const bool bon = ((lane & 3) == (lane >> 4)) && myq < NQ;
+    const unsigned qstep = bon ? (unsigned)(U * 32) : 0u;
+    unsigned qa = bon ? qx0 + (unsigned)(myq * QS) : zx0;
+    const unsigned qa_start = qa;
+    unsigned cur = 0;
+    int marked = 0;
+    bool first = true;
+    ScanWave w[NQ];
+    for (int t = 0; t <= rounds; ++t) {
+        int64_t base;
+        int cnt;
+        AS_CHUNK(t, base, cnt);
+        if (cnt <= 0) continue;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),
+                                         (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga.p[0].fa8 + base + lane),
+                                         (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 0);
+        bool nobound = false;   // (every member reads or none: the ring's counts assume NQ reads)
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) nobound = nobound || w[qq].jb_last < 0;
+        const bool hread = t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0 || nobound);
+        if (hread) {
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga.p[qq].sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
+                                                 (__attribute__((address_space(3))) void*)(myp + RING + 512 + qq * QAREA), 4, 0, 16);
+        }
+        marked = first ? 0 : inflight;
+        const bool hmark = hread;
+        first = false;
+        i32x4g hi = {0, 0, 0, 0}, xs = {0, 0, 0, 0};
+        qa = qa_start;
+        for (int c = 0; c < C; c += U) {
+            if (inflight == NSLOT - U) {
+                if (marked > 0 && hmark) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB + NQ) : "memory");
+                else if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            marked = marked > U ? marked - U : 0;
+            inflight -= U;
+            AS_TILE_ISSUE();
+            i32x4g xv0, xv1, b10, b20, b11, b21;
+            const unsigned a0 = my0 + cur + lane * 16;
+            asm volatile(
+                "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
+                "ds_read_b128 %4, %8\n\tds_read_b128 %5, %8 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(xv0), "=&v"(xv1), "=&v"(b10), "=&v"(b20), "=&v"(b11), "=&v"(b21)
+                : "v"(a0), "v"(qa), "v"(qa + (qstep >> 1))
+                : "memory");
+            cur = cur + U * 1024 == RING ? 0 : cur + U * 1024;
+            qa += qstep;
+            hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv0, b10, hi, 0, 0, 0);
+            xs = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv0, b20, xs, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv1, b11, hi, 0, 0, 0);
+            xs = __builtin_amdgcn_mfma_i32_16x16x64_i8(xv1, b21, xs, 0, 0, 0);
+        }
+        if (C <= NSLOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float aux = lds_read1(ax0 + lane * 4);
+        const float fa = lds_read1(fx0 + lane * 4);
+        // the accumulators into "lane r holds row r": [HI | XS][query][64 rows]; lane l writes rows 16 (l % 4) + 4 (l / 16) + {0..3} of its query
+        if (myq < NQ) {
+            const unsigned ta = tr0 + (unsigned)((myq * 64 + 16 * (lane & 3) + 4 * (lane >> 4)) * 4);
+            asm volatile("s_nop 15\n\ts_nop 3\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:%3" ::"v"(ta), "v"(hi), "v"(xs), "n"(NQ * 256) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) {
+            const int h_ = (int)lds_read1u(tr0 + (unsigned)((qq * 64 + lane) * 4));
+            const int x_ = (int)lds_read1u(tr0 + (unsigned)(NQ * 256 + (qq * 64 + lane) * 4));
+            const long long tot = (long long)h_ * 128 + (long long)x_;
+            const float mydot = (float)tot * (fa * ga.p[qq].faq);
+            scan_chunk_end<true, GANG_PEND>(ga.p[qq], w[qq], ga.dots[qq], t, rounds, gw, lane, base, cnt, mydot, aux, hread, qa0 + (unsigned)(qq * QAREA),
+                                 qa0 + (unsigned)(qq * QAREA + 256), nq32[qq], inq32[qq]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) scan_wave_report<true>(ga.p[qq], w[qq], gw, lane, qa0 + (unsigned)(qq * QAREA + 256));
 #undef AS_TILE_ISSUE
 #undef AS_TILE_ENTER
 #undef AS_CHUNK
@@ -1362,8 +1632,12 @@ static constexpr size_t dma_lds(int nch, int nslot, bool sc = false, bool i8 = f
 static std::atomic<int> g_tile_geom{getenv("ARROWSPACE_TILE_GEOM") ? atoi(getenv("ARROWSPACE_TILE_GEOM")) : 208};
 void set_tile_geom(int v) { g_tile_geom.store(v, std::memory_order_relaxed); }
 
+static constexpr size_t gang_lds(int nslot, int nq, int64_t chunks) {
+    return 4 * ((size_t)nslot * 1024 + 512 + (size_t)nq * (256 + GANG_PEND * 8) + (size_t)nq * 512) + (size_t)nq * chunks * 32 + 32;
+}
+
 static constexpr size_t tile_lds(int nslot, bool sc, int64_t chunks) {
-    return 4 * ((size_t)nslot * 1024 + 512 + (sc ? 256 + SC_PEND * 8 : 0)) + (size_t)chunks * 32;
+    return 4 * ((size_t)nslot * 1024 + 512 + (sc ? 256 + TILE_PEND * 8 : 0)) + (size_t)chunks * 32;
 }
 
 // The dynamic-LDS opt-in is a per-device attribute of a kernel: set it for every scan kernel on the device a
@@ -1387,6 +1661,9 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_tile_kernel<12, true>), tile_lds(12, true, 256));
     AS_ATTR((scan_tile_kernel<16, true>), tile_lds(16, true, 256));
     AS_ATTR((scan_tile_kernel<8, false>), tile_lds(8, false, 256));
+    AS_ATTR((scan_tile_gang_kernel<8, 2>), gang_lds(8, 2, 256));
+    AS_ATTR((scan_tile_gang_kernel<8, 3>), gang_lds(8, 3, 256));
+    AS_ATTR((scan_tile_gang_kernel<8, 4>), gang_lds(8, 4, 256));
     AS_ATTR((scan_tile_kernel<8, true, 4>), tile_lds(8, true, 256));
     AS_ATTR((scan_tile_kernel<12, true, 4>), tile_lds(12, true, 256));
     AS_ATTR((scan_tile_kernel<16, true, 4>), tile_lds(16, true, 256));
@@ -1421,6 +1698,53 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_dma_kernel<3, 5, true>), dma_lds(3, 5, true));
     AS_ATTR((scan_dma_kernel<4, 4, true>), dma_lds(4, 4, true));
 #undef AS_ATTR
+    return AS_OK;
+}
+
+// chunk schedule of a tile scan over `rows` rows that collects the scorer's candidates (launch_scan's, for the coarse operand)
+static void tile_schedule(const as_query* q, int64_t rows, int bpc, int64_t* nblk, int* rounds, int* tail_rows, int* crows) {
+    static const int sc_rows_per_block = getenv("ARROWSPACE_SC_ROWS_PER_BLOCK") ? atoi(getenv("ARROWSPACE_SC_ROWS_PER_BLOCK")) : 128;
+    const int64_t want = std::max<int64_t>(1, (rows + 63) / 64);
+    const int64_t want_sc = std::max<int64_t>(1, rows / std::max(sc_rows_per_block, 64));
+    *nblk = std::min<int64_t>(std::min(want, want_sc), bpc * (int64_t)q->cus);
+    const int64_t NW = *nblk * 4;
+    auto chunks = [&](int c) { return rows / (NW * c) + (rows % (NW * c) ? 1 : 0); };
+    *crows = chunks(64) >= 2 ? 64 : (chunks(32) >= 2 ? 32 : (chunks(16) >= 2 ? 16 : 64));
+    *rounds = (int)(rows / (NW * *crows));
+    const int64_t rem = rows - (int64_t)*rounds * NW * *crows;
+    *tail_rows = (int)((rem + NW - 1) / NW);
+}
+
+// ONE coarse tile scan for the single queries of n = 2 .. 4 workspaces of one space (every member host-prepared, coarse, collecting
+// scorer candidates, over all rows), on `st`; pre[i] = make_pre of member i
+as_status launch_scan_gang(as_query* const* m, const PreArgs* pre, int n, hipStream_t st) {
+    const as_space* sp = m[0]->sp;
+    const int64_t rows = m[0]->r1 - m[0]->r0;
+    if (n < 2 || n > 4 || rows <= 0 || !sp->x8h) {
+        set_err("launch_scan_gang: bad gang");
+        return AS_EINVAL;
+    }
+    int64_t nblk;
+    int rounds, tail_rows, crows;
+    tile_schedule(m[0], rows, 2, &nblk, &rounds, &tail_rows, &crows);
+    GangArgs ga;
+    for (int i = 0; i < 4; ++i) {
+        ga.p[i] = pre[i < n ? i : 0];
+        ga.dots[i] = m[i < n ? i : 0]->dots32;
+    }
+    for (int i = 0; i < n; ++i) {
+        m[i]->sc_nw = (int)(nblk * 4);
+        m[i]->dots_half = 0;
+    }
+    const int C = (int)(sp->dp8 / 16);
+    const signed char* xt = (const signed char*)sp->x8h;
+    if (n == 2)
+        hipLaunchKernelGGL((scan_tile_gang_kernel<8, 2>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 2, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
+    else if (n == 3)
+        hipLaunchKernelGGL((scan_tile_gang_kernel<8, 3>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 3, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
+    else
+        hipLaunchKernelGGL((scan_tile_gang_kernel<8, 4>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 4, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
+    AS_HIP(hipGetLastError());
     return AS_OK;
 }
 

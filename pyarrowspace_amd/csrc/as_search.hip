@@ -10,6 +10,7 @@
 // ranks the few survivors.  Survivors are re-evaluated in fp64 and an a-posteriori check
 // proves the result equals the fp64 answer, else the search is rerun in fp64.  A
 // wavefront-shuffle list path (WaveList) is kept as the overflow fallback.
+#include <chrono>
 #include "as_query.hpp"
 
 namespace as {
@@ -1879,7 +1880,10 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         for (int64_t c = threadIdx.x; c < ak.dp; c += blockDim.x) qs[c] = ak.q64[c];
         qx = qs;
     }
-    char* work = smem + sizeof(double) * Q_LDS_MAX;
+    // (the coarse tail's blocks take only what the query needs in front of their 64 KB of work area -- 70 KB at 768 columns: a CU
+    // keeps two blocks of a scan beside one of them; with the 137 KB of the other form a tail kernel held back the scan blocks of
+    // the next caller's search on half the chip)
+    char* work = smem + (xk ? (ak.dp <= Q_LDS_MAX ? sizeof(double) * (size_t)ak.dp : 0) : sizeof(double) * Q_LDS_MAX);
     if (blockIdx.x == 0 && !xk) {
         knn_finish_body<float>(ak, work, qx);
         if (threadIdx.x == 0) {   // (wave 0 ran the whole body: its own stores)
@@ -1932,7 +1936,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         if (s_ovf || tot > room) {
             if (threadIdx.x == 0) {
                 atomicOr(&head->flags, 16);
-                atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
+                atomicMax(&head->pad[0], tot >> 4);       // (what did not fit, in sixteens: read by the host's debug line only)
                 if (s_ovf) atomicAdd(&head->pad[1], 1);
             }
             tot = 0;
@@ -2000,7 +2004,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         const bool sc_fits = !(s_ovf || tot > X1_LOCAL_CAP);
         if (!sc_fits && threadIdx.x == 0) {
             atomicOr(&head->flags, 16);
-            atomicMax(&head->pad[0], tot);       // (what did not fit: read by the host's debug line only)
+            atomicMax(&head->pad[0], tot >> 4);       // (what did not fit, in sixteens: read by the host's debug line only)
             if (s_ovf) atomicAdd(&head->pad[1], 1);
         }
         const double nq = as_.info->nq;
@@ -2043,9 +2047,9 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
     if (s_ticket != nb - 1) return;
     const int raw = ak.info->knn_cnt;
     const int P = raw <= CAND_CAP ? __hip_atomic_load(xk_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    double* rk = (double*)work;            // P keys (P <= CAND_CAP: 32 KB + 16 KB + 16 KB of the work area)
+    double* rk = (double*)work;            // P keys (P <= CAND_CAP: 32 KB + 16 KB + 8 KB of the work area)
     int* ri = (int*)(rk + CAND_CAP);
-    int* sel = ri + CAND_CAP;              // entries that may be among the k nearest
+    unsigned short* sel = (unsigned short*)(ri + CAND_CAP);   // entries that may be among the k nearest (P <= CAND_CAP = 4096: 16 bits)
     __shared__ unsigned int khist[1024];
     __shared__ unsigned long long s_kmin, s_kmax;
     __shared__ int s_kbin, s_nsel;
@@ -2125,7 +2129,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
     __syncthreads();
     const int kbin = s_kbin;
     for (int u = threadIdx.x; u < P; u += blockDim.x)
-        if (kbin_of(rk[u]) <= kbin) sel[atomicAdd(&s_nsel, 1)] = u;
+        if (kbin_of(rk[u]) <= kbin) sel[atomicAdd(&s_nsel, 1)] = (unsigned short)u;
     __syncthreads();
     const int nsel = s_nsel;
     {
@@ -2300,6 +2304,9 @@ __global__ __launch_bounds__(1024) void staged_x1_final_kernel(const char* __res
         out->state_reset = clean;
         if (clean) reset_query_state(info);
         if (own_head) {   // this rank's block starts the next pass empty (its count and flags are accumulated by atomics)
+            // (what did not fit, for the host's debug line: candidates written, the largest share of a block that did not fit, blocks
+            // that met an overflowed wave report)
+            out->pad_ = (flags & 16) ? ((own_head->count & 0xffff) | ((own_head->pad[0] & 0xff) << 16) | ((own_head->pad[1] & 0xff) << 24)) : 0;
             own_head->count = 0;
             own_head->flags = 0;
             own_head->pad[0] = 0;
@@ -2776,6 +2783,104 @@ static bool batch_coef_holds(as_query* q) {
     return ok;
 }
 
+}  // namespace as
+as_gang::~as_gang() { delete[] pre; }
+namespace as {
+
+// Gang scans.  as_search is re-entrant, but N host threads that each launch a scan only share the HBM bandwidth one scan already
+// takes: 4 threads measured 0.84 x the single-thread rate in round 4.  Callers that arrive together share ONE pass instead
+// (scan_tile_gang_kernel: up to four queries per read of the tiles).  The first caller to arrive opens a gang and -- only when
+// concurrent callers were seen lately (a lone thread never waits) -- lingers a few microseconds for the callers it expects; those
+// that arrive meanwhile file their prepared workspace and wait for the leader's launch; the leader launches one kernel for all
+// on its own stream and records an event, every follower's stream waits for the event and each member runs its own tail and
+// publishes on its own stream as always.  Per-call results are bit-identical to serial runs: the scan's integer sums are exact
+// and everything a search returns is re-evaluated behind it.
+static double gang_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static as_status gang_launch(as_query* q, const PreArgs& pre) {
+    const as_space* sp = q->sp;
+    static const bool gang_off = getenv("ARROWSPACE_GANG") && atoi(getenv("ARROWSPACE_GANG")) == 0;
+    static const double linger_us = getenv("ARROWSPACE_GANG_LINGER_US") ? atof(getenv("ARROWSPACE_GANG_LINGER_US")) : 60.0;
+    if (gang_off || !q->gang_ok || sp->gang_hint.load(std::memory_order_relaxed) <= 0) return launch_scan(q, pre);
+    std::shared_ptr<as_gang> g;
+    bool leader = false;
+    {
+        std::lock_guard<std::mutex> lk(sp->gmu);
+        g = sp->gang_open;
+        if (g && g->n.load(std::memory_order_relaxed) < 4) {
+            const int my = g->n.load(std::memory_order_relaxed);
+            g->m[my] = q;
+            g->pre[my] = pre;
+            g->n.store(my + 1, std::memory_order_release);
+            if (my + 1 == 4) sp->gang_open.reset();
+        } else {
+            g = std::make_shared<as_gang>();
+            g->pre = new PreArgs[4];
+            g->m[0] = q;
+            g->pre[0] = pre;
+            g->n.store(1, std::memory_order_release);
+            g->seq = sp->gang_seq_next++;
+            sp->gang_open = g;
+            leader = true;
+        }
+    }
+    if (!leader) {
+        // (the leader launches once the scan in front of it has finished; a leader that failed says so)
+        while (g->state.load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
+        if (g->state.load(std::memory_order_acquire) != 1) return launch_scan(q, pre);
+        AS_HIP(hipStreamWaitEvent(q->stream, g->ev, 0));
+        return AS_OK;
+    }
+    // The leader waits for (a) its turn -- the gangs opened before this one have launched, and the scan launched last has
+    // FINISHED: one shared scan at a time per space.  Two scans at once only split the bandwidth, and a scan that shares the
+    // chip learns its cosine bound late (scan_chunk_end).  Callers that arrive meanwhile join: under load a gang gathers
+    // everybody who arrived during the previous scan.  (b) From its turn on, the callers it still expects (the most seen at once
+    // over the last 64 searches: they are busy with the tail of their previous scan or between two calls, and back within tens
+    // of microseconds), for at most linger_us.  Four closed-loop threads otherwise settle into scans of one and three callers
+    // in turn: the one that returns first never meets the others.  (Counting the callers inside as_search at that moment
+    // instead let the leader go the instant its partner was between two calls.)  A wait beyond 5 ms gives up waiting (never
+    // observed; a stuck event must not hang a search).
+    const int expect = std::min(4, std::max(sp->gang_width.load(std::memory_order_relaxed), sp->active_callers.load(std::memory_order_relaxed)));
+    const double t_open = gang_now_us();
+    double t_turn = -1.0;
+    for (;;) {
+        const double now = gang_now_us();
+        bool turn = sp->gang_seq_launched.load(std::memory_order_acquire) == g->seq;
+        if (turn) {
+            const hipEvent_t pe = sp->last_scan_ev.load(std::memory_order_acquire);
+            if (pe && hipEventQuery(pe) == hipErrorNotReady) turn = false;
+            else (void)hipGetLastError();
+        }
+        if (turn) {
+            if (t_turn < 0.0) t_turn = now;
+            const int n_now = g->n.load(std::memory_order_acquire);
+            if (n_now >= expect || now - t_turn >= linger_us) break;
+        }
+        if (now - t_open > 5000.0) break;
+        __builtin_ia32_pause();
+    }
+    int n;
+    {
+        std::lock_guard<std::mutex> lk(sp->gmu);
+        if (sp->gang_open == g) sp->gang_open.reset();   // closed: whoever comes now opens the next gang
+        n = g->n.load(std::memory_order_acquire);
+        sp->gang_scans[n] += 1;
+    }
+    as_status s = n == 1 ? launch_scan(q, pre) : launch_scan_gang(g->m, g->pre, n, q->stream);
+    if (s == AS_OK) {
+        if (!q->gang_ev && hipEventCreateWithFlags(&q->gang_ev, hipEventDisableTiming) != hipSuccess) s = AS_EHIP;
+        if (s == AS_OK && hipEventRecord(q->gang_ev, q->stream) != hipSuccess) s = AS_EHIP;
+        if (s != AS_OK) set_err("gang scan: %s", hipGetErrorString(hipGetLastError()));
+    }
+    g->ev = q->gang_ev;
+    if (s == AS_OK) sp->last_scan_ev.store(q->gang_ev, std::memory_order_release);
+    // (the next gang's turn: only ever advanced by the gang whose turn it is -- or by one that gave up waiting, to its own successor)
+    int64_t cur = sp->gang_seq_launched.load(std::memory_order_relaxed);
+    while (cur <= g->seq && !sp->gang_seq_launched.compare_exchange_weak(cur, g->seq + 1, std::memory_order_release)) {}
+    g->state.store(s == AS_OK ? 1 : 2, std::memory_order_release);
+    return s;
+}
+
 static as_status query_begin(as_query* q, const double* query_host, int64_t src_row, int64_t d, int64_t r0, int64_t r1,
                              double eps, int64_t exclude) {
     const as_space* sp = q->sp;
@@ -2838,11 +2943,15 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         // (device memory: the scan copies the fp64 query there on its way, PreArgs::q64_dev -- an empty row range launches no scan)
         q->q64_src = r1 > r0 ? q->q64 : q->hq_dev;
         q->q32_src = q->hq32_dev;
+        const bool was_clean = q->info_clean != 0;
         if (!q->info_clean) hipLaunchKernelGGL(reset_info_kernel, dim3(1), dim3(64), 0, st, q->info, q->sc_hist);
         q->info_clean = 0;
         if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
         const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !q->crowded_direct);
-        AS_TRY(launch_scan(q, pre));
+        // (a scan that may be shared with other callers': the coarse scan of a whole single space that collects scorer candidates,
+        // nothing queued on this workspace's stream that the scan must follow, no per-launch timing asked for)
+        if (q->gang_ok && q->coarse && pre.sc_enabled && was_clean && !stats && r0 == 0 && r1 == sp->n) AS_TRY(gang_launch(q, pre));
+        else AS_TRY(launch_scan(q, pre));
         if (stats) AS_HIP(hipEventRecord(q->ev[1], st));
         q->ev_valid = stats ? 1 : 0;
         return AS_OK;
@@ -3111,6 +3220,11 @@ void as_query_free(as_query* q) {
     if (q->hq32) hipHostFree(q->hq32);
     if (q->hq8) hipHostFree(q->hq8);
     if (q->hq8h) hipHostFree(q->hq8h);
+    if (q->gang_ev) {
+        hipEvent_t mine = q->gang_ev;
+        if (q->sp) q->sp->last_scan_ev.compare_exchange_strong(mine, nullptr);   // (nobody may poll an event that is gone)
+        hipEventDestroy(q->gang_ev);
+    }
     if (q->hx8stat) hipHostFree(q->hx8stat);
     if (q->q8img_dev) hipFree(q->q8img_dev);
     if (q->faqv_dev) hipFree(q->faqv_dev);
@@ -3253,7 +3367,8 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     }
     // (a rank that could not collect candidates -- no fused scan for this query here -- says so: every rank reads the flag and
     // the pass is rerun on the two-exchange chain)
-    hipLaunchKernelGGL(staged_x1_kernel, dim3(exact_knn ? X1_BLOCKS_COARSE : 1 + X1_BLOCKS), dim3(1024), x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
+    const size_t lds_xk = (sp->dp <= Q_LDS_MAX ? sizeof(double) * (size_t)sp->dp : 0) + (sizeof(double) + sizeof(int) + sizeof(short)) * (size_t)CAND_CAP + 64;
+    hipLaunchKernelGGL(staged_x1_kernel, dim3(exact_knn ? X1_BLOCKS_COARSE : 1 + X1_BLOCKS), dim3(1024), exact_knn ? lds_xk : x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
                        !sc_ran && rows > 0 ? 16 : 0, exact_knn ? (XKnn*)q->xknn : (XKnn*)nullptr);
     AS_HIP(hipGetLastError());
     q->x1_head = head;
@@ -3550,8 +3665,16 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     q->tau_cur = tau;
     static const bool fused_x1_on = !(getenv("ARROWSPACE_FUSED_X1") && atoi(getenv("ARROWSPACE_FUSED_X1")) == 0);
     q->allow_coarse = want_fused && fused_x1_on ? 1 : 0;   // (the coarse scan needs the two-launch tail: its k-NN candidates are evaluated by all blocks)
+    q->gang_ok = q->allow_coarse;
+    // (ARROWSPACE_HOST_TIMING=1: host microseconds of the fused path's parts -- preparation + scan launch, the two tail launches,
+    // the wait for the publication -- averaged over 200 searches, on stderr)
+    static const bool host_timing = getenv("ARROWSPACE_HOST_TIMING") != nullptr;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ht0 = host_timing ? now_us() : 0.0;
     const as_status qb = query_begin(q, query, -1, d, 0, q->sp->n, q->gr->gp.eps, -1);
+    const double ht1 = host_timing ? now_us() : 0.0;
     q->allow_coarse = 0;
+    q->gang_ok = 0;
     const bool fused = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->crowded_direct = 0;
     q->fused_tail = 0;
@@ -3573,15 +3696,32 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
         q->seq += 1;
         AS_TRY(x1_launch_block(q, q->x1_own, 1, true, q->coarse != 0));
         AS_TRY(x1_launch_final(q, q->x1_own, 1, tau));
+        const double ht2 = host_timing ? now_us() : 0.0;
         if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
         AS_TRY(wait_published(q));
+        if (host_timing) {
+            static double acc[4] = {0, 0, 0, 0}, last_end = 0.0;
+            static int cnt = 0;
+            const double ht3 = now_us();
+            acc[0] += ht1 - ht0; acc[1] += ht2 - ht1; acc[2] += ht3 - ht2;
+            if (last_end > 0.0) acc[3] += ht0 - last_end;
+            last_end = ht3;
+            if (++cnt == 200) {
+                fprintf(stderr, "[pyarrowspace] host us per search: prepare + scan launch %.1f, tail launches %.1f, wait %.1f, between calls (return, caller, entry) %.1f\n",
+                        acc[0] / 200, acc[1] / 200, acc[2] / 200, acc[3] / 199);
+                acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+                cnt = 0;
+                last_end = 0.0;
+            }
+        }
         q->x1_dirty = 0;
         q->xknn_dirty = 0;
         if (q->coarse && (q->hout->overflow & 5)) {
             // the coarse scan's candidates did not fit (its wider windows took in too many rows): the same query on the two-digit
             // image straight away -- the chains behind an overflow would price the coarse dots and fail their proofs
-            dbg("coarse scan: candidates did not fit (overflow bits %d, coefficient %.3e) -> the two-digit scan for this and the next 63 searches",
-                q->hout->overflow, q->coef_i8h);
+            dbg("coarse scan: candidates did not fit (overflow bits %d, coefficient %.3e; candidates written %d, a block's share that did not fit / 16: %d, blocks "
+                "with an overflowed wave report %d, k-NN candidates %d) -> the two-digit scan for this and the next 63 searches",
+                q->hout->overflow, q->coef_i8h, q->hout->pad_ & 0xffff, (q->hout->pad_ >> 16) & 0xff, (q->hout->pad_ >> 24) & 0xff, 0);
             q->coarse_off = 1;
             q->coarse_never = 1;   // (for the call below, whatever the switches say: it must not come back here)
             q->info_clean = 0;

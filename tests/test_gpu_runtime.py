@@ -132,3 +132,47 @@ def test_two_graph_handles_on_one_space_from_two_threads():
     for th in ths:
         th.join()
     assert not errors, errors[:4]
+
+
+def test_concurrent_callers_share_scans_and_get_the_serial_answers():
+    """Gang scans: as_search callers that arrive together are served by ONE pass over the items (up to four queries per launch,
+    scan_tile_gang_kernel).  Native threads against the C ABI (tools/probe/thread_driver.cpp; no interpreter lock between their
+    calls) on a 300 000 x 128 index: every call's best hit is the serial one, multi-member scans did form, and Python threads
+    on the same space still get the serial answers element for element."""
+    import threading
+
+    import numpy as np
+
+    import pyarrowspace_amd as asp
+    from conftest import calibrate_eps, clustered
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import thread_bench
+    n, d = 300000, 128
+    X = clustered(n, d, nclust=1024, seed=5)
+    gp = {"eps": calibrate_eps(X, 10, "l2"), "k": 10, "topk": 8, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    rng = np.random.default_rng(11)
+    Q = np.ascontiguousarray(X[rng.integers(0, n, 96)] + 0.02 * rng.standard_normal((96, d)) / np.sqrt(d))
+    want = [aspace.search(q, gl, 0.62) for q in Q]
+    assert aspace.last_scan_operand == "int8-high"
+    first = np.array([w[0][0] for w in want], dtype=np.int64)
+    for nthr in (2, 4, 3):
+        rate, errs, gangs = thread_bench.native_rate(aspace, gl, Q, 0.62, nthr, 150, first)
+        assert errs == 0 and rate > 0
+        assert sum(gangs[1:]) > 0, gangs          # scans with two or more members
+    bad = []
+
+    def worker(t):
+        for i in range(120):
+            j = (t * 31 + i) % len(Q)
+            if aspace.search(Q[j], gl, 0.62) != want[j]:
+                bad.append((t, i))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not bad, bad[:5]
+    c = aspace.search_counters()
+    assert c["searches_with_rerun"] <= 0.02 * c["searches"]
