@@ -262,7 +262,10 @@ int32_t as_last_batch_int8(const as_space* sp);
 int32_t as_search_pool_size(const as_space* sp);
 /* Concurrent as_search callers on one space share a pass over the items where they can (coarse scans of tau >= 0.4 searches that
  * arrive within a few microseconds of each other run as ONE launch for up to four queries: "gang scans"; ARROWSPACE_GANG=0:
- * never).  out[i] = scans this space launched through that path with i + 1 members (i = 0 .. 3).  Results never depend on it. */
+ * never).  out[i] = scans this space launched through that path with i + 1 members (i = 0 .. 3); out[4 .. 9] = host-prepared scans
+ * that did not take it, by first reason: no concurrent callers lately, not a search for the fused tail (tau < 0.4, crowded
+ * candidates lately), not a coarse scan, per-search state still to be reset, per-launch timing on, a row range.  Results never
+ * depend on any of it. */
 as_status as_gang_counters(const as_space* sp, int64_t* out, int32_t n);
 
 /* B queries, row-major [b][d]; outputs [b][topk]; status per query in out_status

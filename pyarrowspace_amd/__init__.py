@@ -350,6 +350,15 @@ class ArrowSpace:
             _raise(st)
         return [int(v) for v in out]
 
+    def gang_skips(self) -> dict:
+        """Extension: host-prepared single-query scans that did not take the shared path, by first reason."""
+        out = np.zeros(10, dtype=np.int64)
+        st = _L.as_gang_counters(self._h, out.ctypes.data_as(C.c_void_p), 10)
+        if st:
+            _raise(st)
+        keys = ("no_concurrent_callers", "not_fused_tail", "not_coarse", "state_to_reset", "timed", "row_range")
+        return dict(zip(keys, (int(v) for v in out[4:])))
+
     def save(self, gl: GraphLaplacian, path: str) -> None:
         """Extension: write the built index (items, lambdas, graph) to one file."""
         st = _L.as_index_save(self._h, gl._h, os.fsencode(path))

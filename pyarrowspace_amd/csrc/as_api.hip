@@ -715,6 +715,7 @@ as_status as_gang_counters(const as_space* sp, int64_t* out, int32_t n) {
     }
     std::lock_guard<std::mutex> lk(sp->gmu);
     for (int i = 0; i < n && i < 4; ++i) out[i] = sp->gang_scans[i + 1];
+    for (int i = 4; i < n && i < 10; ++i) out[i] = sp->gang_skip[i - 4].load(std::memory_order_relaxed);
     return AS_OK;
 }
 

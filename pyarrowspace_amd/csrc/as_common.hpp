@@ -117,6 +117,10 @@ struct as_space {
     mutable std::atomic<int64_t> gang_seq_launched{0};
     mutable std::atomic<hipEvent_t> last_scan_ev{nullptr};
     mutable int64_t gang_scans[5] = {0, 0, 0, 0, 0};   // scans launched with 1 .. 4 members (index = members; under gmu)
+    // host-prepared single-query scans that did NOT take the shared path, by first reason: [0] no concurrent callers lately, [1] the
+    // search is not one for the fused tail (tau < 0.4, crowded candidates lately, ...), [2] not a coarse scan, [3] per-search
+    // state still to be reset on the workspace's stream, [4] per-launch timing on, [5] a row range
+    mutable std::atomic<int64_t> gang_skip[6] = {};
     // as_search_counters: [0] searches, [1] zero-lambda results, [2] reruns because the k-NN a-posteriori check failed,
     // [3] reruns because a candidate buffer overflowed, [4] reruns because the scorer's check failed, [5] searches that
     // took at least one rerun (under qmu)

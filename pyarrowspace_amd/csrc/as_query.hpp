@@ -64,6 +64,9 @@ struct QInfo {
 // 256-byte line at the end of a short scan queued up for 40 us.
 constexpr int SC_COPIES = 16;
 constexpr int SC_HSTRIDE = 1088;
+// a scan wave's report whose count carries this bit may lack rows of cosine up to the float in the report's last word: valid
+// when that cosine lies below the bound of the FINAL histogram (scan_wave_report, PreArgs::sc_late; report_rows below)
+constexpr int SC_REPORT_LOSSY = 0x40000000;
 
 // everything a search writes into QInfo after the query itself was prepared (norms stay)
 __device__ __forceinline__ void reset_query_state(QInfo* info) {
@@ -84,6 +87,29 @@ __device__ __forceinline__ void reset_query_hist(unsigned int* hist, int tid, in
     if (hist)
         for (int i = tid; i < SC_COPIES * 64; i += nthreads) hist[(i >> 6) * SC_HSTRIDE + (i & 63)] = 0u;
 }
+
+#ifdef __HIPCC__
+// lower edge of the highest cosine bin with at least m rows at or above it (-2: no such bin yet), and that bin;
+// lane b holds the count of bin b
+__device__ __forceinline__ float sc_bound(unsigned h, int m, int lane, int& jb) {
+    // suffix sums over the lanes: S_b = sum of the bins >= b (6 shuffle steps, once per 64 rows)
+    unsigned sfx = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(sfx, o, 64);
+        if (lane + o < 64) sfx += t;
+    }
+    const unsigned long long ok = __ballot(sfx >= (unsigned)m);
+    jb = ok ? 63 - __builtin_clzll(ok) : -1;
+    return jb >= 0 ? (float)jb * (1.0f / 32.0f) - 1.0f : -2.0f;
+}
+// rows of a scan wave's report against the final bound: the count, or -1 (overflow: the report cannot be used)
+__device__ __forceinline__ int report_rows(const int* rep, float thr_final) {
+    const int c2 = rep[0];
+    if (c2 < 0 || !(c2 & SC_REPORT_LOSSY)) return c2;
+    return __int_as_float(rep[SC_WCAP - 1]) < thr_final ? (c2 & 0xffff) : -1;
+}
+#endif
 
 struct HostOut {
     volatile int64_t seq;
@@ -191,6 +217,9 @@ struct as_query {
     int* sc_widx = nullptr;  // fused tail: the scan's scorer candidates, a report of SC_WCAP words per wave of the scan
     unsigned int* sc_hist = nullptr;   // SC_COPIES x SC_HSTRIDE words, zero between searches
     int sc_nw = 0;           // waves of the last fused scan
+    int sc_late = 0;         // this search's tail validates lossy wave reports (set around query_begin by the paths whose tail is staged_x1_kernel)
+    int last_sc_m = 0;       // what the last fused scan collected with (make_pre): the tail recomputes the bound from the final histogram
+    float last_sc_w = 0.0f;
     void* gmin = nullptr;    // group minima of the scorer key
     as::RSel* rsel = nullptr; // state of the exact global selection
     as_knn_rec* knn = nullptr;
@@ -258,6 +287,7 @@ struct PreArgs {
     float sc_w = 0.0f;
     int* sc_idx = nullptr;   // [waves of the scan][SC_WCAP]: a wave's report -- [0] its number of candidates (-1: more than fit), [1 ..] their rows
     unsigned int* sc_hist = nullptr;   // SC_COPIES cosine histograms
+    int sc_late = 0;         // the tail kernels validate lossy reports against the final histogram (scan_wave_report)
     int sc_dbg = 0;          // measurement only, -DAS_ABLATION builds (ARROWSPACE_SC_DBG): 1 no publication, 2 no histogram read, 4 no candidates
     // Scan of the int8 two-digit image (scan_dma_kernel<..., I8>: half the bytes of the fp32 items): the rows' scales, the
     // query's digits in the lanes' register order (per 16-byte chunk of an image row: 16 bytes that multiply into the

@@ -626,20 +626,6 @@ __device__ __forceinline__ unsigned lds_read1u(unsigned a) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
     return v;
 }
-// lower edge of the highest cosine bin with at least m rows at or above it (-2: no such bin yet), and that bin;
-// lane b holds the count of bin b
-__device__ __forceinline__ float sc_bound(unsigned h, int m, int lane, int& jb) {
-    // suffix sums over the lanes: S_b = sum of the bins >= b (6 shuffle steps, once per 64 rows)
-    unsigned sfx = h;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_down(sfx, o, 64);
-        if (lane + o < 64) sfx += t;
-    }
-    const unsigned long long ok = __ballot(sfx >= (unsigned)m);
-    jb = ok ? 63 - __builtin_clzll(ok) : -1;
-    return jb >= 0 ? (float)jb * (1.0f / 32.0f) - 1.0f : -2.0f;
-}
 __device__ __forceinline__ int sc_bin(float c) {
     const int b = (int)floorf((c + 1.0f) * 32.0f);
     return b < 0 ? 0 : (b > SC_BINS - 1 ? SC_BINS - 1 : b);
@@ -797,8 +783,16 @@ __device__ __forceinline__ void scan_wave_report(const PreArgs& pre, ScanWave& w
         // wave's OWN region of the candidate buffer (SC_WCAP words: the count, then the rows -- one 16-byte load tells the
         // finish kernel the count and the first three) -- plain stores: a returning atomic per wave on one counter, all
         // waves ending together, cost the launch 20 us.
+        // Late validation (pre.sc_late: the tail kernels recompute the bound from the FINAL histogram): a wave that ends with a
+        // loose bound or none -- it ran ahead of the publications it needed: a launch that shares the chip, a scan of two or three
+        // chunks per wave -- does not give up.  It reports its rows of the largest cosines (at most SC_WCAP - 2) and the largest
+        // cosine it may have let go (w.floor, the cut of this selection) in the region's last word, flagged in the count; the
+        // tail accepts the report when that cosine lies below the final bound, and only otherwise calls it an overflow.
         int keep = 0;
         int* region = pre.sc_idx + gw * SC_WCAP;   // [0] = number of candidates (-1: more than the region holds), [1 ..] = their rows
+        const bool late = pre.sc_late != 0;
+        float lossy = w.floor;
+        bool flagged = false;
         if (w.npend > 0 && !w.sc_over) {
             // (a wave of three or more chunks has read the histogram with its last chunks: that threshold will do -- a
             // fresh read past the L2 at every wave's end is two microseconds of every launch's tail)
@@ -808,17 +802,52 @@ __device__ __forceinline__ void scan_wave_report(const PreArgs& pre, ScanWave& w
                 const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
             }
-            if (!(thr > w.floor)) w.sc_over = 1;   // (rows the wave let go of might pass the bound it ends with)
-            for (int e0 = 0; e0 < w.npend; e0 += 64) {
+            if (!(thr > w.floor)) {   // (rows the wave let go of might pass the bound it ends with)
+                if (late) flagged = true;
+                else w.sc_over = 1;
+            }
+            const int cap = late ? SC_WCAP - 2 : SC_WCAP - 1;
+            // survivors, in registers (at most four entries per lane: the lists hold up to 256)
+            auto okey = [](float f) -> unsigned { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+            unsigned ek[4];
+            int er[4];
+            int nsurv = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = lane + 64 * u;
                 float ce = 0.0f;
-                int re = 0;
-                if (e0 + lane < w.npend) lds_read2(px0 + (unsigned)(e0 + lane) * 8, ce, re);
-                const bool kp = e0 + lane < w.npend && ce >= thr;
+                er[u] = 0;
+                if (e < w.npend) lds_read2(px0 + (unsigned)e * 8, ce, er[u]);
+                const bool kp = e < w.npend && ce >= thr;
+                ek[u] = kp ? okey(ce) : 0u;   // (0: not a survivor -- below every real key)
+                nsurv += __popcll(__ballot(kp));
+            }
+            unsigned cut = 0u;   // survivors with a key above the cut are reported
+            if (nsurv > cap && late) {
+                // the rows of the largest cosines: the smallest cut that leaves at most `cap` survivors above it
+                unsigned lo = 1u, hi = 0xfffffffeu;
+                while (lo < hi) {   // (wave-uniform: 32 trips; a rare path)
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    int above = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) above += __popcll(__ballot(ek[u] > mid));
+                    if (above <= cap) hi = mid;
+                    else lo = mid + 1u;
+                }
+                cut = lo;
+                const unsigned cb_ = (cut & 0x80000000u) ? (cut & 0x7fffffffu) : ~cut;
+                lossy = fmaxf(lossy, __uint_as_float(cb_));
+                flagged = true;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool kp = ek[u] > cut;
                 const unsigned long long km = __ballot(kp);
                 const int pos = keep + __popcll(km & ((1ull << lane) - 1));
-                if (kp && pos < SC_WCAP - 1) region[1 + pos] = re;
+                if (kp && pos < cap) region[1 + pos] = er[u];
                 keep += __popcll(km);
             }
+            if (keep > cap) w.sc_over = 1;   // (not late: more survivors than the region holds)
         } else if (w.npend == 0 && !w.sc_over && w.floor > -3.0e38f) {
             // (nothing pending, but rows were let go of: the same question against the bound the wave knows)
             float thr = w.thr_last;
@@ -827,9 +856,15 @@ __device__ __forceinline__ void scan_wave_report(const PreArgs& pre, ScanWave& w
                 const unsigned h = __hip_atomic_load(&pre.sc_hist[(gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 thr = sc_bound(h, pre.sc_m, lane, jb) - pre.sc_w;
             }
-            if (!(thr > w.floor)) w.sc_over = 1;
+            if (!(thr > w.floor)) {
+                if (late) flagged = true;
+                else w.sc_over = 1;
+            }
         }
-        if (lane == 0) region[0] = w.sc_over || keep > SC_WCAP - 1 ? -1 : keep;
+        if (lane == 0) {
+            if (flagged && !w.sc_over) region[SC_WCAP - 1] = __float_as_int(lossy);
+            region[0] = w.sc_over ? -1 : (flagged ? (keep | SC_REPORT_LOSSY) : keep);
+        }
     }
 }
 
@@ -1615,6 +1650,9 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
         p.sc_w = (float)((1.0 - q->tau_cur) / (2.0 * q->tau_cur) + 2.0 * p.coef * 1.0001 + 1.0e-5);
         p.sc_idx = q->sc_widx;
         p.sc_hist = q->sc_hist;
+        p.sc_late = q->sc_late;
+        q->last_sc_m = p.sc_m;
+        q->last_sc_w = p.sc_w;
 #ifdef AS_ABLATION   // measurement switches that return wrong answers exist in `make ABLATION=1` builds only
         static const int dbg = getenv("ARROWSPACE_SC_DBG") ? atoi(getenv("ARROWSPACE_SC_DBG")) : 0;
         p.sc_dbg = dbg;

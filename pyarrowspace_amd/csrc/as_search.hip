@@ -1175,6 +1175,9 @@ struct FinishArgs {
     int* unproven;      // build fallback: counts the rows whose list failed the a-posteriori check even in fp64
     int auto_reset;     // score_finish (fused publish, single query): clear QInfo's per-search state behind a clean search
     int sc_nw;          // fused tail: waves of the scan, each with a report of SC_WCAP words in ci (count, then rows)
+    const unsigned int* sc_hist = nullptr;   // ... and, where the tail validates lossy reports (PreArgs::sc_late): the scan's histogram as it
+    int sc_m = 0;                            // ended, the rows its bound needs and the window below it
+    float sc_w = 0.0f;
 };
 
 // SPEC S10 given the selected neighbours in LDS in (key, index) rank order; one wave, lane t
@@ -1893,6 +1896,17 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         return;
     }
     __shared__ int s_tot, s_ovf, s_base;
+    __shared__ float s_thrf;
+    if (threadIdx.x < 64) {
+        // the bound of the FINAL histogram: what a lossy wave report is held against (report_rows)
+        float thrf = 3.0e38f;   // (no histogram handed over: a lossy report is an overflow)
+        if (as_.sc_hist) {
+            int jb;
+            const unsigned h = __hip_atomic_load(&as_.sc_hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            thrf = sc_bound(h, as_.sc_m, (int)threadIdx.x, jb) - as_.sc_w;
+        }
+        if (threadIdx.x == 0) s_thrf = thrf;
+    }
     int* si = (int*)work;                          // X1_LOCAL_CAP rows
     double* o_sq = (double*)(si + X1_LOCAL_CAP);   // 64 + 64 results of a round
     double* o_dot = o_sq + 64;
@@ -1923,7 +1937,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         const int room = X1_LOCAL_CAP - mine;
         for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
             const int* rep = as_.ci + (int64_t)w * SC_WCAP;
-            const int c2 = rep[0];
+            const int c2 = report_rows(rep, s_thrf);
             if (c2 < 0) s_ovf = 1;
             else if (c2 > 0) {
                 const int base = atomicAdd(&s_tot, c2);
@@ -1991,7 +2005,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
     if (!xk) {
         for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
             const int* rep = as_.ci + (int64_t)w * SC_WCAP;
-            const int c2 = rep[0];
+            const int c2 = report_rows(rep, s_thrf);
             if (c2 < 0) s_ovf = 1;
             else if (c2 > 0) {
                 const int base = atomicAdd(&s_tot, c2);
@@ -2950,8 +2964,13 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !q->crowded_direct);
         // (a scan that may be shared with other callers': the coarse scan of a whole single space that collects scorer candidates,
         // nothing queued on this workspace's stream that the scan must follow, no per-launch timing asked for)
-        if (q->gang_ok && q->coarse && pre.sc_enabled && was_clean && !stats && r0 == 0 && r1 == sp->n) AS_TRY(gang_launch(q, pre));
-        else AS_TRY(launch_scan(q, pre));
+        const int why = sp->gang_hint.load(std::memory_order_relaxed) <= 0 ? 0 : (!q->gang_ok || !pre.sc_enabled) ? 1 : !q->coarse ? 2 : !was_clean ? 3 : stats ? 4 : (r0 != 0 || r1 != sp->n) ? 5 : -1;
+        if (why < 0) {
+            AS_TRY(gang_launch(q, pre));
+        } else {
+            if (q->cap == 1) sp->gang_skip[why].fetch_add(1, std::memory_order_relaxed);
+            AS_TRY(launch_scan(q, pre));
+        }
         if (stats) AS_HIP(hipEventRecord(q->ev[1], st));
         q->ev_valid = stats ? 1 : 0;
         return AS_OK;
@@ -3359,6 +3378,7 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     if (exact_knn) q->xknn_dirty = 1;
     FinishArgs fs = make_finish(q);
     fs.ci = q->sc_widx; fs.sc_nw = sc_ran && rows > 0 ? q->sc_nw : 0;
+    fs.sc_hist = q->sc_hist; fs.sc_m = q->last_sc_m; fs.sc_w = q->last_sc_w;
     static bool attr_set[64] = {};
     if (sp->device >= 0 && sp->device < 64 && !attr_set[sp->device]) {
         AS_HIP(hipFuncSetAttribute((const void*)staged_x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x1_lds_a()));
@@ -3410,8 +3430,10 @@ as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, in
     q->fused_tail = sc ? 1 : 0;
     q->tau_cur = tau;
     q->allow_coarse = sc ? 1 : 0;   // (the block kernels evaluate every k-NN candidate of a coarse scan: x1_launch_block, exact_knn)
+    q->sc_late = sc ? 1 : 0;
     const as_status qb = query_begin(q, query_host, -1, d, row_begin, row_end, q->gr->gp.eps, -1);
     q->allow_coarse = 0;
+    q->sc_late = 0;
     const bool sc_ran = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->fused_tail = 0;
     q->staged_sc = 0;
@@ -3666,6 +3688,7 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     static const bool fused_x1_on = !(getenv("ARROWSPACE_FUSED_X1") && atoi(getenv("ARROWSPACE_FUSED_X1")) == 0);
     q->allow_coarse = want_fused && fused_x1_on ? 1 : 0;   // (the coarse scan needs the two-launch tail: its k-NN candidates are evaluated by all blocks)
     q->gang_ok = q->allow_coarse;
+    q->sc_late = want_fused && fused_x1_on ? 1 : 0;   // (the two-launch tail validates lossy wave reports against the final histogram)
     // (ARROWSPACE_HOST_TIMING=1: host microseconds of the fused path's parts -- preparation + scan launch, the two tail launches,
     // the wait for the publication -- averaged over 200 searches, on stderr)
     static const bool host_timing = getenv("ARROWSPACE_HOST_TIMING") != nullptr;
@@ -3675,6 +3698,7 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     const double ht1 = host_timing ? now_us() : 0.0;
     q->allow_coarse = 0;
     q->gang_ok = 0;
+    q->sc_late = 0;
     const bool fused = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
     q->crowded_direct = 0;
     q->fused_tail = 0;

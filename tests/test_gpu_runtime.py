@@ -147,6 +147,7 @@ def test_concurrent_callers_share_scans_and_get_the_serial_answers():
     from conftest import calibrate_eps, clustered
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import thread_bench
+    asp.enable_search_stats(False)     # (process-global; a scan that is timed per launch is not shared)
     n, d = 300000, 128
     X = clustered(n, d, nclust=1024, seed=5)
     gp = {"eps": calibrate_eps(X, 10, "l2"), "k": 10, "topk": 8, "p": 2.0, "sigma": None}
@@ -159,7 +160,7 @@ def test_concurrent_callers_share_scans_and_get_the_serial_answers():
     for nthr in (2, 4, 3):
         rate, errs, gangs = thread_bench.native_rate(aspace, gl, Q, 0.62, nthr, 150, first)
         assert errs == 0 and rate > 0
-        assert sum(gangs[1:]) > 0, gangs          # scans with two or more members
+        assert sum(gangs[1:]) > 0, (gangs, aspace.gang_skips(), aspace.search_counters())          # scans with two or more members
     bad = []
 
     def worker(t):
