@@ -200,6 +200,9 @@ struct as_query {
     int coarse_off = 0;                  // > 0: counting the searches that skip it
     int coarse_never = 0;                // set around the redo of a query whose coarse candidates did not fit
     int allow_coarse = 0;                // set by search_once around query_begin: the caller's tail evaluates every k-NN candidate exactly
+    int chainc = 0;                      // ... and this search is a COARSE CHAIN: coarse scan without scan-side scorer candidates, every candidate list
+                                         // derived from the kept dots and evaluated exactly (search_once, coarse_score_stage)
+    int chainc_off = 0;                  // > 0: a coarse chain did not serve a recent query cleanly (counts the searches that skip it)
     int xknn_dirty = 0;                  // ... its counter may be non-zero (a pass died before its finish kernel)
     void* xknn = nullptr;                // [CAND_CAP] exact (id, key, distance, gy) of the coarse scan's k-NN candidates (staged_x1_kernel, xk)
     int pool_slot = 0;       // slot in the space's pool of single-query workspaces (as_search): picks the stream's priority

@@ -184,6 +184,7 @@ struct SelArgs {
     int64_t n, r0, r1, exclude;
     int M, metric;
     double epskey, coef, tau;
+    double margin;   // filter path: rows up to this far above the picked threshold are kept as well (the coarse chain: twice the keys' error)
     T* pkey;
     int* pidx;
     T* gmin;      // filter path: group minima, candidate buffers (CAND_CAP per slot)
@@ -495,7 +496,7 @@ template <typename T, int KEY>
 __global__ __launch_bounds__(1024) void score_pickfilter_kernel(SelArgs<T> a, int ng, int M) {
     sel_slot(a);
     if (KEY == 0 && a.info->status == AS_EZEROLAMBDA) return;   // (as score_gmin_kernel: an empty candidate list for the finish kernel)
-    const double thr_d = pick_thr_block<T>(a.gmin, ng, M);
+    const double thr_d = pick_thr_block<T>(a.gmin, ng, M) + a.margin;
     const T thr = (T)thr_d;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (sizeof(T) == 4) a.info_w->thr32 = (float)thr_d;
@@ -506,26 +507,45 @@ __global__ __launch_bounds__(1024) void score_pickfilter_kernel(SelArgs<T> a, in
     int* counter = KEY ? &a.info_w->knn_cnt : &a.info_w->sc_cnt;
     const ScoreCtx c = load_ctx(a.info, a.tau);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    bool full = false;   // mass ties at the threshold: the counter only has to exceed CAND_CAP
-    // (reading only the groups whose minimum is under the threshold was tried here: no gain -- this kernel is its
-    // threshold prologue; the batched filter, which streams 134 MB of dots, does skip them)
-    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1 && !full; row += stride) {
+    // The rows a block keeps are gathered in LDS and reach the candidate buffer through ONE returning atomic per block: the
+    // counter is a single word every XCD has to reach -- a thousand returning atomics on it, one per kept row, were 45 of this
+    // kernel's 50 us (a coarse chain keeps a whole cluster inside its margin).  Mass ties at the threshold (tau = 0 with
+    // thousands of isolated items at lambda = 0): once the counter has passed the capacity nobody needs a slot any more.
+    constexpr int LCAP = 1024;
+    __shared__ T l_key[LCAP];
+    __shared__ int l_idx[LCAP];
+    __shared__ int s_ln, s_gbase;
+    if (threadIdx.x == 0) s_ln = 0;
+    __syncthreads();
+    const bool full0 = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > CAND_CAP;   // (block-uniform enough: a late reader only does needless work)
+    for (int64_t row = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.r1 && !full0; row += stride) {
         const T k = sel_key<T, KEY>(a, c, row);
         if (k <= thr && (KEY == 0 || k < key_traits<T>::inf())) {
-            // mass ties at the threshold (tau = 0 with thousands of isolated items at lambda = 0): once the counter has
-            // passed the capacity nobody needs a slot any more -- 100 000 returning atomics on one word cost a millisecond
-            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > CAND_CAP) {
-                full = true;
-                break;
-            }
-            const int slot = atomicAdd(counter, 1);
-            if (slot < CAND_CAP) {
-                ckey[slot] = k;
-                cidx[slot] = (int)row;
+            const int ls = atomicAdd(&s_ln, 1);
+            if (ls < LCAP) {
+                l_key[ls] = k;
+                l_idx[ls] = (int)row;
             } else {
-                full = true;
+                // (more than the block's list holds: straight to the buffer, as every row did before)
+                const int slot = atomicAdd(counter, 1);
+                if (slot < CAND_CAP) {
+                    ckey[slot] = k;
+                    cidx[slot] = (int)row;
+                }
             }
         }
+    }
+    __syncthreads();
+    const int ln = s_ln < LCAP ? s_ln : LCAP;
+    if (threadIdx.x == 0 && ln > 0) s_gbase = atomicAdd(counter, ln);
+    __syncthreads();
+    if (ln > 0) {
+        const int gb = s_gbase;
+        for (int t = threadIdx.x; t < ln; t += blockDim.x)
+            if (gb + t < CAND_CAP) {
+                ckey[gb + t] = l_key[t];
+                cidx[gb + t] = l_idx[t];
+            }
     }
 }
 
@@ -1874,7 +1894,9 @@ struct XKnn {
     int pad;
     double key, dist, gy;
 };
-__global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishArgs as_, XHead* head, XCand* cands, int xcap, int preset_flags, XKnn* xk) {
+// xmode (xk form only): 0 both shares, 1 the k-NN share alone (the coarse chain: the scorer's candidates come later), 2 the scorer's
+// candidates alone, from a FLAT list (as_.ci, as_.info->sc_cnt entries: the threshold filter over the kept dots) -- no ranking
+__global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishArgs as_, XHead* head, XCand* cands, int xcap, int preset_flags, XKnn* xk, int xmode) {
     int* xk_count = (int*)(xk + CAND_CAP);   // (behind the entries: zero at the start of a pass -- the finish kernel leaves it so)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* qs = (double*)smem;
@@ -1922,7 +1944,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         // its share of the scan waves' scorer reports behind -- evaluated exactly in rounds of 64 rows (one round at 1M x 768 on
         // 128 blocks: 10 + 9 rows), each row then filed by its kind.  (Before: the two shares in rounds of their own on 32 blocks,
         // three serial rounds per block.)
-        const int raw = ak.info->knn_cnt;
+        const int raw = xmode == 2 ? 0 : ak.info->knn_cnt;
         int mine = 0;
         if (raw > CAND_CAP) {
             if (b == 0 && threadIdx.x == 0) {
@@ -1935,7 +1957,17 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         }
         if (b == 0 && threadIdx.x == 0 && (preset_flags || (ak.info->overflow & 2))) atomicOr(&head->flags, preset_flags | ((ak.info->overflow & 2) ? 8 : 0));
         const int room = X1_LOCAL_CAP - mine;
-        for (int w = b + nb * (int)threadIdx.x; w < as_.sc_nw; w += nb * (int)blockDim.x) {
+        if (xmode == 2) {
+            const int fc = as_.info->sc_cnt;
+            if (fc > CAND_CAP) {
+                s_ovf = 1;
+            } else {
+                const int ms = fc > b ? (fc - b + nb - 1) / nb : 0;   // this block's entries b, b + nb, ...
+                for (int t = threadIdx.x; t < ms; t += blockDim.x) si[t] = as_.ci[b + nb * t];
+                if (threadIdx.x == 0) s_tot = ms;
+            }
+        }
+        for (int w = b + nb * (int)threadIdx.x; xmode == 0 && w < as_.sc_nw; w += nb * (int)blockDim.x) {
             const int* rep = as_.ci + (int64_t)w * SC_WCAP;
             const int c2 = report_rows(rep, s_thrf);
             if (c2 < 0) s_ovf = 1;
@@ -2045,6 +2077,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         }
         return;
     }
+    if (xmode == 2) return;   // (the records stand from the launch that evaluated the k-NN share)
     // The coarse scan's k-NN records: the LAST block to get here ranks the candidates inside eps that all blocks have appended
     // (a few dozen) by (key, id) and writes the k nearest as records -- knn_finish_body's selection with nothing left to prove.
     // (Release / acquire at agent scope around one ticket per block: the blocks sit on different XCDs, each with its own L2.)
@@ -2410,7 +2443,7 @@ static SelArgs<T> make_sel(as_query* q, const T* dots, int M, int64_t exclude) {
     a.dots = dots; a.dots32 = nullptr; a.n32 = sp->n32; a.inorm32 = sp->inorm32; a.n64 = sp->n64; a.lam32 = sp->lam32; a.lam64 = sp->lam64;
     a.info = q->info; a.info_w = q->info; a.n = sp->n; a.r0 = q->r0; a.r1 = q->r1; a.exclude = exclude;
     a.M = M; a.metric = sp->opts.metric;
-    a.epskey = 0; a.coef = 0; a.tau = 1.0;
+    a.epskey = 0; a.coef = 0; a.tau = 1.0; a.margin = 0.0;
     a.pkey = (T*)q->pkey; a.pidx = q->pidx;
     a.gmin = (T*)q->gmin; a.ckey = (T*)q->ckey_s; a.cidx = q->cidx_s; a.sd = q->ss.dots; a.ts = q->ss.dots_ts; a.rs = q->ss.dots_rs;
     return a;
@@ -2467,6 +2500,9 @@ static void launch_knn_repair(as_query* q, const T* dots, double eps, int64_t ex
     SelArgs<T> a = make_sel<T>(q, dots, q->Mk, exclude);
     a.epskey = q->sp->opts.metric == AS_METRIC_L2 ? eps * eps : eps;
     a.coef = coef_query(q, sizeof(T) == 8);
+    // (coarse dots: the picked threshold bounds the k-th COARSE key; the k nearest rows' coarse keys lie up to twice the keys'
+    // error above it -- everything the filter keeps is evaluated exactly by the tail, nothing is proven from these keys)
+    if (q->coarse) a.margin = (q->sp->opts.metric == AS_METRIC_L2 ? 2.0 * a.coef * (q->sp->nmax + q->h_nq) : 2.0 * a.coef) * 1.0001 + 1.0e-6 * a.epskey;
     a.ckey = (T*)q->ckey_k;
     a.cidx = q->cidx_k;
     const unsigned nb = (unsigned)q->nb;
@@ -2942,7 +2978,7 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
         const char* coarse_env = getenv("ARROWSPACE_SCAN_COARSE");   // (per call: an A/B switch)
         const bool coarse_env_off = coarse_env && atoi(coarse_env) == 0;
         const bool coarse_always = coarse_env && atoi(coarse_env) == 2;   // (tests: probe with every search, whatever the last one did)
-        if (host_path && q->allow_coarse && !q->coarse_never && q->i8_scan && q->fused_tail && q->hq8h && !coarse_env_off && !q->robust && !q->crowded_direct && q->coef_i8h <= 4.0e-2 &&
+        if (host_path && q->allow_coarse && !q->coarse_never && q->i8_scan && (q->fused_tail || q->chainc) && q->hq8h && !coarse_env_off && !q->robust && (!q->crowded_direct || q->chainc) && q->coef_i8h <= 4.0e-2 &&
             (coarse_always || !(q->coarse_off > 0 && (q->coarse_off++ & 63) != 0))) {
             bool have = false;
             if (space_i8h_image(sp, &have) == AS_OK && have) {
@@ -3361,7 +3397,7 @@ static FinishArgs x1_knn_args(as_query* q, void* send_dev) {
 }
 
 // exact_knn: the single space's coarse scan -- no k-NN block, every block evaluates its share of the k-NN candidates into q->xknn
-static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc_ran, bool exact_knn = false) {
+static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc_ran, bool exact_knn = false, int xmode = 0) {
     const as_space* sp = q->sp;
     const int64_t krec = std::max<int64_t>(q->k, 1);
     XHead* head = (XHead*)((char*)send_dev + sizeof(as_knn_rec) * krec);
@@ -3379,6 +3415,7 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     FinishArgs fs = make_finish(q);
     fs.ci = q->sc_widx; fs.sc_nw = sc_ran && rows > 0 ? q->sc_nw : 0;
     fs.sc_hist = q->sc_hist; fs.sc_m = q->last_sc_m; fs.sc_w = q->last_sc_w;
+    if (xmode == 2) fs.ci = q->cidx_s;   // (the flat list of the threshold filter: coarse_score_stage)
     static bool attr_set[64] = {};
     if (sp->device >= 0 && sp->device < 64 && !attr_set[sp->device]) {
         AS_HIP(hipFuncSetAttribute((const void*)staged_x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x1_lds_a()));
@@ -3389,7 +3426,7 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     // the pass is rerun on the two-exchange chain)
     const size_t lds_xk = (sp->dp <= Q_LDS_MAX ? sizeof(double) * (size_t)sp->dp : 0) + (sizeof(double) + sizeof(int) + sizeof(short)) * (size_t)CAND_CAP + 64;
     hipLaunchKernelGGL(staged_x1_kernel, dim3(exact_knn ? X1_BLOCKS_COARSE : 1 + X1_BLOCKS), dim3(1024), exact_knn ? lds_xk : x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
-                       !sc_ran && rows > 0 ? 16 : 0, exact_knn ? (XKnn*)q->xknn : (XKnn*)nullptr);
+                       !sc_ran && rows > 0 && xmode == 0 ? 16 : 0, exact_knn ? (XKnn*)q->xknn : (XKnn*)nullptr, xmode);
     AS_HIP(hipGetLastError());
     q->x1_head = head;
     return AS_OK;
@@ -3403,6 +3440,36 @@ static as_status x1_launch_final(as_query* q, const void* all_dev, int world, do
                        (int64_t)0x7fffffffffffffffll, q->info, q->hout_dev, q->seq, q->sc_hist, (XHead*)q->x1_head);
     AS_HIP(hipGetLastError());
     return AS_OK;
+}
+
+// The coarse chain's scorer (single space; the k-NN records of this query stand in `block`): lambda_q from the records, the
+// threshold chain's two selection kernels over the KEPT dots of the coarse scan -- group minima of the scorer key, the Ms-th
+// smallest as threshold -- keeping every row up to twice the keys' error above the threshold (SelArgs::margin), and the exact
+// evaluation of everything kept by the tail's blocks (staged_x1_kernel, xmode 2).  Nothing is proven from the coarse keys: a
+// row of the true top-k has a coarse key within twice the error of the k-th smallest coarse key, so it is among the rows
+// kept, and the final kernel ranks exact scores.  Serves the queries the scan cannot collect candidates for by a cosine window
+// -- tau below 0.4, data whose background cosine fills the window (isotropic rows, embeddings with a large common direction) --
+// in ONE pass over the one-byte image instead of a pass over the two-byte image and the proof-carrying chain.
+static as_status coarse_score_stage(as_query* q, void* block, double tau) {
+    const as_graph* gr = q->gr;
+    const int64_t krec = std::max<int64_t>(q->k, 1);
+    hipStream_t st = q->stream;
+    hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, st, (const as_knn_rec*)block, krec, krec, krec, q->k, gr->metric, gr->kernel, gr->gp.sigma,
+                       gr->gp.p, gr->tau0, q->info);
+    AS_HIP(hipMemsetAsync(&q->info->sc_cnt, 0, sizeof(int), st));
+    const int64_t rows = q->r1 - q->r0;
+    int64_t G = (rows + CAND_CAP - 1) / CAND_CAP;
+    G = std::max<int64_t>(64, (G + 63) / 64 * 64);
+    const int ng = (int)((rows + G - 1) / G);
+    SelArgs<double> a = make_sel<double>(q, (const double*)nullptr, q->Ms, -1);
+    a.dots32 = q->dots32;
+    a.tau = tau;
+    a.margin = 2.0 * (tau * coef_query(q, false) * 1.0001 + 1.0e-9);
+    hipLaunchKernelGGL((score_gmin_kernel<double, 0>), dim3((unsigned)((ng + 3) / 4), 1, 1), dim3(256), 0, st, a, G, ng);
+    const unsigned pg = (unsigned)std::min<int64_t>((rows + 1023) / 1024, std::max(q->cus, 1));
+    hipLaunchKernelGGL((score_pickfilter_kernel<double, 0>), dim3(pg, 1, 1), dim3(1024), 0, st, a, ng, q->Ms);
+    AS_HIP(hipGetLastError());
+    return x1_launch_block(q, block, 1, false, true, 2);
 }
 
 as_status as_query_x1_begin(as_query* q, const double* query_host, int64_t d, int64_t row_begin, int64_t row_end, double tau, void* send_dev,
@@ -3686,8 +3753,18 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     q->fused_tail = want_fused ? 1 : 0;
     q->tau_cur = tau;
     static const bool fused_x1_on = !(getenv("ARROWSPACE_FUSED_X1") && atoi(getenv("ARROWSPACE_FUSED_X1")) == 0);
-    q->allow_coarse = want_fused && fused_x1_on ? 1 : 0;   // (the coarse scan needs the two-launch tail: its k-NN candidates are evaluated by all blocks)
-    q->gang_ok = q->allow_coarse;
+    // Coarse chain: what the fused tail cannot serve -- tau below 0.4, scorer candidates that overflowed lately (sc_skip), crowded
+    // neighbourhoods (direct) -- still scans the one-byte image: no scan-side scorer candidates, k-NN candidates from the scan's
+    // prefilter or (direct) by threshold over the kept dots, the scorer's by threshold over the kept dots once lambda_q is known,
+    // everything evaluated exactly by the tail's blocks (coarse_score_stage).  A query it does not serve cleanly is redone on the
+    // two-digit image through the proof-carrying chain, and the next 63 skip it.
+    static const bool chainc_on = !(getenv("ARROWSPACE_COARSE_CHAIN") && atoi(getenv("ARROWSPACE_COARSE_CHAIN")) == 0);
+    const bool chainc_skip = q->chainc_off > 0 && (q->chainc_off++ & 63) != 0;
+    const bool want_chainc = chainc_on && fused_x1_on && !want_fused && !feature && !q->robust && !q->exact && !q->no_fused && q->cap == 1 && tau >= 0.0 && tau <= 1.0 &&
+                             q->sp->dp <= 4096 && !(q->scan_variant & 4) && !chainc_skip && !q->coarse_never && (int64_t)std::max<int64_t>(q->k, 1) <= REC_CAP;
+    q->chainc = want_chainc ? 1 : 0;
+    q->allow_coarse = (want_fused || want_chainc) && fused_x1_on ? 1 : 0;   // (the coarse scan needs the two-launch tail: its k-NN candidates are evaluated by all blocks)
+    q->gang_ok = want_fused && fused_x1_on ? 1 : 0;
     q->sc_late = want_fused && fused_x1_on ? 1 : 0;   // (the two-launch tail validates lossy wave reports against the final histogram)
     // (ARROWSPACE_HOST_TIMING=1: host microseconds of the fused path's parts -- preparation + scan launch, the two tail launches,
     // the wait for the publication -- averaged over 200 searches, on stderr)
@@ -3700,9 +3777,44 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
     q->gang_ok = 0;
     q->sc_late = 0;
     const bool fused = q->fused_tail != 0;   // (rows of 1025 .. 4096 floats: only when the int8 image served the scan)
+    const bool chainc = q->chainc && q->coarse;   // (the coarse scan did serve this query's scan)
+    q->chainc = 0;
     q->crowded_direct = 0;
     q->fused_tail = 0;
     AS_TRY(qb);
+    if (chainc) {
+        if (!q->x1_own) {
+            AS_HIP(hipMalloc(&q->x1_own, (size_t)as_query_x1_bytes(q, 1)));
+            AS_HIP(hipMemsetAsync(q->x1_own, 0, (size_t)as_query_x1_bytes(q, 1), q->stream));
+        } else if (q->x1_dirty) {
+            AS_HIP(hipMemsetAsync(q->x1_own + sizeof(as_knn_rec) * std::max<int64_t>(q->k, 1), 0, 16, q->stream));
+        }
+        q->x1_dirty = 1;
+        q->seq += 1;
+        if (direct) AS_TRY(knn_repair(q, q->gr->gp.eps, -1));   // (crowded neighbourhood: the k-NN candidates by threshold over the kept dots)
+        AS_TRY(x1_launch_block(q, q->x1_own, 1, false, true, 1));
+        AS_TRY(coarse_score_stage(q, q->x1_own, tau));
+        AS_TRY(x1_launch_final(q, q->x1_own, 1, tau));
+        if (q->ev_valid) AS_HIP(hipEventRecord(q->ev[2], q->stream));
+        AS_TRY(wait_published(q));
+        q->x1_dirty = 0;
+        q->xknn_dirty = 0;
+        if (!direct) q->crowded = (q->hout->overflow & 1) ? 1 : 0;
+        if (q->hout->overflow || q->hout->knn_inexact || q->hout->score_inexact) {
+            // not served cleanly (a candidate list that did not fit): this query again without the coarse chain -- the next search
+            // of a crowded neighbourhood takes the threshold repair (crowded, above), anything else sends the next 63 past it
+            dbg("coarse chain: overflow bits %d (coefficient %.3e) -> this search again on the two-digit image", q->hout->overflow, q->coef_i8h);
+            if (!(!direct && (q->hout->overflow & 1) && !(q->hout->overflow & 6))) q->chainc_off = 1;
+            q->coarse_never = 1;
+            q->info_clean = 0;
+            const as_status redo = search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
+            q->coarse_never = 0;
+            return redo;
+        }
+        q->chainc_off = 0;
+        q->info_clean = q->hout->state_reset ? 1 : 0;
+        return collect(q, out_idx, out_score, out_len, out_lambda_q);
+    }
     // The fused tail as TWO launches (the one-exchange pass's kernels without an exchange: staged_x1_kernel = the k-NN block beside
     // 16 blocks that finish the scan's scorer candidates to exact cosines, staged_x1_final_kernel = lambda_q, exact scores, ranking)
     // instead of the one 1024-thread block that does the phases one after the other (fused_finish_kernel, ARROWSPACE_FUSED_X1=0).
@@ -3740,6 +3852,16 @@ as_status search_once(as_query* q, const double* query, int64_t d, double tau, i
         }
         q->x1_dirty = 0;
         q->xknn_dirty = 0;
+        if (q->coarse && (q->hout->overflow & 5) && chainc_on && !chainc_skip && !q->coarse_never) {
+            // the scan's candidate lists did not fit -- a neighbourhood of more than 4 096 rows (bit 0), a cosine window that takes in
+            // too many rows (bit 2): this query again as a coarse chain, which derives those lists from the kept dots by threshold;
+            // the next 63 searches go there directly
+            dbg("coarse scan: candidates did not fit (overflow bits %d) -> the coarse chain for this and the next 63 searches", q->hout->overflow);
+            if (q->hout->overflow & 1) q->crowded = 1;
+            if (q->hout->overflow & 4) q->sc_crowded = 1;
+            q->info_clean = 0;
+            return search_once(q, query, d, tau, mode, out_idx, out_score, out_len, out_lambda_q);
+        }
         if (q->coarse && (q->hout->overflow & 5)) {
             // the coarse scan's candidates did not fit (its wider windows took in too many rows): the same query on the two-digit
             // image straight away -- the chains behind an overflow would price the coarse dots and fail their proofs
