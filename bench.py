@@ -296,7 +296,7 @@ def make_data_torch(kind, n, d, seed, device):
     return X
 
 
-def brute_force_verify(aspace, gl, X, queries, tau, topk, rtol=1e-9):
+def brute_force_verify(aspace, gl, X, queries, tau, topk, rtol=1e-9, want=None):
     """The library's hits for `queries` against an fp64 brute force on the GPU (torch): cosines of ALL items in fp64,
     TAUMODE.md:33's score with the library's own lambda_q and lambdas, top-k by (score desc, index asc).  A query counts
     as a mismatch when its scores differ beyond rtol or its indices differ anywhere outside a run of scores equal to
@@ -319,6 +319,8 @@ def brute_force_verify(aspace, gl, X, queries, tau, topk, rtol=1e-9):
         got.append(hits)
         lqs.append(aspace.query_lambda(q, gl))
         keep.append(q)
+        if want is not None and len(keep) >= want:   # (the first `want` queries that have an answer: the rest of `queries` are spares)
+            break
     if not keep:
         return {"n": 0, "mismatches": 0, "zero_lambda": zero}
     Qd = torch.from_numpy(np.stack(keep)).to(dev)                       # [nq, d] fp64
@@ -733,7 +735,8 @@ def main():
     if single and not args.traffic_probe and args.verify_queries > 0:
         nv = min(args.verify_queries, args.steps)
         v1 = brute_force_verify(aspace, gl, X, [Q[(args.warmup + i) % len(Q)] for i in range(nv)], args.tau, min(args.topk, n))
-        v2 = brute_force_verify(aspace, gl, X, [Qin[(args.warmup + i) % len(Qin)] for i in range(nv)], args.tau, min(args.topk, n))
+        # (in-distribution draws without an item inside eps raise the reference's panic and have no answer to verify: spares)
+        v2 = brute_force_verify(aspace, gl, X, [Qin[(args.warmup + i) % len(Qin)] for i in range(min(2 * nv, len(Qin)))], args.tau, min(args.topk, n), want=nv)
         verified = {"n": v1["n"] + v2["n"], "mismatches": v1["mismatches"] + v2["mismatches"],
                     "timed_queries": v1, "in_distribution_queries": v2,
                     "how": "re-issued after the timed loops; torch fp64 cosines of all N items, TAUMODE.md:33 with the library's lambda_q and "
