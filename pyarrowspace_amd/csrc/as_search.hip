@@ -3086,6 +3086,10 @@ int32_t as_set_tuning(const char* key, int32_t value) {
         set_tile_geom(value);
         return 0;
     }
+    if (key && !strcmp(key, "sc_slack")) {
+        set_sc_slack(value);
+        return 0;
+    }
     return 1;
 }
 
