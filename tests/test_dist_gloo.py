@@ -311,7 +311,15 @@ class OracleEngineX1(OracleEngine):
     CAP = 64
 
     def x1_usable(self, tau):
-        return 0.4 <= tau <= 1.0 and not getattr(self, "x1_off", False)
+        return 0.4 <= tau <= 1.0 and not getattr(self, "x1_off", False) and getattr(self, "x1_agreed", True)
+
+    def x1_enabled(self):
+        """as_query_x1_enabled: this rank's own switch (its environment when the workspace was made)."""
+        return getattr(self, "x1_local_switch", True)
+
+    def x1_set_enabled(self, enabled):
+        """as_query_set_x1: what the ranks agreed on."""
+        self.x1_agreed = bool(enabled)
 
     def x1_set_coarse(self, allowed):
         """as_query_set_coarse: the retry of a pass whose candidates did not fit scans both digits (here: a scripted failure
@@ -422,6 +430,53 @@ def test_one_exchange_search_under_gloo(world, cuts):
             np.testing.assert_allclose([s for _, s in hits], [s for _, s in whits], rtol=1e-12)
             assert abs(lq - wlq) <= 1e-12 * abs(wlq)
         assert out[rank][0] == out[0][0]
+
+
+def _x1_vote_worker(rank, world, port, n, d, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyarrowspace_amd.dist import ShardedIndex
+        X = clustered(n, d, nclust=6, seed=21)
+        gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+        shard = torch.from_numpy(X[rank * n // world : (rank + 1) * n // world].copy())
+        eng = OracleEngineX1(gp)
+        eng.x1_local_switch = rank != 1        # rank 1's environment has the one-exchange pass switched off
+        index = ShardedIndex.build(gp, shard, dist, engine=eng)
+        rng = np.random.default_rng(5)
+        res = []
+        for _ in range(3):
+            q = X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d)
+            res.append(index.search(q, 0.62))
+        out[rank] = (eng.x1_agreed, getattr(eng, "x1_calls", 0), res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_exchange_switch_is_agreed_over_the_ranks():
+    """What a rank's environment switches about the query path decides which collectives a search issues (one all-gather of
+    blocks, or two of records): ShardedIndex agrees on it once when the query is opened (MIN over the ranks,
+    _agree_query_switches) -- a rank with ARROWSPACE_STAGED_X1=0 switches the pass off for all, no rank ever takes the
+    one-exchange branch alone (it would wait in an all-gather nobody else enters), and the hits are those of one process."""
+    import torch.multiprocessing as mp
+    from oracle import oracle_np
+    n, d, world = 300, 24, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_x1_vote_worker, args=(world, _free_port(), n, d, out), nprocs=world, join=True)
+    X = clustered(n, d, nclust=6, seed=21)
+    gp = {"eps": calibrate_eps(X, 6), "k": 6, "topk": 5, "p": 2.0, "sigma": None}
+    ref = oracle_np.build(X, gp)
+    rng = np.random.default_rng(5)
+    want = [oracle_np.search(ref, X[rng.integers(0, n)] + 0.02 * rng.standard_normal(d) / np.sqrt(d), 0.62)[0] for _ in range(3)]
+    for rank in range(world):
+        agreed, calls, res = out[rank]
+        assert agreed is False and calls == 0
+        for hits, whits in zip(res, want):
+            assert [i for i, _ in hits] == [i for i, _ in whits]
 
 
 def _free_port():
