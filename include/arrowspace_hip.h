@@ -415,7 +415,8 @@ as_status as_query_stats(const as_query* q, double* out, int32_t n);
  * query); enable it before the searches whose stats are read */
 void as_enable_search_stats(int32_t enabled);
 /* Measurement knob, no reference counterpart: launch parameters the library otherwise picks itself.  "tile_geom" = <blocks per
- * CU><two digits: ring KiB per wave> of the single query's tile scan (e.g. 406, 308, 216; ARROWSPACE_TILE_GEOM at load).
+ * CU><two digits: ring KiB per wave> of the single query's tile scan (e.g. 406, 308, 216; ARROWSPACE_TILE_GEOM at load);
+ * "x1_blocks" = blocks of the coarse scan's exact-evaluation kernel (16 .. 256, default 128).
  * Returns 0, or 1 for an unknown key.  Results never depend on it. */
 int32_t as_set_tuning(const char* key, int32_t value);
 /* same, for the workspace as_search keeps inside the space (last as_search call) */

@@ -291,7 +291,6 @@ struct PreArgs {
     int* sc_idx = nullptr;   // [waves of the scan][SC_WCAP]: a wave's report -- [0] its number of candidates (-1: more than fit), [1 ..] their rows
     unsigned int* sc_hist = nullptr;   // SC_COPIES cosine histograms
     int sc_late = 0;         // the tail kernels validate lossy reports against the final histogram (scan_wave_report)
-    int sc_slack = 0;        // bins above a standing bound a row must lie to be published
     int sc_dbg = 0;          // measurement only, -DAS_ABLATION builds (ARROWSPACE_SC_DBG): 1 no publication, 2 no histogram read, 4 no candidates
     // Scan of the int8 two-digit image (scan_dma_kernel<..., I8>: half the bytes of the fp32 items): the rows' scales, the
     // query's digits in the lanes' register order (per 16-byte chunk of an image row: 16 bytes that multiply into the
@@ -310,7 +309,7 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
 as_status launch_scan(as_query* q, const PreArgs& pre);
 as_status launch_scan_gang(as_query* const* m, const PreArgs* pre, int n, hipStream_t st);
 void set_tile_geom(int v);
-void set_sc_slack(int v);
+void set_x1_blocks(int v);
 as_status set_scan_attrs();   // per-device dynamic-LDS opt-in of the scan kernels
 
 }  // namespace as

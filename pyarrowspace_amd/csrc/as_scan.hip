@@ -678,11 +678,9 @@ __device__ __forceinline__ void scan_chunk_end(const PreArgs& pre, ScanWave& w, 
         const int mybin = fin ? sc_bin(c) : -1;
         // (only a row above the bound's bin can raise the bound: once it stands, the chunk statistics below -- 18
         // cross-lane operations -- are skipped for almost every chunk)
-        // (sc_slack: once a bound stands, only rows MORE than that many bins above its bin publish -- a posted atomic sits in the
-        // wave's in-order queue until every XCD's copy has it, and the window below the bound is ten bins wide: the last bin of
-        // the bound buys nothing a wave should wait for)
-        const int jbp = jb >= 0 ? jb + pre.sc_slack : jb;
-        if (__ballot(mybin > jbp) && (t < rounds || rounds >= 2) && !AS_SC_DBG(1)) {
+        // (publishing only rows two or more bins above a standing bound was tried: no change in the launch's time -- the candidate
+        // bookkeeping's 8 us are not the publications)
+        if (__ballot(mybin > jb) && (t < rounds || rounds >= 2) && !AS_SC_DBG(1)) {
             float cm = fin ? c : -2.0f;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
@@ -700,7 +698,7 @@ __device__ __forceinline__ void scan_chunk_end(const PreArgs& pre, ScanWave& w, 
             const int u = lane % 3, copy = lane / 3;
             const int b = bmax - u;
             const int nb_ = u == 0 ? nb3[0] : (u == 1 ? nb3[1] : nb3[2]);
-            if (copy < SC_COPIES && b > jbp && b > bfloor && nb_ > 0) atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
+            if (copy < SC_COPIES && b > jb && b > bfloor && nb_ > 0) atomicAdd(&pre.sc_hist[copy * SC_HSTRIDE + b], (unsigned)nb_);
         }
         // candidates: c >= thr -- a NaN cosine (a poisoned row) never qualifies, as under the plain chain's `key <= thr`
         bool pass = valid && c >= thr && !AS_SC_DBG(4);
@@ -1624,10 +1622,6 @@ double coef_query(const as_query* q, bool exact) {
     return (double)(dp / 64 + 24) * u;
 }
 
-// bins above a standing bound a row must lie to be published (scan_chunk_end); ARROWSPACE_SC_SLACK, as_set_tuning("sc_slack", v)
-static std::atomic<int> g_sc_slack{getenv("ARROWSPACE_SC_SLACK") ? atoi(getenv("ARROWSPACE_SC_SLACK")) : 0};
-void set_sc_slack(int v) { g_sc_slack.store(v < 0 ? 0 : (v > 8 ? 8 : v), std::memory_order_relaxed); }
-
 PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
     const as_space* sp = q->sp;
     PreArgs p;
@@ -1659,7 +1653,6 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
         p.sc_idx = q->sc_widx;
         p.sc_hist = q->sc_hist;
         p.sc_late = q->sc_late;
-        p.sc_slack = g_sc_slack.load(std::memory_order_relaxed);
         q->last_sc_m = p.sc_m;
         q->last_sc_w = p.sc_w;
 #ifdef AS_ABLATION   // measurement switches that return wrong answers exist in `make ABLATION=1` builds only

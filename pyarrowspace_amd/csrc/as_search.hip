@@ -1883,6 +1883,8 @@ struct XCand {
 constexpr int X1_BLOCKS = 16;        // candidate blocks beside the k-NN block
 constexpr int X1_BLOCKS_COARSE = 128; // blocks of the coarse scan's tail: scorer candidates AND k-NN candidates by the thousand, one round of 64 rows per block
 constexpr int X1_LOCAL_CAP = 4096;   // candidates one block gathers from its share of the scan's reports
+static std::atomic<int> g_x1_blocks{X1_BLOCKS_COARSE};   // measurement: as_set_tuning("x1_blocks", v), 16 .. 256
+void set_x1_blocks(int v) { g_x1_blocks.store(v < 16 ? 16 : (v > 256 ? 256 : v), std::memory_order_relaxed); }
 
 // grid 1 + X1_BLOCKS: block 0 = knn_finish (records into the exchange block), blocks 1.. = the scan waves' reports -> exact
 // cosines.  The two halves do not depend on each other: the k-NN phase (17 us, one block) hides the candidates' evaluation.
@@ -3086,8 +3088,8 @@ int32_t as_set_tuning(const char* key, int32_t value) {
         set_tile_geom(value);
         return 0;
     }
-    if (key && !strcmp(key, "sc_slack")) {
-        set_sc_slack(value);
+    if (key && !strcmp(key, "x1_blocks")) {
+        set_x1_blocks(value);
         return 0;
     }
     return 1;
@@ -3429,7 +3431,7 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     // (a rank that could not collect candidates -- no fused scan for this query here -- says so: every rank reads the flag and
     // the pass is rerun on the two-exchange chain)
     const size_t lds_xk = (sp->dp <= Q_LDS_MAX ? sizeof(double) * (size_t)sp->dp : 0) + (sizeof(double) + sizeof(int) + sizeof(short)) * (size_t)CAND_CAP + 64;
-    hipLaunchKernelGGL(staged_x1_kernel, dim3(exact_knn ? X1_BLOCKS_COARSE : 1 + X1_BLOCKS), dim3(1024), exact_knn ? lds_xk : x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
+    hipLaunchKernelGGL(staged_x1_kernel, dim3(exact_knn ? g_x1_blocks.load(std::memory_order_relaxed) : 1 + X1_BLOCKS), dim3(1024), exact_knn ? lds_xk : x1_lds_a(), q->stream, fk, fs, head, cands, x1_cap(world),
                        !sc_ran && rows > 0 && xmode == 0 ? 16 : 0, exact_knn ? (XKnn*)q->xknn : (XKnn*)nullptr, xmode);
     AS_HIP(hipGetLastError());
     q->x1_head = head;
