@@ -567,18 +567,18 @@ def main():
     # ---------------- index build (timed once, inputs resident in HBM)
     single = world == 1 and not force_dist
     Xh32 = None
+    # one untimed build of a small index of the same kind first: the process's first pass through the build loads the code
+    # object's kernels, sets their attributes and pages the library in (a fresh box measured up to 0.3 s of that inside the
+    # graph stage of the first build and none in the second) -- warm-up, as the W untimed searches are for the search
+    Xw = make_data(16384, d, 7, device, nclust=64)
+    gpw = dict(gp, eps=calibrate_eps(Xw, args.k, args.metric) if not feature else gp["eps"])
+    try:
+        _w = asp.ArrowSpaceBuilder.build_from_device(gpw, Xw.data_ptr(), "float32", 16384, d, d)
+        del _w
+    except (ValueError, RuntimeError):   # (a warm-up that cannot be built says nothing about the index)
+        pass
+    del Xw
     if single:
-        # one untimed build of a small index of the same kind first: the process's first pass through the build loads the code
-        # object's kernels, sets their attributes and pages the library in (a fresh box measured up to 0.3 s of that inside the
-        # graph stage of the first build and none in the second) -- warm-up, as the W untimed searches are for the search
-        Xw = make_data(16384, d, 7, device, nclust=64)
-        gpw = dict(gp, eps=calibrate_eps(Xw, args.k, args.metric) if not feature else gp["eps"])
-        try:
-            _w = asp.ArrowSpaceBuilder.build_from_device(gpw, Xw.data_ptr(), "float32", 16384, d, d)
-            del _w
-        except (ValueError, RuntimeError):   # (a warm-up that cannot be built says nothing about the index)
-            pass
-        del Xw
         barrier()
         t0 = time.perf_counter()
         aspace, gl = asp.ArrowSpaceBuilder.build_from_device(gp, X.data_ptr(), "float32", n, d, d)
