@@ -1993,10 +1993,19 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
         const int total = mine + tot;
         for (int base = 0; base < total; base += 64) {   // (block-uniform)
             const int m = total - base < 64 ? total - base : 64;
-            exact_eval_all(ak.x32, ak.x64, qx ? qx : ak.q64, ak.d, ak.dp, si + base, m, o_sq, o_dot);
             const int sc_lo = base > mine ? base : mine;          // first scorer entry of this round
             const int m_sc = base + m - sc_lo;
-            if (threadIdx.x == 0 && m_sc > 0) s_base = atomicAdd(&head->count, m_sc);   // one ticket per block and round
+            // (in flight under the evaluation instead of behind it: the round's ticket and, per row, its norm and lambda)
+            int ticket = 0;
+            if (threadIdx.x == 0 && m_sc > 0) ticket = atomicAdd(&head->count, m_sc);   // one ticket per block and round
+            double pre_n = 0.0, pre_l = 0.0;
+            if ((int)threadIdx.x < m) {
+                const int jp = si[base + (int)threadIdx.x];
+                pre_n = ak.n64[jp];
+                pre_l = base + (int)threadIdx.x >= mine ? as_.lam64[jp] : 0.0;
+            }
+            exact_eval_all(ak.x32, ak.x64, qx ? qx : ak.q64, ak.d, ak.dp, si + base, m, o_sq, o_dot);
+            if (threadIdx.x == 0 && m_sc > 0) s_base = ticket;
             __syncthreads();
             if ((int)threadIdx.x < m) {
                 const int e_ = base + (int)threadIdx.x;
@@ -2011,7 +2020,7 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
                         e.dist = sqrt(sq);
                         e.gy = dot;
                     } else {
-                        const double den = sqrt(nqk * ak.n64[j]);
+                        const double den = sqrt(nqk * pre_n);
                         const double c = den > 0.0 ? dot / den : 0.0;
                         const double dd = cosine_distance(c);
                         e.key = dd;
@@ -2022,11 +2031,11 @@ __global__ __launch_bounds__(1024) void staged_x1_kernel(FinishArgs ak, FinishAr
                 } else {
                     const int slot = s_base + (e_ - sc_lo);
                     if (slot < xcap) {
-                        const double den = sqrt(as_.n64[j] * nqk);
+                        const double den = sqrt(pre_n * nqk);
                         XCand c;
                         c.idx = (int64_t)j + as_.goff;
                         c.cosv = den > 0.0 ? dot / den : 0.0;
-                        c.lam = as_.lam64[j];
+                        c.lam = pre_l;
                         cands[slot] = c;
                     } else {
                         atomicOr(&head->flags, 16);
