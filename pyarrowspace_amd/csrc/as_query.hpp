@@ -64,6 +64,7 @@ struct QInfo {
 // 256-byte line at the end of a short scan queued up for 40 us.
 constexpr int SC_COPIES = 16;
 constexpr int SC_HSTRIDE = 1088;
+constexpr int SC_CTR_WORD = 128;   // word of a copy's stride that holds a chunk cursor of the tile scan's dynamic schedule (scan_tile_kernel_dyn)
 // a scan wave's report whose count carries this bit may lack rows of cosine up to the float in the report's last word: valid
 // when that cosine lies below the bound of the FINAL histogram (scan_wave_report, PreArgs::sc_late; report_rows below)
 constexpr int SC_REPORT_LOSSY = 0x40000000;
@@ -84,8 +85,10 @@ __device__ __forceinline__ void reset_query_state(QInfo* info) {
 }
 // the cosine histograms of the fused tail, by the threads of one block
 __device__ __forceinline__ void reset_query_hist(unsigned int* hist, int tid, int nthreads) {
-    if (hist)
+    if (hist) {
         for (int i = tid; i < SC_COPIES * 64; i += nthreads) hist[(i >> 6) * SC_HSTRIDE + (i & 63)] = 0u;
+        if (tid < SC_COPIES) hist[tid * SC_HSTRIDE + SC_CTR_WORD] = 0u;   // (the tile scan's chunk cursors)
+    }
 }
 
 #ifdef __HIPCC__
@@ -290,6 +293,7 @@ struct PreArgs {
     float sc_w = 0.0f;
     int* sc_idx = nullptr;   // [waves of the scan][SC_WCAP]: a wave's report -- [0] its number of candidates (-1: more than fit), [1 ..] their rows
     unsigned int* sc_hist = nullptr;   // SC_COPIES cosine histograms
+    unsigned int* tile_ctrs = nullptr; // the same buffer: SC_COPIES chunk cursors in the copies' padding (set whether or not SC is)
     int sc_late = 0;         // the tail kernels validate lossy reports against the final histogram (scan_wave_report)
     int sc_dbg = 0;          // measurement only, -DAS_ABLATION builds (ARROWSPACE_SC_DBG): 1 no publication, 2 no histogram read, 4 no candidates
     // Scan of the int8 two-digit image (scan_dma_kernel<..., I8>: half the bytes of the fp32 items): the rows' scales, the
@@ -309,6 +313,7 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
 as_status launch_scan(as_query* q, const PreArgs& pre);
 as_status launch_scan_gang(as_query* const* m, const PreArgs* pre, int n, hipStream_t st);
 void set_tile_geom(int v);
+void set_tile_dyn(int v);
 void set_x1_blocks(int v);
 as_status set_scan_attrs();   // per-device dynamic-LDS opt-in of the scan kernels
 

@@ -14,6 +14,12 @@
 
 namespace as {
 
+#ifdef AS_STAMPS
+// diagnostic build only (make STAMPS=1): when every wave of the last tile scan started and ended (100 MHz wall clock): the
+// launch's ramp and tail (tools/scan_stamps.py).  No product code reads them.
+__device__ unsigned long long g_scan_stamps[2 * 4096];
+#endif
+
 // ------------------------------------------------------------------ K7a scan: dots[i] = x_i . q  (+ k-NN prefilter)
 
 // aux = n32[row] (L2) or inorm32[row] (cosine), loaded by the caller together with the row
@@ -1104,6 +1110,9 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
     const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
     const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
     const int64_t tail0 = r0 + (int64_t)rounds * NW * crows;
+#ifdef AS_STAMPS
+    if (lane == 0 && gw < 4096) g_scan_stamps[gw] = __builtin_amdgcn_s_memrealtime();
+#endif
 #define AS_CHUNK(t, base, cnt)                                                           \
     do {                                                                                 \
         if ((t) < rounds) {                                                              \
@@ -1255,9 +1264,220 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     scan_wave_report<SC>(pre, w, gw, lane, px0);
+#ifdef AS_STAMPS
+    if (lane == 0 && gw < 4096) g_scan_stamps[4096 + gw] = __builtin_amdgcn_s_memrealtime();
+#endif
 #undef AS_TILE_ISSUE
 #undef AS_TILE_ENTER
 #undef AS_CHUNK
+}
+
+// The same scan with a DYNAMIC chunk schedule.  Waves do not run at one speed: with equal shares the median wave of the 1M x 768
+// scan ended 119 us after the launch, the last one at 131.5 (make STAMPS=1, tools/scan_stamps.py) -- a tail of 12 us at falling
+// occupancy.  Here chunk c is rows [r0 + c crows, + crows); a wave's first chunk is its own (c = wave), every further one is
+// NW + 16 j + g for ticket j of the wave's group g (sixteen atomic cursors, zero between searches).  The ticket for the chunk after
+// next is drawn
+// at a chunk's START by a returning atomic issued through inline asm: it is older than every item issued inside that chunk, so
+// the chunk's counted waits have seen it retire long before its value is read at the chunk's end -- no wait of its own, and
+// nothing the compiler would drain the ring for.  (Rows of fewer than 16 chunks keep the static kernel: the prefetch cursor
+// must not cross two chunk boundaries inside one chunk.)
+// Measured (1M x 768, tools/tile_geom.py, profiles/r05_tile_dyn.txt): ONE cursor for all 2 048 waves ran at the rate of one
+// word's atomics -- 252 us against the static schedule's 138; sixteen cursors 130.7 us against 135.5, the last wave ending at
+// 129.5 us instead of 132.5, the waves' ends 115.5 .. 126 (p10 .. p90) instead of 111 .. 128.  Chunks of 32 rows (half the lanes
+// of every DMA idle) 133.6 us, of 16 rows 193: the chunk stays 64 rows, a tile.
+template <int NSLOT, bool SC>
+__global__ __launch_bounds__(256) void scan_tile_kernel_dyn(const signed char* __restrict__ xt, int C, int64_t r0, int64_t r1, float* __restrict__ dots,
+                                                            PreArgs pre, int crows) {
+    constexpr int U = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RING = NSLOT * 1024;            // bytes per wave
+    constexpr int WAVE_LDS = RING + 256 + 256 + (SC ? 256 + TILE_PEND * 8 : 0);   // + the chunk's 64 norms, 64 scales (+ histogram, pending list)
+    constexpr int K1 = NSLOT - 2 * U;             // DMA operations younger than the oldest pair of a full ring
+    constexpr int KB = 4;                         // operations of a chunk boundary: the dots' store, the norm DMA, the scale DMA, the ticket
+    static_assert((U == 2 || U == 4) && NSLOT % U == 0 && NSLOT >= 2 * U, "ring of whole steps");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* myp = smem + wu * WAVE_LDS;
+    const unsigned s0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned my0 = s0 + wu * WAVE_LDS;
+    const unsigned ax0 = my0 + RING, fx0 = ax0 + 256, hx0 = fx0 + 256, px0 = hx0 + 256;
+    const unsigned qx0 = s0 + 4 * WAVE_LDS;       // the query's digits, shared by the block: per chunk 16 bytes q1, 16 bytes q2
+    const float* __restrict__ auxv = pre.metric == AS_METRIC_L2 ? pre.n32 : pre.inorm32;
+    const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
+#ifdef AS_STAMPS
+    if (lane == 0 && gw < 4096) g_scan_stamps[gw] = __builtin_amdgcn_s_memrealtime();
+#endif
+#define AS_CHUNK_ID(cid, base, cnt)                                                      \
+    do {                                                                                 \
+        base = r0 + (int64_t)(cid) * crows;                                              \
+        const int64_t left_ = r1 - base;                                                 \
+        cnt = (int)(left_ <= 0 ? 0 : (left_ < crows ? left_ : crows));                   \
+    } while (0)
+    // SC_COPIES cursors, each in the unused tail of a histogram copy's stride (different memory channels; zeroed with the
+    // histograms): 2 048 waves x 8 tickets on ONE word ran at the rate of that word's atomics -- 250 us.  A block's group is
+    // (b + b / 8) mod 16: a group's blocks cycle through the XCDs (consecutive blocks go to consecutive XCDs), so a slow XCD
+    // slows every group alike; group g hands out the chunks NW + 16 j + g, j = 0, 1, ...
+    const int grp = (int)((blockIdx.x + (blockIdx.x >> 3)) & (SC_COPIES - 1));
+    int* ctr = (int*)(pre.tile_ctrs + grp * SC_HSTRIDE + SC_CTR_WORD);
+    int tk = 0;                // the ticket in flight (written by the atomic: read only behind the waits described above)
+    const int one = 1;
+    // (one atomic per WAVE: lane 0 draws, v_readfirstlane reads lane 0's register)
+#define AS_TICKET()                                                                                                   \
+    do {                                                                                                              \
+        if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(tk) : "v"(ctr), "v"(one) : "memory"); \
+    } while (0)
+    AS_TICKET();               // the wave's second chunk
+    int64_t ccur = gw, cnxt = 0;   // chunk being consumed; the one the prefetch cursor crosses into
+    // prefetch cursor: chunk pt, column chunk pcol; the lanes' byte offsets from the chunk's first tile
+    int pcol = 0, pcnt = 0, pslot = 0, inflight = 0;
+    int64_t pbase = 0;
+    unsigned pvoff = 0;
+    const signed char* pub = xt;
+    const size_t tile_bytes = (size_t)C * 1024;
+#define AS_TILE_ENTER()                                                                                                  \
+    do {                                                                                                                 \
+        if (pcnt > 0) {                                                                                                  \
+            const int rl_ = lane < pcnt ? lane : pcnt - 1;   /* lanes past the chunk's end fetch its last row again */     \
+            const int tl_ = (int)(pbase & 63) + rl_;                                                                     \
+            pvoff = (unsigned)(tl_ >> 6) * (unsigned)tile_bytes + (unsigned)(tl_ & 63) * 16u;                            \
+            pub = xt + (size_t)(pbase >> 6) * tile_bytes;                                                                \
+        }                                                                                                                \
+    } while (0)
+#define AS_TILE_ISSUE()                                                                                                  \
+    do {                                                                                                                 \
+        if (pcnt > 0) {                                                                                                  \
+            _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                                                             \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pub + pvoff + u_ * 1024), \
+                                                 (__attribute__((address_space(3))) void*)(myp + (pslot + u_) * 1024), 16, 0, 2); \
+            pub += U * 1024;                                                                                             \
+            pslot = pslot + U == NSLOT ? 0 : pslot + U;                                                                  \
+            inflight += U;                                                                                               \
+            pcol += U;                                                                                                   \
+            if (pcol == C) {                                                                                             \
+                pcol = 0;                                                                                                \
+                AS_CHUNK_ID(cnxt, pbase, pcnt);                                                                          \
+                AS_TILE_ENTER();                                                                                         \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
+    AS_CHUNK_ID(ccur, pbase, pcnt);
+    AS_TILE_ENTER();
+#pragma unroll
+    for (int i = 0; i < NSLOT / U - 1; ++i) AS_TILE_ISSUE();
+    // (behind the ring's first fill: the query's digits come from the host's pinned memory -- a PCIe round trip every block
+    // would otherwise take before its first DMA)
+    {
+        int* qd = (int*)(smem + 4 * WAVE_LDS);
+        for (int i = tid; i < C * 8; i += 256) qd[i] = pre.q8[i];
+    }
+    float nq32 = pre.host_q ? pre.nq32 : pre.info->nq32, inq32 = pre.host_q ? pre.inq32 : pre.info->inq32;
+    if (pre.host_q && blockIdx.x == 0 && tid == 0) {   // what q_prepare would have filed: read by the kernels behind the scan
+        pre.infow->nq = pre.nq;
+        pre.infow->inq = pre.inq;
+        pre.infow->nq32 = pre.nq32;
+        pre.infow->inq32 = pre.inq32;
+        pre.infow->tau = 1.0;
+    }
+    if (pre.host_q && pre.q64_dev)   // the fp64 query for the kernels behind the scan: pinned host memory -> device (PreArgs)
+        for (int g = (int)blockIdx.x * 256 + tid; g < pre.qdp; g += (int)gridDim.x * 256) pre.q64_dev[g] = pre.q64_host[g];
+    asm volatile("" : "+v"(nq32), "+v"(inq32));
+    __syncthreads();   // (the only block barrier: the query's digits are in LDS; from here on every LDS access is inline asm)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk) : : "memory");   // (start-up: the ring's first fill and the first ticket)
+    cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * SC_COPIES + grp;
+    unsigned cur = 0;    // byte offset of the oldest pair in the ring
+    int marked = 0;      // items in flight that have a chunk boundary's store + norm + scale DMA behind them in the queue
+    bool first = true;
+    ScanWave w;
+    for (int t = 0;; ++t) {
+        int64_t base;
+        int cnt;
+        AS_CHUNK_ID(ccur, base, cnt);
+        if (cnt <= 0) break;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),   // padded: readable
+                                         (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.fa8 + base + lane),
+                                         (__attribute__((address_space(3))) void*)(myp + RING + 256), 4, 0, 0);
+        // SC: the histogram as the other waves have left it, consumed at the chunk's end (chunks 2, 3, 5, 9, 17, ...: scan_dma_kernel)
+        const bool hread = SC && t >= 2 && (t == 2 || ((t - 1) & (t - 2)) == 0 || w.jb_last < 0) && !AS_SC_DBG(2);
+        if (hread)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre.sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
+                                             (__attribute__((address_space(3))) void*)(myp + RING + 512), 4, 0, 16);
+        AS_TICKET();                     // the chunk after `cnxt`
+        marked = first ? 0 : inflight;   // the first chunk has no store in front of its boundary DMAs: assume nothing
+        const bool hmark = hread;
+        first = false;
+        int hi0 = 0, xs0 = 0, hi1 = 0, xs1 = 0;
+        unsigned qa = qx0;
+        for (int c = 0; c < C; c += U) {
+            // operations retire in issue order: the oldest pair has landed once at most NSLOT - 2 U younger items (+ a chunk
+            // boundary's operations behind it) are outstanding
+            if (inflight == NSLOT - U) {
+                if (marked > 0 && hmark) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB + 1) : "memory");
+                else if (marked > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1 + KB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            marked = marked > U ? marked - U : 0;
+            inflight -= U;
+            AS_TILE_ISSUE();   // into the slots consumed one step ago
+            i32x4s xv[U], qa_[U], qb_[U];
+            const unsigned a0 = my0 + cur + lane * 16;
+            if (U == 2)
+                asm volatile(
+                    "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
+                    "ds_read_b128 %4, %7 offset:32\n\tds_read_b128 %5, %7 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                    : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(qa_[0]), "=&v"(qb_[0]), "=&v"(qa_[1]), "=&v"(qb_[1])
+                    : "v"(a0), "v"(qa)
+                    : "memory");
+            if (U == 4)
+                asm volatile(
+                    "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:1024\n\tds_read_b128 %2, %12 offset:2048\n\tds_read_b128 %3, %12 offset:3072\n\t"
+                    "ds_read_b128 %4, %13\n\tds_read_b128 %5, %13 offset:16\n\tds_read_b128 %6, %13 offset:32\n\tds_read_b128 %7, %13 offset:48\n\t"
+                    "ds_read_b128 %8, %13 offset:64\n\tds_read_b128 %9, %13 offset:80\n\tds_read_b128 %10, %13 offset:96\n\tds_read_b128 %11, %13 offset:112\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[U > 2 ? 2 : 0]), "=&v"(xv[U > 3 ? 3 : 0]), "=&v"(qa_[0]), "=&v"(qb_[0]), "=&v"(qa_[1]), "=&v"(qb_[1]),
+                      "=&v"(qa_[U > 2 ? 2 : 0]), "=&v"(qb_[U > 2 ? 2 : 0]), "=&v"(qa_[U > 3 ? 3 : 0]), "=&v"(qb_[U > 3 ? 3 : 0])
+                    : "v"(a0), "v"(qa)
+                    : "memory");
+            cur = cur + U * 1024 == RING ? 0 : cur + U * 1024;
+            qa += U * 32;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u & 1) {
+                        hi1 = __builtin_amdgcn_sdot4(xv[u][e], qa_[u][e], hi1, false);
+                        xs1 = __builtin_amdgcn_sdot4(xv[u][e], qb_[u][e], xs1, false);
+                    } else {
+                        hi0 = __builtin_amdgcn_sdot4(xv[u][e], qa_[u][e], hi0, false);
+                        xs0 = __builtin_amdgcn_sdot4(xv[u][e], qb_[u][e], xs0, false);
+                    }
+                }
+        }
+        // the boundary DMAs are older than every item issued inside this chunk; one of those has been consumed once the chunk
+        // has more items than the ring keeps in flight
+        if (C <= NSLOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float aux = lds_read1(ax0 + lane * 4);
+        // x_i . q = (128 HI + XS) fa_i fa_q: the integer is exact, its conversion the one rounding the row-ring kernel's fused
+        // multiply-add makes
+        const long long tot = (long long)(hi0 + hi1) * 128 + (long long)(xs0 + xs1);
+        const float mydot = (float)tot * (lds_read1(fx0 + lane * 4) * pre.faq);
+        scan_chunk_end<SC, TILE_PEND>(pre, w, dots, t, 1 << 30, gw, lane, base, cnt, mydot, aux, hread, hx0, px0, nq32, inq32);
+        // (the ticket drawn at this chunk's start has retired: C >= 16 items were issued behind it and all but the ring's youngest waited for)
+        asm volatile("" : "+v"(tk));
+        ccur = cnxt;
+        cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * SC_COPIES + grp;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    scan_wave_report<SC>(pre, w, gw, lane, px0);
+#ifdef AS_STAMPS
+    if (lane == 0 && gw < 4096) g_scan_stamps[4096 + gw] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef AS_TILE_ISSUE
+#undef AS_TILE_ENTER
+#undef AS_CHUNK_ID
+#undef AS_TICKET
 }
 
 // Gang scan: ONE pass over the tiles for up to FOUR single queries of concurrent host threads (as_search is re-entrant: callers
@@ -1637,6 +1857,7 @@ PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled) {
         p.q8 = q->coarse ? q->hq8h_dev : q->hq8_dev;
         p.faq = q->h_faq;
     }
+    p.tile_ctrs = q->sc_hist;   // (the tile scan's chunk cursors live in the histogram copies' padding)
     if (q->host_q) {
         p.nq = q->h_nq; p.inq = q->h_inq;
         p.nq32 = (float)q->h_nq; p.inq32 = q->h_nq > 0.0 ? (float)(1.0 / sqrt(q->h_nq)) : 0.0f;
@@ -1671,6 +1892,9 @@ static constexpr size_t dma_lds(int nch, int nslot, bool sc = false, bool i8 = f
 // launch geometry of the tile scan, <blocks per CU><two digits: ring KiB per wave>; ARROWSPACE_TILE_GEOM at load, as_set_tuning("tile_geom", v) later
 static std::atomic<int> g_tile_geom{getenv("ARROWSPACE_TILE_GEOM") ? atoi(getenv("ARROWSPACE_TILE_GEOM")) : 208};
 void set_tile_geom(int v) { g_tile_geom.store(v, std::memory_order_relaxed); }
+// chunk schedule of the tile scan: 1 dynamic (an atomic cursor: scan_tile_kernel_dyn), 0 equal shares; ARROWSPACE_TILE_DYN, as_set_tuning("tile_dyn", v)
+static std::atomic<int> g_tile_dyn{getenv("ARROWSPACE_TILE_DYN") ? atoi(getenv("ARROWSPACE_TILE_DYN")) : 1};
+void set_tile_dyn(int v) { g_tile_dyn.store(v, std::memory_order_relaxed); }   // (0 static, 1 dynamic, 16 / 32: dynamic with chunks of that many rows)
 
 static constexpr size_t gang_lds(int nslot, int nq, int64_t chunks) {
     return 4 * ((size_t)nslot * 1024 + 512 + (size_t)nq * (256 + GANG_PEND * 8) + (size_t)nq * 512) + (size_t)nq * chunks * 32 + 32;
@@ -1701,6 +1925,8 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_tile_kernel<12, true>), tile_lds(12, true, 256));
     AS_ATTR((scan_tile_kernel<16, true>), tile_lds(16, true, 256));
     AS_ATTR((scan_tile_kernel<8, false>), tile_lds(8, false, 256));
+    AS_ATTR((scan_tile_kernel_dyn<8, true>), tile_lds(8, true, 256));
+    AS_ATTR((scan_tile_kernel_dyn<8, false>), tile_lds(8, false, 256));
     AS_ATTR((scan_tile_gang_kernel<8, 2>), gang_lds(8, 2, 256));
     AS_ATTR((scan_tile_gang_kernel<8, 3>), gang_lds(8, 3, 256));
     AS_ATTR((scan_tile_gang_kernel<8, 4>), gang_lds(8, 4, 256));
@@ -2012,7 +2238,15 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
             hipLaunchKernelGGL((scan_tile_kernel<8, false>), dim3((unsigned)nblk), dim3(256), tile_lds(8, false, C), st, xt, C, q->r0, q->r1, \
                                q->dots32, pre, rounds, tail_rows, crows);                                              \
     } while (0)
-                if (tstep == 4 && pre.sc_enabled) {
+                if (C >= 16 && tslots == 8 && tstep == 2 && pre.tile_ctrs && g_tile_dyn.load(std::memory_order_relaxed)) {
+                    // dynamic chunk schedule (the default): chunks of `crows` rows by id, the waves' first ones their own
+                    const int dynv = g_tile_dyn.load(std::memory_order_relaxed);
+                    if (dynv == 16 || dynv == 32) crows = std::min(crows, dynv);
+                    if (pre.sc_enabled)
+                        hipLaunchKernelGGL((scan_tile_kernel_dyn<8, true>), dim3((unsigned)nblk), dim3(256), tile_lds(8, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, crows);
+                    else
+                        hipLaunchKernelGGL((scan_tile_kernel_dyn<8, false>), dim3((unsigned)nblk), dim3(256), tile_lds(8, false, C), st, xt, C, q->r0, q->r1, q->dots32, pre, crows);
+                } else if (tstep == 4 && pre.sc_enabled) {
                     if (tslots == 16) hipLaunchKernelGGL((scan_tile_kernel<16, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(16, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);
                     else if (tslots == 12) hipLaunchKernelGGL((scan_tile_kernel<12, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(12, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);
                     else hipLaunchKernelGGL((scan_tile_kernel<8, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(8, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);
@@ -2090,3 +2324,10 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
 }
 
 }  // namespace as
+
+#ifdef AS_STAMPS
+// diagnostic build only (not declared in the public header)
+extern "C" int as_debug_scan_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(as::g_scan_stamps), sizeof(unsigned long long) * 2 * 4096) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -3097,6 +3097,10 @@ int32_t as_set_tuning(const char* key, int32_t value) {
         set_tile_geom(value);
         return 0;
     }
+    if (key && !strcmp(key, "tile_dyn")) {
+        set_tile_dyn(value);
+        return 0;
+    }
     if (key && !strcmp(key, "x1_blocks")) {
         set_x1_blocks(value);
         return 0;

@@ -18,7 +18,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
     geoms = [int(a) for a in sys.argv[3:]] or [406, 306, 206, 308, 208, 212, 216, 116]
-    slacks = [int(v) for v in os.environ.get("X1_BLOCKS", "128").split(",")]
+    slacks = [int(v) for v in os.environ.get("TILE_DYN", "1").split(",")]
     dev = torch.device("cuda:0")
     X = bench.make_data(n, d, 42, dev)
     Q = bench.make_queries(X, 256, 43)
@@ -29,7 +29,7 @@ def main():
     for rep in range(2):
         for g, sl in [(g, sl) for g in geoms for sl in slacks]:
             L.as_set_tuning(b"tile_geom", g)
-            L.as_set_tuning(b"x1_blocks", sl)
+            L.as_set_tuning(b"tile_dyn", sl)
             for i in range(20):
                 aspace.search(Q[i], gl, 0.62)
             torch.cuda.synchronize()
@@ -43,7 +43,7 @@ def main():
                 aspace.search(Q[i], gl, 0.62)
                 us.append(aspace.last_search_stats()["scan_us"])
             asp.enable_search_stats(False)
-            print(f"geom={g} x1_blocks={sl} n={n} d={d}: {200 / dt:.0f} q/s, scan {np.mean(us):.1f} us (min {np.min(us):.1f}) = {n * (d8 + 12) / np.mean(us) / 1e6:.2f} TB/s moved, operand {aspace.last_scan_operand}", flush=True)
+            print(f"geom={g} dyn={sl} n={n} d={d}: {200 / dt:.0f} q/s, scan {np.mean(us):.1f} us (min {np.min(us):.1f}) = {n * (d8 + 12) / np.mean(us) / 1e6:.2f} TB/s moved, operand {aspace.last_scan_operand}", flush=True)
 
 
 if __name__ == "__main__":
