@@ -721,11 +721,13 @@ def main():
     # extension, reported next to the headline, never as it: batched search, 32 query
     # slots per pass over the items (GEMM-shaped scan on fp32 MFMA)
     batched_qps = batch_pass_ms = None
+    batch_dual = 0.0
     if len(Q) >= 64:
         QB = np.ascontiguousarray(np.concatenate([Q[:64]] * 4))    # 256 queries = 8 passes of 32
         # N > 1: the staged batched path (ShardedIndex.search_batch: two collectives per pass of 32 queries)
         run_batch = (lambda: aspace.search_batch(QB, gl, args.tau)) if single else (lambda: index.search_batch(QB, args.tau))
         run_batch()
+        dual0 = aspace.batch_dual_scans if single else 0
         tb = []
         for _ in range(7):
             barrier()
@@ -738,6 +740,8 @@ def main():
             dist.all_reduce(tbm, op=dist.ReduceOp.MAX)
         batched_qps = len(QB) / float(tbm.item())
         batch_pass_ms = float(tbm.item()) / (len(QB) / 32) * 1e3
+        # (calls of more than 32 queries launch their passes in pairs, and a pair on the int8 images shares ONE scan: scan_gemm_dual_kernel)
+        batch_dual = ((aspace.batch_dual_scans - dual0) if single else 0) / (7.0 * len(QB) / 32)   # shared scans per 32-query pass: 0 .. 0.5
     batch_i8 = bool(aspace.last_batch_int8) if single else False
 
     # ---------------- parity statement about the workload just timed: the first `verify_queries` TIMED queries and as many
@@ -824,7 +828,8 @@ def main():
         dist.all_gather_object(per_rank, mine)
     moved = scan_moved / (scan_ms * 1e-3) / 1e9
     query_bytes = n * (d + 2) * 4.0                      # whole-query algorithmic bytes
-    batch_moved = (n * (2.0 * d8 + 8.0 + 64.0) if batch_i8 else query_bytes + n * 64.0) / world   # a 32-query pass: operand + norms + scales + 32 fp16 cosines per row
+    # a 32-query pass: operand + norms + scales + 32 fp16 cosines per row; a pass that shares its scan with its pair's other pass reads half the operand
+    batch_moved = (n * (2.0 * d8 * (1.0 - batch_dual) + 8.0 + 64.0) if batch_i8 else query_bytes + n * 64.0) / world
     # Build kernel: bstats["mfma_flops"] counts 2 * (pairs computed) * D -- the fp32-equivalent work.  The default kernel
     # (as_k2bf.hip) issues THREE bf16 products per such flop (head x head, head x tail, tail x head): the roofline
     # fraction is issued bf16 flops / 2.5 PFLOP/s; the fp32-equivalent rate is kept beside it.  ARROWSPACE_K2_FP32=1: the
@@ -857,7 +862,7 @@ def main():
     if scan_coarse:
         scan_kernel = "scan_tile_kernel"   # (the coarse operand lies in tiles of 64 rows x 16 columns: as_scan.hip)
     if live:
-        traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), (live.get("knn_mfma_kernel") if k2_fp32_env else live.get("knn_bf16_kernel")), live.get("scan_gemm_kernel")
+        traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), (live.get("knn_mfma_kernel") if k2_fp32_env else live.get("knn_bf16_kernel")), (live.get("scan_gemm_dual_kernel") if batch_dual > 0 else None) or live.get("scan_gemm_kernel")
         traffic_source = live_note
     else:
         try:
@@ -865,7 +870,7 @@ def main():
             if tj["workload"] == {"n": n, "d": d} and world == 1 and args.metric == "l2" and not feature:
                 traffic_scan = tj.get(scan_kernel, {}).get("bytes_per_launch")
                 traffic_mfma = tj.get("knn_mfma_kernel" if k2_fp32_env else "knn_bf16_kernel", {}).get("bytes_per_launch")
-                traffic_batch = tj.get("scan_gemm_kernel", {}).get("bytes_per_launch")
+                traffic_batch = tj.get("scan_gemm_dual_kernel" if batch_dual > 0 else "scan_gemm_kernel", {}).get("bytes_per_launch")
                 traffic_source = ("profiles/traffic.json (rocprofv3 --pmc passes of this workload, profiles/collect.sh); live passes: %s"
                                   % live_note)
         except (OSError, KeyError, ValueError):
@@ -937,14 +942,16 @@ def main():
                            "algorithmic_speedup": query_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "note": "whole query, host-visible latency, per GPU: the scan's bytes moved over ms_per_step"},
         "roofline_batch": None if batch_pass_ms is None else {
-            "kernel": "scan_gemm_kernel + per-slot selection", "bound": "hbm", "queries_per_pass": 32,
+            "kernel": ("scan_gemm_dual_kernel" if batch_dual > 0 else "scan_gemm_kernel") + " + per-slot selection", "bound": "hbm", "queries_per_pass": 32,
+            "queries_per_scan": 32.0 / (1.0 - batch_dual), "shared_scans_per_pass": batch_dual,
             "achieved": batch_moved / (batch_pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": batch_moved / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": batch_pass_ms,
             "bytes_per_pass": batch_moved, "traffic": traffic_batch,
             "operand": "int8 two-digit images of items and queries (2 B per element)" if batch_i8 else "fp32 items as bf16 head + tail",
             "algorithmic_speedup": query_bytes / world / (batch_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "whole 32-query pass, host-visible, per GPU; `frac`: the bytes the pass moves (operand + norms + 32 fp16 cosines per "
-                    "row) against the peak; `algorithmic_speedup`: SURVEY 8(d)'s N*(D+2)*4 per pass over the same time.  int8 "
+            "note": "whole 32-query pass, host-visible, per GPU; `frac`: the bytes the pass moves (operand -- HALF of it where two passes "
+                    "share one scan, `shared_scans_per_pass` = 0.5 --, norms, 32 fp16 cosines per row; `traffic`: per LAUNCH, which then "
+                    "serves 64 queries) against the peak; `algorithmic_speedup`: SURVEY 8(d)'s N*(D+2)*4 per pass over the same time.  int8 "
                     "operand: three v_mfma_i32_32x32x32_i8 products per column, exact int32 sums; bf16 operand (the items' or the queries' "
                     "quantisation error too large, ARROWSPACE_SCAN_FP32=1): three bf16 products.  Either way the pass only prefilters: its "
                     "error bound sits in the prefilter's and the proof's coefficients (DESIGN.md 5.5).  ARROWSPACE_BATCH_F32_DOTS=1 is the "

@@ -258,6 +258,10 @@ int32_t as_last_scan_int8(const as_space* sp);
 /* 1 when the last batched pass of as_search_batch (its first workspace) ran on the int8 images of items and queries
  * (v_mfma_i32_32x32x32_i8, three products per column) rather than on the bf16 head + tail of the fp32 items. */
 int32_t as_last_batch_int8(const as_space* sp);
+/* Scans of as_search_batch that served TWO passes (64 queries) with one read of the items: calls of more than 32 queries launch
+ * their passes in pairs, and a pair on the int8 images of rows up to 768 columns shares its scan (ARROWSPACE_NO_BATCH_DUAL=1:
+ * never).  A count since the space was made. */
+int64_t as_batch_dual_scans(const as_space* sp);
 /* workspaces the pool of as_search holds at the moment (1 after single-threaded use) */
 int32_t as_search_pool_size(const as_space* sp);
 /* Concurrent as_search callers on one space share a pass over the items where they can (coarse scans of tau >= 0.4 searches that

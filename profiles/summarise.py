@@ -104,7 +104,7 @@ def traffic(fetch_csv, write_csv, n, d, out):
                        "Valid only for the workload named in 'workload'.",
            "workload": {"n": int(n), "d": int(d)}}
     for key, prefix in (("scan_tile_kernel", "as::scan_tile_kernel"), ("scan_dma_kernel", "as::scan_dma_kernel"), ("scan_dots_f32_kernel", "as::scan_dots_f32_kernel"),
-                        ("scan_gemm_kernel", "as::scan_gemm_kernel"), ("knn_mfma_kernel", "as::knn_mfma"),
+                        ("scan_gemm_kernel", "as::scan_gemm_kernel"), ("scan_gemm_dual_kernel", "as::scan_gemm_dual_kernel"), ("knn_mfma_kernel", "as::knn_mfma"),
                         ("knn_bf16_kernel", "as::knn_bf16_kernel")):
         fk = [k for k in f if k.startswith(prefix)]
         if not fk:

@@ -336,6 +336,11 @@ class ArrowSpace:
         return bool(_L.as_last_batch_int8(self._h))
 
     @property
+    def batch_dual_scans(self) -> int:
+        """Extension: scans of `search_batch` that served two passes (64 queries) with one read of the items."""
+        return int(_L.as_batch_dual_scans(self._h))
+
+    @property
     def search_pool_size(self) -> int:
         """Extension: single-query workspaces the library holds for this space -- `search` is re-entrant across host threads
         (ctypes releases the GIL around the call), each concurrent call runs on a workspace and stream of its own."""

@@ -43,7 +43,7 @@ SYMBOLS = [
     "as_feat_energy", "as_feat_lambdas", "as_feat_lambdas_global", "as_graph_lambda_mode", "as_knn_list_width", "as_space_nmax", "as_space_norms",
     "as_space_row_offset", "as_knn_block", "as_knn_block_pair", "as_knn_thresholds", "as_knn_merge", "as_knn_fold", "as_knn_block_band", "as_knn_block_exact", "as_record_capacity", "as_graph_from_knn_global", "as_graph_shard_csr", "as_graph_deg_copy", "as_graph_shard_energy",
     "as_graph_energy_copy", "as_graph_shard_lambdas", "as_graph_row_offset", "as_graph_ncols", "as_graph_nitems", "as_search",
-    "as_search_batch", "as_search_pool_size", "as_gang_counters", "as_space_knn_pipe", "as_query_scan_int8", "as_last_scan_int8", "as_last_batch_int8", "as_unproven_searches", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
+    "as_search_batch", "as_search_pool_size", "as_gang_counters", "as_space_knn_pipe", "as_query_scan_int8", "as_last_scan_int8", "as_last_batch_int8", "as_batch_dual_scans", "as_unproven_searches", "as_query_create", "as_query_free", "as_query_scan", "as_query_knn_records",
     "as_query_knn_capacity", "as_query_lambda", "as_query_score", "as_query_hit_records", "as_query_hit_capacity",
     "as_query_finish", "as_query_create_batch", "as_query_slots", "as_query_scan_batch", "as_query_lambda_batch",
     "as_query_score_batch", "as_query_finish_batch", "as_query_set_exact", "as_query_flags", "as_query_stream", "as_query_set_stream", "as_query_bind_records", "as_nitems", "as_nfeatures",
@@ -138,6 +138,7 @@ def load():
         "as_query_scan_int8": (C.c_int32, [vp]),
         "as_last_scan_int8": (C.c_int32, [vp]),
         "as_last_batch_int8": (C.c_int32, [vp]),
+        "as_batch_dual_scans": (C.c_int64, [vp]),
         "as_query_create": (i32, [vp, vp, pvp]),
         "as_query_free": (None, [vp]),
         "as_query_scan": (i32, [vp, vp, i64, i64, i64]),

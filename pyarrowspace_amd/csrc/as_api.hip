@@ -106,6 +106,8 @@ void as_free_space(as_space* sp) {
         if (sp->qpool[i]) as_query_free(sp->qpool[i]);
     if (sp->qcache_b) as_query_free(sp->qcache_b);
     if (sp->qcache_b2) as_query_free(sp->qcache_b2);
+    if (sp->qcache_b3) as_query_free(sp->qcache_b3);
+    if (sp->qcache_b4) as_query_free(sp->qcache_b4);
     if (sp->stream) hipStreamSynchronize(sp->stream);
     hipFree(sp->x32); hipFree(sp->xs); hipFree(sp->x8); hipFree(sp->x8h); hipFree(sp->fa8); hipFree(sp->x64); hipFree(sp->n64); hipFree(sp->n32); hipFree(sp->inorm32);
     hipFree(sp->lam64); hipFree(sp->lam32);
@@ -706,6 +708,7 @@ static as_status graph_matches(const as_space* sp, const as_graph* gr, const cha
 
 int32_t as_space_knn_pipe(const as_space* sp) { return sp ? sp->k2_last_pipe : -1; }
 int32_t as_last_scan_int8(const as_space* sp) { return sp && sp->qcache ? as_query_scan_int8(sp->qcache) : 0; }
+int64_t as_batch_dual_scans(const as_space* sp) { return sp ? (int64_t)sp->batch_dual_scans.load(std::memory_order_relaxed) : 0; }
 int32_t as_last_batch_int8(const as_space* sp) { return sp && sp->qcache_b ? as_query_scan_int8(sp->qcache_b) : 0; }
 
 as_status as_gang_counters(const as_space* sp, int64_t* out, int32_t n) {
@@ -811,33 +814,49 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
     const bool batched = !sp->opts.force_exact && (sp->opts.search_mode & 3) == 0 && b > 1;
     if (batched) {
         if (sp->qcache_b && sp->qcache_b_gr != gr) {
-            as_query_free(sp->qcache_b);
-            sp->qcache_b = nullptr;
-            if (sp->qcache_b2) as_query_free(sp->qcache_b2);
-            sp->qcache_b2 = nullptr;
+            for (as_query** w : {&sp->qcache_b, &sp->qcache_b2, &sp->qcache_b3, &sp->qcache_b4}) {
+                if (*w) as_query_free(*w);
+                *w = nullptr;
+            }
         }
         if (!sp->qcache_b) {
             AS_TRY(query_create(sp, gr, QUERY_BATCH, &sp->qcache_b));
             sp->qcache_b_gr = gr;
         }
-        // more than one pass: a second workspace, and the passes alternate -- pass p + 1 is queued (on its own stream)
-        // before pass p is waited for, so its scan runs under pass p's selection and finish kernels
-        if (b > QUERY_BATCH && !sp->qcache_b2 && !getenv("ARROWSPACE_NO_BATCH_PIPELINE")) {
-            if (query_create(sp, gr, QUERY_BATCH, &sp->qcache_b2) != AS_OK) sp->qcache_b2 = nullptr;   // (memory: stay sequential)
+        // more than one pass: a second workspace -- the two launch their passes as a pair, ONE scan for both (64 queries per read
+        // of the items); more than one pair: a second pair of workspaces, pair p + 1 is queued before pair p is waited for, so its
+        // scan runs under pair p's selection and finish kernels.  (No memory for them: fewer workspaces, the same results.)
+        static const bool no_pipe = getenv("ARROWSPACE_NO_BATCH_PIPELINE") != nullptr;
+        if (b > QUERY_BATCH && !sp->qcache_b2 && !no_pipe) {
+            if (query_create(sp, gr, QUERY_BATCH, &sp->qcache_b2) != AS_OK) sp->qcache_b2 = nullptr;
+        }
+        if (b > 2 * QUERY_BATCH && sp->qcache_b2 && !sp->qcache_b4 && !no_pipe) {
+            if (!sp->qcache_b3 && query_create(sp, gr, QUERY_BATCH, &sp->qcache_b3) != AS_OK) sp->qcache_b3 = nullptr;
+            if (sp->qcache_b3 && query_create(sp, gr, QUERY_BATCH, &sp->qcache_b4) != AS_OK) sp->qcache_b4 = nullptr;
         }
     }
-    as_query* ws[2] = {sp->qcache_b, sp->qcache_b2 && b > QUERY_BATCH ? sp->qcache_b2 : sp->qcache_b};
-    const bool piped = batched && ws[1] != ws[0];
-    // an error leaves no pass in flight behind it (the other workspace's kernels would otherwise still be running when the
+    const bool paired = batched && sp->qcache_b2 && b > QUERY_BATCH;
+    const bool piped = paired && sp->qcache_b3 && sp->qcache_b4 && b > 2 * QUERY_BATCH;
+    as_query* ws[4] = {sp->qcache_b, sp->qcache_b2, sp->qcache_b3, sp->qcache_b4};
+    // an error leaves no pass in flight behind it (the other workspaces' kernels would otherwise still be running when the
     // caller comes back)
     auto drain = [&](as_status s) {
-        if (piped)
-            for (int w = 0; w < 2; ++w) (void)hipStreamSynchronize((hipStream_t)as_query_stream(ws[w]));
+        if (paired)
+            for (int w = 0; w < (piped ? 4 : 2); ++w) (void)hipStreamSynchronize((hipStream_t)as_query_stream(ws[w]));
         return s;
     };
     int32_t st_chunk[QUERY_BATCH];
+    // pair j = the passes over the queries [64 j, 64 j + 64) on the workspaces 2 (j & 1), 2 (j & 1) + 1 (the first two when not piped)
+    const int64_t PAIR = 2 * QUERY_BATCH;
+    auto launch_pair = [&](int64_t j) -> as_status {
+        as_query* const* w = ws + (piped ? 2 * (j & 1) : 0);
+        const int64_t i0 = j * PAIR, i1 = i0 + QUERY_BATCH;
+        const int nb0 = (int)std::min<int64_t>(QUERY_BATCH, b - i0);
+        if (i1 < b) return search_batch_launch_pair(w[0], w[1], queries + i0 * d, nb0, queries + i1 * d, (int)std::min<int64_t>(QUERY_BATCH, b - i1), d, tau);
+        return search_batch_launch(w[0], queries + i0 * d, nb0, d, tau);
+    };
     if (piped) {
-        const as_status s0 = search_batch_launch(ws[0], queries, (int)std::min<int64_t>(QUERY_BATCH, b), d, tau);
+        const as_status s0 = launch_pair(0);
         if (s0 != AS_OK) return drain(s0);
     }
     int64_t pass = 0;
@@ -847,14 +866,15 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
     for (int64_t i0 = 0; i0 < b; i0 += QUERY_BATCH, ++pass) {
         const int nb = (int)std::min<int64_t>(QUERY_BATCH, b - i0);
         if (batched) {
-            as_query* cur = ws[pass & 1];
+            const int64_t j = pass >> 1;
+            as_query* cur = paired ? ws[(piped ? 2 * (j & 1) : 0) + (pass & 1)] : ws[0];
             as_status s = AS_OK;
             const double t0 = timing ? now() : 0.0;
-            if (piped) {
-                const int64_t i1 = i0 + QUERY_BATCH;
-                if (i1 < b) s = search_batch_launch(ws[(pass + 1) & 1], queries + i1 * d, (int)std::min<int64_t>(QUERY_BATCH, b - i1), d, tau);
-            } else {
+            if (!paired) {
                 s = search_batch_launch(cur, queries + i0 * d, nb, d, tau);
+            } else if ((pass & 1) == 0) {   // a pair's first pass: queue the next pair (piped), or this one
+                if (!piped) s = launch_pair(j);
+                else if ((j + 1) * PAIR < b) s = launch_pair(j + 1);
             }
             const double t1 = timing ? now() : 0.0;
             if (s == AS_OK)

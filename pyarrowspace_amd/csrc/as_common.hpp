@@ -66,7 +66,7 @@ struct as_space {
     // coefficient of a product of rows of two shards from the ring-wide maxima of U and V
     int ring_i8 = 0;
     double ring_u8 = 0.0, ring_v8 = 0.0, ring_coef8 = 0.0;
-    mutable double uq_est = 0.0, vq_est = 0.0;   // batched int8 pass: 1.05 x the queries' measured residue norms of the previous passes (as_search.hip, host_batch_coef)
+    mutable double uq_est = 0.0, vq_est = 0.0;   // batched int8 pass: 1.15 x the queries' measured residue norms of the previous passes (as_search.hip, host_batch_coef)
     mutable double u8max = 0.0, v8max = 0.0;   // max_i s_i |theta_i|_2 / (16256 |x_i|), max_i s_i |a2_i|_2 / (16256 |x_i|)
     mutable int x8_bad = 0;           // 1: non-finite items (the image exists but cannot be used), 2: no memory for the image (not retried)
     // image state for readers that do not take imu: 0 nothing decided, 1 x8 / fa8 / coef8 published (or x8_bad set): read-only from now on
@@ -98,7 +98,10 @@ struct as_space {
     mutable as_query* qcache = nullptr;       // lazily created by as_search
     mutable const as_graph* qcache_gr = nullptr;
     mutable as_query* qcache_b = nullptr;     // batched workspace (QUERY_BATCH slots), lazily created
-    mutable as_query* qcache_b2 = nullptr;    // its twin: passes alternate, one scans while the other finishes
+    mutable as_query* qcache_b2 = nullptr;    // its twin: the two launch their passes as a PAIR that shares one scan (search_batch_launch_pair)
+    mutable as_query* qcache_b3 = nullptr;    // a second pair (calls of more than 64 queries): one pair scans while the other's selection and
+    mutable as_query* qcache_b4 = nullptr;    // finish kernels run and its results are read
+    mutable std::atomic<long long> batch_dual_scans{0};   // scans that served two workspaces' passes (as_batch_counters)
     mutable const as_graph* qcache_b_gr = nullptr;
     mutable std::mutex qmu;
     // Gang scans (as_search.hip, gang_launch): single queries of host threads that arrive together share ONE pass over the tiles
@@ -472,6 +475,7 @@ void query_flags(const as_query* q, int* knn_inexact, int* score_inexact);
 int query_overflow_bits(const as_query* q);
 as_status query_create(const as_space* sp, const as_graph* gr, int cap, as_query** out, int pool_slot = 0);
 as_status search_batch_launch(as_query* q, const double* queries, int nb, int64_t d, double tau);
+as_status search_batch_launch_pair(as_query* a, as_query* b, const double* qa, int nba, const double* qb, int nbb, int64_t d, double tau);
 as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, int64_t* out_idx, double* out_score, int64_t* out_len,
                                double* out_lambda_q, int32_t* out_status);
 constexpr int QUERY_BATCH = 32;  // == GQ in as_search.hip: query slots of the batched workspace

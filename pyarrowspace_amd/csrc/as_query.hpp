@@ -210,6 +210,7 @@ struct as_query {
     void* xknn = nullptr;                // [CAND_CAP] exact (id, key, distance, gy) of the coarse scan's k-NN candidates (staged_x1_kernel, xk)
     int pool_slot = 0;       // slot in the space's pool of single-query workspaces (as_search): picks the stream's priority
     int gang_ok = 0;         // set by search_once around query_begin: this scan may be shared with other callers' (gang_launch)
+    as::PreArgs* defer_pre = nullptr;   // set: query_begin stops in front of the scan's launch and leaves its arguments there (search_batch_launch_pair)
     hipEvent_t gang_ev = nullptr;   // recorded behind a gang's scan on its leader's stream: the followers' tails wait for it
     float* dots32 = nullptr; // [np]
     float* part32 = nullptr; // batched workspace of rows wider than 768 floats: [K-chunk pass][slots x np] fp32 partial dots (as_scan.hip, gemm_chunks)
@@ -311,6 +312,8 @@ double coef_query(const as_query* q, bool exact);
 int gemm_chunks(int64_t dp, int64_t* chunk, bool bf16_products);
 PreArgs make_pre(as_query* q, double eps, int64_t exclude, bool enabled);
 as_status launch_scan(as_query* q, const PreArgs& pre);
+bool scan_dual_ok(const as_query* a, const as_query* b);
+as_status launch_scan_dual(as_query* a, as_query* b, const PreArgs& pa, const PreArgs& pb, hipStream_t st);
 as_status launch_scan_gang(as_query* const* m, const PreArgs* pre, int n, hipStream_t st);
 void set_tile_geom(int v);
 void set_tile_dyn(int v);

@@ -580,6 +580,213 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef AS_ISSUE_SLAB
 }
 
+// The int8 batched pass for TWO workspaces at once: 64 queries per read of the items.  A block's wave keeps the query fragments of its
+// quarter of the columns in registers -- at up to 768 columns (image rows of up to 384 floats, 3 slabs per wave) the single-set
+// kernel's six slabs of fragments are half empty: the second workspace's 32 queries take the other half.  One read of every slab
+// from LDS feeds both sets' products (12 MFMAs per slab instead of 6); the epilogue (exchange of the waves' partial sums, scales,
+// fp16 cosines, k-NN prefilter) runs once per set, each on its own workspace's buffers.  Measured before (rocprofv3 trace of the
+// 256-query bench call): the two workspaces' scans ran side by side and shared the HBM -- 291 us alone, 458 us overlapped --
+// and the first one's selection kernels starved behind the second scan (knn_finish 265 us instead of 30).
+struct DualArgs {
+    PreArgs p[2];
+    const float* q[2];   // the sets' query images ([32 slots][ld floats])
+    float* dots[2];
+    int nb[2];
+};
+template <int NBUF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_gemm_dual_kernel(
+    const float* __restrict__ x32, int64_t dp, int64_t r0, int64_t r1, int64_t ts, DualArgs da) {
+    constexpr int NS = 3;   // slabs per wave and set
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    float* St = (float*)smem;   // the single-set kernel's layout: slabs, exchange, norms, scales
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ex0 = lds0 + 4 * NBUF * 4096, ax0 = ex0 + 4 * 3 * 64 * 16, fx0 = ax0 + 4 * 64 * 4;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bx = blockIdx.x, gx = gridDim.x;
+    const int nslab = (int)(dp / 32), nsw = (nslab + 3) / 4;
+    const int ks0 = wu * nsw;
+    const int myns = max(0, min(nsw, nslab - ks0));
+    f32x4 qf[2][NS][4];
+    float nqv[2][4], iqv[2][4], fqv[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qf[s][ks][j] = ks < myns ? *(const f32x4*)(da.q[s] + (int64_t)l31 * dp + (ks0 + ks) * 32 + (2 * j + h) * 4) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const QInfo* in = da.p[s].info + (e + 8 * wu + 4 * h);
+            nqv[s][e] = da.p[s].metric == AS_METRIC_L2 ? in->nq32 : in->inq32;
+            iqv[s][e] = in->inq32;
+            fqv[s][e] = da.p[s].faqv[e + 8 * wu + 4 * h];
+        }
+    }
+    // (the loads complete here, once: see scan_gemm_kernel)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qf[s][ks][j]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(nqv[s][e]), "+v"(iqv[s][e]), "+v"(fqv[s][e]));
+    }
+    float* my = St + wu * NBUF * 1024;
+    const unsigned my0 = lds0 + wu * NBUF * 4096;
+    const int drow = lane >> 3;
+    const int csw0 = (lane & 7) ^ ((lane >> 4) & 7), csw1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+    const unsigned lo0 = (unsigned)((drow * dp + csw0 * 4) * 4), lo1 = (unsigned)((drow * dp + csw1 * 4) * 4);
+    unsigned foff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) foff[j] = my0 + (unsigned)(l31 * 128 + (((2 * j + h) ^ ((l31 >> 1) & 7)) << 4));
+    const int64_t nrb = (r1 - r0 + 31) / 32;
+    const float* __restrict__ auxv = da.p[0].metric == AS_METRIC_L2 ? da.p[0].n32 : da.p[0].inorm32;
+    int64_t prb = myns > 0 ? bx : nrb;
+    int pks = 0, pbuf = 0, inflight = 0;
+    int x0 = 0, x1 = 0, x2 = 0;   // (other vector-memory operations behind the oldest / 2nd / 3rd slab in flight: scan_gemm_kernel)
+#define AS_ISSUE_SLAB()                                                                                                   \
+    do {                                                                                                                  \
+        if (prb < nrb) {                                                                                                  \
+            const char* base_ = (const char*)(x32 + (size_t)(r0 + prb * 32) * dp + (ks0 + pks) * 32);                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+                const char* src_ = base_ + (size_t)(8 * j) * dp * 4 + ((j & 1) ? lo1 : lo0);                              \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                     \
+                                                 (__attribute__((address_space(3))) void*)(my + pbuf * 1024 + 8 * j * 32), 16, 0, 2); \
+            }                                                                                                             \
+            pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;                                                                       \
+            if (++pks == myns) {                                                                                          \
+                pks = 0;                                                                                                  \
+                prb += gx;                                                                                                \
+            }                                                                                                             \
+            if (inflight == 0) x0 = 0;                                                                                    \
+            else if (inflight == 1) x1 = 0;                                                                               \
+            else x2 = 0;                                                                                                  \
+            ++inflight;                                                                                                   \
+        }                                                                                                                 \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) AS_ISSUE_SLAB();
+    unsigned cur = 0;
+    int full = 0;   // bit 4 s + e: query e of set s (of this lane) has overflowed its candidate buffer
+    for (int64_t rb = bx; rb < nrb; rb += gx) {
+        i32x16 acc1[2], accx[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc1[s][r] = 0;
+                accx[s][r] = 0;
+            }
+        const int64_t row = r0 + rb * 32 + l31;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + row),   // padded arrays: readable
+                                         (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + wu * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da.p[0].fa8 + row),
+                                         (__attribute__((address_space(3))) void*)(St + 4 * NBUF * 1024 + 4 * 3 * 64 * 4 + 4 * 64 + wu * 64), 4, 0, 0);
+        x0 += 1;
+        x1 += 1;
+        x2 += 1;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            if (ks < myns) {
+                wait_vmcnt(4 * (inflight - 1) + (x0 >= 2 ? 2 : 0));
+                --inflight;
+                x0 = x1;
+                x1 = x2;
+                AS_ISSUE_SLAB();
+                f32x4 v0, v1, v2, v3;   // a1 of k-steps 0, 1; a2 of k-steps 0, 1
+                lds_read4x4(foff[0] + cur, foff[1] + cur, foff[2] + cur, foff[3] + cur, v0, v1, v2, v3);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[s][ks][0]), __builtin_bit_cast(i32x4, v0), acc1[s], 0, 0, 0);
+                    acc1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[s][ks][1]), __builtin_bit_cast(i32x4, v1), acc1[s], 0, 0, 0);
+                    accx[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[s][ks][0]), __builtin_bit_cast(i32x4, v2), accx[s], 0, 0, 0);
+                    accx[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[s][ks][1]), __builtin_bit_cast(i32x4, v3), accx[s], 0, 0, 0);
+                    accx[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[s][ks][2]), __builtin_bit_cast(i32x4, v0), accx[s], 0, 0, 0);
+                    accx[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, qf[s][ks][3]), __builtin_bit_cast(i32x4, v1), accx[s], 0, 0, 0);
+                }
+                cur = cur + 4096 == NBUF * 4096 ? 0 : cur + 4096;
+            }
+        }
+        float aux = 0.0f, far = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            // the exchange of scan_gemm_kernel, once per set: wave o owns registers [4 o, 4 o + 4) = queries 8 o + {0..3} + 4 h
+            __builtin_amdgcn_s_barrier();   // the previous exchange has been read
+            f32x4 mine = {0, 0, 0, 0};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                f32x4 part;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[e] = fmaf((float)acc1[s][4 * o + e], 128.0f, (float)accx[s][4 * o + e]);
+                if (o != wu) lds_write4(ex0 + (unsigned)(((o * 3 + (wu < o ? wu : wu - 1)) * 64 + lane) * 16), part);
+                else mine = part;
+            }
+            AS_LDS_FENCE();
+            __builtin_amdgcn_s_barrier();
+            {
+                f32x4 p0, p1, p2;
+                const unsigned pa = ex0 + (unsigned)((wu * 3 * 64 + lane) * 16);
+                lds_read4x3(pa, pa + 1024, pa + 2048, p0, p1, p2);
+                mine += p0;
+                mine += p1;
+                mine += p2;
+            }
+            if (s == 0) {
+                // the norms and scales: older than the slabs in flight, which were all issued inside this row block (myns = NBUF - 1)
+                wait_vmcnt(myns >= NBUF - 1 ? 4 * inflight : 0);
+                aux = lds_read1(ax0 + (unsigned)((wu * 64 + lane) * 4));
+                far = lds_read1(fx0 + (unsigned)((wu * 64 + lane) * 4));
+            }
+            const PreArgs& pre = da.p[s];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine[e] *= far * fqv[s][e];
+            {
+                const float inr = pre.metric == AS_METRIC_L2 ? (aux > 0.0f ? rsqrtf(aux) : 0.0f) : aux;
+                u32x2 pk;
+                pk[0] = pack_half2(mine[0] * inr * iqv[s][0], mine[1] * inr * iqv[s][1]);
+                pk[1] = pack_half2(mine[2] * inr * iqv[s][2], mine[3] * inr * iqv[s][3]);
+                store_x2_issued((char*)da.dots[s] + ((row >> 5) * ts + ((2 * wu + h) * 32 + (row & 31)) * 4) * 2, pk);
+            }
+            x0 += 1;
+            x1 += 1;
+            x2 += 1;
+            const bool pf = pre.enabled && row < r1 && row < pre.n && row != pre.exclude;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = e + 8 * wu + 4 * h;
+                if (b >= da.nb[s]) continue;   // idle slot
+                const float dot = mine[e];
+                if (pf && !((full >> (4 * s + e)) & 1)) {
+                    float key, bound;
+                    if (pre.metric == AS_METRIC_L2) {
+                        key = fmaf(-2.0f, dot, aux + nqv[s][e]);
+                        bound = ((float)pre.epskey + (float)pre.coef * (aux + nqv[s][e])) * 1.000001f;
+                    } else {
+                        key = 1.0f - fmaxf(0.0f, dot * aux * nqv[s][e]);
+                        bound = ((float)pre.epskey + (float)pre.coef) * 1.000001f;
+                    }
+                    if (key <= bound) {
+                        const int slot = atomicAdd(&pre.infow[b].knn_cnt, 1);
+                        if (slot < CAND_CAP) {
+                            ((float*)pre.ckey)[(int64_t)b * CAND_CAP + slot] = key;
+                            pre.cidx[(int64_t)b * CAND_CAP + slot] = (int)row;
+                        } else {
+                            full |= 1 << (4 * s + e);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef AS_ISSUE_SLAB
+}
+
 // Wave-wide sum on the DPP crossbar (6 VALU adds, no LDS round trips: a __shfl_xor butterfly is 6 dependent
 // ds_bpermute, ~600 cycles of latency per row): xor-1 and xor-2 inside quads, half-row and row mirrors, then
 // row_bcast15 / row_bcast31 carry the row sums up to lane 63.  Returns the total in every lane (readlane 63).
@@ -1920,6 +2127,7 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_gemm_kernel<4, 0, 2, true, GEMM_NSW_WIDE>), gemm_lds(4));
     AS_ATTR((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW, true>), gemm_lds(4, true));
     AS_ATTR((scan_gemm_kernel<4, 0, 2, false, GEMM_NSW_WIDE, true>), gemm_lds(4, true));
+    AS_ATTR((scan_gemm_dual_kernel<4>), gemm_lds(4, true));
     AS_ATTR((scan_tile_kernel<6, true>), tile_lds(6, true, 256));
     AS_ATTR((scan_tile_kernel<8, true>), tile_lds(8, true, 256));
     AS_ATTR((scan_tile_kernel<12, true>), tile_lds(12, true, 256));
@@ -2010,6 +2218,42 @@ as_status launch_scan_gang(as_query* const* m, const PreArgs* pre, int n, hipStr
         hipLaunchKernelGGL((scan_tile_gang_kernel<8, 3>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 3, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
     else
         hipLaunchKernelGGL((scan_tile_gang_kernel<8, 4>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 4, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
+    AS_HIP(hipGetLastError());
+    return AS_OK;
+}
+
+// Can the batched passes of workspaces a and b (both begun with defer_scan: their queries staged and quantised, their PreArgs
+// made) share one read of the items?  Both on the int8 image with fp16 cosines, the same rows, image rows of up to 384 floats.
+bool scan_dual_ok(const as_query* a, const as_query* b) {
+    static const bool off = getenv("ARROWSPACE_NO_BATCH_DUAL") != nullptr;
+    if (off || a == b || a->sp != b->sp) return false;
+    const as_space* sp = a->sp;
+    for (const as_query* q : {a, b})
+        if (q->cap != QUERY_BATCH || q->exact || q->ss.dots_rs != 4 || !q->i8_scan || !q->q8img_dev || !q->faqv_dev || !q->half_enabled || !q->dots32) return false;
+    if (!sp->x8 || !sp->fa8 || a->r0 != b->r0 || a->r1 != b->r1 || a->r1 <= a->r0 || a->ss.dots_ts != b->ss.dots_ts) return false;
+    return sp->dp8 / 2 <= 4 * 3 * 32;
+}
+
+// ... then ONE launch on a's stream serves both (scan_gemm_dual_kernel); the caller orders b's stream around it
+as_status launch_scan_dual(as_query* a, as_query* b, const PreArgs& pa, const PreArgs& pb, hipStream_t st) {
+    const as_space* sp = a->sp;
+    const int64_t rows = a->r1 - a->r0, ld = sp->dp8 / 2;
+    DualArgs da;
+    as_query* m[2] = {a, b};
+    const PreArgs* pr[2] = {&pa, &pb};
+    for (int s = 0; s < 2; ++s) {
+        da.p[s] = *pr[s];
+        da.p[s].fa8 = sp->fa8;
+        da.p[s].faqv = m[s]->faqv_dev;
+        da.q[s] = (const float*)m[s]->q8img_dev;
+        da.dots[s] = m[s]->dots32;
+        da.nb[s] = m[s]->nb;
+        m[s]->dots_half = 1;
+    }
+    const int64_t nrb = (rows + 31) / 32;
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(nrb, 2 * a->cus));   // (50 .. 87 % of it, for the other pair's kernels to run beside: 122 000 .. 125 000 against 129 700 queries/s)
+    hipLaunchKernelGGL((scan_gemm_dual_kernel<4>), dim3((unsigned)grid), dim3(256), gemm_lds(4, true), st, (const float*)sp->x8, ld, a->r0, a->r1,
+                       a->ss.dots_ts, da);
     AS_HIP(hipGetLastError());
     return AS_OK;
 }

@@ -2831,8 +2831,11 @@ static bool batch_coef_holds(as_query* q) {
         }
     }
     if (mu > 0.0f) {
-        sp->uq_est = std::max(1.05 * (double)mu, 0.97 * sp->uq_est);
-        sp->vq_est = std::max(1.05 * (double)mv, 0.97 * sp->vq_est);
+        // (the largest residue of 32 queries moves by several per cent from pass to pass -- s_q / |q| is the queries' largest component
+        // over their norm --, and a pass beyond its assumption costs a whole second pass: 1.05 x with a decay of 3 % per pass failed
+        // two passes in eight on 256 distinct queries of the bench's recipe; the margin costs a few per cent of ONE term of the error)
+        sp->uq_est = std::max(1.15 * (double)mu, 0.99 * sp->uq_est);
+        sp->vq_est = std::max(1.15 * (double)mv, 0.99 * sp->vq_est);
     }
     if (!ok) {   // what a second pass over the same queries is priced with
         q->x8_au = (double)mu * 1.0005;
@@ -3042,6 +3045,11 @@ static as_status query_begin(as_query* q, const double* query_host, int64_t src_
                            (const QInfo*)q->info, q->hx8stat_dev);
     if (stats) AS_HIP(hipEventRecord(q->ev[0], st));
     const PreArgs pre = make_pre(q, eps, exclude, !q->robust && !feature && !q->crowded_direct);
+    if (q->defer_pre) {   // (a batched pass that may share its scan with the other workspace of its pair: search_batch_launch_pair)
+        *q->defer_pre = pre;
+        q->ev_valid = 0;
+        return AS_OK;
+    }
     AS_TRY(launch_scan(q, pre));
     if (stats) AS_HIP(hipEventRecord(q->ev[1], st));
     q->ev_valid = stats ? 1 : 0;
@@ -3972,6 +3980,50 @@ as_status search_batch_launch(as_query* q, const double* queries, int nb, int64_
     if (q->gr->lambda_mode != AS_LAMBDA_FEATURE) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
     q->seq += 1;
     return run_score(q, tau, 1);
+}
+
+// Two passes launched together: both workspaces stage and quantise their queries on their own streams, ONE scan serves the 64
+// queries (scan_gemm_dual_kernel, on a's stream; b's stream joins it through events), the selection and finish kernels of the
+// two passes run side by side.  Where the pair cannot share (no int8 image for these queries, rows wider than 768 columns) each
+// workspace scans for itself as before.
+as_status search_batch_launch_pair(as_query* a, as_query* b, const double* qa, int nba, const double* qb, int nbb, int64_t d, double tau) {
+    as_query* m[2] = {a, b};
+    const double* qs[2] = {qa, qb};
+    const int nbs[2] = {nba, nbb};
+    PreArgs pre[2];
+    for (int s = 0; s < 2; ++s) {
+        as_query* q = m[s];
+        q->exact = 0;
+        q->robust = 0;
+        q->nb = nbs[s];
+        q->batch_assume = 1;
+        q->defer_pre = &pre[s];
+        const as_status st = query_begin(q, qs[s], -1, d, 0, q->sp->n, q->gr->gp.eps, -1);
+        q->defer_pre = nullptr;
+        AS_TRY(st);
+    }
+    // (Measured and dropped, profiles/r05_batch_dual.txt: this pair's scan ordered behind the other pair's selection and finish
+    // kernels -- they starve beside a scan that holds every CU's LDS and registers --: 117 700 against 129 700 queries/s; the scan
+    // on a stream of its own at the lowest priority, with blocks that retire during the scan: 77 900 .. 107 000.)
+    if (scan_dual_ok(a, b)) {
+        for (int s = 0; s < 2; ++s)
+            if (!m[s]->gang_ev) AS_HIP(hipEventCreateWithFlags(&m[s]->gang_ev, hipEventDisableTiming));
+        AS_HIP(hipEventRecord(b->gang_ev, b->stream));          // b's queries are staged ...
+        AS_HIP(hipStreamWaitEvent(a->stream, b->gang_ev, 0));
+        AS_TRY(launch_scan_dual(a, b, pre[0], pre[1], a->stream));
+        AS_HIP(hipEventRecord(a->gang_ev, a->stream));          // ... and its tail follows the shared scan
+        AS_HIP(hipStreamWaitEvent(b->stream, a->gang_ev, 0));
+        a->sp->batch_dual_scans.fetch_add(1, std::memory_order_relaxed);
+    } else {
+        for (int s = 0; s < 2; ++s) AS_TRY(launch_scan(m[s], pre[s]));
+    }
+    for (int s = 0; s < 2; ++s) {
+        as_query* q = m[s];
+        if (q->gr->lambda_mode != AS_LAMBDA_FEATURE) AS_TRY(run_knn(q, q->gr->gp.eps, -1, 1, nullptr, nullptr, nullptr, nullptr, nullptr));
+        q->seq += 1;
+        AS_TRY(run_score(q, tau, 1));
+    }
+    return AS_OK;
 }
 
 as_status search_batch_collect(as_query* q, int nb, double tau, int64_t topk, int64_t* out_idx, double* out_score, int64_t* out_len,

@@ -133,6 +133,53 @@ def test_search_batch_matches_single_and_oracle(oracle_lib, metric, d):
         aspace.search_batch(far, gl, 0.62)
 
 
+@pytest.mark.parametrize("metric,d", [("l2", 768), ("cosine", 320)])
+def test_search_batch_pairs_share_one_scan(oracle_lib, metric, d):
+    """as_search_batch, more than 32 queries: the passes are launched in PAIRS and a pair on the int8 images (rows of up to 768
+    columns) is served by ONE scan for its 64 queries (scan_gemm_dual_kernel); more than 64 queries: two pairs of workspaces
+    alternate.  200 queries (three pairs and a single pass of 8), 64 (one pair), 45 (32 + 13): every slot is what the single
+    search returns and what the oracle returns; with ARROWSPACE_NO_BATCH_DUAL=1 (each workspace scans for itself) the same."""
+    import os
+
+    import pyarrowspace_amd as asp
+    n, k, topk = 5000, 9, 7
+    X = clustered(n, d, nclust=12, seed=29)
+    gp = {"eps": calibrate_eps(X, k, metric), "k": k, "topk": topk, "p": 2.0, "sigma": None, "metric": metric}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    ref = oracle_lib.OracleIndex(X, gp)
+    rng = np.random.default_rng(19)
+    Q = np.stack([X[rng.integers(0, n)] + 0.03 * rng.standard_normal(d) / np.sqrt(d) for _ in range(200)])
+    single = [aspace.search(np.ascontiguousarray(q), gl, 0.62) for q in Q]
+    for b in range(0, 200, 9):
+        want, lq = ref.search(Q[b], 0.62)
+        assert_hits_match(single[b], want, ref.scores(Q[b], 0.62, lq), rtol=RTOL)
+    before = aspace.batch_dual_scans
+    for nq, pairs in ((200, 3), (64, 1), (45, 1), (33, 1), (32, 0)):
+        got = aspace.search_batch(Q[:nq], gl, 0.62)
+        assert aspace.last_batch_int8
+        assert got == single[:nq], nq
+        assert aspace.batch_dual_scans - before == pairs, (nq, aspace.batch_dual_scans - before)
+        before = aspace.batch_dual_scans
+    os.environ["ARROWSPACE_NO_BATCH_DUAL"] = "1"     # (read once per process: a child decides)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import pyarrowspace_amd as asp\n"
+            "d = np.load(sys.argv[1]); gp = dict(eps=float(d['eps']), k=%d, topk=%d, p=2.0, sigma=None, metric=%r)\n"
+            "a, gl = asp.ArrowSpaceBuilder.build(gp, d['X']); got = a.search_batch(d['Q'], gl, 0.62)\n"
+            "assert a.batch_dual_scans == 0\n"
+            "np.save(sys.argv[2], np.array([[i for i, _ in h] for h in got]))\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), k, topk, metric)
+    import subprocess
+    import sys
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            np.savez(os.path.join(tmp, "in.npz"), X=X, Q=Q[:100], eps=gp["eps"])
+            out = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npy")], capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stderr[-2000:]
+            idx = np.load(os.path.join(tmp, "out.npy"))
+    finally:
+        os.environ.pop("ARROWSPACE_NO_BATCH_DUAL", None)
+    assert [list(r) for r in idx] == [[i for i, _ in h] for h in single[:100]]
+
+
 def test_int8_image_scan_returns_what_the_fp32_scan_returns(oracle_lib):
     """The single-query scan reads the int8 two-digit image of the items (half the bytes) when the items' and the query's
     quantisation error allow it; it only prefilters -- k-NN candidates and scorer candidates are re-evaluated exactly and proven
