@@ -4004,7 +4004,8 @@ as_status search_batch_launch_pair(as_query* a, as_query* b, const double* qa, i
     }
     // (Measured and dropped, profiles/r05_batch_dual.txt: this pair's scan ordered behind the other pair's selection and finish
     // kernels -- they starve beside a scan that holds every CU's LDS and registers --: 117 700 against 129 700 queries/s; the scan
-    // on a stream of its own at the lowest priority, with blocks that retire during the scan: 77 900 .. 107 000.)
+    // on a stream of its own at the lowest priority, with blocks that retire during the scan: 77 900 .. 107 000; on a stream whose
+    // CU mask leaves 1 .. 3 of every 8 CUs to those kernels: 80 300 .. 93 600 against 131 700.)
     if (scan_dual_ok(a, b)) {
         for (int s = 0; s < 2; ++s)
             if (!m[s]->gang_ev) AS_HIP(hipEventCreateWithFlags(&m[s]->gang_ev, hipEventDisableTiming));
