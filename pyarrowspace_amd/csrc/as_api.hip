@@ -812,6 +812,7 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
     // the batched pass serves QUERY_BATCH queries per read of the items (MFMA pass; rows wider than 768 floats in
     // K-chunk passes of the same kernel): fp32 fast path only
     const bool batched = !sp->opts.force_exact && (sp->opts.search_mode & 3) == 0 && b > 1;
+    int unit = 1;   // passes launched together
     if (batched) {
         if (sp->qcache_b && sp->qcache_b_gr != gr) {
             for (as_query** w : {&sp->qcache_b, &sp->qcache_b2, &sp->qcache_b3, &sp->qcache_b4}) {
@@ -823,40 +824,45 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
             AS_TRY(query_create(sp, gr, QUERY_BATCH, &sp->qcache_b));
             sp->qcache_b_gr = gr;
         }
-        // more than one pass: a second workspace -- the two launch their passes as a pair, ONE scan for both (64 queries per read
-        // of the items); more than one pair: a second pair of workspaces, pair p + 1 is queued before pair p is waited for, so its
-        // scan runs under pair p's selection and finish kernels.  (No memory for them: fewer workspaces, the same results.)
+        // More than one pass: a second workspace.  Rows of up to 768 columns: the two launch their passes as a PAIR, one scan for
+        // both (64 queries per read of the items: search_batch_launch_pair); more than one pair: a second pair of workspaces, pair
+        // p + 1 is queued before pair p is waited for.  Wider rows (a scan serves one workspace): the passes alternate between
+        // the two workspaces -- pass p + 1 is queued before pass p is waited for.  (No memory: fewer workspaces, the same results.)
         static const bool no_pipe = getenv("ARROWSPACE_NO_BATCH_PIPELINE") != nullptr;
+        static const bool no_dual = getenv("ARROWSPACE_NO_BATCH_DUAL") != nullptr;
+        const bool pairs = !no_dual && (sp->dp + 63) / 64 * 64 / 2 <= 4 * 3 * 32 && gr->lambda_mode != AS_LAMBDA_FEATURE;
         if (b > QUERY_BATCH && !sp->qcache_b2 && !no_pipe) {
             if (query_create(sp, gr, QUERY_BATCH, &sp->qcache_b2) != AS_OK) sp->qcache_b2 = nullptr;
         }
-        if (b > 2 * QUERY_BATCH && sp->qcache_b2 && !sp->qcache_b4 && !no_pipe) {
+        if (pairs && b > 2 * QUERY_BATCH && sp->qcache_b2 && !sp->qcache_b4 && !no_pipe) {
             if (!sp->qcache_b3 && query_create(sp, gr, QUERY_BATCH, &sp->qcache_b3) != AS_OK) sp->qcache_b3 = nullptr;
             if (sp->qcache_b3 && query_create(sp, gr, QUERY_BATCH, &sp->qcache_b4) != AS_OK) sp->qcache_b4 = nullptr;
         }
+        unit = pairs && sp->qcache_b2 && b > QUERY_BATCH ? 2 : 1;
     }
-    const bool paired = batched && sp->qcache_b2 && b > QUERY_BATCH;
-    const bool piped = paired && sp->qcache_b3 && sp->qcache_b4 && b > 2 * QUERY_BATCH;
+    // a UNIT = the passes launched together: a pair (two workspaces), or one pass; two sets of workspaces alternate when there is
+    // more than one unit and the workspaces exist (`piped`)
     as_query* ws[4] = {sp->qcache_b, sp->qcache_b2, sp->qcache_b3, sp->qcache_b4};
+    const bool piped = batched && b > unit * QUERY_BATCH && ws[2 * unit - 1] != nullptr;
+    const int nws = batched ? unit * (piped ? 2 : 1) : 0;
     // an error leaves no pass in flight behind it (the other workspaces' kernels would otherwise still be running when the
     // caller comes back)
     auto drain = [&](as_status s) {
-        if (paired)
-            for (int w = 0; w < (piped ? 4 : 2); ++w) (void)hipStreamSynchronize((hipStream_t)as_query_stream(ws[w]));
+        if (nws > 1)
+            for (int w = 0; w < nws; ++w) (void)hipStreamSynchronize((hipStream_t)as_query_stream(ws[w]));
         return s;
     };
     int32_t st_chunk[QUERY_BATCH];
-    // pair j = the passes over the queries [64 j, 64 j + 64) on the workspaces 2 (j & 1), 2 (j & 1) + 1 (the first two when not piped)
-    const int64_t PAIR = 2 * QUERY_BATCH;
-    auto launch_pair = [&](int64_t j) -> as_status {
-        as_query* const* w = ws + (piped ? 2 * (j & 1) : 0);
-        const int64_t i0 = j * PAIR, i1 = i0 + QUERY_BATCH;
+    const int64_t UNIT = (int64_t)unit * QUERY_BATCH;
+    auto launch_unit = [&](int64_t j) -> as_status {
+        as_query* const* w = ws + (piped ? unit * (j & 1) : 0);
+        const int64_t i0 = j * UNIT, i1 = i0 + QUERY_BATCH;
         const int nb0 = (int)std::min<int64_t>(QUERY_BATCH, b - i0);
-        if (i1 < b) return search_batch_launch_pair(w[0], w[1], queries + i0 * d, nb0, queries + i1 * d, (int)std::min<int64_t>(QUERY_BATCH, b - i1), d, tau);
+        if (unit == 2 && i1 < b) return search_batch_launch_pair(w[0], w[1], queries + i0 * d, nb0, queries + i1 * d, (int)std::min<int64_t>(QUERY_BATCH, b - i1), d, tau);
         return search_batch_launch(w[0], queries + i0 * d, nb0, d, tau);
     };
     if (piped) {
-        const as_status s0 = launch_pair(0);
+        const as_status s0 = launch_unit(0);
         if (s0 != AS_OK) return drain(s0);
     }
     int64_t pass = 0;
@@ -866,15 +872,13 @@ as_status as_search_batch(const as_space* sp, const as_graph* gr, const double* 
     for (int64_t i0 = 0; i0 < b; i0 += QUERY_BATCH, ++pass) {
         const int nb = (int)std::min<int64_t>(QUERY_BATCH, b - i0);
         if (batched) {
-            const int64_t j = pass >> 1;
-            as_query* cur = paired ? ws[(piped ? 2 * (j & 1) : 0) + (pass & 1)] : ws[0];
+            const int64_t j = pass / unit;
+            as_query* cur = ws[(piped ? unit * (j & 1) : 0) + (int)(pass % unit)];
             as_status s = AS_OK;
             const double t0 = timing ? now() : 0.0;
-            if (!paired) {
-                s = search_batch_launch(cur, queries + i0 * d, nb, d, tau);
-            } else if ((pass & 1) == 0) {   // a pair's first pass: queue the next pair (piped), or this one
-                if (!piped) s = launch_pair(j);
-                else if ((j + 1) * PAIR < b) s = launch_pair(j + 1);
+            if (pass % unit == 0) {   // a unit's first pass: queue the next unit (piped), or this one
+                if (!piped) s = launch_unit(j);
+                else if ((j + 1) * UNIT < b) s = launch_unit(j + 1);
             }
             const double t1 = timing ? now() : 0.0;
             if (s == AS_OK)
