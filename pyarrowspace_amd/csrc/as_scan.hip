@@ -1491,7 +1491,8 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
 // Measured (1M x 768, tools/tile_geom.py, profiles/r05_tile_dyn.txt): ONE cursor for all 2 048 waves ran at the rate of one
 // word's atomics -- 252 us against the static schedule's 138; sixteen cursors 130.7 us against 135.5, the last wave ending at
 // 129.5 us instead of 132.5, the waves' ends 115.5 .. 126 (p10 .. p90) instead of 111 .. 128.  Chunks of 32 rows (half the lanes
-// of every DMA idle) 133.6 us, of 16 rows 193: the chunk stays 64 rows, a tile.
+// of every DMA idle) 133.6 us, of 16 rows 193: the chunk stays 64 rows, a tile.  Half chunks for the waves' LAST tickets only (the
+// last 1/16 .. 1/4 of the rows): 134-136 us against 132-133 on the same box -- no gain, not kept.
 template <int NSLOT, bool SC>
 __global__ __launch_bounds__(256) void scan_tile_kernel_dyn(const signed char* __restrict__ xt, int C, int64_t r0, int64_t r1, float* __restrict__ dots,
                                                             PreArgs pre, int crows) {
