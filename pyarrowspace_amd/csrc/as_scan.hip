@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
 // The same scan with a DYNAMIC chunk schedule.  Waves do not run at one speed: with equal shares the median wave of the 1M x 768
 // scan ended 119 us after the launch, the last one at 131.5 (make STAMPS=1, tools/scan_stamps.py) -- a tail of 12 us at falling
 // occupancy.  Here chunk c is rows [r0 + c crows, + crows); a wave's first chunk is its own (c = wave), every further one is
-// NW + 16 j + g for ticket j of the wave's group g (sixteen atomic cursors, zero between searches).  The ticket for the chunk after
+// NW + ng j + g for ticket j of the wave's group g (ng = 16 atomic cursors on a full grid, zero between searches).  The ticket for the chunk after
 // next is drawn
 // at a chunk's START by a returning atomic issued through inline asm: it is older than every item issued inside that chunk, so
 // the chunk's counted waits have seen it retire long before its value is read at the chunk's end -- no wait of its own, and
@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const signed char* __res
 // last 1/16 .. 1/4 of the rows): 134-136 us against 132-133 on the same box -- no gain, not kept.
 template <int NSLOT, bool SC>
 __global__ __launch_bounds__(256) void scan_tile_kernel_dyn(const signed char* __restrict__ xt, int C, int64_t r0, int64_t r1, float* __restrict__ dots,
-                                                            PreArgs pre, int crows) {
+                                                            PreArgs pre, int crows, int ng) {
     constexpr int U = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RING = NSLOT * 1024;            // bytes per wave
@@ -1524,8 +1524,10 @@ __global__ __launch_bounds__(256) void scan_tile_kernel_dyn(const signed char* _
     // SC_COPIES cursors, each in the unused tail of a histogram copy's stride (different memory channels; zeroed with the
     // histograms): 2 048 waves x 8 tickets on ONE word ran at the rate of that word's atomics -- 250 us.  A block's group is
     // (b + b / 8) mod 16: a group's blocks cycle through the XCDs (consecutive blocks go to consecutive XCDs), so a slow XCD
-    // slows every group alike; group g hands out the chunks NW + 16 j + g, j = 0, 1, ...
-    const int grp = (int)((blockIdx.x + (blockIdx.x >> 3)) & (SC_COPIES - 1));
+    // slows every group alike; group g hands out the chunks NW + ng j + g, j = 0, 1, ...
+    // (ng groups, a power of two up to SC_COPIES that the host picks so that EVERY group has a block: a grid of fewer than 32
+    // blocks -- a shard of a few thousand rows -- with sixteen groups left some of them, and their chunks, without a wave)
+    const int grp = (int)((blockIdx.x + (blockIdx.x >> 3)) & (unsigned)(ng - 1));
     int* ctr = (int*)(pre.tile_ctrs + grp * SC_HSTRIDE + SC_CTR_WORD);
     int tk = 0;                // the ticket in flight (written by the atomic: read only behind the waits described above)
     const int one = 1;
@@ -1591,7 +1593,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel_dyn(const signed char* _
     asm volatile("" : "+v"(nq32), "+v"(inq32));
     __syncthreads();   // (the only block barrier: the query's digits are in LDS; from here on every LDS access is inline asm)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk) : : "memory");   // (start-up: the ring's first fill and the first ticket)
-    cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * SC_COPIES + grp;
+    cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * ng + grp;
     unsigned cur = 0;    // byte offset of the oldest pair in the ring
     int marked = 0;      // items in flight that have a chunk boundary's store + norm + scale DMA behind them in the queue
     bool first = true;
@@ -1675,7 +1677,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel_dyn(const signed char* _
         // (the ticket drawn at this chunk's start has retired: C >= 16 items were issued behind it and all but the ring's youngest waited for)
         asm volatile("" : "+v"(tk));
         ccur = cnxt;
-        cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * SC_COPIES + grp;
+        cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * ng + grp;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     scan_wave_report<SC>(pre, w, gw, lane, px0);
@@ -2487,10 +2489,13 @@ as_status launch_scan(as_query* q, const PreArgs& pre) {
                     // dynamic chunk schedule (the default): chunks of `crows` rows by id, the waves' first ones their own
                     const int dynv = g_tile_dyn.load(std::memory_order_relaxed);
                     if (dynv == 16 || dynv == 32) crows = std::min(crows, dynv);
+                    // groups of blocks, each with a cursor of its own: block b is in group (b + b / 8) mod ng -- with ng <= 8 the first
+                    // ng blocks are the groups' first members, with 16 groups every group has a member among the first 23 blocks
+                    const int ng = nblk >= 32 ? SC_COPIES : (nblk >= 8 ? 8 : (nblk >= 4 ? 4 : (nblk >= 2 ? 2 : 1)));
                     if (pre.sc_enabled)
-                        hipLaunchKernelGGL((scan_tile_kernel_dyn<8, true>), dim3((unsigned)nblk), dim3(256), tile_lds(8, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, crows);
+                        hipLaunchKernelGGL((scan_tile_kernel_dyn<8, true>), dim3((unsigned)nblk), dim3(256), tile_lds(8, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, crows, ng);
                     else
-                        hipLaunchKernelGGL((scan_tile_kernel_dyn<8, false>), dim3((unsigned)nblk), dim3(256), tile_lds(8, false, C), st, xt, C, q->r0, q->r1, q->dots32, pre, crows);
+                        hipLaunchKernelGGL((scan_tile_kernel_dyn<8, false>), dim3((unsigned)nblk), dim3(256), tile_lds(8, false, C), st, xt, C, q->r0, q->r1, q->dots32, pre, crows, ng);
                 } else if (tstep == 4 && pre.sc_enabled) {
                     if (tslots == 16) hipLaunchKernelGGL((scan_tile_kernel<16, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(16, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);
                     else if (tslots == 12) hipLaunchKernelGGL((scan_tile_kernel<12, true, 4>), dim3((unsigned)nblk), dim3(256), tile_lds(12, true, C), st, xt, C, q->r0, q->r1, q->dots32, pre, rounds, tail_rows, crows);

@@ -438,3 +438,45 @@ def test_host_build_streams_chunks_and_matches_the_device_build(monkeypatch):
     Yd = torch.from_numpy(Y).cuda()
     a5, g5 = asp.ArrowSpaceBuilder.build_from_device(gp, Yd.data_ptr(), "float64", n, d, d)
     assert np.array_equal(a4.lambdas(), a5.lambdas())
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+@pytest.mark.parametrize("n,d", [(130, 320), (700, 320), (1500, 256), (2900, 768), (5200, 320), (40000, 256)])
+def test_every_row_is_scanned_whatever_the_grid(n, d, sharded):
+    """The coarse tile scan hands its chunks out while it runs (scan_tile_kernel_dyn: groups of blocks, a cursor each).  Whatever
+    the grid -- 1, 5, 11, 22, 40 or 312 blocks here: fewer blocks than sixteen groups once left chunks without a wave (a fuzz case
+    on two ranks with shards of 115 and 142 rows found it) -- every row is read: each item, taken as the query, comes back as its
+    own best hit (cosine 1), across the whole row range, on one space and on a row shard's one-exchange pass (one rank, no process
+    group), under the scan that collects the scorer's candidates (tau = 0.62) and under the coarse chain's plain scan (tau = 0.2)."""
+    import torch
+
+    import pyarrowspace_amd as asp
+    from pyarrowspace_amd.dist import ShardedIndex
+    X = clustered(n, d, nclust=max(2, n // 400), seed=n)
+    gp = {"eps": 1.25 * calibrate_eps(X, 8, "l2"), "k": 8, "topk": 5, "p": 2.0, "sigma": None}
+    if sharded:
+        index = ShardedIndex.build(gp, torch.from_numpy(X).cuda())
+        search, operand = (lambda q, tau: index.search(q, tau)), (lambda: index.last_scan_operand())
+    else:
+        aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+        search, operand = (lambda q, tau: aspace.search(q, gl, tau)), (lambda: aspace.last_scan_operand)
+    step = max(1, n // 260)
+    ops = {0.62: set(), 0.2: set()}
+    served = 0
+    for tau in (0.62, 0.2):
+        for i in list(range(0, n, step)) + [n - 1]:
+            try:
+                hits = search(np.ascontiguousarray(X[i]), tau)
+            except asp.PanicException:      # (an item without a neighbour inside eps: the reference's assert)
+                continue
+            served += 1
+            ops[tau].add(operand())
+            if tau == 0.62:
+                assert hits[0][0] == i, (n, d, tau, i, hits[:2])
+            else:       # (the lambda term dominates at tau = 0.2: the item need not be among the hits)
+                assert len(hits) == 5
+    assert served >= 200, served
+    if sharded or n >= 5000:
+        assert "int8-high" in ops[0.62], ops     # (the scan under test did run)
+    if sharded:
+        index.close()

@@ -266,3 +266,17 @@ def test_bench_line_of_a_two_rank_job():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "4 single queries over the full N=120000" in cb["sample"]
     assert out["index_build_sec"] > 0 and out["batched_queries_per_sec"] > 0
+
+
+@pytest.mark.parametrize("cases,seed,world", [(18, 12008, 2), (8, 12010, 4)])
+def test_fuzz_seeds_that_found_unscanned_chunks(cases, seed, world):
+    """Regression by seed (tools/fuzz_2rank.py): round 5's first dynamic chunk schedule of the coarse tile scan used sixteen cursor
+    groups whatever the grid -- on a shard of 115 / 142 rows x 300 columns (one block: one group) the chunks of the other fifteen
+    groups were never handed out, a neighbour went missing and lambda_q was off by 1e-4 (2 ranks, seed 12008, case 17; 4 ranks,
+    seed 12010, case 7).  The groups now follow the grid (launch_scan); these seeds stay green."""
+    import subprocess
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_2rank.py"), str(cases), str(seed), str(world)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert "failures in []" in p.stdout, tail

@@ -187,10 +187,12 @@ def extras_case(rng, aspace, gl, X, gp, cfg):
 
 
 def batch_case(rng, aspace, gl, X, cfg):
-    """40 mixed queries through as_search_batch (two passes of the 32-slot workspace) against the single-query path."""
+    """40 / 70 / 150 mixed queries through as_search_batch (passes of the 32-slot workspaces, launched in pairs that share a scan where the
+    rows allow it; two pairs alternating beyond 64 queries) against the single-query path."""
     n, d = X.shape
-    rows = rng.integers(0, n, 40)
-    kinds = rng.integers(0, 3, 40)
+    nq = int(rng.choice([40, 40, 70, 150]))
+    rows = rng.integers(0, n, nq)
+    kinds = rng.integers(0, 3, nq)
     Q = np.stack([X[r] * 1.01 + (0.02 * rng.standard_normal(d) * (np.abs(X[r]).mean() + 1e-9) if kd == 0 else 0.0) if kd < 2
                   else rng.standard_normal(d) * (np.abs(X).mean() + 1e-9) for r, kd in zip(rows, kinds)])
     tau = float(rng.choice([1.0, 0.62, 0.3]))
@@ -207,7 +209,7 @@ def batch_case(rng, aspace, gl, X, cfg):
         assert panics, ("batch panicked, no single query did", cfg)
         return
     assert not panics, ("a single query panicked, the batch did not", cfg)
-    assert got == singles, ("batch != singles", cfg, [i for i in range(40) if got[i] != singles[i]][:5])
+    assert got == singles, ("batch != singles", cfg, [i for i in range(nq) if got[i] != singles[i]][:5])
 
 
 def sharded_case(rng, X, gp, cfg):
