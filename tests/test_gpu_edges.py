@@ -476,7 +476,7 @@ def test_every_row_is_scanned_whatever_the_grid(n, d, sharded):
             else:       # (the lambda term dominates at tau = 0.2: the item need not be among the hits)
                 assert len(hits) == 5
     assert served >= 200, served
-    if sharded or n >= 5000:
-        assert "int8-high" in ops[0.62], ops     # (the scan under test did run)
+    if n >= 5000:
+        assert "int8-high" in ops[0.62], ops     # (the scan under test did run; small shards may be served by the two-digit scan)
     if sharded:
         index.close()
