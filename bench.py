@@ -861,6 +861,8 @@ def main():
     scan_kernel = "scan_dma_kernel" if d <= 1024 and os.environ.get("ARROWSPACE_SCAN_VARIANT", "0") in ("", "0") else "scan_dots_f32_kernel"
     if scan_coarse:
         scan_kernel = "scan_tile_kernel"   # (the coarse operand lies in tiles of 64 rows x 16 columns: as_scan.hip)
+    # (the name the rocprofv3 summaries under profiles/ carry: rows of 256 columns and more run the tile scan with its dynamic chunk schedule)
+    scan_kernel_name = ("scan_tile_kernel_dyn" if scan_coarse and d8 // 16 >= 16 and os.environ.get("ARROWSPACE_TILE_DYN", "1") != "0" else scan_kernel)
     if live:
         traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), (live.get("knn_mfma_kernel") if k2_fp32_env else live.get("knn_bf16_kernel")), (live.get("scan_gemm_dual_kernel") if batch_dual > 0 else None) or live.get("scan_gemm_kernel")
         traffic_source = live_note
@@ -926,7 +928,7 @@ def main():
         # PMC measurement of the same) over the launch's duration, against the 8 TB/s peak -- a roofline fraction, <= 1.
         # SURVEY 8(d)'s ALGORITHMIC bytes N (D + 2) 4 (an fp32 scan of the items) over the same time is kept beside it as
         # `algorithmic_speedup`: how many fp32-scan rooflines the launch is worth (above 1 when it reads the 1- or 2-byte image).
-        "roofline": {"kernel": scan_kernel, "bound": "hbm", "achieved": moved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": scan_kernel_name, "bound": "hbm", "achieved": moved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": moved / HBM_PEAK_GBS, "traffic": traffic_scan,
                      "frac_from_traffic": None if traffic_scan is None else traffic_scan / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic_source": traffic_source if traffic_scan is not None else "none (live passes: %s)" % live_note,
