@@ -181,3 +181,53 @@ def test_concurrent_callers_share_scans_and_get_the_serial_answers():
     assert not bad, bad[:5]
     c = aspace.search_counters()
     assert c["searches_with_rerun"] <= 0.02 * c["searches"]
+
+
+def test_batched_calls_beside_concurrent_single_searches():
+    """One thread in `search_batch` (pairs of passes sharing a scan, two pairs of workspaces alternating) while three threads run
+    single searches on the same space (pooled workspaces, gang scans): every result equals the serial one.  The batched
+    workspaces are the space's own (one batched call at a time: `bmu`), the single searches take workspaces from the pool --
+    nothing is shared between them but the items and the graph."""
+    import threading
+
+    import numpy as np
+
+    import pyarrowspace_amd as asp
+    from conftest import calibrate_eps, clustered
+    n, d = 120000, 256
+    X = clustered(n, d, nclust=400, seed=17)
+    gp = {"eps": calibrate_eps(X, 10, "l2"), "k": 10, "topk": 8, "p": 2.0, "sigma": None}
+    aspace, gl = asp.ArrowSpaceBuilder.build(gp, X)
+    rng = np.random.default_rng(23)
+    Q = np.ascontiguousarray(X[rng.integers(0, n, 160)] + 0.02 * rng.standard_normal((160, d)) / np.sqrt(d))
+    want = [aspace.search(q, gl, 0.62) for q in Q]
+    assert aspace.search_batch(Q, gl, 0.62) == want
+    bad, errors = [], []
+
+    def batcher():
+        try:
+            for rep in range(12):
+                lo = (rep * 7) % 40
+                got = aspace.search_batch(Q[lo : lo + 120], gl, 0.62)
+                if got != want[lo : lo + 120]:
+                    bad.append(("batch", rep))
+        except BaseException as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    def single(t):
+        try:
+            for i in range(150):
+                j = (t * 37 + i) % len(Q)
+                if aspace.search(Q[j], gl, 0.62) != want[j]:
+                    bad.append(("single", t, i))
+        except BaseException as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=batcher)] + [threading.Thread(target=single, args=(t,)) for t in range(3)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:3]
+    assert not bad, bad[:5]
+    assert aspace.batch_dual_scans > 0
