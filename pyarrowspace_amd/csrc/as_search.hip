@@ -1495,8 +1495,11 @@ __device__ __forceinline__ void q_lambda_body(const as_knn_rec* __restrict__ rec
 }
 
 __global__ __launch_bounds__(64) void q_lambda_kernel(const as_knn_rec* __restrict__ recs_all, int64_t m, int64_t per, int64_t rstride,
-                                                      int64_t k, int metric, int kernel, double sigma, double p, double tau0, QInfo* info) {
+                                                      int64_t k, int metric, int kernel, double sigma, double p, double tau0, QInfo* info, int zero_sc) {
     q_lambda_body(recs_all, m, per, rstride, k, metric, kernel, sigma, p, tau0, info, blockIdx.x);
+    // (the coarse chain: the scorer's candidate count starts at zero for the selection kernels behind this one -- a 4-byte memset
+    // between two kernels is 5 us of an idle GPU)
+    if (zero_sc && threadIdx.x == 0) info[blockIdx.x].sc_cnt = 0;
 }
 
 // the blend of src/lib.rs:166-173 as SPEC S11 has it, from an exact cosine: ONE definition, so that every path that ranks
@@ -3435,8 +3438,10 @@ static as_status x1_launch_block(as_query* q, void* send_dev, int world, bool sc
     if (exact_knn && !q->xknn) {
         AS_HIP(hipMalloc(&q->xknn, sizeof(XKnn) * CAND_CAP + 16));
         AS_HIP(hipMemsetAsync((char*)q->xknn + sizeof(XKnn) * CAND_CAP, 0, 16, q->stream));
-    } else if (exact_knn && q->xknn_dirty) {
-        AS_HIP(hipMemsetAsync((char*)q->xknn + sizeof(XKnn) * CAND_CAP, 0, 16, q->stream));   // (a pass that never reached its finish kernel)
+    } else if (exact_knn && q->xknn_dirty && xmode != 2) {
+        // (a pass that never reached its finish kernel.  Not in front of the coarse chain's SECOND launch, xmode 2: the first one's last
+        // block has left the counters at zero, and the memset is 5 us between two kernels)
+        AS_HIP(hipMemsetAsync((char*)q->xknn + sizeof(XKnn) * CAND_CAP, 0, 16, q->stream));
     }
     if (exact_knn) q->xknn_dirty = 1;
     FinishArgs fs = make_finish(q);
@@ -3482,8 +3487,7 @@ static as_status coarse_score_stage(as_query* q, void* block, double tau) {
     const int64_t krec = std::max<int64_t>(q->k, 1);
     hipStream_t st = q->stream;
     hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, st, (const as_knn_rec*)block, krec, krec, krec, q->k, gr->metric, gr->kernel, gr->gp.sigma,
-                       gr->gp.p, gr->tau0, q->info);
-    AS_HIP(hipMemsetAsync(&q->info->sc_cnt, 0, sizeof(int), st));
+                       gr->gp.p, gr->tau0, q->info, 1);
     const int64_t rows = q->r1 - q->r0;
     int64_t G = (rows + CAND_CAP - 1) / CAND_CAP;
     G = std::max<int64_t>(64, (G + 63) / 64 * 64);
@@ -3580,7 +3584,7 @@ as_status as_query_lambda(as_query* q, const as_knn_rec* recs_dev, int64_t m) {
     q->staged_m = m;
     if (q->staged_sc) return AS_OK;   // lambda_q is formed by staged_score_kernel (as_query_score), in front of the scorer
     hipLaunchKernelGGL(q_lambda_kernel, dim3(1), dim3(64), 0, q->stream, recs_dev, m, m, m, q->k, gr->metric, gr->kernel,
-                       gr->gp.sigma, gr->gp.p, gr->tau0, q->info);
+                       gr->gp.sigma, gr->gp.p, gr->tau0, q->info, 0);
     AS_HIP(hipGetLastError());
     return AS_OK;
 }
@@ -3667,7 +3671,7 @@ as_status as_query_lambda_batch(as_query* q, const as_knn_rec* recs_dev, int32_t
         return AS_EUNSUPPORTED;
     }
     hipLaunchKernelGGL(q_lambda_kernel, dim3((unsigned)q->cap), dim3(64), 0, q->stream, recs_dev, m, per, per * q->cap, q->k, gr->metric,
-                       gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, q->info);
+                       gr->kernel, gr->gp.sigma, gr->gp.p, gr->tau0, q->info, 0);
     AS_HIP(hipGetLastError());
     return AS_OK;
 }
