@@ -868,7 +868,10 @@ def main():
     if scan_coarse:
         scan_kernel = "scan_tile_kernel"   # (the coarse operand lies in tiles of 64 rows x 16 columns: as_scan.hip)
     # (the name the rocprofv3 summaries under profiles/ carry: rows of 256 columns and more run the tile scan with its dynamic chunk schedule)
-    scan_kernel_name = ("scan_tile_kernel_dyn" if scan_coarse and d8 // 16 >= 16 and os.environ.get("ARROWSPACE_TILE_DYN", "1") != "0" else scan_kernel)
+    # (... and three chunks of 64 rows per wave or more: launch_scan in as_scan.hip)
+    waves = 4 * min(max(n // world // 128, 1), 2 * torch.cuda.get_device_properties(device).multi_processor_count)
+    scan_kernel_name = ("scan_tile_kernel_dyn" if scan_coarse and d8 // 16 >= 16 and n // world >= waves * 64 * 3
+                        and os.environ.get("ARROWSPACE_TILE_DYN", "1") != "0" else scan_kernel)
     if live:
         traffic_scan, traffic_mfma, traffic_batch = live.get(scan_kernel), (live.get("knn_mfma_kernel") if k2_fp32_env else live.get("knn_bf16_kernel")), (live.get("scan_gemm_dual_kernel") if batch_dual > 0 else None) or live.get("scan_gemm_kernel")
         traffic_source = live_note
