@@ -1706,9 +1706,12 @@ struct GangArgs {
     float* dots[4];
 };
 typedef int i32x4g __attribute__((ext_vector_type(4)));
-template <int NSLOT, int NQ>
+// DYN: the chunks by tickets as in scan_tile_kernel_dyn (the cursors are the first member's: ga.p[0].tile_ctrs, `ng` groups) --
+// a gang's scan shares the chip with its members' previous tail kernels more often than not, and equal shares cannot adapt to
+// CUs that are busy with something else.
+template <int NSLOT, int NQ, bool DYN = false>
 __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* __restrict__ xt, int C, int64_t r0, int64_t r1, GangArgs ga, int rounds,
-                                                             int tail_rows, int crows) {
+                                                             int tail_rows, int crows, int ng) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int U = 2;
     constexpr int RING = NSLOT * 1024;
@@ -1716,7 +1719,7 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
     constexpr int TR = NQ * 64 * 4 * 2;                            // per wave: the accumulators on their way to "lane r = row r" (HI and XS)
     constexpr int WAVE_LDS = RING + 512 + NQ * QAREA + TR;
     constexpr int K1 = NSLOT - 2 * U;
-    constexpr int KB = NQ + 2;                                     // a chunk boundary: NQ dot stores, the norm DMA, the scale DMA
+    constexpr int KB = NQ + 2 + (DYN ? 1 : 0);                     // a chunk boundary: NQ dot stores, the norm DMA, the scale DMA (DYN: the ticket)
     static_assert(NSLOT % U == 0 && NSLOT >= 2 * U && NQ >= 2 && NQ <= 4, "ring of whole steps, two to four queries");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1734,6 +1737,23 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
     const size_t tile_bytes = (size_t)C * 1024;
     const int64_t NW = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wu;
     const int64_t tail0 = r0 + (int64_t)rounds * NW * crows;
+    // DYN: chunk c = rows [r0 + c crows, + crows); the wave's first chunk is its own, the others NW + ng j + g for ticket j of its group g
+    const int grp = (int)((blockIdx.x + (blockIdx.x >> 3)) & (unsigned)(ng - 1));
+    int* ctr = DYN ? (int*)(ga.p[0].tile_ctrs + grp * SC_HSTRIDE + SC_CTR_WORD) : nullptr;
+    int tk = 0;
+    const int one = 1;
+    int64_t ccur = gw, cnxt = 0;
+#define AS_CHUNK_ID(cid, base, cnt)                                                      \
+    do {                                                                                 \
+        base = r0 + (int64_t)(cid) * crows;                                              \
+        const int64_t left_ = r1 - base;                                                 \
+        cnt = (int)(left_ <= 0 ? 0 : (left_ < crows ? left_ : crows));                   \
+    } while (0)
+#define AS_TICKET()                                                                                                   \
+    do {                                                                                                              \
+        if (DYN && lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(tk) : "v"(ctr), "v"(one) : "memory"); \
+    } while (0)
+    AS_TICKET();
 #define AS_CHUNK(t, base, cnt)                                                           \
     do {                                                                                 \
         if ((t) < rounds) {                                                              \
@@ -1769,13 +1789,21 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
             pcol += U;                                                                                                   \
             if (pcol == C) {                                                                                             \
                 pcol = 0;                                                                                                \
-                ++pt;                                                                                                    \
-                AS_CHUNK(pt, pbase, pcnt);                                                                               \
+                if (DYN) {                                                                                               \
+                    AS_CHUNK_ID(cnxt, pbase, pcnt);                                                                      \
+                } else {                                                                                                 \
+                    ++pt;                                                                                                \
+                    AS_CHUNK(pt, pbase, pcnt);                                                                           \
+                }                                                                                                        \
                 AS_TILE_ENTER();                                                                                         \
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
-    AS_CHUNK(0, pbase, pcnt);
+    if (DYN) {
+        AS_CHUNK_ID(ccur, pbase, pcnt);
+    } else {
+        AS_CHUNK(0, pbase, pcnt);
+    }
     AS_TILE_ENTER();
 #pragma unroll
     for (int i = 0; i < NSLOT / U - 1; ++i) AS_TILE_ISSUE();
@@ -1803,6 +1831,10 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
             for (int g = (int)blockIdx.x * 256 + tid; g < pre.qdp; g += (int)gridDim.x * 256) pre.q64_dev[g] = pre.q64_host[g];
     }
     __syncthreads();
+    if (DYN) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk) : : "memory");   // (start-up: the ring's first fill and the first ticket)
+        cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * ng + grp;
+    }
     const float* __restrict__ auxv = ga.p[0].metric == AS_METRIC_L2 ? ga.p[0].n32 : ga.p[0].inorm32;
     // this lane's B fragment: slot lane % 16 = (query qq, row group g'); its k-chunk is lane / 16: digits where g' == lane / 16
     const int myq = (lane & 15) >> 2;
@@ -1814,11 +1846,16 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
     int marked = 0;
     bool first = true;
     ScanWave w[NQ];
-    for (int t = 0; t <= rounds; ++t) {
+    for (int t = 0; DYN || t <= rounds; ++t) {
         int64_t base;
         int cnt;
-        AS_CHUNK(t, base, cnt);
-        if (cnt <= 0) continue;
+        if (DYN) {
+            AS_CHUNK_ID(ccur, base, cnt);
+            if (cnt <= 0) break;
+        } else {
+            AS_CHUNK(t, base, cnt);
+            if (cnt <= 0) continue;
+        }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(auxv + base + lane),
                                          (__attribute__((address_space(3))) void*)(myp + RING), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga.p[0].fa8 + base + lane),
@@ -1833,6 +1870,7 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga.p[qq].sc_hist + (gw & (SC_COPIES - 1)) * SC_HSTRIDE + lane),
                                                  (__attribute__((address_space(3))) void*)(myp + RING + 512 + qq * QAREA), 4, 0, 16);
         }
+        AS_TICKET();                     // (DYN: the chunk after `cnxt`)
         marked = first ? 0 : inflight;
         const bool hmark = hread;
         first = false;
@@ -1879,8 +1917,13 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
             const int x_ = (int)lds_read1u(tr0 + (unsigned)(NQ * 256 + (qq * 64 + lane) * 4));
             const long long tot = (long long)h_ * 128 + (long long)x_;
             const float mydot = (float)tot * (fa * ga.p[qq].faq);
-            scan_chunk_end<true, GANG_PEND>(ga.p[qq], w[qq], ga.dots[qq], t, rounds, gw, lane, base, cnt, mydot, aux, hread, qa0 + (unsigned)(qq * QAREA),
+            scan_chunk_end<true, GANG_PEND>(ga.p[qq], w[qq], ga.dots[qq], t, DYN ? (1 << 30) : rounds, gw, lane, base, cnt, mydot, aux, hread, qa0 + (unsigned)(qq * QAREA),
                                  qa0 + (unsigned)(qq * QAREA + 256), nq32[qq], inq32[qq]);
+        }
+        if (DYN) {   // (the ticket drawn at this chunk's start has retired: C >= 16 items were issued behind it)
+            asm volatile("" : "+v"(tk));
+            ccur = cnxt;
+            cnxt = NW + (int64_t)__builtin_amdgcn_readfirstlane(tk) * ng + grp;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1889,6 +1932,8 @@ __global__ __launch_bounds__(256) void scan_tile_gang_kernel(const signed char* 
 #undef AS_TILE_ISSUE
 #undef AS_TILE_ENTER
 #undef AS_CHUNK
+#undef AS_CHUNK_ID
+#undef AS_TICKET
 }
 
 // generic width (dp > 2048): query re-read from L1 per chunk
@@ -2141,6 +2186,9 @@ as_status set_scan_attrs() {
     AS_ATTR((scan_tile_gang_kernel<8, 2>), gang_lds(8, 2, 256));
     AS_ATTR((scan_tile_gang_kernel<8, 3>), gang_lds(8, 3, 256));
     AS_ATTR((scan_tile_gang_kernel<8, 4>), gang_lds(8, 4, 256));
+    AS_ATTR((scan_tile_gang_kernel<8, 2, true>), gang_lds(8, 2, 256));
+    AS_ATTR((scan_tile_gang_kernel<8, 3, true>), gang_lds(8, 3, 256));
+    AS_ATTR((scan_tile_gang_kernel<8, 4, true>), gang_lds(8, 4, 256));
     AS_ATTR((scan_tile_kernel<8, true, 4>), tile_lds(8, true, 256));
     AS_ATTR((scan_tile_kernel<12, true, 4>), tile_lds(12, true, 256));
     AS_ATTR((scan_tile_kernel<16, true, 4>), tile_lds(16, true, 256));
@@ -2215,12 +2263,23 @@ as_status launch_scan_gang(as_query* const* m, const PreArgs* pre, int n, hipStr
     }
     const int C = (int)(sp->dp8 / 16);
     const signed char* xt = (const signed char*)sp->x8h;
-    if (n == 2)
-        hipLaunchKernelGGL((scan_tile_gang_kernel<8, 2>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 2, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
-    else if (n == 3)
-        hipLaunchKernelGGL((scan_tile_gang_kernel<8, 3>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 3, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
-    else
-        hipLaunchKernelGGL((scan_tile_gang_kernel<8, 4>), dim3((unsigned)nblk), dim3(256), gang_lds(8, 4, C), st, xt, C, m[0]->r0, m[0]->r1, ga, rounds, tail_rows, crows);
+    // (the chunks by tickets under the single-query kernel's conditions: launch_scan)
+    const int64_t NWg = nblk * 4;
+    const int ng = nblk >= 32 ? SC_COPIES : (nblk >= 8 ? 8 : (nblk >= 4 ? 4 : (nblk >= 2 ? 2 : 1)));
+    const bool dyn = C >= 16 && ga.p[0].tile_ctrs && g_tile_dyn.load(std::memory_order_relaxed) && rows >= NWg * crows * 3;
+#define AS_GANG(NQ_)                                                                                                   \
+    do {                                                                                                               \
+        if (dyn)                                                                                                       \
+            hipLaunchKernelGGL((scan_tile_gang_kernel<8, NQ_, true>), dim3((unsigned)nblk), dim3(256), gang_lds(8, NQ_, C), st, xt, C, m[0]->r0, m[0]->r1, ga, \
+                               rounds, tail_rows, crows, ng);                                                           \
+        else                                                                                                           \
+            hipLaunchKernelGGL((scan_tile_gang_kernel<8, NQ_, false>), dim3((unsigned)nblk), dim3(256), gang_lds(8, NQ_, C), st, xt, C, m[0]->r0, m[0]->r1, ga, \
+                               rounds, tail_rows, crows, ng);                                                           \
+    } while (0)
+    if (n == 2) AS_GANG(2);
+    else if (n == 3) AS_GANG(3);
+    else AS_GANG(4);
+#undef AS_GANG
     AS_HIP(hipGetLastError());
     return AS_OK;
 }

@@ -224,3 +224,51 @@ def test_coarse_scan_against_the_oracle_at_headline_size(big):
     assert zero < per * 3                                # (some in-distribution draws have no neighbour inside eps; not all)
     c = aspace.search_counters()
     assert c["searches_with_rerun"] <= 0.05 * c["searches"]
+
+
+def test_shared_scans_at_headline_size(big):
+    """Concurrent callers at 1M x 768: their scans are shared (scan_tile_gang_kernel, chunks handed out by tickets at this size --
+    the dynamic schedule needs three chunks per wave: nothing smaller exercises it), every call's hits are the serial ones
+    (Python threads: element for element; native threads against the C ABI: the best hit of every call)."""
+    import threading
+
+    import torch
+
+    import pyarrowspace_amd as asp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import thread_bench
+    X, aspace, gl = big["X"], big["aspace"], big["gl"]
+    rng = np.random.default_rng(5)
+    rows = rng.integers(0, N, 96)
+    Q = X[torch.from_numpy(rows).cuda()].double().cpu().numpy() + 0.02 * rng.standard_normal((96, D)) / np.sqrt(D)
+    Q = np.ascontiguousarray(Q / np.linalg.norm(Q, axis=1, keepdims=True))
+    want, keep = [], []
+    for i, q in enumerate(Q):
+        try:
+            want.append(aspace.search(q, gl, 0.62))
+            keep.append(i)
+        except asp.PanicException:
+            pass
+    Q = np.ascontiguousarray(Q[keep])
+    assert len(Q) >= 48
+    before = aspace.gang_counters()
+    bad = []
+
+    def worker(t):
+        for i in range(60):
+            j = (t * 29 + i) % len(Q)
+            if aspace.search(Q[j], gl, 0.62) != want[j]:
+                bad.append((t, i))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not bad, bad[:5]
+    first = np.array([w[0][0] for w in want], dtype=np.int64)
+    for nthr in (2, 4):
+        rate, errs, gangs = thread_bench.native_rate(aspace, gl, Q, 0.62, nthr, 120, first)
+        assert errs == 0 and rate > 0
+    after = aspace.gang_counters()
+    assert sum(after[1:]) > sum(before[1:]), (before, after)      # scans with two or more members did form
