@@ -25,7 +25,9 @@ import numpy as np
 # batched workspaces); the ROCm runtime multiplexes a process's streams over 4 hardware queues unless told otherwise, and
 # streams that share a queue run strictly one kernel after the other ("Hardware queues").  Read at the first
 # HIP call: set before torch is imported.  (Same box, tools/hwq_bench_ab.sh: batched 98 000 -> 117 000-120 000 queries/s, B = 1 unchanged.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Only when this file is the program: a test or tool that imports it keeps the runtime's default.
+if __name__ == "__main__":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

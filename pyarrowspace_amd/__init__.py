@@ -14,10 +14,6 @@ import os
 
 import numpy as np
 
-# (the library's workspaces run on up to a dozen streams of their own; the runtime's default of 4 hardware queues makes some of them
-# share a queue -- strictly one kernel after the other.  Read at the process's first HIP call: no effect if that has happened already)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 from . import _lib
 from ._lib import GraphParams, Opts
 
